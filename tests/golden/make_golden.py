@@ -1,0 +1,374 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/ by running the REFERENCE's own
+NumPy code (lukebhan/PDEControlGym checkout at /root/reference) in the build container.
+
+Only inputs and expected outputs are stored (small .npz files); no reference source, bytecode or
+pickles.  The reference cannot be imported as shipped (SyntaxError in pde_control_gym/__init__.py,
+and gymnasium is not installed) so a metadata-only shim is used: it supplies ``gymnasium.Env``,
+``spaces.Box`` and ``register`` as no-ops and mounts the reference's package directory under a
+synthetic parent so the broken ``__init__`` is skipped.  The shim contains no arithmetic: every
+number written below is produced by the reference's own step()/reset()/reward() code.
+
+Run:  python tests/golden/make_golden.py      (needs /root/reference; NOT run on the GPU box)
+"""
+import importlib
+import math
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+REF = os.environ.get("PDEGYM_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+warnings.filterwarnings("ignore", category=DeprecationWarning)
+
+
+def import_reference():
+    import matplotlib
+    matplotlib.use("Agg")
+    gym = types.ModuleType("gymnasium")
+
+    class Env:
+        def __init__(self):
+            pass
+
+    class Wrapper(Env):
+        def __init__(self, env):
+            self.env = env
+
+    class Box:
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.low = np.broadcast_to(np.asarray(low, dtype=dtype), shape) if shape is not None else np.asarray(low, dtype=dtype)
+            self.high = np.broadcast_to(np.asarray(high, dtype=dtype), shape) if shape is not None else np.asarray(high, dtype=dtype)
+            self.shape, self.dtype = self.low.shape, np.dtype(dtype)
+
+    gym.Env, gym.Wrapper = Env, Wrapper
+    spaces = types.ModuleType("gymnasium.spaces")
+    spaces.Box = Box
+    gym.spaces = spaces
+    envs = types.ModuleType("gymnasium.envs")
+    reg = types.ModuleType("gymnasium.envs.registration")
+    reg.register = lambda **k: None
+    envs.registration = reg
+    gym.envs = envs
+    sys.modules.update({"gymnasium": gym, "gymnasium.spaces": spaces,
+                        "gymnasium.envs": envs, "gymnasium.envs.registration": reg})
+    pkg = types.ModuleType("pde_control_gym")
+    pkg.__path__ = [os.path.join(REF, "pde_control_gym")]
+    sys.modules["pde_control_gym"] = pkg
+    sys.dont_write_bytecode = True
+    return importlib.import_module("pde_control_gym.src")
+
+
+def cheb_beta(x, gamma, amp):
+    beta = np.zeros(len(x), dtype=np.float32)
+    for idx, val in enumerate(x):
+        beta[idx] = amp * math.cos(gamma * math.acos(val))
+    return beta
+
+
+def run_1d(src, cls_name, kw, init, beta, actions, reward_args, extra=None):
+    """Drive one reference 1D env with float32 (1,) actions like SB3 does; record everything."""
+    cls = getattr(src, cls_name)
+    kw = dict(kw)
+    kw["reward_class"] = src.TunedReward1D(*reward_args)
+    kw["sensing_noise_func"] = lambda s: s
+    kw["reset_init_condition_func"] = lambda nx: init
+    kw["reset_recirculation_func"] = lambda nx: beta
+    env = cls(**kw)
+    obs0, _ = env.reset()
+    obs, rew, term, trunc, tidx, rows = [np.array(obs0, dtype=np.float32)], [], [], [], [], []
+    for a in actions:
+        o, r, te, tr, _ = env.step(np.array([a], dtype=np.float32))
+        obs.append(np.array(o, dtype=np.float32).reshape(-1))
+        rew.append(np.float64(r))
+        term.append(te)
+        trunc.append(tr)
+        tidx.append(env.time_index)
+        rows.append(np.array(env.u[env.time_index], dtype=np.float32))
+    obs[0] = obs[0].reshape(-1)
+    return dict(obs=np.stack(obs), reward=np.array(rew), terminate=np.array(term), truncate=np.array(trunc),
+                time_index=np.array(tidx), rows=np.stack(rows), init=np.asarray(init), beta=np.asarray(beta),
+                actions=np.asarray(actions, dtype=np.float32), reward_args=np.array(reward_args, dtype=np.float64))
+
+
+def pack(prefix, d, store):
+    for k, v in d.items():
+        store[f"{prefix}/{k}"] = v
+
+
+def gen_transport(src):
+    store = {}
+    rng = np.random.default_rng(1234)
+    # F-H1: BASELINE config 1 (nx=100, T=1, dt=1e-4, S=1000)
+    base = dict(T=1, dt=1e-4, X=1, dx=1e-2, normalize=False, sensing_loc="full", control_type="Dirchilet",
+                sensing_type=None, limit_pde_state_size=True, max_state_value=1e10, max_control_value=20,
+                control_sample_rate=0.1)
+    nx = 100
+    beta = cheb_beta(np.linspace(0, 1, nx), 7.35, 5)
+    acts = rng.uniform(-1, 1, 10).astype(np.float32)
+    pack("H1", run_1d(src, "TransportPDE1D", base, np.ones(nx) * 5.0, beta, acts, (10000, -1e3, 3e2)), store)
+    # F-H2: Neumann + normalize, every sensing mode
+    for name, (ct, sl, st) in {
+        "neu_full": ("Neumann", "full", None), "neu_col": ("Neumann", "collocated", None),
+        "neu_opp_neu": ("Neumann", "opposite", "Neumann"), "neu_opp_dir": ("Neumann", "opposite", "Dirchilet"),
+        "dir_col": ("Dirchilet", "collocated", None), "dir_opp_neu": ("Dirchilet", "opposite", "Neumann"),
+        "dir_opp_dir": ("Dirchilet", "opposite", "Dirchilet"),
+    }.items():
+        kw = dict(base, T=0.3, control_type=ct, sensing_loc=sl, sensing_type=st, normalize=True, control_sample_rate=0.05)
+        acts = rng.uniform(-1, 1, 6).astype(np.float32)
+        pack(f"H2_{name}", run_1d(src, "TransportPDE1D", kw, np.ones(nx) * 3.0, beta, acts, (3000, -1e3, 3e2)), store)
+    # F-H3: BASELINE config 3 shape (nx=512, dt=0.5dx, S=100), smooth random IC / beta
+    nx = 512
+    dx = 1.0 / 512
+    dt = 0.5 * dx
+    x = np.linspace(0, 1, nx)
+    init = (2.0 + np.sin(2 * np.pi * x * rng.uniform(0.5, 2)) * rng.uniform(0.5, 3)).astype(np.float32)
+    beta = cheb_beta(x, rng.uniform(7, 7.7), 5)
+    kw = dict(base, T=700 * dt, dt=dt, dx=dx, control_sample_rate=100 * dt)
+    acts = rng.uniform(-1, 1, 8).astype(np.float32)     # 7 steps reach nt-1, the 8th is a post-terminal call
+    pack("H3", run_1d(src, "TransportPDE1D", kw, init, beta, acts, (700, -1e3, 3e2)), store)
+    # F-R: reward edge cases. (a) S=30 (<100: look-back wraps into zero rows, then hits non-step-end rows),
+    # clipped last step, terminate with ||u|| >= 20; (b) truncation through a small max_state_value
+    nx = 100
+    beta = cheb_beta(np.linspace(0, 1, nx), 7.35, 5)
+    kw = dict(base, T=0.0400, dt=1e-4, control_sample_rate=30e-4)     # nt=401, S=30 -> 14 steps, last has 10 sub-steps
+    acts = rng.uniform(-1, 1, 15).astype(np.float32)
+    pack("R_s30", run_1d(src, "TransportPDE1D", kw, np.ones(nx) * 8.0, beta, acts, (400, -1e3, 3e2)), store)
+    kw = dict(base, T=0.0400, dt=1e-4, control_sample_rate=30e-4)
+    pack("R_s30_small", run_1d(src, "TransportPDE1D", kw, np.ones(nx) * 0.5, beta, acts, (400, -1e3, 3e2)), store)
+    kw = dict(base, T=1, max_state_value=46.5)     # ||u|| = 46.08, 46.96 -> truncates at step 2 (and 46.38 < 46.5 at step 3)
+    acts = (np.ones(10) * 0.9).astype(np.float32)
+    pack("R_trunc", run_1d(src, "TransportPDE1D", kw, np.ones(nx) * 5.0, beta, acts, (10000, -1e3, 3e2)), store)
+    # tiny horizon: nt <= 100, negative look-back index wraps onto rows that HAVE been written
+    # (the reference raises IndexError when t-100 < -nt, so S must be >= 100-nt+1)
+    kw = dict(base, T=0.0090, dt=1e-4, control_sample_rate=15e-4)      # nt=91, S=15: t-100 -> rows 6,21,36,...
+    acts = rng.uniform(-1, 1, 6).astype(np.float32)
+    pack("R_tiny", run_1d(src, "TransportPDE1D", kw, np.ones(nx) * 2.0, beta, acts, (90, -1e3, 3e2)), store)
+    np.savez_compressed(os.path.join(OUT, "transport.npz"), **store)
+
+
+def gen_parabolic(src):
+    store = {}
+    rng = np.random.default_rng(4321)
+    base = dict(T=1, dt=1e-5, X=1, dx=5e-3, normalize=False, sensing_loc="full", control_type="Dirchilet",
+                sensing_type=None, limit_pde_state_size=True, max_state_value=1e10, max_control_value=20,
+                control_sample_rate=1e-3)
+    # F-P1: shipped example config (nx=200, S=100), 20 steps
+    nx = 200
+    beta = cheb_beta(np.linspace(0, 1, nx + 1), 8, 50)
+    acts = rng.uniform(-1, 1, 20).astype(np.float32)
+    pack("P1", run_1d(src, "ReactionDiffusionPDE1D", base, np.ones(nx + 1) * 4.0, beta, acts, (100000, -1e3, 3e2)), store)
+    # F-P2: BASELINE config 2 shape (nx=256, F=0.25), S in {1, 100}; Dirichlet and Neumann+normalize
+    nx = 256
+    dx = 1.0 / 256
+    dt = 0.25 * dx * dx
+    x = np.linspace(0, 1, nx + 1)
+    beta = cheb_beta(x, 8.2, 50)
+    init = (np.ones(nx + 1) * 6.5).astype(np.float32)
+    for name, S, ct, norm, nsteps, T in [("P2_s100", 100, "Dirchilet", False, 12, 1000 * dt),
+                                         ("P2_s1", 1, "Dirchilet", False, 12, 1000 * dt),
+                                         ("P2_s100_neu", 100, "Neumann", False, 8, 1000 * dt),
+                                         ("P2_s1_neu", 1, "Neumann", False, 150, 1000 * dt),
+                                         # normalize also scales the Neumann neighbour (x20 per sub-step): keep it short
+                                         ("P2_s1_neu_norm", 1, "Neumann", True, 6, 1000 * dt),
+                                         ("P2_s100_dir_norm", 100, "Dirchilet", True, 6, 1000 * dt)]:
+        kw = dict(base, T=T, dt=dt, dx=dx, control_sample_rate=S * dt, control_type=ct, normalize=norm)
+        acts = rng.uniform(-1, 1, nsteps).astype(np.float32)
+        pack(name, run_1d(src, "ReactionDiffusionPDE1D", kw, init, beta, acts, (1000, -1e3, 3e2)), store)
+    # sensing variants
+    for name, (ct, sl, st) in {"col_neu": ("Neumann", "collocated", None), "col_dir": ("Dirchilet", "collocated", None),
+                               "opp_neu": ("Dirchilet", "opposite", "Neumann")}.items():
+        kw = dict(base, T=600 * dt, dt=dt, dx=dx, control_sample_rate=50 * dt, control_type=ct, sensing_loc=sl, sensing_type=st)
+        acts = rng.uniform(-1, 1, 5).astype(np.float32)
+        pack(f"P3_{name}", run_1d(src, "ReactionDiffusionPDE1D", kw, init, beta, acts, (600, -1e3, 3e2)), store)
+    np.savez_compressed(os.path.join(OUT, "parabolic.npz"), **store)
+
+
+def gen_kat(src):
+    """Published known answers (backstepping episodes, notebook stored outputs)."""
+    store = {}
+    # transport: examples/transportPDE/transport1Dbackstepping.py:22-36,48-99
+    T, dt, dx, X = 5, 1e-4, 1e-2, 1
+    nx = 100
+
+    def kernel_transport(theta):
+        kappa = np.zeros(len(theta))
+        for i in range(len(theta)):
+            s = 0
+            for j in range(i):
+                s += (kappa[i - j] * theta[j]) * dx
+            kappa[i] = s - theta[i]
+        return np.flip(kappa)
+
+    beta = cheb_beta(np.linspace(0, 1, nx), 7.35, 5)
+    kern = kernel_transport(cheb_beta(np.linspace(dx, X, nx), 7.35, 5))
+    for u0 in (1, 10):
+        kw = dict(T=T, dt=dt, X=X, dx=dx, reward_class=src.TunedReward1D(int(round(T / dt)), -1e3, 3e2), normalize=False,
+                  sensing_loc="full", control_type="Dirchilet", sensing_type=None, sensing_noise_func=lambda s: s,
+                  limit_pde_state_size=True, max_state_value=1e10, max_control_value=20,
+                  reset_init_condition_func=lambda n, u0=u0: np.ones(n) * u0, reset_recirculation_func=lambda n: beta,
+                  control_sample_rate=0.1)
+        env = src.TransportPDE1D(**kw)
+        obs, _ = env.reset()
+        te = tr = False
+        total, l2, acts, rews = 0.0, 0.0, [], []
+        while not te and not tr:
+            a = 0
+            for i in range(len(obs)):
+                a += kern[i] * obs[i]
+            a = a * 1e-2
+            obs, r, te, tr, _ = env.step(a)
+            total += r
+            l2 += np.linalg.norm(obs)
+            acts.append(a)
+            rews.append(r)
+        pack(f"T_u{u0}", dict(total=np.float64(total), sum_l2=np.float64(l2), actions=np.array(acts, dtype=np.float64),
+                              rewards=np.array(rews, dtype=np.float64), kernel=kern, beta=beta, last_obs=np.array(obs)), store)
+        print("KAT transport", u0, total, l2)
+
+    # parabolic: examples/reactionDiffusionPDE/reactionDiffusion1DBackstepping.py:22-39,51-102
+    T, dt, dx, X = 1, 1e-5, 5e-3, 1
+    nx = 200
+
+    def kernel_parabolic(a):
+        k = np.zeros((len(a), len(a)))
+        k[1][1] = -(a[1] + a[0]) * dx / 4
+        for i in range(1, len(a) - 1):
+            k[i + 1][0] = 0
+            k[i + 1][i + 1] = k[i][i] - dx / 4.0 * (a[i - 1] + a[i])
+            k[i + 1][i] = k[i][i] - dx / 2 * a[i]
+            for j in range(1, i):
+                k[i + 1][j] = -k[i - 1][j] + k[i][j + 1] + k[i][j - 1] + a[j] * (dx ** 2) * (k[i][j + 1] + k[i][j - 1]) / 2
+        return k
+
+    beta = cheb_beta(np.linspace(0, 1, nx + 1), 8, 50)
+    kern = kernel_parabolic(cheb_beta(np.linspace(dx, X, nx), 8, 50))   # notebook cell 11 grid
+    for u0 in (1, 10):
+        kw = dict(T=T, dt=dt, X=X, dx=dx, reward_class=src.TunedReward1D(int(round(T / dt)), -1e3, 3e2), normalize=False,
+                  sensing_loc="full", control_type="Dirchilet", sensing_type=None, sensing_noise_func=lambda s: s,
+                  limit_pde_state_size=True, max_state_value=1e10, max_control_value=20,
+                  reset_init_condition_func=lambda n, u0=u0: np.ones(n + 1) * u0, reset_recirculation_func=lambda n: beta,
+                  control_sample_rate=0.001)
+        env = src.ReactionDiffusionPDE1D(**kw)
+        obs, _ = env.reset()
+        te = tr = False
+        total, l2, acts, rews = 0.0, 0.0, [], []
+        krow = kern[-1]
+        while not te and not tr:
+            m = min(len(krow), len(obs) - 1)
+            a = sum(krow[0:m] * obs[0:m]) * dx
+            obs, r, te, tr, _ = env.step(a)
+            total += r
+            l2 += np.linalg.norm(obs)
+            acts.append(a)
+            rews.append(r)
+        pack(f"P_u{u0}", dict(total=np.float64(total), sum_l2=np.float64(l2), actions=np.array(acts, dtype=np.float64),
+                              rewards=np.array(rews, dtype=np.float64), kernel_row=krow, beta=beta, last_obs=np.array(obs)), store)
+        print("KAT parabolic", u0, total, l2)
+    np.savez_compressed(os.path.join(OUT, "kat.npz"), **store)
+
+
+NS_BC = {"upper": ["Controllable", "Dirchilet"], "lower": ["Dirchilet", "Dirchilet"],
+         "left": ["Dirchilet", "Dirchilet"], "right": ["Dirchilet", "Dirchilet"]}
+
+
+def gen_ns(src):
+    store = {}
+    # F-N1: the reference's own golden trajectory examples/NavierStokes/target.npz (NS2Dppo.py:21-50)
+    tgt = np.load(os.path.join(REF, "examples/NavierStokes/target.npz"))
+    ut, vt = tgt["u"], tgt["v"]
+    Uref = np.stack([ut, vt], axis=-1)
+    kw = dict(T=0.2, dt=1e-3, X=1, dx=0.05, Y=1, dy=0.05, action_dim=1, reward_class=src.NSReward(0.1), normalize=False,
+              reset_init_condition_func=lambda X: (ut[0].copy(), vt[0].copy(), np.zeros_like(ut[0])),
+              boundary_condition=NS_BC, U_ref=Uref, action_ref=2.0 * np.ones(1000))
+    env = src.NavierStokes2D(**kw)
+    env.reset()
+    rews, frames = [], {}
+    keep = [0, 1, 2, 50, 120, 199]
+    acts = ut[1:200, -1, 10].copy()          # = 4 - 0.01 t up to rounding; the stored values are the exact inputs
+    for t in range(1, 200):
+        obs, r, te, tr, _ = env.step(acts[t - 1])
+        rews.append(r)
+    U = env.U
+    assert np.array_equal(U[:200, :, :, 0], ut) and np.array_equal(U[:200, :, :, 1], vt), "reference no longer reproduces target.npz"
+    for t in keep:
+        frames[f"u{t}"] = ut[t]
+        frames[f"v{t}"] = vt[t]
+    pack("N1", dict(rewards=np.array(rews), p_final=env.p, keep=np.array(keep), actions=acts, **frames), store)
+    # a different reference trajectory so the reward is non-trivial
+    env2 = src.NavierStokes2D(**dict(kw, U_ref=0.5 * Uref))
+    env2.reset()
+    rews2 = [env2.step(acts[t - 1])[1] for t in range(1, 6)]
+    pack("N1b", dict(rewards=np.array(rews2)), store)
+
+    # F-N2: mixed boundary conditions, random smooth IC, K=50
+    rng = np.random.default_rng(99)
+    for name, n, bc in [("N2_32", 32, {"upper": ["Controllable", "Neumann"], "lower": ["Dirchilet", "Controllable"],
+                                          "left": ["Neumann", "Dirchilet"], "right": ["Dirchilet", "Neumann"]}),
+                        ("N2_64", 64, {"upper": ["Neumann", "Neumann"], "lower": ["Controllable", "Dirchilet"],
+                                          "left": ["Controllable", "Controllable"], "right": ["Neumann", "Dirchilet"]}),
+                        ("N2_48", 48, NS_BC)]:
+        dx = 1.0 / (n - 1)
+        dt = 0.2 * 0.5 * dx * dx / 0.1
+        xs = np.linspace(0, 1, n)
+        Xg, Yg = np.meshgrid(xs, xs)
+        u0 = np.sin(2 * np.pi * Xg) * np.cos(np.pi * Yg) * rng.uniform(0.5, 2) + rng.uniform(-1, 1)
+        v0 = np.cos(np.pi * Xg) * np.sin(2 * np.pi * Yg) * rng.uniform(0.5, 2) + rng.uniform(-1, 1)
+        p0 = rng.uniform(-1, 1, (n, n))
+        nt = 10
+        Uref = rng.uniform(-1, 1, (nt, n, n, 2))
+        aref = rng.uniform(1, 3, nt)
+        kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, action_dim=1, reward_class=src.NSReward(0.1), normalize=False,
+                  reset_init_condition_func=lambda X: (u0.copy(), v0.copy(), p0.copy()), boundary_condition=bc,
+                  U_ref=Uref, action_ref=aref, maximum_pressure_iteration=50)
+        env = src.NavierStokes2D(**kw)
+        assert env.nx == n
+        env.reset()
+        acts = rng.uniform(2, 4, 3)
+        obs_l, p_l, r_l = [], [], []
+        for a in acts:
+            obs, r, te, tr, _ = env.step(a)
+            obs_l.append(np.array(obs))
+            p_l.append(np.array(env.p))
+            r_l.append(r)
+        pack(name, dict(u0=u0, v0=v0, p0=p0, U_ref=Uref, action_ref=aref, actions=acts, obs=np.stack(obs_l), p=np.stack(p_l),
+                        rewards=np.array(r_l), dx=np.float64(dx), dt=np.float64(dt), nt=np.int64(nt),
+                        bc=np.array([bc[k][i] for k in ("upper", "lower", "left", "right") for i in (0, 1)])), store)
+
+    # F-N3: BASELINE config 4 shape (128x128, K=50): checksums + sampled points only
+    n = 128
+    dx = 1.0 / (n - 1)
+    dt = 0.2 * 0.5 * dx * dx / 0.1
+    cu, cv, cp = 1.7, -2.3, 0.4
+    nt = 10
+    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, action_dim=1, reward_class=src.NSReward(0.1), normalize=False,
+              reset_init_condition_func=lambda X: (cu * np.ones_like(X), cv * np.ones_like(X), cp * np.ones_like(X)),
+              boundary_condition=NS_BC, U_ref=np.zeros((nt, n, n, 2)), action_ref=2.0 * np.ones(nt), maximum_pressure_iteration=50)
+    env = src.NavierStokes2D(**kw)
+    env.reset()
+    pts = rng.integers(0, n, (16, 2))
+    acts = np.array([3.1, 2.4])
+    sums, samples, rews = [], [], []
+    for a in acts:
+        obs, r, te, tr, _ = env.step(a)
+        sums.append([np.linalg.norm(obs[..., 0]), np.linalg.norm(obs[..., 1]), np.linalg.norm(env.p),
+                     obs.min(), obs.max(), env.p.min(), env.p.max()])
+        samples.append(np.stack([obs[pts[:, 0], pts[:, 1], 0], obs[pts[:, 0], pts[:, 1], 1], env.p[pts[:, 0], pts[:, 1]]], axis=-1))
+        rews.append(r)
+    pack("N3", dict(ic=np.array([cu, cv, cp]), actions=acts, sums=np.array(sums), pts=pts, samples=np.stack(samples),
+                    rewards=np.array(rews), dx=np.float64(dx), dt=np.float64(dt), nt=np.int64(nt)), store)
+    np.savez_compressed(os.path.join(OUT, "ns2d.npz"), **store)
+
+
+if __name__ == "__main__":
+    src = import_reference()
+    which = sys.argv[1:] or ["transport", "parabolic", "kat", "ns"]
+    store_meta = dict(numpy=np.__version__)
+    for w in which:
+        {"transport": gen_transport, "parabolic": gen_parabolic, "kat": gen_kat, "ns": gen_ns}[w](src)
+        print("wrote", w)
+    with open(os.path.join(OUT, "VERSIONS.txt"), "w") as f:
+        f.write(f"numpy {np.__version__}\nreference snapshot 2026-01-09 (lukebhan/PDEControlGym)\n")

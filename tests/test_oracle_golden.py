@@ -1,0 +1,195 @@
+"""Pin the NumPy oracle (oracle/pde_oracle.py) against golden vectors produced by the reference's
+own code (tests/golden/make_golden.py) and against its published known answers.
+
+Bars: 1D float32 fields bit-exact; rewards rtol 1e-6 (BLAS dot order / f32 scalar accumulation);
+NS float64 fields bit-exact, rewards rtol 1e-12.
+"""
+import numpy as np
+import pytest
+
+from oracle import pde_oracle as po
+from tests.cases import NS_BC, PARABOLIC_CASES, TRANSPORT_CASES, ns_bc_from_array
+
+
+def _oracle_kwargs(kw):
+    return {k: kw[k] for k in ("T", "dt", "X", "dx", "control_sample_rate", "control_type", "sensing_loc",
+                               "sensing_type", "normalize", "max_control_value", "limit_pde_state_size",
+                               "max_state_value")}
+
+
+def _run_1d(cls, kw, g, keep_history):
+    rw = po.TunedReward1DOracle(int(g.reward_args[0]), g.reward_args[1], g.reward_args[2])
+    env = cls(reward=rw, keep_history=keep_history, **_oracle_kwargs(kw))
+    obs0 = env.reset(g.init[None, :], g.beta[None, :])
+    np.testing.assert_array_equal(np.asarray(obs0, dtype=np.float32).reshape(-1), g.obs[0])
+    for i, a in enumerate(g.actions):
+        with np.errstate(all="ignore"):
+            obs, r, te, tr = env.step(np.array([a], dtype=np.float32))
+        np.testing.assert_array_equal(env.row[0], g.rows[i], err_msg=f"row step {i}")
+        np.testing.assert_array_equal(np.asarray(obs, dtype=np.float32).reshape(-1), g.obs[i + 1], err_msg=f"obs step {i}")
+        assert int(env.time_index[0]) == int(g.time_index[i])
+        assert bool(te[0]) == bool(g.terminate[i]) and bool(tr[0]) == bool(g.truncate[i])
+        if np.isfinite(g.reward[i]):
+            np.testing.assert_allclose(r[0], g.reward[i], rtol=1e-6, atol=1e-6 * max(1.0, abs(float(env.norm_now[0]))),
+                                       err_msg=f"reward step {i}")
+        else:
+            assert not np.isfinite(r[0])
+
+
+@pytest.mark.parametrize("case", sorted(TRANSPORT_CASES))
+@pytest.mark.parametrize("keep_history", [True, False])
+def test_transport_oracle_matches_reference(golden_transport, case, keep_history):
+    _run_1d(po.TransportOracle, TRANSPORT_CASES[case], golden_transport[case], keep_history)
+
+
+@pytest.mark.parametrize("case", sorted(PARABOLIC_CASES))
+@pytest.mark.parametrize("keep_history", [True, False])
+def test_parabolic_oracle_matches_reference(golden_parabolic, case, keep_history):
+    if case == "P1" and keep_history:
+        pytest.skip("80 MB history; the streaming variant covers P1")
+    _run_1d(po.ParabolicOracle, PARABOLIC_CASES[case], golden_parabolic[case], keep_history)
+
+
+def test_reward_edge_cases_present(golden_transport):
+    """The fixtures really exercise every TunedReward1D branch (tuned_reward_1d.py:36-40)."""
+    g = golden_transport["R_s30"]          # terminate with ||u|| >= 20 -> falls through to the delta branch
+    assert g.terminate[-1] and np.linalg.norm(g.rows[-1]) >= 20
+    g = golden_transport["R_s30_small"]    # terminal bonus branch
+    assert g.terminate[-2] and np.linalg.norm(g.rows[-2]) < 20 and g.reward[-2] > 250
+    g = golden_transport["R_trunc"]        # truncation penalty branch
+    assert g.truncate.any() and (g.reward[g.truncate] < -1e5).all()
+    g = golden_transport["H1"]             # S=1000 >= 100: look-back inside the step
+    assert g.time_index[0] == 1000
+
+
+# ---- published known answers (notebook stored outputs) ---------------------
+KAT_PUBLISHED = {"T_u1": (289.8379892610982, 106.08644131330854), "T_u10": (198.37980383622647, 1060.8641808569605),
+                 "P_u1": (299.82330386477986, 1275.4394707666174), "P_u10": (298.23300542427603, 12754.398135204445)}
+
+
+@pytest.mark.parametrize("name", sorted(KAT_PUBLISHED))
+def test_known_answers_closed_loop(golden_kat, name):
+    """Closed-loop backstepping episode on the ORACLE reproduces the reference's published numbers."""
+    g = golden_kat[name]
+    u0 = 1.0 if name.endswith("u1") else 10.0
+    if name.startswith("T"):
+        kw = dict(TRANSPORT_CASES["H1"], T=5)
+        env = po.TransportOracle(reward=po.TunedReward1DOracle(50000, -1e3, 3e2), keep_history=False, **_oracle_kwargs(kw))
+        obs = env.reset(np.ones((1, 100)) * u0, g.beta[None])
+        ctrl = lambda o: np.float32(np.dot(g.kernel, o.astype(np.float64)) * 1e-2)
+    else:
+        kw = dict(PARABOLIC_CASES["P1"])
+        env = po.ParabolicOracle(reward=po.TunedReward1DOracle(100000, -1e3, 3e2), keep_history=False, **_oracle_kwargs(kw))
+        obs = env.reset(np.ones((1, 201)) * u0, g.beta[None])
+        m = min(len(g.kernel_row), 200)
+        ctrl = lambda o: np.float32(np.sum(g.kernel_row[:m] * o[:m].astype(np.float64)) * 5e-3)
+    total, l2, te, tr, n = 0.0, 0.0, False, False, 0
+    while not te and not tr:
+        a = ctrl(obs[0])
+        obs, r, te, tr = env.step(np.array([a]))
+        te, tr = bool(te[0]), bool(tr[0])
+        total += float(r[0])
+        l2 += float(env.norm_now[0])
+        n += 1
+    assert n == len(g.actions)
+    pub_total, pub_l2 = KAT_PUBLISHED[name]
+    # published numbers were produced with NumPy 1.26 (float64 scalar accumulation): rtol 1e-5
+    np.testing.assert_allclose(total, pub_total, rtol=1e-5)
+    np.testing.assert_allclose(l2, pub_l2, rtol=1e-5)
+    np.testing.assert_allclose(total, float(g.total), rtol=2e-6)
+    np.testing.assert_allclose(l2, float(g.sum_l2), rtol=2e-6)
+
+
+# ---- Navier-Stokes ------------------------------------------------------------------------------
+def test_ns_oracle_reproduces_target_npz_frames(golden_ns):
+    """examples/NavierStokes/target.npz: bit-exact 21x21, 2000 Jacobi sweeps, 199 steps."""
+    g = golden_ns["N1"]
+    nt = 200
+    Uref = np.zeros((nt, 21, 21, 2))
+    env = po.NavierStokesOracle(T=0.2, dt=1e-3, X=1, dx=0.05, Y=1, dy=0.05, boundary_condition=NS_BC,
+                                U_ref=Uref, action_ref=2.0 * np.ones(1000), gamma=0.1)
+    env.reset(g.u0[None], g.v0[None], np.zeros((1, 21, 21)))
+    keep = set(int(k) for k in g.keep)
+    for t in range(1, 200):
+        obs, r, te, tr = env.step(np.array([g.actions[t - 1]]))
+        if t in keep:
+            np.testing.assert_array_equal(obs[0, :, :, 0], g[f"u{t}"])
+            np.testing.assert_array_equal(obs[0, :, :, 1], g[f"v{t}"])
+    assert bool(te[0])
+    np.testing.assert_array_equal(env.p[0], g.p_final)
+
+
+@pytest.mark.parametrize("case", ["N2_32", "N2_64", "N2_48"])
+def test_ns_oracle_mixed_bc(golden_ns, case):
+    g = golden_ns[case]
+    n = g.u0.shape[0]
+    env = po.NavierStokesOracle(T=int(g.nt) * float(g.dt), dt=float(g.dt), X=1, dx=float(g.dx), Y=1, dy=float(g.dx),
+                                boundary_condition=ns_bc_from_array(g.bc), U_ref=g.U_ref, action_ref=g.action_ref,
+                                gamma=0.1, maximum_pressure_iteration=50)
+    assert env.nx == n
+    env.reset(g.u0[None], g.v0[None], g.p0[None])
+    for i, a in enumerate(g.actions):
+        obs, r, te, tr = env.step(np.array([a]))
+        np.testing.assert_array_equal(obs[0], g.obs[i])
+        np.testing.assert_array_equal(env.p[0], g.p[i])
+        np.testing.assert_allclose(r[0], g.rewards[i], rtol=1e-12)
+
+
+def test_ns_oracle_reward_and_batching(golden_ns):
+    """NSReward with a non-trivial reference, and batched instances == single instances."""
+    g, gb = golden_ns["N1"], golden_ns["N1b"]
+    frames = {int(k): np.stack([g[f"u{int(k)}"], g[f"v{int(k)}"]], -1) for k in g.keep}
+    Uref = np.zeros((200, 21, 21, 2))
+    for k, f in frames.items():
+        Uref[k] = 0.5 * f
+    env = po.NavierStokesOracle(T=0.2, dt=1e-3, X=1, dx=0.05, Y=1, dy=0.05, boundary_condition=NS_BC,
+                                U_ref=Uref, action_ref=2.0 * np.ones(1000), gamma=0.1)
+    u0 = np.stack([g.u0, 0.5 * g.u0])
+    env.reset(u0, np.zeros_like(u0), np.zeros_like(u0))
+    for t in (1, 2):
+        obs, r, te, tr = env.step(np.array([g.actions[t - 1], 1.0]))
+        np.testing.assert_array_equal(obs[0, :, :, 0], g[f"u{t}"])
+        np.testing.assert_allclose(r[0], gb.rewards[t - 1], rtol=1e-12)
+
+
+def test_ns_oracle_c4_checksums(golden_ns):
+    g = golden_ns["N3"]
+    n, nt = 128, int(g.nt)
+    env = po.NavierStokesOracle(T=nt * float(g.dt), dt=float(g.dt), X=1, dx=float(g.dx), Y=1, dy=float(g.dx),
+                                boundary_condition=NS_BC, U_ref=np.zeros((nt, n, n, 2)), action_ref=2.0 * np.ones(nt),
+                                gamma=0.1, maximum_pressure_iteration=50)
+    one = np.ones((1, n, n))
+    env.reset(g.ic[0] * one, g.ic[1] * one, g.ic[2] * one)
+    for i, a in enumerate(g.actions):
+        obs, r, te, tr = env.step(np.array([a]))
+        o = obs[0]
+        sums = [np.linalg.norm(o[..., 0]), np.linalg.norm(o[..., 1]), np.linalg.norm(env.p[0]), o.min(), o.max(),
+                env.p[0].min(), env.p[0].max()]
+        np.testing.assert_allclose(sums, g.sums[i], rtol=1e-13)
+        pts = g.pts
+        smp = np.stack([o[pts[:, 0], pts[:, 1], 0], o[pts[:, 0], pts[:, 1], 1], env.p[0][pts[:, 0], pts[:, 1]]], -1)
+        np.testing.assert_array_equal(smp, g.samples[i])
+        np.testing.assert_allclose(r[0], g.rewards[i], rtol=1e-12)
+
+
+def test_batched_oracle_equals_per_instance():
+    """Instance b of a batched oracle call == the same instance run alone (bitwise)."""
+    rng = np.random.default_rng(0)
+    kw = _oracle_kwargs(PARABOLIC_CASES["P2_s100"])
+    B, n = 5, 257
+    init = rng.uniform(1, 10, (B, 1)).astype(np.float32) * np.ones((B, n), dtype=np.float32)
+    beta = (50 * np.cos(rng.uniform(7.5, 8.5, (B, 1)) * np.arccos(np.linspace(0, 1, n)))).astype(np.float32)
+    acts = rng.uniform(-1, 1, (3, B)).astype(np.float32)
+    rw = lambda: po.TunedReward1DOracle(1000, -1e3, 3e2)
+    env = po.ParabolicOracle(reward=rw(), keep_history=False, **kw)
+    env.reset(init, beta)
+    rows = []
+    for a in acts:
+        env.step(a)
+        rows.append(env.row.copy())
+    for b in range(B):
+        e1 = po.ParabolicOracle(reward=rw(), keep_history=False, **kw)
+        e1.reset(init[b:b + 1], beta[b:b + 1])
+        for i, a in enumerate(acts):
+            e1.step(a[b:b + 1])
+            np.testing.assert_array_equal(e1.row[0], rows[i][b])
