@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched PDE-environment stepper on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N>1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  (one rank per GPU; instances are independent, so there is NO data-path collective: the only
+  communication is the barrier / max-over-ranks of the timing).
+
+A "step" = one env-step of EVERY instance of the batch = one launch of the fused step kernel
+(S PDE sub-steps + norms + reward + observation + auto-reset), inputs already resident in HBM.
+Default workload = BASELINE.json configs[1]: ReactionDiffusionPDE1D ("Parabolic1D") nx=256, batch 4096
+per GPU, fp32, S=100 sub-steps per env-step.  Other workloads: --workload
+transport_c3 | ns2d_c4 (reported as their own line; the default run adds them under "also").
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import platform
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def _dist_setup(n_gpus):
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    return rank, local, world
+
+
+def _barrier(world):
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+class Parabolic1D:
+    """BASELINE config 2: ReactionDiffusionPDE1D nx=256 (257 nodes), F=dt/dx^2=0.25, S=100, B=4096/GPU."""
+    name = "ReactionDiffusionPDE1D nx=256 B=4096 S=100 (BASELINE configs[1])"
+    kind, nx, B, S, amp, glo, ghi = "parabolic", 256, 4096, 100, 50.0, 7.5, 8.5
+    dtype = "f32"
+
+    def __init__(self, device, seed, B=None, S=None):
+        import torch
+        from pdecontrolgym_amd import _native as N
+        from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
+        self.B = B or self.B
+        self.S = S or self.S
+        nx = self.nx
+        dx = 1.0 / nx
+        dt = 0.25 * dx * dx if self.kind == "parabolic" else 0.5 * dx
+        self.kw = dict(T=1000 * self.S * dt, dt=dt, X=1, dx=dx, control_sample_rate=self.S * dt, control_type="Dirchilet",
+                       sensing_loc="full", sensing_type=None, normalize=True, max_control_value=20,
+                       limit_pde_state_size=True, max_state_value=1e10)
+        nt1 = int(round(self.kw["T"] / dt))
+        self.reward_args = (nt1, -1e3, 3e2)
+        self.env = PDEBatch1D(self.kind, reward=RewardSpec(N.REWARD_TUNED1D, *self.reward_args), num_envs=self.B,
+                              device=device, **self.kw)
+        n = self.env.n
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        x = torch.linspace(0, 1, n, dtype=torch.float64)
+        gam = torch.rand(self.B, 1, generator=g, dtype=torch.float64) * (self.ghi - self.glo) + self.glo
+        self.beta = (self.amp * torch.cos(gam * torch.acos(x))).float().to(device)
+        c = torch.rand(self.B, 1, generator=g) * 9 + 1
+        self.init = (c * torch.ones(1, n)).float().to(device)
+        c2 = torch.rand(self.B, 1, generator=g) * 9 + 1
+        self.pool = (c2 * torch.ones(1, n)).float().to(device)
+        self.gen = g
+        self.device = device
+
+    def prepare(self, total_steps):
+        import torch
+        self.actions = (torch.rand(total_steps, self.B, generator=self.gen) * 2 - 1).float().to(self.device)
+        self.env.reset(self.init, self.beta)
+        self.env.enable_auto_reset(self.pool, keep_final_obs=True)
+        self.i = 0
+
+    def step(self):
+        out = self.env.step(self.actions[self.i])
+        self.i += 1
+        return out
+
+    def units_per_step(self):
+        return self.B
+
+    def algorithmic_bytes_per_step(self):
+        return self.env.algorithmic_bytes_per_env_step() * self.B
+
+    def compulsory_bytes_per_step(self):
+        return self.env.compulsory_bytes_per_env_step() * self.B
+
+    def config(self):
+        return {"workload": self.name, "env": "PDEControlGym-ReactionDiffusionPDE1D" if self.kind == "parabolic" else "PDEControlGym-TransportPDE1D",
+                "nx": self.nx, "nodes": self.env.n, "batch_per_gpu": self.B, "substeps_per_env_step": self.S,
+                "reward": "TunedReward1D", "auto_reset": "fused", "parallelism": "independent instances, no collective"}
+
+    # ---- CPU baseline: the NumPy restatement run like the reference (one instance, Python loop) ----
+    def cpu_baseline(self, seconds=10.0):
+        import numpy as np
+        from oracle import pde_oracle as po
+        cls = po.ParabolicOracle if self.kind == "parabolic" else po.TransportOracle
+        okw = {k: self.kw[k] for k in ("T", "dt", "X", "dx", "control_sample_rate", "control_type", "sensing_loc",
+                                       "sensing_type", "normalize", "max_control_value", "limit_pde_state_size", "max_state_value")}
+        env = cls(reward=po.TunedReward1DOracle(*self.reward_args), keep_history=False, **okw)
+        init = self.init[:1].cpu().numpy()
+        beta = self.beta[:1].cpu().numpy()
+        env.reset(init, beta)
+        acts = self.actions[:, :1].cpu().numpy()
+        n, t0 = 0, time.perf_counter()
+        with np.errstate(all="ignore"):
+            while time.perf_counter() - t0 < seconds:
+                _, _, te, tr = env.step(acts[n % len(acts)])
+                n += 1
+                if te[0] or tr[0]:
+                    env.reset(init, beta)
+        el = time.perf_counter() - t0
+        return {"value": n / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                "sample": f"{n} env-steps of ONE instance ({self.S} sub-steps each) in a Python loop over the NumPy oracle, "
+                          f"{el:.1f} s on {platform.processor() or platform.machine()}; batching B instances on one core keeps "
+                          "the same aggregate rate (SURVEY.md section 6)"}
+
+
+class Transport1D(Parabolic1D):
+    """BASELINE config 3 shape: TransportPDE1D nx=512, dt=0.5dx, S=100, B=16384/GPU (the reference has no
+    Burgers env)."""
+    name = "TransportPDE1D nx=512 B=16384 S=100 (BASELINE configs[2] shape)"
+    kind, nx, B, S, amp, glo, ghi = "transport", 512, 16384, 100, 5.0, 7.0, 7.7
+
+
+WORKLOADS = {"parabolic_c2": Parabolic1D, "transport_c3": Transport1D}
+try:
+    from bench_ns2d import NavierStokesC4  # noqa: E402
+    WORKLOADS["ns2d_c4"] = NavierStokesC4
+except Exception:  # pragma: no cover - NS workload is optional at import time
+    pass
+
+
+def run_workload(wl, steps, warmup, world):
+    """Returns (seconds for `steps` steps [max over ranks], avg kernel ms from per-launch HIP events)."""
+    import torch
+    extra = min(steps, 50)
+    wl.prepare(warmup + steps + extra)
+    for _ in range(warmup):
+        wl.step()
+    _barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    _barrier(world)
+    el = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    # per-launch kernel duration with HIP events on the launch stream (outside the timed region)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(extra)]
+    for a, b in evs:
+        a.record()
+        wl.step()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    kernel_ms = sum(ms) / len(ms)
+    return el, kernel_ms, ms[len(ms) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="parabolic_c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default: the BASELINE batch)")
+    ap.add_argument("--substeps", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads in the default run")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path to benchmark)")
+    rank, local, world = _dist_setup(args.gpus)
+    device = torch.device("cuda", local)
+    kw = {}
+    if args.batch:
+        kw["B"] = args.batch
+    if args.substeps:
+        kw["S"] = args.substeps
+    wl = WORKLOADS[args.workload](device, 1234 + rank, **kw)
+    el, kernel_ms, kernel_ms_med = run_workload(wl, args.steps, args.warmup, world)
+    value = wl.units_per_step() * args.steps * world / el
+    alg = wl.algorithmic_bytes_per_step()
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
+        "config": wl.config(),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel_ms_avg": kernel_ms, "kernel_ms_median": kernel_ms_med,
+                     "algorithmic_bytes_per_launch": alg, "compulsory_bytes_per_launch": wl.compulsory_bytes_per_step(),
+                     "note": "achieved = streaming-model algorithmic bytes / kernel time; the fused kernel keeps state "
+                             "on-chip across sub-steps, so this is an EFFECTIVE bandwidth and may exceed the HBM peak "
+                             "(real HBM traffic ~ compulsory bytes; see DESIGN.md)"},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
+    if rank == 0 and world == 1 and not args.no_also and args.workload == "parabolic_c2" and not args.batch:
+        also = {}
+        for name, cls in WORKLOADS.items():
+            if name == args.workload:
+                continue
+            try:
+                w2 = cls(device, 99)
+                e2, k2, k2m = run_workload(w2, max(20, args.steps // 4), max(5, args.warmup // 2), 1)
+                n2 = max(20, args.steps // 4)
+                a2 = w2.algorithmic_bytes_per_step() / (k2 * 1e-3) / 1e9
+                also[name] = {"value": w2.units_per_step() * n2 / e2, "unit": "env-steps/s", "ms_per_step": e2 / n2 * 1e3,
+                              "kernel_ms_avg": k2, "roofline_frac": a2 / HBM_PEAK_GBPS, "config": w2.config()}
+                del w2
+            except Exception as ex:  # keep the headline line alive
+                also[name] = {"error": repr(ex)}
+        out["also"] = also
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

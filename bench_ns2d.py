@@ -1,0 +1,80 @@
+"""NS2D workload of bench.py: BASELINE configs[3] (NavierStokes2D 128x128, 50 Jacobi sweeps/step, batch 512, fp32)."""
+from __future__ import annotations
+
+import platform
+import time
+
+
+class NavierStokesC4:
+    name = "NavierStokes2D 128x128 K=50 B=512 fp32 (BASELINE configs[3])"
+    n, B, K = 128, 512, 50
+    dtype = "f32"
+    BC = {"upper": ["Controllable", "Dirchilet"], "lower": ["Dirchilet", "Dirchilet"],
+          "left": ["Dirchilet", "Dirchilet"], "right": ["Dirchilet", "Dirchilet"]}
+
+    def __init__(self, device, seed, B=None, S=None):
+        import torch
+        from pdecontrolgym_amd.batch2d import NSBatch2D
+        self.B = B or self.B
+        self.K = S or self.K
+        n = self.n
+        dx = 1.0 / (n - 1)
+        dt = 0.2 * 0.5 * dx * dx / 0.1
+        self.nt = 1000
+        self.kw = dict(T=self.nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=self.BC, gamma=0.1,
+                       viscosity=0.1, density=1.0, maximum_pressure_iteration=self.K)
+        self.device = device
+        U_ref = torch.zeros(self.nt, n, n, 2, dtype=torch.float32, device=device)
+        a_ref = 2.0 * torch.ones(self.nt, dtype=torch.float32, device=device)
+        self.env = NSBatch2D(U_ref=U_ref, action_ref=a_ref, num_envs=self.B, device=device, dtype=torch.float32, **self.kw)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.gen = g
+        c = torch.rand(self.B, 3, generator=g) * 10 - 5
+        one = torch.ones(1, n, n)
+        self.ic = [(c[:, k].reshape(self.B, 1, 1) * one).float().to(device) for k in range(3)]
+
+    def prepare(self, total_steps):
+        import torch
+        self.actions = (torch.rand(total_steps, self.B, generator=self.gen) * 2 + 2).float().to(self.device)
+        self.env.reset(*self.ic)
+        self.i = 0
+
+    def step(self):
+        out = self.env.step(self.actions[self.i])
+        self.i += 1
+        return out
+
+    def units_per_step(self):
+        return self.B
+
+    def algorithmic_bytes_per_step(self):
+        return self.env.algorithmic_bytes_per_env_step() * self.B
+
+    def compulsory_bytes_per_step(self):
+        return self.env.compulsory_bytes_per_env_step() * self.B
+
+    def config(self):
+        return {"workload": self.name, "env": "PDEControlGym-NavierStokes2D", "nx": self.n, "ny": self.n,
+                "batch_per_gpu": self.B, "jacobi_sweeps_per_step": self.K, "reward": "NSReward(0.1)",
+                "parallelism": "independent instances, no collective"}
+
+    def cpu_baseline(self, seconds=10.0):
+        import numpy as np
+        from oracle import pde_oracle as po
+        n = self.n
+        env = po.NavierStokesOracle(U_ref=np.zeros((self.nt, n, n, 2)), action_ref=2.0 * np.ones(self.nt), **self.kw)
+        ic = [x[:1].cpu().numpy().astype(np.float64) for x in self.ic]
+        env.reset(*ic)
+        acts = self.actions[:, :1].cpu().numpy().astype(np.float64)
+        for i in range(10):                      # skip the denormal slow start
+            env.step(acts[i % len(acts)])
+        k, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            env.step(acts[k % len(acts)])
+            k += 1
+            if env.time_index[0] >= self.nt - 2:
+                env.reset(*ic)
+        el = time.perf_counter() - t0
+        return {"value": k / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                "sample": f"{k} env-steps of ONE float64 instance ({self.K} Jacobi sweeps each) over the NumPy oracle, "
+                          f"{el:.1f} s on {platform.processor() or platform.machine()}"}

@@ -1,0 +1,173 @@
+/*
+ * pdegym.h -- C ABI of the MI355X (gfx950) batched PDE-environment stepper.
+ *
+ * Drop-in boundary for the hot path of lukebhan/PDEControlGym (reference checkout paths below are
+ * relative to that repository):
+ *
+ *   pdegym_transport_step   replaces TransportPDE1D.step          environments1d/hyperbolic.py:126-169
+ *                           + terminate()/truncate()              environments1d/hyperbolic.py:171-194
+ *                           + TunedReward1D.reward                rewards/tuned_reward_1d.py:25-40
+ *   pdegym_parabolic_step   replaces ReactionDiffusionPDE1D.step  environments1d/parabolic.py:126-164
+ *                           + terminate()/truncate()              environments1d/parabolic.py:166-189
+ *   pdegym_reset1d_masked   replaces the state part of reset()    hyperbolic.py:214-219, parabolic.py:208-213
+ *   pdegym_ns2d_step_f32/_f64  replaces NavierStokes2D.step       environments2d/navier_stokes2D.py:118-157
+ *                           (apply_boundary :68-91, solve_pressure :94-116, NSReward ns_reward.py:28)
+ *   pdegym_ns2d_solve_pressure_f32/_f64  replaces NavierStokes2D.solve_pressure  navier_stokes2D.py:94-116
+ *                           (public API: examples/NavierStokes/NS2Doptimization.py:97)
+ *   pdegym_ns2d_reset_masked_f32/_f64    replaces the state part of NavierStokes2D.reset  navier_stokes2D.py:186-192
+ *   pdegym_rownorm2_f32     replaces np.linalg.norm(row, 2)       hyperbolic.py:190, parabolic.py:185
+ *
+ * One call advances EVERY instance of a batch by one env-step (S PDE sub-steps for the 1D envs, one
+ * Chorin projection step with K Jacobi sweeps for NS2D).  Instances are independent.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm tensors in this repo); the
+ *     library allocates nothing and keeps no state besides a thread-local error string;
+ *   - calls only ENQUEUE work on `stream` (a hipStream_t passed as void*); they never synchronise;
+ *   - return value 0 = success, negative = error (message via pdegym_last_error()); nothing throws;
+ *   - arrays are C-contiguous; the grid axis is the fastest axis.
+ */
+#ifndef PDEGYM_H
+#define PDEGYM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDEGYM_ABI_VERSION 1
+#define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
+#define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
+#define PDEGYM_MAX_N1D 1024      /* nodes per 1D row handled by the wave-per-instance kernels */
+
+/* control_type (hyperbolic.py:66-124): the reference's (mis)spelling "Dirchilet" is kept in the Python layer */
+enum { PDEGYM_CONTROL_DIRICHLET = 0, PDEGYM_CONTROL_NEUMANN = 1 };
+/* sensing_update variants (hyperbolic.py:72-116, parabolic.py:72-116) */
+enum {
+  PDEGYM_SENSE_FULL = 0,        /* obs = row                              obs_dim = n */
+  PDEGYM_SENSE_LAST = 1,        /* obs = row[-1]                          (Neumann control, collocated) */
+  PDEGYM_SENSE_LAST_DERIV = 2,  /* obs = (row[-1]-row[-2])/dx             (Dirichlet control, collocated) */
+  PDEGYM_SENSE_FIRST_DERIV = 3, /* obs = (row[1]-row[0])/dx               (opposite, Neumann sensing) */
+  PDEGYM_SENSE_FIRST = 4        /* obs = row[0]                           (opposite, Dirichlet sensing) */
+};
+/* reward evaluated inside the step kernel */
+enum {
+  PDEGYM_REWARD_NONE = 0,       /* reward[] untouched; norms/flags still produced (host-side custom rewards) */
+  PDEGYM_REWARD_TUNED1D = 1,    /* rewards/tuned_reward_1d.py:25-40 */
+  PDEGYM_REWARD_NORM_L1 = 2,    /* rewards/norm_reward.py "temporal" intent (parity unpinned: reference class raises) */
+  PDEGYM_REWARD_NORM_L2 = 3,
+  PDEGYM_REWARD_NORM_LINF = 4
+};
+
+/* Scalars of one 1D environment family (same for every instance of the batch). */
+typedef struct pdegym_params1d {
+  int32_t n;                /* nodes per row: nx (transport) or nx+1 (parabolic ghost point, parabolic.py:124) */
+  int32_t nt;               /* rows per episode, int(round(T/dt)+1)                       base_env_1d.py:23 */
+  int32_t substeps;         /* S = int(round(control_sample_rate/dt))                     hyperbolic.py:137 */
+  int32_t control_type;     /* PDEGYM_CONTROL_*                                                              */
+  int32_t normalize;        /* (a+1)*max-max if non-zero                                  base_env_1d.py:36-39 */
+  int32_t sensing;          /* PDEGYM_SENSE_*                                                                */
+  int32_t limit_state;      /* limit_pde_state_size                                       hyperbolic.py:188-191 */
+  int32_t reward_kind;      /* PDEGYM_REWARD_*                                                               */
+  int32_t reward_nt;        /* TunedReward1D(nt, ...) ctor argument                       tuned_reward_1d.py:17-23 */
+  float dt;                 /* float32 cast of the Python doubles: NumPy casts them where they meet a float32 array */
+  float dx;
+  float F;                  /* (float)(dt/dx**2)                                          parabolic.py:138 */
+  float max_control;        /* max_control_value */
+  float max_state;          /* max_state_value */
+  float truncate_penalty;   /* TunedReward1D / NormReward arguments */
+  float terminate_reward;
+} pdegym_params1d;
+
+/* Per-instance device buffers of a 1D batch (B instances). */
+typedef struct pdegym_bufs1d {
+  float* u;                 /* [B, n]   live row (in/out)                                                     */
+  const float* beta;        /* [B, n] or [n]   plant parameter beta(x) / lambda(x)                            */
+  int64_t beta_stride;      /* elements between instances; 0 = one shared row                                 */
+  const float* action;      /* [B]      control input of this env-step                                        */
+  int32_t* time_index;      /* [B]      in/out                                                                */
+  double* bsum;             /* [B]      running sum |u[tau,-1]| over written rows (in/out)  tuned_reward_1d.py:37 */
+  float* ring;              /* [B, PDEGYM_RING]  row norms that a later look-back will read (in/out)          */
+  float* obs;               /* [B, obs_dim] out                                                               */
+  float* reward;            /* [B] out                                                                        */
+  float* norm_now;          /* [B] out  ||u_t||_2                                                             */
+  float* norm_back;         /* [B] out  ||u_{t-100}||_2 (0 for an unwritten row)                              */
+  uint8_t* terminated;      /* [B] out                                                                        */
+  uint8_t* truncated;       /* [B] out                                                                        */
+  float* history;           /* optional [B, nt, n] full trajectory (NULL = keep only the live row)            */
+  const float* reset_init;  /* optional [B, n] pool of next initial conditions: when non-NULL an instance whose
+                               step ends terminated|truncated is restarted INSIDE the same launch (state := pool row,
+                               time_index := 0) and obs[b] is the first observation of the new episode            */
+  float* final_obs;         /* optional [B, obs_dim]: last observation of the finished episode (written only for
+                               instances that were auto-reset in this call; SB3's "terminal_observation")          */
+} pdegym_bufs1d;
+
+int pdegym_abi_version(void);
+const char* pdegym_last_error(void);
+
+int pdegym_transport_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int32_t B, void* stream);
+int pdegym_parabolic_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int32_t B, void* stream);
+
+/* Where mask[b] != 0 (or mask == NULL): u[b] = init[b], beta untouched, time_index = 0, bsum = |init[b,-1]|,
+ * ring[b, 0] = ||init[b]|| , obs[b] = sensing(init[b]).  (hyperbolic.py:214-227) */
+int pdegym_reset1d_masked(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const float* init,
+                          const uint8_t* mask, int32_t B, void* stream);
+
+/* out[b] = ||rows[b, 0:n]||_2 */
+int pdegym_rownorm2_f32(const float* rows, float* out, int32_t n, int32_t B, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Navier-Stokes 2D (collocated grid, Chorin projection, Jacobi pressure Poisson)
+ * ------------------------------------------------------------------------------------------------ */
+enum { PDEGYM_BC_NEUMANN = 0, PDEGYM_BC_DIRICHLET = 1, PDEGYM_BC_CONTROLLABLE = 2 };
+/* edge order of apply_boundary (navier_stokes2D.py:76): lower (row 0), upper (row ny-1), left (col 0), right (col nx-1) */
+enum { PDEGYM_EDGE_LOWER = 0, PDEGYM_EDGE_UPPER = 1, PDEGYM_EDGE_LEFT = 2, PDEGYM_EDGE_RIGHT = 3 };
+
+typedef struct pdegym_params_ns2d {
+  int32_t nx, ny;           /* int(round(X/dx+1)), int(round(Y/dy+1))                      base_env_2d.py:28-29 */
+  int32_t nt;               /* int(round(T/dt))                                           base_env_2d.py:27 */
+  int32_t iters;            /* maximum_pressure_iteration (Jacobi sweeps per step)        navier_stokes2D.py:104 */
+  int32_t action_dim;       /* 1 = one scalar per instance; nx (== ny) = one value per edge node */
+  int32_t bc[4][2];         /* [edge][component u,v] -> PDEGYM_BC_*                        navier_stokes2D.py:61-91 */
+  double dt, dx, dy;        /* the float32 entry points cast them */
+  double viscosity, density;
+  double gamma;             /* NSReward(gamma)                                             ns_reward.py:15-28 */
+} pdegym_params_ns2d;
+
+/* T = float (f32 entry points) or double (f64 entry points). Fields are [B, ny, nx], row = y, col = x. */
+typedef struct pdegym_bufs_ns2d {
+  void* u;                  /* [B, ny, nx] in/out                                                             */
+  void* v;                  /* [B, ny, nx] in/out                                                             */
+  void* p;                  /* [B, ny, nx] in/out (warm start of the next step, navier_stokes2D.py:115)        */
+  void* scratch;            /* [B, 4, ny, nx] work space (u*, v*, rhs, p')                                    */
+  const void* action;       /* [B, action_dim]                                                                */
+  int32_t* time_index;      /* [B] in/out                                                                     */
+  const void* U_ref;        /* [nt_ref, ny, nx, 2] shared reference trajectory (indexed AFTER the increment)  */
+  const void* action_ref;   /* [>= nt] shared reference actions                                               */
+  int32_t nt_ref;           /* rows of U_ref / action_ref (index is clamped to nt_ref-1)                       */
+  void* obs;                /* [B, ny, nx, 2] out (u,v interleaved; base_env_2d.py:50)                         */
+  void* reward;             /* [B] out                                                                        */
+  uint8_t* terminated;      /* [B] out; truncated is always False in the reference (navier_stokes2D.py:155)    */
+} pdegym_bufs_ns2d;
+
+int pdegym_ns2d_step_f32(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int32_t B, void* stream);
+int pdegym_ns2d_step_f64(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int32_t B, void* stream);
+
+/* p_out = K Jacobi sweeps from p_in with rhs = rho/dt*(d/dx u + d/dy v)  (navier_stokes2D.py:94-116).
+ * u, v, p_in, p_out: [B, ny, nx]; scratch: [B, 2, ny, nx]. p_out may alias p_in. */
+int pdegym_ns2d_solve_pressure_f32(const pdegym_params_ns2d* prm, const void* u, const void* v, const void* p_in,
+                                   void* p_out, void* scratch, int32_t B, void* stream);
+int pdegym_ns2d_solve_pressure_f64(const pdegym_params_ns2d* prm, const void* u, const void* v, const void* p_in,
+                                   void* p_out, void* scratch, int32_t B, void* stream);
+
+/* Where mask[b] != 0 (or mask == NULL): u,v,p[b] = u0,v0,p0[b]; time_index = 0; obs[b] = (u0,v0). */
+int pdegym_ns2d_reset_masked_f32(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, const void* u0,
+                                 const void* v0, const void* p0, const uint8_t* mask, int32_t B, void* stream);
+int pdegym_ns2d_reset_masked_f64(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, const void* u0,
+                                 const void* v0, const void* p0, const uint8_t* mask, int32_t B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDEGYM_H */

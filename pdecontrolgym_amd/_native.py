@@ -1,0 +1,127 @@
+"""ctypes binding of libpdegym_hip.so (C ABI declared in include/pdegym.h).
+
+There is NO fallback: if the shared library is missing, or a call is made with tensors that are not on
+a HIP device, this module raises.  PyTorch is used only as the owner of device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
+
+ABI_VERSION = 1
+RING = 128
+LOOKBACK = 100
+MAX_N1D = 1024
+
+CONTROL = {"Dirchilet": 0, "Neumann": 1}
+SENSE_FULL, SENSE_LAST, SENSE_LAST_DERIV, SENSE_FIRST_DERIV, SENSE_FIRST = range(5)
+REWARD_NONE, REWARD_TUNED1D, REWARD_NORM_L1, REWARD_NORM_L2, REWARD_NORM_LINF = range(5)
+BC = {"Neumann": 0, "Dirchilet": 1, "Controllable": 2}
+EDGES = ("lower", "upper", "left", "right")
+
+EXPORTS = [
+    "pdegym_abi_version", "pdegym_last_error", "pdegym_transport_step", "pdegym_parabolic_step",
+    "pdegym_reset1d_masked", "pdegym_rownorm2_f32", "pdegym_ns2d_step_f32", "pdegym_ns2d_step_f64",
+    "pdegym_ns2d_solve_pressure_f32", "pdegym_ns2d_solve_pressure_f64", "pdegym_ns2d_reset_masked_f32",
+    "pdegym_ns2d_reset_masked_f64",
+]
+
+
+class Params1D(C.Structure):
+    _fields_ = [("n", C.c_int32), ("nt", C.c_int32), ("substeps", C.c_int32), ("control_type", C.c_int32),
+                ("normalize", C.c_int32), ("sensing", C.c_int32), ("limit_state", C.c_int32),
+                ("reward_kind", C.c_int32), ("reward_nt", C.c_int32), ("dt", C.c_float), ("dx", C.c_float),
+                ("F", C.c_float), ("max_control", C.c_float), ("max_state", C.c_float),
+                ("truncate_penalty", C.c_float), ("terminate_reward", C.c_float)]
+
+
+class Bufs1D(C.Structure):
+    _fields_ = [("u", C.c_void_p), ("beta", C.c_void_p), ("beta_stride", C.c_int64), ("action", C.c_void_p),
+                ("time_index", C.c_void_p), ("bsum", C.c_void_p), ("ring", C.c_void_p), ("obs", C.c_void_p),
+                ("reward", C.c_void_p), ("norm_now", C.c_void_p), ("norm_back", C.c_void_p),
+                ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("history", C.c_void_p),
+                ("reset_init", C.c_void_p), ("final_obs", C.c_void_p)]
+
+
+class ParamsNS2D(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nt", C.c_int32), ("iters", C.c_int32),
+                ("action_dim", C.c_int32), ("bc", (C.c_int32 * 2) * 4), ("dt", C.c_double), ("dx", C.c_double),
+                ("dy", C.c_double), ("viscosity", C.c_double), ("density", C.c_double), ("gamma", C.c_double)]
+
+
+class BufsNS2D(C.Structure):
+    _fields_ = [("u", C.c_void_p), ("v", C.c_void_p), ("p", C.c_void_p), ("scratch", C.c_void_p),
+                ("action", C.c_void_p), ("time_index", C.c_void_p), ("U_ref", C.c_void_p),
+                ("action_ref", C.c_void_p), ("nt_ref", C.c_int32), ("obs", C.c_void_p), ("reward", C.c_void_p),
+                ("terminated", C.c_void_p)]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen libpdegym_hip.so (once) and declare the prototypes. Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            f"{LIB_PATH} is missing: build it with `python -m pdecontrolgym_amd.build` "
+            "(there is no CPU fallback for the PDE steppers)")
+    lib = C.CDLL(LIB_PATH)
+    lib.pdegym_abi_version.restype = C.c_int
+    lib.pdegym_last_error.restype = C.c_char_p
+    for name in ("pdegym_transport_step", "pdegym_parabolic_step"):
+        f = getattr(lib, name)
+        f.argtypes = [C.POINTER(Params1D), C.POINTER(Bufs1D), C.c_int32, C.c_void_p]
+        f.restype = C.c_int
+    lib.pdegym_reset1d_masked.argtypes = [C.POINTER(Params1D), C.POINTER(Bufs1D), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.pdegym_reset1d_masked.restype = C.c_int
+    lib.pdegym_rownorm2_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.pdegym_rownorm2_f32.restype = C.c_int
+    for sfx in ("f32", "f64"):
+        if not hasattr(lib, "pdegym_ns2d_step_" + sfx):   # TEMP until pdegym_ns2d.hip lands
+            continue
+        f = getattr(lib, "pdegym_ns2d_step_" + sfx)
+        f.argtypes = [C.POINTER(ParamsNS2D), C.POINTER(BufsNS2D), C.c_int32, C.c_void_p]
+        f.restype = C.c_int
+        f = getattr(lib, "pdegym_ns2d_solve_pressure_" + sfx)
+        f.argtypes = [C.POINTER(ParamsNS2D), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        f.restype = C.c_int
+        f = getattr(lib, "pdegym_ns2d_reset_masked_" + sfx)
+        f.argtypes = [C.POINTER(ParamsNS2D), C.POINTER(BufsNS2D), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        f.restype = C.c_int
+    if lib.pdegym_abi_version() != ABI_VERSION:
+        raise NativeError(f"ABI mismatch: library {lib.pdegym_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise NativeError(f"{what} failed ({rc}): {load().pdegym_last_error().decode()}")
+
+
+def dptr(t, dtype=None):
+    """Device pointer of a torch tensor, with the checks the C side cannot do."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NativeError("pdegym kernels need tensors on a HIP device (got a CPU tensor); there is no CPU path")
+    if not t.is_contiguous():
+        raise NativeError("pdegym kernels need contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise NativeError(f"expected dtype {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def current_stream_ptr(device=None):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

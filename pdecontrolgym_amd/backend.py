@@ -1,0 +1,110 @@
+"""HIP backend: turns (params struct, dict of torch tensors) into C-ABI calls on libpdegym_hip.so.
+
+The batched environment cores (batch1d.py / batch2d.py) talk to a backend object with this small
+interface.  ``HipBackend`` is the only backend the product ships; it refuses CPU tensors.  (The CPU test
+suite injects an oracle-backed double from tests/ to exercise host logic without a GPU.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import _native as N
+
+
+class HipBackend:
+    name = "hip-gfx950"
+
+    def __init__(self):
+        self.lib = N.load()
+
+    # ---- 1D -------------------------------------------------------------------------------------
+    @staticmethod
+    def _bufs1d(T) -> N.Bufs1D:
+        import torch
+        b = N.Bufs1D()
+        b.u = N.dptr(T["u"], torch.float32)
+        b.beta = N.dptr(T["beta"], torch.float32)
+        b.beta_stride = 0 if T["beta"].dim() == 1 else T["beta"].stride(0)
+        b.action = N.dptr(T["action"], torch.float32)
+        b.time_index = N.dptr(T["time_index"], torch.int32)
+        b.bsum = N.dptr(T["bsum"], torch.float64)
+        b.ring = N.dptr(T["ring"], torch.float32)
+        b.obs = N.dptr(T["obs"], torch.float32)
+        b.reward = N.dptr(T["reward"], torch.float32)
+        b.norm_now = N.dptr(T["norm_now"], torch.float32)
+        b.norm_back = N.dptr(T["norm_back"], torch.float32)
+        b.terminated = N.dptr(T["terminated"], torch.uint8)
+        b.truncated = N.dptr(T["truncated"], torch.uint8)
+        h = T.get("history")
+        b.history = N.dptr(h, torch.float32) if h is not None else None
+        ri, fo = T.get("reset_init"), T.get("final_obs")
+        b.reset_init = N.dptr(ri, torch.float32) if ri is not None else None
+        b.final_obs = N.dptr(fo, torch.float32) if fo is not None else None
+        return b
+
+    def step1d(self, kind: str, P: N.Params1D, T: dict, B: int):
+        fn = self.lib.pdegym_transport_step if kind == "transport" else self.lib.pdegym_parabolic_step
+        bufs = self._bufs1d(T)
+        N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["u"].device)), f"pdegym_{kind}_step")
+
+    def reset1d(self, P: N.Params1D, T: dict, init, mask, B: int):
+        import torch
+        bufs = self._bufs1d(T)
+        m = N.dptr(mask, torch.uint8) if mask is not None else None
+        N.check(self.lib.pdegym_reset1d_masked(C.byref(P), C.byref(bufs), N.dptr(init, torch.float32), m, B,
+                                               N.current_stream_ptr(T["u"].device)), "pdegym_reset1d_masked")
+
+    def rownorm2(self, rows, out):
+        import torch
+        B, n = rows.shape
+        N.check(self.lib.pdegym_rownorm2_f32(N.dptr(rows, torch.float32), N.dptr(out, torch.float32), n, B,
+                                             N.current_stream_ptr(rows.device)), "pdegym_rownorm2_f32")
+
+    # ---- NS2D -----------------------------------------------------------------------------------
+    @staticmethod
+    def _bufs_ns(T, dtype) -> N.BufsNS2D:
+        import torch
+        b = N.BufsNS2D()
+        for k in ("u", "v", "p", "scratch", "action", "U_ref", "action_ref", "obs", "reward"):
+            setattr(b, k, N.dptr(T[k], dtype))
+        b.time_index = N.dptr(T["time_index"], torch.int32)
+        b.terminated = N.dptr(T["terminated"], torch.uint8)
+        b.nt_ref = int(min(T["U_ref"].shape[0], T["action_ref"].shape[0]))
+        return b
+
+    @staticmethod
+    def _sfx(dtype):
+        import torch
+        return "f32" if dtype == torch.float32 else "f64"
+
+    def ns2d_step(self, P: N.ParamsNS2D, T: dict, B: int):
+        dtype = T["u"].dtype
+        bufs = self._bufs_ns(T, dtype)
+        fn = getattr(self.lib, "pdegym_ns2d_step_" + self._sfx(dtype))
+        N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["u"].device)), "pdegym_ns2d_step")
+
+    def ns2d_reset(self, P: N.ParamsNS2D, T: dict, u0, v0, p0, mask, B: int):
+        import torch
+        dtype = T["u"].dtype
+        bufs = self._bufs_ns(T, dtype)
+        fn = getattr(self.lib, "pdegym_ns2d_reset_masked_" + self._sfx(dtype))
+        m = N.dptr(mask, torch.uint8) if mask is not None else None
+        N.check(fn(C.byref(P), C.byref(bufs), N.dptr(u0, dtype), N.dptr(v0, dtype), N.dptr(p0, dtype), m, B,
+                   N.current_stream_ptr(T["u"].device)), "pdegym_ns2d_reset_masked")
+
+    def ns2d_solve_pressure(self, P: N.ParamsNS2D, u, v, p_in, p_out, scratch, B: int):
+        dtype = u.dtype
+        fn = getattr(self.lib, "pdegym_ns2d_solve_pressure_" + self._sfx(dtype))
+        N.check(fn(C.byref(P), N.dptr(u, dtype), N.dptr(v, dtype), N.dptr(p_in, dtype), N.dptr(p_out, dtype),
+                   N.dptr(scratch, dtype), B, N.current_stream_ptr(u.device)), "pdegym_ns2d_solve_pressure")
+
+
+_default = None
+
+
+def default_backend():
+    """The process-wide HIP backend (loads libpdegym_hip.so; raises if it is missing)."""
+    global _default
+    if _default is None:
+        _default = HipBackend()
+    return _default

@@ -1,0 +1,197 @@
+"""Batched 1D PDE environments (transport / reaction-diffusion) on device tensors.
+
+``PDEBatch1D`` owns the per-instance state of B independent environments as PyTorch-ROCm tensors and
+advances all of them with ONE kernel launch per env-step through the C ABI (include/pdegym.h).  It
+mirrors the reference's constructor arithmetic:
+
+    nt = int(round(T/dt)+1), nx = int(round(X/dx))          environments1d/base_env_1d.py:23-24
+    S  = int(round(control_sample_rate/dt))                 environments1d/hyperbolic.py:137
+    parabolic rows carry a ghost node (nx+1)                environments1d/parabolic.py:124
+    sensing / control enums and their error strings         environments1d/hyperbolic.py:48-124
+
+The full trajectory ``u[nt, nx]`` the reference keeps per environment (80 MB each at the shipped
+parabolic settings) is NOT kept: only the live row plus the three scalars TunedReward1D needs
+(SURVEY.md section 8a, rows R1/R2).  ``record_history=True`` restores the full history on device for
+small batches (custom reward callbacks, plotting).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+from . import _native as N
+
+
+@dataclass
+class RewardSpec:
+    """Which reward the step kernel evaluates in its epilogue."""
+    kind: int = N.REWARD_NONE
+    nt: int = 0
+    truncate_penalty: float = -1e-4
+    terminate_reward: float = 1e2
+
+
+_BAD_SENSING_LOC = "Invalid sensing_loc parameter. Please use 'full', 'collocated', or 'opposite'. See documentation for details."
+_BAD_SENSING_TYPE = "Invalid sensing_type parameter. Please use 'Neumann' or 'Dirchilet'. See documentation for details."
+_BAD_CONTROL = "Invalid control_type parameter. Please use 'Neumann' or 'Dirchilet'. See documentation for details."
+_PARABOLIC_OPPOSITE_DIR = "In the parabolic PDE system, u(0, t)=0 and so Dirchilet sensing at u(0, t) is not viable. See documentation for details."
+
+
+def sensing_mode(kind: str, control_type: str, sensing_loc: str, sensing_type) -> int:
+    """Maps the reference's (control_type, sensing_loc, sensing_type) table onto one PDEGYM_SENSE_* code,
+    raising the same bare ``Exception`` messages (hyperbolic.py:66-124, parabolic.py:66-122)."""
+    if sensing_loc not in ("full", "collocated", "opposite"):
+        raise Exception(_BAD_SENSING_LOC)
+    if control_type not in ("Neumann", "Dirchilet"):
+        raise Exception(_BAD_CONTROL)
+    if sensing_loc == "full":
+        return N.SENSE_FULL
+    if sensing_loc == "collocated":
+        return N.SENSE_LAST if control_type == "Neumann" else N.SENSE_LAST_DERIV
+    if sensing_type == "Neumann":
+        return N.SENSE_FIRST_DERIV
+    if sensing_type == "Dirchilet":
+        if kind == "parabolic":
+            raise Exception(_PARABOLIC_OPPOSITE_DIR)
+        return N.SENSE_FIRST
+    raise Exception(_BAD_SENSING_TYPE)
+
+
+class PDEBatch1D:
+    def __init__(self, kind: str, T: float, dt: float, X: float, dx: float, control_sample_rate: float,
+                 control_type: str = "Dirchilet", sensing_loc: str = "full", sensing_type="Dirchilet",
+                 normalize: bool = False, max_control_value: float = 20, limit_pde_state_size: bool = False,
+                 max_state_value: float = 1e10, reward: RewardSpec | None = None, num_envs: int = 1,
+                 device="cuda", backend=None, record_history: bool = False):
+        import torch
+        assert kind in ("transport", "parabolic")
+        self.kind = kind
+        self.T, self.dt, self.X, self.dx = T, dt, X, dx
+        self.nt = int(round(T / dt) + 1)
+        self.nx = int(round(X / dx))
+        self.n = self.nx + (1 if kind == "parabolic" else 0)
+        self.substeps = int(round(control_sample_rate / dt))
+        self.sensing = sensing_mode(kind, control_type, sensing_loc, sensing_type)
+        self.obs_dim = self.n if self.sensing == N.SENSE_FULL else 1
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        self.reward_spec = reward or RewardSpec()
+        if backend is None:
+            from .backend import default_backend
+            backend = default_backend()
+        self.backend = backend
+
+        P = N.Params1D()
+        P.n, P.nt, P.substeps = self.n, self.nt, self.substeps
+        P.control_type = N.CONTROL[control_type]
+        P.normalize = 1 if normalize else 0
+        P.sensing = self.sensing
+        P.limit_state = 1 if limit_pde_state_size else 0
+        P.reward_kind = self.reward_spec.kind
+        P.reward_nt = int(self.reward_spec.nt)
+        P.dt, P.dx = dt, dx                       # ctypes c_float rounds the Python double to float32
+        P.F = dt / (dx ** 2)                      # parabolic.py:138, computed in double then cast
+        P.max_control = max_control_value
+        P.max_state = min(max_state_value, 3.4028234663852886e38)
+        P.truncate_penalty = self.reward_spec.truncate_penalty
+        P.terminate_reward = self.reward_spec.terminate_reward
+        self.params = P
+
+        B, n, dev = self.num_envs, self.n, self.device
+        f32 = torch.float32
+        self.t = {
+            "u": torch.zeros(B, n, dtype=f32, device=dev),
+            "beta": torch.zeros(B, n, dtype=f32, device=dev),
+            "action": torch.zeros(B, dtype=f32, device=dev),
+            "time_index": torch.zeros(B, dtype=torch.int32, device=dev),
+            "bsum": torch.zeros(B, dtype=torch.float64, device=dev),
+            "ring": torch.zeros(B, N.RING, dtype=f32, device=dev),
+            "obs": None,
+            "reward": torch.zeros(B, dtype=f32, device=dev),
+            "norm_now": torch.zeros(B, dtype=f32, device=dev),
+            "norm_back": torch.zeros(B, dtype=f32, device=dev),
+            "terminated": torch.zeros(B, dtype=torch.uint8, device=dev),
+            "truncated": torch.zeros(B, dtype=torch.uint8, device=dev),
+            "history": torch.zeros(B, self.nt, n, dtype=f32, device=dev) if record_history else None,
+            "reset_init": None,
+            "final_obs": None,
+        }
+        # observations are double-buffered: the tensor returned by step k stays valid during step k+1
+        self._obs = [torch.zeros(B, self.obs_dim, dtype=f32, device=dev) for _ in range(2)]
+        self._flip = 0
+        self.t["obs"] = self._obs[0]
+
+    # ---- state accessors ---------------------------------------------------------------------------
+    @property
+    def u(self):
+        return self.t["u"]
+
+    @property
+    def time_index(self):
+        return self.t["time_index"]
+
+    def _next_obs(self):
+        self._flip ^= 1
+        self.t["obs"] = self._obs[self._flip]
+        return self.t["obs"]
+
+    # ---- API -----------------------------------------------------------------------------------------
+    def set_beta(self, beta):
+        """beta: [n] (shared) or [B, n] float32 device tensor."""
+        import torch
+        beta = torch.as_tensor(beta, dtype=torch.float32, device=self.device).contiguous()
+        if beta.shape[-1] != self.n:
+            raise ValueError(f"beta must have {self.n} nodes, got {tuple(beta.shape)}")
+        self.t["beta"] = beta
+
+    def reset(self, init, beta=None, mask=None):
+        """(Re)start instances from ``init`` [B, n]; where ``mask`` [B] (uint8/bool) is given only those."""
+        import torch
+        if beta is not None:
+            self.set_beta(beta)
+        init = torch.as_tensor(init, dtype=torch.float32, device=self.device).contiguous()
+        if init.shape != (self.num_envs, self.n):
+            raise ValueError(f"init must be [{self.num_envs}, {self.n}], got {tuple(init.shape)}")
+        if mask is not None:
+            mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            # masked reset writes into the CURRENT obs buffer so untouched instances keep their observation
+        else:
+            self._next_obs()
+        self.backend.reset1d(self.params, self.t, init, mask, self.num_envs)
+        return self.t["obs"]
+
+    def enable_auto_reset(self, init_pool, keep_final_obs: bool = True):
+        """Fused VecEnv auto-reset: an instance that ends a step terminated|truncated restarts from
+        ``init_pool[b]`` inside the same kernel launch (no host round trip).  The pool is a caller-owned
+        [B, n] tensor that may be refreshed between steps (e.g. re-sampled on device)."""
+        import torch
+        pool = torch.as_tensor(init_pool, dtype=torch.float32, device=self.device).contiguous()
+        if pool.shape != (self.num_envs, self.n):
+            raise ValueError(f"init_pool must be [{self.num_envs}, {self.n}], got {tuple(pool.shape)}")
+        self.t["reset_init"] = pool
+        self.t["final_obs"] = (torch.zeros(self.num_envs, self.obs_dim, dtype=torch.float32, device=self.device)
+                               if keep_final_obs else None)
+
+    def disable_auto_reset(self):
+        self.t["reset_init"] = None
+        self.t["final_obs"] = None
+
+    def step(self, action):
+        """Advance every instance by one env-step (S sub-steps). action: [B] float32 tensor.
+        Returns (obs, reward, terminated, truncated) device tensors (uint8 flags)."""
+        import torch
+        a = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs).contiguous()
+        self.t["action"] = a
+        self._next_obs()
+        self.backend.step1d(self.kind, self.params, self.t, self.num_envs)
+        return self.t["obs"], self.t["reward"], self.t["terminated"], self.t["truncated"]
+
+    # ---- roofline bookkeeping ---------------------------------------------
+    def algorithmic_bytes_per_env_step(self) -> int:
+        """Streaming model: each sub-step reads the previous row and beta and writes the new row
+        (12 B per node), plus the observation row and ~16 B of scalars per env-step."""
+        return self.substeps * 12 * self.n + 4 * self.n + 16
+
+    def compulsory_bytes_per_env_step(self) -> int:
+        """What the fused kernel must move: row in, beta in, row out, obs out (+ scalars)."""
+        return 4 * self.n * 3 + 4 * self.obs_dim + 64

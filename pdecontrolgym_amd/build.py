@@ -1,0 +1,70 @@
+"""Build recipe for libpdegym_hip.so (hand-written HIP for gfx950, C ABI in include/pdegym.h).
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so stays
+in-tree (git-ignored) and travels to the GPU box with the repository snapshot.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libpdegym_hip.so")
+SOURCES = ["pdegym_abi.hip", "pdegym_1d.hip", "pdegym_ns2d.hip"]
+# -ffp-contract=off: NumPy rounds after every operation; a fused multiply-add would break bit parity.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _fingerprint() -> str:
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)) + ["../../include/pdegym.h"]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP translation unit for gfx950 and link libpdegym_hip.so. Returns its path."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    stamp = os.path.join(LIBDIR, "libpdegym_hip.stamp")
+    fp = _fingerprint()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == fp:
+        return LIB
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libpdegym_hip.so")
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    procs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out.decode()}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout.decode())
+    with open(stamp, "w") as f:
+        f.write(fp)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,243 @@
+"""GPU parity tests for the 1D HIP kernels, called through the C ABI (libpdegym_hip.so).
+
+Bars (stated tolerances):
+  * fields / observations: BIT-EXACT float32 vs the reference's golden vectors and vs the oracle
+    (kernels are built with -ffp-contract=off and use true IEEE division);
+  * norms / rewards: rtol 1e-6 (wave butterfly vs BLAS sdot summation order, float32).
+"""
+import numpy as np
+import pytest
+
+from tests.cases import PARABOLIC_CASES, TRANSPORT_CASES
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _mk(kind, kw, reward_args, B, record_history=False):
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
+    spec = RewardSpec(N.REWARD_TUNED1D, int(reward_args[0]), float(reward_args[1]), float(reward_args[2]))
+    return PDEBatch1D(kind, kw["T"], kw["dt"], kw["X"], kw["dx"], kw["control_sample_rate"],
+                      control_type=kw["control_type"], sensing_loc=kw["sensing_loc"], sensing_type=kw["sensing_type"],
+                      normalize=kw["normalize"], max_control_value=kw["max_control_value"],
+                      limit_pde_state_size=kw["limit_pde_state_size"], max_state_value=kw["max_state_value"],
+                      reward=spec, num_envs=B, device="cuda", record_history=record_history)
+
+
+def _run_golden(kind, kw, g, B=3):
+    """Instance 0..B-1 all run the golden case (every instance must reproduce it)."""
+    env = _mk(kind, kw, g.reward_args, B)
+    init = torch.tensor(np.tile(g.init.astype(np.float32)[None], (B, 1)))
+    beta = torch.tensor(np.tile(g.beta.astype(np.float32)[None], (B, 1)))
+    obs = env.reset(init, beta)
+    np.testing.assert_array_equal(obs.cpu().numpy()[B - 1].reshape(-1), g.obs[0])
+    for i, a in enumerate(g.actions):
+        obs, r, te, tr = env.step(torch.full((B,), float(a), dtype=torch.float32))
+        obs, r, te, tr = obs.cpu().numpy(), r.cpu().numpy(), te.cpu().numpy(), tr.cpu().numpy()
+        rows = env.u.cpu().numpy()
+        for b in (0, B - 1):
+            np.testing.assert_array_equal(rows[b], g.rows[i], err_msg=f"row step {i} inst {b}")
+            np.testing.assert_array_equal(obs[b].reshape(-1), g.obs[i + 1], err_msg=f"obs step {i}")
+            assert int(env.time_index[b]) == int(g.time_index[i])
+            assert bool(te[b]) == bool(g.terminate[i]) and bool(tr[b]) == bool(g.truncate[i]), f"flags step {i}"
+            if np.isfinite(g.reward[i]):
+                nrm = float(np.linalg.norm(g.rows[i]))
+                np.testing.assert_allclose(r[b], g.reward[i], rtol=1e-6, atol=2e-6 * max(1.0, nrm), err_msg=f"reward step {i}")
+
+
+@pytest.mark.parametrize("case", sorted(TRANSPORT_CASES))
+def test_transport_hip_matches_reference_golden(golden_transport, case):
+    _run_golden("transport", TRANSPORT_CASES[case], golden_transport[case])
+
+
+@pytest.mark.parametrize("case", sorted(PARABOLIC_CASES))
+def test_parabolic_hip_matches_reference_golden(golden_parabolic, case):
+    _run_golden("parabolic", PARABOLIC_CASES[case], golden_parabolic[case])
+
+
+def _oracle_kwargs(kw):
+    return {k: kw[k] for k in ("T", "dt", "X", "dx", "control_sample_rate", "control_type", "sensing_loc",
+                               "sensing_type", "normalize", "max_control_value", "limit_pde_state_size",
+                               "max_state_value")}
+
+
+@pytest.mark.parametrize("kind,nx,S,B,ctrl", [
+    ("parabolic", 256, 100, 64, "Dirchilet"), ("parabolic", 256, 7, 33, "Neumann"), ("parabolic", 200, 100, 16, "Dirchilet"),
+    ("parabolic", 63, 10, 9, "Dirchilet"), ("parabolic", 640, 20, 5, "Dirchilet"), ("parabolic", 1000, 5, 3, "Neumann"),
+    ("transport", 512, 100, 64, "Dirchilet"), ("transport", 100, 50, 17, "Neumann"), ("transport", 64, 10, 8, "Dirchilet"),
+    ("transport", 65, 10, 8, "Dirchilet"), ("transport", 300, 25, 6, "Dirchilet"), ("transport", 1024, 12, 4, "Dirchilet"),
+    ("transport", 31, 12, 5, "Dirchilet"), ("parabolic", 2, 3, 4, "Dirchilet"),
+])
+def test_hip_matches_oracle_random_batches(kind, nx, S, B, ctrl):
+    """Seeded random per-instance IC / beta / actions: every row bit-exact vs the oracle."""
+    from oracle import pde_oracle as po
+    rng = np.random.default_rng(nx * 1000 + S)
+    dx = 1.0 / nx
+    dt = 0.25 * dx * dx if kind == "parabolic" else 0.5 * dx
+    nsteps = 6
+    kw = dict(T=(nsteps - 1) * S * dt + 3 * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type=ctrl,
+              sensing_loc="full", sensing_type=None, normalize=False, max_control_value=20,
+              limit_pde_state_size=True, max_state_value=1e10)
+    n = nx + (1 if kind == "parabolic" else 0)
+    x = np.linspace(0, 1, n)
+    amp = 50 if kind == "parabolic" else 5
+    beta = (amp * np.cos(rng.uniform(7, 8.5, (B, 1)) * np.arccos(x))).astype(np.float32)
+    init = (rng.uniform(1, 10, (B, 1)) * (1 + 0.3 * np.sin(2 * np.pi * x * rng.uniform(0.5, 3, (B, 1))))).astype(np.float32)
+    rargs = (int(round(kw["T"] / dt)), -1e3, 3e2)
+    cls = po.ParabolicOracle if kind == "parabolic" else po.TransportOracle
+    orc = cls(reward=po.TunedReward1DOracle(*rargs), keep_history=False, **_oracle_kwargs(kw))
+    env = _mk(kind, kw, rargs, B)
+    o_ref = orc.reset(init, beta)
+    o_gpu = env.reset(torch.tensor(init), torch.tensor(beta))
+    np.testing.assert_array_equal(o_gpu.cpu().numpy(), o_ref)
+    for i in range(nsteps + 1):          # the last call is post-terminal (0 sub-steps)
+        a = rng.uniform(-1, 1, B).astype(np.float32)
+        with np.errstate(all="ignore"):
+            o_ref, r_ref, te_ref, tr_ref = orc.step(a)
+        o_gpu, r_gpu, te_gpu, tr_gpu = env.step(torch.tensor(a))
+        np.testing.assert_array_equal(env.u.cpu().numpy(), orc.row, err_msg=f"step {i}")
+        np.testing.assert_array_equal(o_gpu.cpu().numpy(), o_ref)
+        np.testing.assert_array_equal(env.time_index.cpu().numpy(), orc.time_index)
+        np.testing.assert_array_equal(te_gpu.cpu().numpy().astype(bool), te_ref)
+        np.testing.assert_array_equal(tr_gpu.cpu().numpy().astype(bool), tr_ref)
+        np.testing.assert_allclose(env.t["norm_now"].cpu().numpy(), orc.norm_now, rtol=1e-6)
+        np.testing.assert_allclose(r_gpu.cpu().numpy(), r_ref, rtol=1e-6, atol=2e-6 * float(np.max(orc.norm_now)))
+
+
+def test_history_recording_matches_oracle():
+    from oracle import pde_oracle as po
+    kw = dict(PARABOLIC_CASES["P2_s1"])
+    B, n = 2, 257
+    rng = np.random.default_rng(5)
+    init = rng.uniform(1, 3, (B, n)).astype(np.float32)
+    beta = rng.uniform(-10, 10, (B, n)).astype(np.float32)
+    orc = po.ParabolicOracle(reward=po.TunedReward1DOracle(1000, -1e3, 3e2), keep_history=True, **_oracle_kwargs(kw))
+    env = _mk("parabolic", kw, (1000, -1e3, 3e2), B, record_history=True)
+    orc.reset(init, beta)
+    env.reset(torch.tensor(init), torch.tensor(beta))
+    for i in range(20):
+        a = rng.uniform(-1, 1, B).astype(np.float32)
+        orc.step(a)
+        env.step(torch.tensor(a))
+    np.testing.assert_array_equal(env.t["history"].cpu().numpy(), orc.hist)
+
+
+def test_masked_reset_and_shared_beta():
+    from oracle import pde_oracle as po
+    kw = dict(TRANSPORT_CASES["H1"])
+    B, n = 6, 100
+    rng = np.random.default_rng(11)
+    beta = (5 * np.cos(7.35 * np.arccos(np.linspace(0, 1, n)))).astype(np.float32)
+    init = rng.uniform(1, 10, (B, n)).astype(np.float32)
+    env = _mk("transport", kw, (10000, -1e3, 3e2), B)
+    env.reset(torch.tensor(init), torch.tensor(beta))          # 1-D beta = shared row (stride 0)
+    a = rng.uniform(-1, 1, B).astype(np.float32)
+    env.step(torch.tensor(a))
+    env.step(torch.tensor(a))
+    mask = np.array([1, 0, 0, 1, 0, 1], dtype=np.uint8)
+    init2 = rng.uniform(1, 10, (B, n)).astype(np.float32)
+    obs = env.reset(torch.tensor(init2), mask=torch.tensor(mask))
+    ti = env.time_index.cpu().numpy()
+    np.testing.assert_array_equal(ti, np.where(mask, 0, 2000))
+    np.testing.assert_array_equal(env.u.cpu().numpy()[mask.astype(bool)], init2[mask.astype(bool)])
+    np.testing.assert_array_equal(obs.cpu().numpy()[mask.astype(bool)], init2[mask.astype(bool)])
+    # continue: reset instances behave like fresh oracles, the others like 3-step-old ones
+    a3 = rng.uniform(-1, 1, B).astype(np.float32)
+    env.step(torch.tensor(a3))
+    kwargs = _oracle_kwargs(kw)
+    for b in range(B):
+        orc = po.TransportOracle(reward=po.TunedReward1DOracle(10000, -1e3, 3e2), keep_history=False, **kwargs)
+        if mask[b]:
+            orc.reset(init2[b:b + 1], beta[None])
+        else:
+            orc.reset(init[b:b + 1], beta[None])
+            orc.step(a[b:b + 1])
+            orc.step(a[b:b + 1])
+        _, r, _, _ = orc.step(a3[b:b + 1])
+        np.testing.assert_array_equal(env.u.cpu().numpy()[b], orc.row[0])
+        np.testing.assert_allclose(env.t["reward"].cpu().numpy()[b], r[0], rtol=1e-6, atol=1e-4)
+
+
+def test_baseline_size_properties_c2():
+    """BASELINE config 2 (nx=256, B=4096, S=100): properties that need no oracle at full size:
+    (1) batch invariance -- duplicated instances give identical rows; (2) u(0,t) == 0 and the boundary
+    node equals the action; (3) linearity of the (linear) plant in the state for zero action."""
+    from pdecontrolgym_amd import _native as N
+    B, n = 4096, 257
+    dx = 1.0 / 256
+    dt = 0.25 * dx * dx
+    kw = dict(T=1000 * 100 * dt, dt=dt, X=1, dx=dx, control_sample_rate=100 * dt, control_type="Dirchilet",
+              sensing_loc="full", sensing_type=None, normalize=False, max_control_value=20,
+              limit_pde_state_size=True, max_state_value=1e10)
+    env = _mk("parabolic", kw, (100000, -1e3, 3e2), B)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.linspace(0, 1, n)
+    gam = torch.rand(B // 2, 1, generator=g) + 7.5
+    beta = (50 * torch.cos(gam * torch.acos(x))).float()
+    beta = torch.cat([beta, beta])
+    init = (torch.rand(B // 2, 1, generator=g) * 9 + 1) * torch.ones(1, n)
+    init = torch.cat([init, init]).float()
+    env.reset(init, beta)
+    for _ in range(3):
+        a = torch.rand(B // 2, generator=g) * 2 - 1
+        a = torch.cat([a, a])
+        env.step(a)
+    u = env.u.cpu()
+    assert torch.equal(u[: B // 2], u[B // 2:])
+    assert torch.all(u[:, 0] == 0) and torch.equal(u[:, -1], a)
+    assert torch.isfinite(u).all()
+    # scaling by a power of two is exact in binary floating point -> exact linearity check
+    env2 = _mk("parabolic", kw, (100000, -1e3, 3e2), B)
+    env2.reset(init * 4, beta)
+    env.reset(init, beta)
+    z = torch.zeros(B)
+    env.step(z)
+    env2.step(z)
+    assert torch.equal(env.u.cpu() * 4, env2.u.cpu())
+    # checksum of row norms == norm_now
+    nn = env.t["norm_now"].cpu()
+    torch.testing.assert_close(nn, torch.linalg.vector_norm(env.u.cpu().double(), dim=1).float(), rtol=1e-6, atol=0)
+
+
+def test_abi_rejects_bad_arguments():
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D
+    with pytest.raises(N.NativeError):
+        env = PDEBatch1D("transport", 1, 1e-3, 1, 1.0 / 2000, 0.01, num_envs=2, device="cuda")   # n = 2000 > 1024
+        env.step(torch.zeros(2))
+
+
+def test_fused_auto_reset():
+    """Instances that finish restart from the pool inside the launch; others are untouched."""
+    from oracle import pde_oracle as po
+    kw = dict(TRANSPORT_CASES["R_s30"])                 # nt=401, S=30 -> terminates at step 14
+    B, n = 5, 100
+    rng = np.random.default_rng(3)
+    beta = (5 * np.cos(7.35 * np.arccos(np.linspace(0, 1, n)))).astype(np.float32)
+    init = rng.uniform(1, 3, (B, n)).astype(np.float32)
+    pool = rng.uniform(1, 3, (B, n)).astype(np.float32)
+    env = _mk("transport", kw, (400, -1e3, 3e2), B)
+    env.reset(torch.tensor(init), torch.tensor(beta))
+    env.enable_auto_reset(torch.tensor(pool))
+    orc = po.TransportOracle(reward=po.TunedReward1DOracle(400, -1e3, 3e2), keep_history=False, **_oracle_kwargs(kw))
+    orc.reset(init, np.tile(beta, (B, 1)))
+    for i in range(14):
+        a = rng.uniform(-1, 1, B).astype(np.float32)
+        o_ref, r_ref, te_ref, tr_ref = orc.step(a)
+        o, r, te, tr = env.step(torch.tensor(a))
+    assert te.cpu().numpy().all() and te_ref.all()
+    np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-6, atol=1e-4)
+    np.testing.assert_array_equal(env.t["final_obs"].cpu().numpy(), o_ref)      # terminal observation kept
+    np.testing.assert_array_equal(o.cpu().numpy(), pool)                        # first obs of the new episode
+    np.testing.assert_array_equal(env.u.cpu().numpy(), pool)
+    assert (env.time_index.cpu().numpy() == 0).all()
+    # the new episode evolves like a fresh oracle
+    orc.reset(pool, np.tile(beta, (B, 1)))
+    for i in range(3):
+        a = rng.uniform(-1, 1, B).astype(np.float32)
+        o_ref, r_ref, _, _ = orc.step(a)
+        o, r, te, tr = env.step(torch.tensor(a))
+        np.testing.assert_array_equal(o.cpu().numpy(), o_ref)
+        np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-6, atol=1e-4)

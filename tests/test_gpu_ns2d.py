@@ -1,0 +1,198 @@
+"""GPU parity tests for the NS2D HIP kernels, through the C ABI.
+
+Stated tolerances:
+  * float64 build vs reference golden vectors / oracle: fields BIT-EXACT (same operation order, no FMA
+    contraction, IEEE division); rewards rtol 1e-12 (summation order of the Frobenius norm);
+  * float32 build vs the float64 oracle from identical state, ONE step: rtol 1e-5, atol 2e-6*max|field|
+    (velocity), pressure atol 5e-5*max|p| (K Jacobi sweeps accumulate rounding); reward rtol 1e-4.
+"""
+import numpy as np
+import pytest
+
+from tests.cases import NS_BC, ns_bc_from_array
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _mk(kw, B, dtype):
+    from pdecontrolgym_amd.batch2d import NSBatch2D
+    return NSBatch2D(num_envs=B, device="cuda", dtype=dtype, **kw)
+
+
+def test_ns_f64_reproduces_target_npz_frames(golden_ns):
+    """examples/NavierStokes/target.npz (21x21, K=2000, 199 steps): bit-exact, every instance."""
+    g = golden_ns["N1"]
+    B = 3
+    kw = dict(T=0.2, dt=1e-3, X=1, dx=0.05, Y=1, dy=0.05, boundary_condition=NS_BC, U_ref=np.zeros((200, 21, 21, 2)),
+              action_ref=2.0 * np.ones(1000), gamma=0.1)
+    env = _mk(kw, B, torch.float64)
+    env.reset(g.u0, g.v0, np.zeros((21, 21)))
+    keep = set(int(k) for k in g.keep)
+    for t in range(1, 200):
+        obs, r, te = env.step(np.full(B, g.actions[t - 1]))
+        if t in keep:
+            o = obs.cpu().numpy()
+            for b in (0, B - 1):
+                np.testing.assert_array_equal(o[b, :, :, 0], g[f"u{t}"], err_msg=f"u frame {t}")
+                np.testing.assert_array_equal(o[b, :, :, 1], g[f"v{t}"], err_msg=f"v frame {t}")
+    assert te.cpu().numpy().all()
+    np.testing.assert_array_equal(env.p.cpu().numpy()[1], g.p_final)
+
+
+@pytest.mark.parametrize("case", ["N2_32", "N2_64", "N2_48"])
+def test_ns_f64_mixed_bc_golden(golden_ns, case):
+    g = golden_ns[case]
+    kw = dict(T=int(g.nt) * float(g.dt), dt=float(g.dt), X=1, dx=float(g.dx), Y=1, dy=float(g.dx),
+              boundary_condition=ns_bc_from_array(g.bc), U_ref=g.U_ref, action_ref=g.action_ref, gamma=0.1,
+              maximum_pressure_iteration=50)
+    env = _mk(kw, 2, torch.float64)
+    env.reset(g.u0, g.v0, g.p0)
+    for i, a in enumerate(g.actions):
+        obs, r, te = env.step(np.full(2, a))
+        np.testing.assert_array_equal(obs.cpu().numpy()[1], g.obs[i])
+        np.testing.assert_array_equal(env.p.cpu().numpy()[1], g.p[i])
+        np.testing.assert_allclose(r.cpu().numpy()[1], g.rewards[i], rtol=1e-12)
+
+
+def test_ns_f64_reward_with_reference_trajectory(golden_ns):
+    g, gb = golden_ns["N1"], golden_ns["N1b"]
+    Uref = np.zeros((200, 21, 21, 2))
+    for k in g.keep:
+        Uref[int(k)] = 0.5 * np.stack([g[f"u{int(k)}"], g[f"v{int(k)}"]], -1)
+    kw = dict(T=0.2, dt=1e-3, X=1, dx=0.05, Y=1, dy=0.05, boundary_condition=NS_BC, U_ref=Uref,
+              action_ref=2.0 * np.ones(1000), gamma=0.1)
+    env = _mk(kw, 1, torch.float64)
+    env.reset(g.u0, g.v0, np.zeros((21, 21)))
+    for t in (1, 2):
+        obs, r, te = env.step(np.array([g.actions[t - 1]]))
+        np.testing.assert_allclose(r.cpu().numpy()[0], gb.rewards[t - 1], rtol=1e-12)
+
+
+def test_ns_f64_c4_checksums(golden_ns):
+    """BASELINE config 4 shape (128x128, K=50) against the reference's checksums and sampled points."""
+    g = golden_ns["N3"]
+    n, nt = 128, int(g.nt)
+    kw = dict(T=nt * float(g.dt), dt=float(g.dt), X=1, dx=float(g.dx), Y=1, dy=float(g.dx), boundary_condition=NS_BC,
+              U_ref=np.zeros((nt, n, n, 2)), action_ref=2.0 * np.ones(nt), gamma=0.1, maximum_pressure_iteration=50)
+    env = _mk(kw, 2, torch.float64)
+    one = np.ones((n, n))
+    env.reset(g.ic[0] * one, g.ic[1] * one, g.ic[2] * one)
+    for i, a in enumerate(g.actions):
+        obs, r, te = env.step(np.full(2, a))
+        o = obs.cpu().numpy()[1]
+        p = env.p.cpu().numpy()[1]
+        sums = [np.linalg.norm(o[..., 0]), np.linalg.norm(o[..., 1]), np.linalg.norm(p), o.min(), o.max(), p.min(), p.max()]
+        np.testing.assert_allclose(sums, g.sums[i], rtol=1e-13)
+        pts = g.pts
+        smp = np.stack([o[pts[:, 0], pts[:, 1], 0], o[pts[:, 0], pts[:, 1], 1], p[pts[:, 0], pts[:, 1]]], -1)
+        np.testing.assert_array_equal(smp, g.samples[i])
+        np.testing.assert_allclose(r.cpu().numpy()[1], g.rewards[i], rtol=1e-12)
+
+
+def _random_case(n, B, K, seed, bc, action_dim=1):
+    rng = np.random.default_rng(seed)
+    dx = 1.0 / (n - 1)
+    dt = 0.2 * 0.5 * dx * dx / 0.1
+    nt = 8
+    xs = np.linspace(0, 1, n)
+    Xg, Yg = np.meshgrid(xs, xs)
+    u0 = np.stack([np.sin(2 * np.pi * Xg * rng.uniform(0.5, 2)) * np.cos(np.pi * Yg) * rng.uniform(0.5, 2) + rng.uniform(-1, 1) for _ in range(B)])
+    v0 = np.stack([np.cos(np.pi * Xg) * np.sin(2 * np.pi * Yg * rng.uniform(0.5, 2)) * rng.uniform(0.5, 2) + rng.uniform(-1, 1) for _ in range(B)])
+    p0 = rng.uniform(-1, 1, (B, n, n))
+    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=bc, U_ref=rng.uniform(-1, 1, (nt, n, n, 2)),
+              action_ref=rng.uniform(1, 3, nt), gamma=0.1, maximum_pressure_iteration=K)
+    acts = rng.uniform(2, 4, (3, B, action_dim))
+    return kw, u0, v0, p0, acts
+
+
+BC_MIX = {"upper": ["Controllable", "Neumann"], "lower": ["Neumann", "Controllable"],
+          "left": ["Neumann", "Dirchilet"], "right": ["Controllable", "Neumann"]}
+
+
+@pytest.mark.parametrize("n,B,K,bc,adim", [(21, 5, 7, BC_MIX, 1), (40, 3, 50, NS_BC, 1), (128, 2, 50, BC_MIX, 1),
+                                           (33, 2, 11, BC_MIX, 33), (8, 4, 3, BC_MIX, 1)])
+def test_ns_f64_matches_oracle_random(n, B, K, bc, adim):
+    from oracle import pde_oracle as po
+    kw, u0, v0, p0, acts = _random_case(n, B, K, 100 + n, bc, adim)
+    orc = po.NavierStokesOracle(**kw)
+    env = _mk(dict(kw, action_dim=adim), B, torch.float64)
+    orc.reset(u0, v0, p0)
+    env.reset(u0, v0, p0)
+    for a in acts:
+        o_ref, r_ref, te_ref, _ = orc.step(a)
+        obs, r, te = env.step(a)
+        np.testing.assert_array_equal(obs.cpu().numpy(), o_ref)
+        np.testing.assert_array_equal(env.p.cpu().numpy(), orc.p)
+        np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-12)
+        np.testing.assert_array_equal(te.cpu().numpy().astype(bool), te_ref)
+
+
+@pytest.mark.parametrize("n,B,K,bc", [(21, 4, 50, NS_BC), (64, 3, 50, BC_MIX), (128, 4, 50, NS_BC), (128, 2, 50, BC_MIX),
+                                      (100, 2, 20, BC_MIX), (48, 2, 200, NS_BC)])
+def test_ns_f32_single_step_vs_f64_oracle(n, B, K, bc):
+    """float32 throughput build: one step from identical state vs the float64 oracle (tolerances in the header)."""
+    from oracle import pde_oracle as po
+    kw, u0, v0, p0, acts = _random_case(n, B, K, 7 + n, bc)
+    orc = po.NavierStokesOracle(**kw)
+    env = _mk(kw, B, torch.float32)
+    for a in acts:
+        # restart both from the SAME float32-representable state each step (single-step comparison)
+        u32, v32, p32 = (x.astype(np.float32) for x in (u0, v0, p0))
+        orc.reset(u32.astype(np.float64), v32.astype(np.float64), p32.astype(np.float64))
+        env.reset(u32, v32, p32)
+        a32 = a.astype(np.float32)
+        o_ref, r_ref, _, _ = orc.step(a32.astype(np.float64))
+        obs, r, te = env.step(a32)
+        o = obs.cpu().numpy().astype(np.float64)
+        scale = np.abs(o_ref).max()
+        np.testing.assert_allclose(o, o_ref, rtol=1e-5, atol=2e-6 * scale)
+        pscale = np.abs(orc.p).max()
+        np.testing.assert_allclose(env.p.cpu().numpy().astype(np.float64), orc.p, rtol=1e-4, atol=5e-5 * pscale)
+        np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-4)
+        u0, v0, p0 = o_ref[..., 0], o_ref[..., 1], orc.p
+
+
+def test_solve_pressure_public_api_f64():
+    """env.solve_pressure on arbitrary fields (examples/NavierStokes/NS2Doptimization.py:97)."""
+    from oracle import pde_oracle as po
+    kw, u0, v0, p0, _ = _random_case(21, 3, 60, 5, NS_BC)
+    orc = po.NavierStokesOracle(**kw)
+    env = _mk(kw, 3, torch.float64)
+    out = env.solve_pressure(u0, v0, p0)
+    np.testing.assert_array_equal(out.cpu().numpy(), orc.solve_pressure(u0, v0, p0))
+
+
+def test_ns_masked_reset_and_properties_c4_size():
+    """BASELINE config 4 size (128x128, K=50, B=512, float32): batch invariance + masked reset + finiteness."""
+    B, n = 512, 128
+    dx = 1.0 / (n - 1)
+    dt = 0.2 * 0.5 * dx * dx / 0.1
+    nt = 20
+    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=NS_BC, U_ref=np.zeros((nt, n, n, 2), dtype=np.float32),
+              action_ref=2.0 * np.ones(nt), gamma=0.1, maximum_pressure_iteration=50)
+    env = _mk(kw, B, torch.float32)
+    g = torch.Generator().manual_seed(3)
+    c = (torch.rand(B // 2, 3, generator=g) * 10 - 5)
+    c = torch.cat([c, c])
+    one = torch.ones(1, n, n)
+    u0, v0, p0 = (c[:, k].reshape(B, 1, 1) * one for k in range(3))
+    env.reset(u0, v0, p0)
+    for _ in range(3):
+        a = torch.rand(B // 2, generator=g) * 2 + 2
+        a = torch.cat([a, a])
+        obs, r, te = env.step(a)
+    o = obs.cpu()
+    assert torch.isfinite(o).all()
+    assert torch.equal(o[: B // 2], o[B // 2:])                       # duplicated instances agree bitwise
+    assert torch.equal(o[:, -1, 1:-1, 0], a.reshape(B, 1).expand(B, n - 2).float())   # upper edge u = action
+    assert (o[:, 0, :, :] == 0).all() and (o[:, :, 0, :] == 0).all()  # Dirichlet walls
+    # reward == -0.5*||U||^2/n^2 - gamma/2*(a-2)^2 recomputed from obs
+    rr = -0.5 * (o.double() ** 2).sum(dim=(1, 2, 3)) / n / n - 0.05 * (a.double() - 2) ** 2
+    torch.testing.assert_close(r.cpu().double(), rr, rtol=1e-5, atol=1e-6)
+    mask = torch.zeros(B, dtype=torch.uint8)
+    mask[::3] = 1
+    env.reset(u0, v0, p0, mask=mask)
+    ti = env.time_index.cpu()
+    assert torch.equal(ti, torch.where(mask.bool(), 0, 3).int())
+    assert torch.equal(env.u.cpu()[::3], u0[::3].float())
