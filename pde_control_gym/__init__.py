@@ -1,5 +1,26 @@
-"""Drop-in replacement for lukebhan/PDEControlGym's ``pde_control_gym`` package (MI355X-native engine).
+"""Drop-in replacement for lukebhan/PDEControlGym's ``pde_control_gym`` package, MI355X-native engine.
 
-Registers the reference's environment ids (pde_control_gym/__init__.py:3-18 there; the reference's file has
-a syntax error at :11-14 that merges two ``register`` calls -- fixed here) when gymnasium is importable.
+Importing it registers the reference's environment ids (reference pde_control_gym/__init__.py:3-18; the
+reference file merges two ``register`` calls at :11-14 and does not parse -- the ids and entry points are kept,
+the syntax is fixed).  With gymnasium installed ``gym.make(id, **kwargs)`` works unchanged; without it
+``pde_control_gym.make`` offers the same call.
 """
+from pde_control_gym._compat import HAVE_GYMNASIUM, make, register
+
+_IDS = {
+    "PDEControlGym-TransportPDE1D": "pde_control_gym.src:TransportPDE1D",
+    "PDEControlGym-ReactionDiffusionPDE1D": "pde_control_gym.src:ReactionDiffusionPDE1D",
+    "PDEControlGym-BrainTumor1D": "pde_control_gym.src:BrainTumor1D",
+    "PDEControlGym-TrafficPDE1D": "pde_control_gym.src:TrafficPDE1D",
+    "PDEControlGym-NavierStokes2D": "pde_control_gym.src:NavierStokes2D",
+}
+
+for _id, _entry in _IDS.items():
+    try:
+        register(id=_id, entry_point=_entry)
+    except Exception:  # already registered (module re-import under gymnasium)
+        pass
+
+from pde_control_gym.vector import PDEVecEnv, make_vec  # noqa: E402
+
+__all__ = ["make", "register", "make_vec", "PDEVecEnv", "HAVE_GYMNASIUM"]

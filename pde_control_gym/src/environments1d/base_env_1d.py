@@ -1,0 +1,161 @@
+"""PDEEnv1D -- base class of the 1D boundary-control environments (interface of the reference's
+environments1d/base_env_1d.py:9-69), backed by the batched HIP engine with a batch of one.
+
+What stays identical to the reference: constructor keywords, ``nt = int(round(T/dt)+1)``,
+``nx = int(round(X/dx))``, the action space ``Box(-1, 1, (1,), float32)``, the ``normalize`` callable,
+``reset(seed, options) -> (obs, {})`` and ``step(action) -> (obs, reward, terminated, truncated, {})`` with
+NumPy float32 observations.  What changes: the PDE sub-steps run in one kernel launch on the GPU
+(pdecontrolgym_amd/csrc/pdegym_1d.hip) instead of a Python ``while`` loop over NumPy slices.
+"""
+from __future__ import annotations
+
+from abc import abstractmethod
+
+import numpy as np
+
+from pde_control_gym._compat import Env, spaces
+from pde_control_gym.src.rewards import BaseReward, NormReward, TunedReward1D
+
+_RESET_ERR = ("Please pass both an initial condition and a recirculation function in the parameters dictionary. "
+              "See documentation for more details")
+
+
+class HistoryView:
+    """Lazy NumPy-style view of the on-device trajectory ``u[nt, n]`` of one instance, for user reward
+    callbacks (``uVec[t]``, ``uVec[t - 100]``, ``uVec[:, -1]`` ... are fetched on demand)."""
+
+    def __init__(self, hist_tensor):
+        self._h = hist_tensor          # [nt, n] device tensor
+        self.shape = tuple(hist_tensor.shape)
+        self.dtype = np.dtype(np.float32)
+        self.ndim = 2
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, idx):
+        out = self._h[idx]
+        return out.cpu().numpy() if hasattr(out, "cpu") else out
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._h.cpu().numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+
+def reward_spec_for(reward_class):
+    """Type-dispatch of the shipped rewards onto the in-kernel reward codes; None -> host callback path."""
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import RewardSpec
+    if type(reward_class) is TunedReward1D:
+        return RewardSpec(N.REWARD_TUNED1D, int(reward_class.nt), float(reward_class.truncate_penalty),
+                          float(reward_class.terminate_reward))
+    if type(reward_class) is NormReward and reward_class.horizon == "temporal":
+        kind = {"1": N.REWARD_NORM_L1, "2": N.REWARD_NORM_L2, "inf": N.REWARD_NORM_LINF}[reward_class.norm]
+        return RewardSpec(kind, int(reward_class.nt), float(reward_class.truncate_penalty),
+                          float(reward_class.terminate_reward))
+    return None
+
+
+class PDEEnv1D(Env):
+    """:param T: end time.  :param dt: time step.  :param X: spatial length.  :param dx: spatial step.
+    :param reward_class: a BaseReward instance.  :param normalize: map actions from [-1, 1] onto
+    [-max_control_value, max_control_value] with ``(a+1)*max - max`` (kept literally: it also scales a Neumann
+    neighbour value, as in the reference)."""
+
+    _kind = None  # "transport" | "parabolic"
+
+    def __init__(self, T: float, dt: float, X: float, dx: float, reward_class: BaseReward, normalize: bool = False):
+        super().__init__()
+        self.nt = int(round(T / dt) + 1)
+        self.nx = int(round(X / dx))
+        self.dt, self.T, self.dx, self.X = dt, T, dx, X
+        self.action_space = spaces.Box(np.full(1, -1, dtype="float32"), np.full(1, 1, dtype="float32"))
+        self._normalize_flag = bool(normalize)
+        if normalize:
+            self.normalize = lambda action, max_value: (action + 1) * max_value - max_value
+        else:
+            self.normalize = lambda action, max_value: action
+        self.time_index = 0
+        self.reward_class = reward_class
+
+    # ---- engine glue shared by TransportPDE1D / ReactionDiffusionPDE1D ------------------------------------
+    def _build_engine(self, device, record_history, backend):
+        from pdecontrolgym_amd.batch1d import PDEBatch1D
+        spec = reward_spec_for(self.reward_class)
+        self._fused_reward = spec is not None
+        if not self._fused_reward:
+            record_history = True           # a user reward callback receives the trajectory
+        self._core = PDEBatch1D(self._kind, self.T, self.dt, self.X, self.dx, self.control_sample_rate,
+                                control_type=self.control_type, sensing_loc=self.sensing_loc,
+                                sensing_type=self.sensing_type, normalize=self._normalize_flag,
+                                max_control_value=self.max_control_value,
+                                limit_pde_state_size=self.limit_pde_state_size, max_state_value=self.max_state_value,
+                                reward=spec, num_envs=1, device=device, backend=backend,
+                                record_history=record_history)
+        self._terminated = False
+        self._truncated = False
+
+    @property
+    def u(self):
+        """Trajectory ``u[nt, n]`` (float32) like the reference's ``env.u`` when history recording is on,
+        otherwise the live row as a [1, n] array."""
+        h = self._core.t["history"]
+        if h is not None:
+            return h[0].cpu().numpy()
+        return self._core.u.cpu().numpy()
+
+    def terminate(self):
+        """True once ``T`` is reached (reference hyperbolic.py:171-180)."""
+        return bool(self.time_index >= self.nt - 1)
+
+    def truncate(self):
+        """True if ``limit_pde_state_size`` and ||u||_2 >= max_state_value (reference hyperbolic.py:182-194)."""
+        return bool(self._truncated)
+
+    def _obs_to_user(self, obs_row):
+        o = obs_row.cpu().numpy()
+        o = o[0].copy() if self._core.obs_dim > 1 else np.float32(o[0, 0])
+        return self.sensing_noise_func(o)
+
+    def reset(self, seed=None, options=None):
+        """Calls the two user callbacks with ``nx`` exactly like the reference (seed/options are accepted and,
+        as there, ignored) and uploads the initial condition and the plant parameter."""
+        try:
+            init_condition = self.reset_init_condition_func(self.nx)
+            beta = self.reset_recirculation_func(self.nx)
+        except:  # noqa: E722 - the reference converts ANY failure into this generic message (hyperbolic.py:207-213)
+            raise Exception(_RESET_ERR)
+        n = self._core.n
+        init = np.zeros(n, dtype=np.float32)
+        init[:] = init_condition                      # same broadcast/cast as ``self.u[0] = init_condition``
+        self.beta = beta
+        b = np.asarray(beta, dtype=np.float32).reshape(-1)
+        if b.shape[0] != n:
+            raise Exception(_RESET_ERR)
+        obs = self._core.reset(init[None], b)
+        self.time_index = 0
+        self._terminated = self._truncated = False
+        return self._obs_to_user(obs), {}
+
+    def step(self, control):
+        """Advance ``control_sample_rate/dt`` PDE sub-steps under boundary input ``control`` (a float, 0-d or
+        size-1 array).  Returns ``(obs, reward, terminated, truncated, {})``."""
+        import torch
+        a = float(np.asarray(control, dtype=np.float32).reshape(-1)[0])
+        obs, rew, te, tr = self._core.step(torch.tensor([a], dtype=torch.float32))
+        flags = torch.stack([te, tr]).cpu().numpy()
+        self._terminated, self._truncated = bool(flags[0, 0]), bool(flags[1, 0])
+        self.time_index = int(self._core.time_index.cpu()[0])
+        if self._fused_reward:
+            reward = rew.cpu().numpy()[0]
+        else:
+            view = HistoryView(self._core.t["history"][0])
+            reward = self.reward_class.reward(view, self.time_index, self._terminated, self._truncated,
+                                              view[self.time_index][-1])
+        return self._obs_to_user(obs), reward, self._terminated, self._truncated, {}
+
+
+def validate_1d_options(kind, sensing_loc, control_type, sensing_type):
+    """Same checks, same order of precedence and same messages as the reference's nested ``match`` blocks."""
+    from pdecontrolgym_amd.batch1d import sensing_mode
+    return sensing_mode(kind, control_type, sensing_loc, sensing_type)

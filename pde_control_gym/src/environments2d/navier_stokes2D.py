@@ -1,0 +1,154 @@
+"""NavierStokes2D -- incompressible Navier-Stokes on a collocated grid with boundary control
+(interface of the reference's environments2d/navier_stokes2D.py:9-194).
+
+``step`` = Chorin projection: predictor (central differences + 5-point Laplacian), boundary conditions,
+Jacobi pressure-Poisson sweeps with Neumann walls (warm-started from the previous step), corrector, boundary
+conditions -- all inside ONE kernel launch (pdecontrolgym_amd/csrc/pdegym_ns2d.hip).  dtype float64 (default)
+reproduces the reference bit for bit (``examples/NavierStokes/target.npz`` is a test fixture); float32 is the
+throughput mode.
+
+``central_difference`` / ``laplace`` are the module-level stencil helpers that the reference's adjoint example
+imports (examples/NavierStokes/NS2Doptimization.py:5); they work on NumPy arrays and on torch tensors alike.
+"""
+from __future__ import annotations
+
+from typing import Callable, Union
+
+import numpy as np
+
+from pde_control_gym.src.environments2d.base_env_2d import PDEEnv2D
+from pde_control_gym.src.rewards import NSReward
+
+_RESET_ERR = ("Please pass both an initial condition and a recirculation function in the parameters dictionary. "
+              "See documentation for more details")
+
+
+def _zeros_like(f):
+    return np.zeros_like(f) if isinstance(f, np.ndarray) else f.new_zeros(f.shape)
+
+
+def central_difference(f, coordinate, step=0.01):
+    """Second-order central difference on interior nodes, zero on the boundary ring.
+    ``coordinate`` "x" differentiates along axis 1 (columns), "y" along axis 0 (rows)."""
+    out = _zeros_like(f)
+    if coordinate == "x":
+        out[1:-1, 1:-1] = (f[1:-1, 2:] - f[1:-1, :-2]) / (2 * step)
+    elif coordinate == "y":
+        out[1:-1, 1:-1] = (f[2:, 1:-1] - f[:-2, 1:-1]) / (2 * step)
+    return out
+
+
+def laplace(f, dx=0.01, dy=0.01):
+    """Five-point Laplacian on interior nodes (west + south - 4 centre + east + north) / (dx dy)."""
+    out = _zeros_like(f)
+    out[1:-1, 1:-1] = (f[1:-1, :-2] + f[:-2, 1:-1] - 4 * f[1:-1, 1:-1] + f[1:-1, 2:] + f[2:, 1:-1]) / (dx * dy)
+    return out
+
+
+class NavierStokes2D(PDEEnv2D):
+    """:param reset_init_condition_func: ``f(X_meshgrid) -> (u, v, p)`` arrays of shape (ny, nx).
+    :param boundary_condition: ``{"upper"|"lower"|"left"|"right": [cond_u, cond_v]}`` with conditions
+        "Neumann" | "Dirchilet" | "Controllable" (edges are applied in the order lower, upper, left, right).
+    :param U_ref: reference trajectory (nt, nx, ny, 2).  :param action_ref: reference actions (>= nt,).
+    :param viscosity, density: fluid constants.  :param maximum_pressure_iteration: Jacobi sweeps per step.
+    :param stable_factor: safety factor of the diffusive time-step limit (RuntimeError if violated).
+    Extra (not in the reference): ``device``, ``dtype`` ("float64" | "float32")."""
+
+    def __init__(self, reset_init_condition_func: Callable, boundary_condition: dict, U_ref: np.ndarray,
+                 action_ref: np.ndarray, viscosity: float = 0.1, density: float = 1.0,
+                 maximum_pressure_iteration: float = 2000, stable_factor: float = 0.5, device="cuda",
+                 dtype="float64", backend=None, **kwargs):
+        super().__init__(**kwargs)
+        import torch
+        from pdecontrolgym_amd.batch2d import NSBatch2D
+        self.reset_init_condition_func = reset_init_condition_func
+        self.KINEMATIC_VISCOSITY = viscosity
+        self.DENSITY = density
+        self.N_PRESSURE_POISSON_ITERATIONS = maximum_pressure_iteration
+        self.U_ref = U_ref
+        self.action_ref = action_ref
+        self.boundary_condition = boundary_condition
+        self._fused_reward = type(self.reward_class) is NSReward
+        gamma = self.reward_class.gamma if self._fused_reward else 0.0
+        tdtype = {"float64": torch.float64, "float32": torch.float32}[str(dtype).replace("torch.", "")]
+        self._np_dtype = np.float64 if tdtype == torch.float64 else np.float32
+        # NSBatch2D raises RuntimeError("Stability is not guarenteed") like navier_stokes2D.py:56-58
+        self._core = NSBatch2D(T=self.nt * self.dt, dt=self.dt, X=(self.nx - 1) * self.dx, dx=self.dx,
+                               Y=(self.ny - 1) * self.dy, dy=self.dy, boundary_condition=boundary_condition,
+                               U_ref=np.asarray(U_ref), action_ref=np.asarray(action_ref), action_dim=self.action_dim,
+                               gamma=gamma, viscosity=viscosity, density=density,
+                               maximum_pressure_iteration=int(maximum_pressure_iteration), stable_factor=stable_factor,
+                               num_envs=1, device=device, dtype=tdtype, backend=backend)
+        assert (self._core.nt, self._core.nx, self._core.ny) == (self.nt, self.nx, self.ny)
+        self.BoundaryControlInit(boundary_condition)
+
+    def BoundaryControlInit(self, boundary_condition: dict):
+        """Index tables of the four edges and of the lines next to them (kept for API compatibility)."""
+        self.boundary_condition = boundary_condition
+        xx, yy = np.arange(0, self.nx), np.arange(0, self.ny)
+        self.pos_idx = {"lower": (0, xx), "upper": (-1, xx), "left": (yy, 0), "right": (yy, -1)}
+        self.pos_idx_neuman = {"lower": (1, xx), "upper": (-2, xx), "left": (yy, 1), "right": (yy, -2)}
+
+    def apply_boundary(self, u, v, action):
+        """Host-side edge update on caller arrays, in the reference's order (lower, upper, left, right; u then v).
+        ``step`` does NOT call this: the kernels apply the same rule on device."""
+        for pos in ("lower", "upper", "left", "right"):
+            for comp, f in enumerate((u, v)):
+                cond = self.boundary_condition[pos][comp]
+                if cond == "Neumann":
+                    f[self.pos_idx[pos]] = f[self.pos_idx_neuman[pos]]
+                elif cond == "Dirchilet":
+                    f[self.pos_idx[pos]] = 0
+                elif cond == "Controllable":
+                    f[self.pos_idx[pos]] = action
+        return u, v
+
+    def solve_pressure(self, u, v, p_prev):
+        """Jacobi pressure solve for arbitrary fields on the GPU; NumPy in, NumPy out (the adjoint example calls
+        this directly).  Like the reference it also stores the result as the warm start ``self.p``."""
+        out = self._core.solve_pressure(np.asarray(u)[None], np.asarray(v)[None], np.asarray(p_prev)[None])
+        self._core.t["p"].copy_(out)
+        return out[0].cpu().numpy().astype(np.float64 if self._np_dtype == np.float64 else np.float32)
+
+    @property
+    def u(self):
+        return self._core.u[0].cpu().numpy()
+
+    @property
+    def v(self):
+        return self._core.v[0].cpu().numpy()
+
+    @property
+    def p(self):
+        return self._core.p[0].cpu().numpy()
+
+    def terminate(self):
+        return bool(self.time_index >= self.nt - 1)
+
+    def reset(self, seed=None, options=None):
+        try:
+            init_u, init_v, init_p = self.reset_init_condition_func(self.X)
+        except:  # noqa: E722 - same blanket conversion as the reference (navier_stokes2D.py:180-185)
+            raise Exception(_RESET_ERR)
+        self.U = np.zeros((self.nt, self.nx, self.ny, 2))
+        self.time_index = 0
+        obs = self._core.reset(np.asarray(init_u), np.asarray(init_v), np.asarray(init_p))
+        self.U[0] = obs[0].cpu().numpy()
+        return self.U[0], {}
+
+    def step(self, action: Union[float, np.ndarray]):
+        a = np.asarray(action, dtype=np.float64).reshape(-1)
+        if a.size == 1 and self.action_dim != 1:
+            a = np.full(self.action_dim, a[0])
+        obs, rew, te = self._core.step(a[None])
+        self.time_index += 1
+        o = obs[0].cpu().numpy()
+        if self.time_index < self.nt:
+            self.U[self.time_index] = o
+            o = self.U[self.time_index]
+        terminate = self.terminate()
+        if self._fused_reward:
+            reward = float(rew.cpu().numpy()[0])
+        else:
+            reward = self.reward_class.reward(self.U, self.time_index, self.U_ref, action, self.action_ref)
+        return o, reward, terminate, False, {}

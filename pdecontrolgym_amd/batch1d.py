@@ -76,10 +76,14 @@ class PDEBatch1D:
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
         self.reward_spec = reward or RewardSpec()
+        self.control_sample_rate, self.control_type = control_sample_rate, control_type
+        self.sensing_loc, self.sensing_type, self.normalize = sensing_loc, sensing_type, bool(normalize)
+        self.max_control_value, self.max_state_value = max_control_value, max_state_value
+        self.limit_pde_state_size = limit_pde_state_size
         if backend is None:
             from .backend import default_backend
             backend = default_backend()
-        self.backend = backend
+        self.backend = backend.bind(self) if hasattr(backend, "bind") else backend
 
         P = N.Params1D()
         P.n, P.nt, P.substeps = self.n, self.nt, self.substeps

@@ -48,10 +48,13 @@ class NSBatch2D:
         self.dtype = dtype or torch.float64
         self.action_dim = int(action_dim)
         self.iters = int(maximum_pressure_iteration)
+        self.ctor = dict(T=T, dt=dt, X=X, dx=dx, Y=Y, dy=dy, boundary_condition=boundary_condition, gamma=gamma,
+                         viscosity=viscosity, density=density, maximum_pressure_iteration=self.iters,
+                         stable_factor=stable_factor)
         if backend is None:
             from .backend import default_backend
             backend = default_backend()
-        self.backend = backend
+        self.backend = backend.bind(self) if hasattr(backend, "bind") else backend
 
         P = N.ParamsNS2D()
         P.nx, P.ny, P.nt, P.iters, P.action_dim = self.nx, self.ny, self.nt, self.iters, self.action_dim
@@ -146,32 +149,3 @@ class NSBatch2D:
     def compulsory_bytes_per_env_step(self) -> int:
         word = 4 if str(self.dtype).endswith("float32") else 8
         return word * (3 + 3 + 2 + 2) * self.nx * self.ny
-
-
-def smoke_ns2d():
-    """Tiny NS2D step on cuda:0 checked against the oracle (used by __graft_entry__.smoke)."""
-    import numpy as np
-    import torch
-    from oracle import pde_oracle as po
-    rng = np.random.default_rng(1)
-    n, B, nt = 24, 3, 6
-    dx = 1.0 / (n - 1)
-    dt = 0.2 * 0.5 * dx * dx / 0.1
-    bc = {"upper": ["Controllable", "Dirchilet"], "lower": ["Dirchilet", "Neumann"],
-          "left": ["Neumann", "Dirchilet"], "right": ["Dirchilet", "Dirchilet"]}
-    Uref = rng.uniform(-1, 1, (nt, n, n, 2))
-    aref = rng.uniform(1, 3, nt)
-    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=bc, U_ref=Uref, action_ref=aref,
-              maximum_pressure_iteration=20)
-    orc = po.NavierStokesOracle(gamma=0.1, **kw)
-    env = NSBatch2D(gamma=0.1, num_envs=B, device="cuda:0", dtype=torch.float64, **kw)
-    u0, v0, p0 = (rng.uniform(-1, 1, (B, n, n)) for _ in range(3))
-    orc.reset(u0, v0, p0)
-    env.reset(u0, v0, p0)
-    for _ in range(2):
-        a = rng.uniform(2, 4, B)
-        o_ref, r_ref, _, _ = orc.step(a)
-        o, r, te = env.step(a)
-    torch.cuda.synchronize()
-    assert np.allclose(o.cpu().numpy(), o_ref, rtol=1e-12, atol=1e-13), "NS2D f64 fields differ from the oracle"
-    assert np.allclose(r.cpu().numpy(), r_ref, rtol=1e-11), "NS2D reward differs from the oracle"

@@ -269,17 +269,12 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void reset1d_kernel(pdegym_p
   const int n = P.n;
   const float* src = init + (size_t)inst * n;
   float* urow = Bf.u + (size_t)inst * n;
-  float* hist = Bf.history ? Bf.history + (size_t)inst * P.nt * n : nullptr;
   float ss = 0.f;
   for (int j = lane; j < n; j += kWave) {
     const float v = src[j];
     urow[j] = v;
-    if (hist) hist[j] = v;
     if (P.sensing == PDEGYM_SENSE_FULL) Bf.obs[(size_t)inst * n + j] = v;
     ss += v * v;
-  }
-  if (hist) {
-    for (size_t q = n + lane; q < (size_t)P.nt * n; q += kWave) hist[q] = 0.f;  // np.zeros((nt, nx)) hyperbolic.py:214
   }
   ss = wave_sum(ss);
   if (lane == 0) {
@@ -300,6 +295,18 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void reset1d_kernel(pdegym_p
       Bf.obs[inst] = o;
     }
   }
+}
+
+// history[b] = zeros((nt, n)); history[b, 0] = init[b]   (hyperbolic.py:214-217), spread over blockIdx.x chunks
+__global__ __launch_bounds__(256) void reset_history_kernel(pdegym_params1d P, float* history, const float* init,
+                                                            const uint8_t* mask, int B) {
+  const int inst = blockIdx.y;
+  if (inst >= B || (mask && !mask[inst])) return;
+  const size_t total = (size_t)P.nt * P.n;
+  float* h = history + (size_t)inst * total;
+  const float* src = init + (size_t)inst * P.n;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (size_t)gridDim.x * blockDim.x)
+    h[q] = (q < (size_t)P.n) ? src[q] : 0.f;
 }
 
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void rownorm2_kernel(const float* rows, float* out, int n, int B) {
@@ -368,6 +375,12 @@ int pdegym_reset1d_masked(const pdegym_params1d* prm, const pdegym_bufs1d* buf, 
   if (prm->n < 3) return pdegym::fail(-2, "n must be >= 3");
   const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
   hipLaunchKernelGGL(reset1d_kernel, grid, block, 0, (hipStream_t)stream, *prm, *buf, init, mask, B);
+  if (buf->history) {
+    const size_t total = (size_t)prm->nt * prm->n;
+    const int gx = (int)((total + 255) / 256 > 512 ? 512 : (total + 255) / 256);
+    hipLaunchKernelGGL(reset_history_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, *prm, buf->history, init,
+                       mask, B);
+  }
   return pdegym::check_launch("reset1d");
 }
 

@@ -1,0 +1,133 @@
+"""Oracle-on-tensors test double for the HIP backend (CPU tests of the HOST logic only).
+
+Implements the backend interface of pdecontrolgym_amd/backend.py on CPU torch tensors by running the NumPy
+oracle.  It lives under tests/ because only tests may touch the oracle; the product ships no CPU path.
+"""
+import numpy as np
+import torch
+
+from oracle import pde_oracle as po
+from pdecontrolgym_amd import _native as N
+
+
+class FakeBackend:
+    name = "oracle-test-double"
+
+    def __init__(self):
+        self.core = None
+
+    def bind(self, core):
+        self.core = core
+        return self
+
+    # ---- 1D -------------------------------------------------------------------------------------
+    def _orc1d(self, P):
+        c = self.core
+        if P.reward_kind == N.REWARD_TUNED1D:
+            rw = po.TunedReward1DOracle(P.reward_nt, P.truncate_penalty, P.terminate_reward)
+        elif P.reward_kind >= N.REWARD_NORM_L1:
+            rw = po.NormRewardOracle(P.reward_nt, {2: "1", 3: "2", 4: "inf"}[P.reward_kind], P.truncate_penalty, P.terminate_reward)
+        else:
+            rw = None
+        cls = po.ParabolicOracle if c.kind == "parabolic" else po.TransportOracle
+        return cls(c.T, c.dt, c.X, c.dx, c.control_sample_rate, control_type=c.control_type, sensing_loc=c.sensing_loc,
+                   sensing_type=c.sensing_type, normalize=c.normalize, max_control_value=c.max_control_value,
+                   limit_pde_state_size=c.limit_pde_state_size, max_state_value=c.max_state_value, reward=rw,
+                   keep_history=False)
+
+    @staticmethod
+    def _beta(T, B):
+        b = T["beta"].numpy()
+        return np.tile(b[None], (B, 1)) if b.ndim == 1 else b
+
+    def _load(self, orc, T, B):
+        orc.B = B
+        orc.beta = self._beta(T, B)
+        orc.row = T["u"].numpy().copy()
+        orc.time_index = T["time_index"].numpy().astype(np.int64)
+        orc.bsum = T["bsum"].numpy().copy()
+        orc.ring = T["ring"].numpy().copy()
+        if T.get("history") is not None:
+            orc.keep_history = True
+            orc.hist = T["history"].numpy()          # shares memory with the tensor: rows are written in place
+
+    def _store(self, orc, T):
+        T["u"].copy_(torch.from_numpy(orc.row))
+        T["time_index"].copy_(torch.from_numpy(orc.time_index.astype(np.int32)))
+        T["bsum"].copy_(torch.from_numpy(orc.bsum))
+        T["ring"].copy_(torch.from_numpy(orc.ring))
+
+    def step1d(self, kind, P, T, B):
+        orc = self._orc1d(P)
+        self._load(orc, T, B)
+        with np.errstate(all="ignore"):
+            obs, r, te, tr = orc.step(T["action"].numpy())
+        T["obs"].copy_(torch.from_numpy(np.asarray(obs, dtype=np.float32).reshape(B, -1)))
+        if r is not None:
+            T["reward"].copy_(torch.from_numpy(r.astype(np.float32)))
+        T["norm_now"].copy_(torch.from_numpy(orc.norm_now.astype(np.float32)))
+        T["norm_back"].copy_(torch.from_numpy(orc.norm_back.astype(np.float32)))
+        T["terminated"].copy_(torch.from_numpy(te.astype(np.uint8)))
+        T["truncated"].copy_(torch.from_numpy(tr.astype(np.uint8)))
+        self._store(orc, T)
+        if T.get("reset_init") is not None:
+            done = te | tr
+            if done.any():
+                if T.get("final_obs") is not None:
+                    T["final_obs"][torch.from_numpy(done)] = T["obs"][torch.from_numpy(done)]
+                self.reset1d(P, T, T["reset_init"], torch.from_numpy(done.astype(np.uint8)), B, _keep_flags=True)
+
+    def reset1d(self, P, T, init, mask, B, _keep_flags=False):
+        orc = self._orc1d(P)
+        m = np.ones(B, dtype=bool) if mask is None else mask.numpy().astype(bool)
+        init = init.numpy()
+        fresh = self._orc1d(P)
+        obs = fresh.reset(init, self._beta(T, B))
+        self._load(orc, T, B)
+        orc.row[m] = fresh.row[m]
+        orc.time_index[m] = 0
+        orc.bsum[m] = fresh.bsum[m]
+        orc.ring[m, 0] = po._rownorm(fresh.row[m])
+        if T.get("history") is not None:
+            h = T["history"].numpy()
+            h[m] = 0
+            h[m, 0] = fresh.row[m]
+        self._store(orc, T)
+        o = np.asarray(obs, dtype=np.float32).reshape(B, -1)
+        T["obs"][torch.from_numpy(m)] = torch.from_numpy(o[m])
+        if not _keep_flags:
+            T["terminated"][torch.from_numpy(m)] = 0
+            T["truncated"][torch.from_numpy(m)] = 0
+
+    def rownorm2(self, rows, out):
+        out.copy_(torch.from_numpy(po._rownorm(rows.numpy())))
+
+    # ---- NS2D -----------------------------------------------------------------------------------
+    def _orc_ns(self, T):
+        c = self.core
+        np_dt = np.float64 if T["u"].dtype == torch.float64 else np.float32
+        kw = dict(c.ctor)
+        return po.NavierStokesOracle(U_ref=T["U_ref"].numpy(), action_ref=T["action_ref"].numpy(), dtype=np_dt, **kw)
+
+    def ns2d_step(self, P, T, B):
+        orc = self._orc_ns(T)
+        orc.reset(T["u"].numpy(), T["v"].numpy(), T["p"].numpy())
+        orc.time_index = T["time_index"].numpy().astype(np.int64)
+        obs, r, te, _ = orc.step(T["action"].numpy())
+        for k, a in (("u", orc.u), ("v", orc.v), ("p", orc.p), ("obs", obs), ("reward", r)):
+            T[k].copy_(torch.from_numpy(np.ascontiguousarray(a)).to(T[k].dtype))
+        T["time_index"].copy_(torch.from_numpy(orc.time_index.astype(np.int32)))
+        T["terminated"].copy_(torch.from_numpy(te.astype(np.uint8)))
+
+    def ns2d_reset(self, P, T, u0, v0, p0, mask, B):
+        m = torch.ones(B, dtype=torch.bool) if mask is None else mask.bool()
+        T["u"][m] = u0[m]
+        T["v"][m] = v0[m]
+        T["p"][m] = p0[m]
+        T["obs"][m] = torch.stack([u0[m], v0[m]], dim=-1)
+        T["time_index"][m] = 0
+        T["terminated"][m] = 0
+
+    def ns2d_solve_pressure(self, P, u, v, p_in, p_out, scratch, B):
+        orc = self._orc_ns({"u": u, "U_ref": torch.zeros(1, self.core.ny, self.core.nx, 2), "action_ref": torch.zeros(1)})
+        p_out.copy_(torch.from_numpy(orc.solve_pressure(u.numpy(), v.numpy(), p_in.numpy())))
