@@ -1,14 +1,20 @@
 // pdegym_1d.hip -- gfx950 kernels for the 1D transport / reaction-diffusion environment steppers.
 //
 // Design (MI355X-first, not a translation of the reference's NumPy slicing):
-//   * one 64-lane wavefront owns one environment instance; lane l holds EPL consecutive grid nodes
-//     [l*EPL, (l+1)*EPL) of the row in VGPRs for ALL S sub-steps of an env-step (temporal fusion: the row
-//     is read from HBM once and written once per env-step instead of once per sub-step);
-//   * halo values cross lanes with one wave shift per side per sub-step; the non-local transport term
-//     u(0,t)*beta(x) is a readfirstlane broadcast;
+//   * one 64-lane wavefront owns one environment instance.  The row minus its fixed left node (parabolic
+//     u(0,t)=0) is spread over "slots": lane l keeps EPL consecutive slots in VGPRs for ALL S sub-steps of an
+//     env-step (temporal fusion: the row is read from HBM once and written once per env-step instead of once
+//     per sub-step).  nx=256 (257 nodes) -> 256 slots = 4 per lane with every lane busy; nx=512 -> 8 per lane;
+//   * halo values cross lanes with ONE DPP wave shift per side per sub-step (v_mov_b32 wave_shr/wave_shl, no
+//     LDS traffic); the lane that has no neighbour receives the boundary value through the DPP "old" operand;
+//     the non-local transport term u(0,t)*beta(x) is a readfirstlane broadcast;
+//   * the controlled boundary node and the padding slots carry zero stencil coefficients, so the inner loop has
+//     no selects: y = (p + F_e*lap) + c_e*p leaves them unchanged.  0*inf would poison them, so a step whose
+//     result norm is not finite is recomputed from the untouched HBM row with explicit selects (EXACT mode):
+//     results are bit-identical to the reference in every case, finite or not;
 //   * L2-norm reductions for truncate()/TunedReward1D are butterfly shuffles inside the wavefront;
 //   * arithmetic follows the reference's float32 operation order exactly (built with -ffp-contract=off,
-//     true IEEE division) so fields are bit-identical to NumPy:
+//     IEEE division and sqrt) so fields are bit-identical to NumPy:
 //       transport  environments1d/hyperbolic.py:143-155
 //       parabolic  environments1d/parabolic.py:138-150
 //       reward     rewards/tuned_reward_1d.py:25-40 (streaming form)
@@ -25,8 +31,26 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 
-__device__ __forceinline__ float from_left_lane(float v) { return __shfl_up(v, 1); }
-__device__ __forceinline__ float from_right_lane(float v) { return __shfl_down(v, 1); }
+// lane i <- lane i-1 ; lane 0 <- `edge`      (DPP wave_shr:1, gfx9 wave-wide shift)
+__device__ __forceinline__ float from_left_lane(float v, float edge) {
+#ifdef PDEGYM_NO_DPP
+  const float r = __shfl_up(v, 1);
+  return (threadIdx.x & 63) == 0 ? edge : r;
+#else
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v),
+                                                               0x138, 0xf, 0xf, false));
+#endif
+}
+// lane i <- lane i+1 ; lane 63 <- `edge`     (DPP wave_shl:1)
+__device__ __forceinline__ float from_right_lane(float v, float edge) {
+#ifdef PDEGYM_NO_DPP
+  const float r = __shfl_down(v, 1);
+  return (threadIdx.x & 63) == 63 ? edge : r;
+#else
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v),
+                                                               0x130, 0xf, 0xf, false));
+#endif
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -39,10 +63,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// value of row element j when lane l holds elements [l*EPL, l*EPL+EPL)
+// value of slot s when lane l holds slots [l*EPL, l*EPL+EPL)
 template <int EPL>
-__device__ __forceinline__ float row_get(const float (&x)[EPL], int j) {
-  const int src = j / EPL, e = j - src * EPL;
+__device__ __forceinline__ float slot_get(const float (&x)[EPL], int s) {
+  const int src = s / EPL, e = s - src * EPL;
   float sel = x[0];
 #pragma unroll
   for (int k = 1; k < EPL; ++k) sel = (e == k) ? x[k] : sel;
@@ -50,116 +74,190 @@ __device__ __forceinline__ float row_get(const float (&x)[EPL], int j) {
 }
 
 template <int EPL>
-__device__ __forceinline__ float row_sumsq(const float (&x)[EPL], int j0, int n) {
+__device__ __forceinline__ float slots_sumsq(const float (&x)[EPL], int s0, int ns) {
   float s = 0.f;
 #pragma unroll
-  for (int e = 0; e < EPL; ++e) s += (j0 + e < n) ? x[e] * x[e] : 0.f;
+  for (int e = 0; e < EPL; ++e) s += (s0 + e < ns) ? x[e] * x[e] : 0.f;
   return wave_sum(s);
 }
 
 // (a+1)*m-m, base_env_1d.py:36-39
 __device__ __forceinline__ float normalize_ctrl(float a, float m, int on) { return on ? (a + 1.0f) * m - m : a; }
 
-template <int EPL, bool PARABOLIC, bool NEUMANN>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_params1d P, pdegym_bufs1d Bf, int B) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (inst >= B) return;  // wave-uniform
-  const int n = P.n;
-  const int j0 = lane * EPL;
-  float* urow = Bf.u + (size_t)inst * n;
-  const float* brow = Bf.beta + (size_t)inst * Bf.beta_stride;
+// Per-wave state of one instance while it is stepped.
+template <int EPL>
+struct Row {
+  float x[EPL];   // slots (row nodes J0 .. n-1)
+  float bl;       // parabolic: node 0 (u(0,t)); unused for transport
+  int t;          // time_index
+  int k;          // (t + LOOKBACK) mod S
+  double bsum;    // running sum of |u[tau,-1]|
+};
 
-  float x[EPL], c[EPL];
-#pragma unroll
-  for (int e = 0; e < EPL; ++e) {
-    const int j = j0 + e;
-    const bool ok = j < n;
-    x[e] = ok ? urow[j] : 0.f;
-    const float b = ok ? brow[j] : 0.f;
-    c[e] = PARABOLIC ? P.dt * b : b;  // parabolic.py:144: (dt*beta) is formed first, then *u
-  }
-
-  int t = __builtin_amdgcn_readfirstlane(Bf.time_index[inst]);
-  const int S = P.substeps > 0 ? P.substeps : 1;
-  int nsub = P.nt - 1 - t;  // hyperbolic.py:140: while i < sample_rate and time_index < nt-1
-  nsub = nsub < P.substeps ? nsub : P.substeps;
-  nsub = nsub > 0 ? nsub : 0;
-
-  const float a = Bf.action[inst];
+// S sub-steps of one instance.  FAST: boundary/padding slots are frozen by zero coefficients (no selects);
+// otherwise explicit selects (exact for non-finite states, and required when the boundary value changes every
+// sub-step, i.e. parabolic Neumann control).
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool FAST, bool HIST>
+__device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EPL], const pdegym_params1d& P, int nsub,
+                                             float a, float* ring, float* hist, int lane) {
+  static_assert(!(FAST && (NEUMANN || HIST)), "fast mode is the Dirichlet, history-free path");
+  constexpr int J0 = PARABOLIC ? 1 : 0;
+  const int n = P.n, ns = n - J0, s0 = lane * EPL;
   const float dx = P.dx, dt = P.dt, F = P.F;
-  // control_update (hyperbolic.py:68,95). Transport/Neumann reads u[t][-2] of the NEW row, which is still
-  // zero (hyperbolic.py:144), so its boundary value is constant over the sub-steps.
+  const int S = P.substeps > 0 ? P.substeps : 1;
+  const bool rec_all = P.nt <= PDEGYM_RING;
+  // control_update (hyperbolic.py:68,95). Transport/Neumann reads u[t][-2] of the NEW row, which is still zero
+  // (hyperbolic.py:144), so its boundary value is constant over the sub-steps.
   const float cdx = a * dx;
   float bval = NEUMANN ? normalize_ctrl(cdx + 0.0f, P.max_control, P.normalize) : normalize_ctrl(a, P.max_control, P.normalize);
 
-  double bsum = Bf.bsum[inst];
-  const bool rec_all = P.nt <= PDEGYM_RING;
-  int k = (t + PDEGYM_LOOKBACK) % S;
-  float* ring = Bf.ring + (size_t)inst * PDEGYM_RING;
-  float* hist = Bf.history ? Bf.history + (size_t)inst * P.nt * n : nullptr;
+  // per-slot coefficients: parabolic c = dt*beta (parabolic.py:144 forms dt*beta first), transport c = beta
+  float c[EPL], fe[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const bool interior = (s0 + e < ns - 1);
+    const float cc = PARABOLIC ? dt * beta[e] : beta[e];
+    if constexpr (FAST) {
+      c[e] = interior ? cc : 0.0f;
+      fe[e] = interior ? (PARABOLIC ? F : dt) : 0.0f;
+    } else {
+      c[e] = cc;
+      fe[e] = PARABOLIC ? F : dt;
+    }
+  }
 
   for (int s = 0; s < nsub; ++s) {
-    const float xl = from_left_lane(x[EPL - 1]);  // p[j0-1]
-    const float xr = from_right_lane(x[0]);       // p[j0+EPL]
+    const float xl = PARABOLIC ? from_left_lane(R.x[EPL - 1], R.bl) : 0.0f;  // p[first slot - 1]
+    const float xr = from_right_lane(R.x[0], 0.0f);                          // p[last slot + 1]
     float p0 = 0.f;
-    if constexpr (!PARABOLIC) p0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x[0])));
+    if constexpr (!PARABOLIC) p0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, R.x[0])));
     if constexpr (PARABOLIC && NEUMANN) {
       // parabolic.py:148-150: previous row's neighbour u[t-1][-2]
-      bval = normalize_ctrl(cdx + row_get<EPL>(x, n - 2), P.max_control, P.normalize);
+      bval = normalize_ctrl(cdx + slot_get<EPL>(R.x, ns - 2), P.max_control, P.normalize);
     }
     float y[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-      const int j = j0 + e;
-      const float p = x[e];
-      const float pm = (e == 0) ? xl : x[e - 1];
-      const float pp = (e == EPL - 1) ? xr : x[e + 1];
+      const float p = R.x[e];
+      const float pm = (e == 0) ? xl : R.x[e - 1];
+      const float pp = (e == EPL - 1) ? xr : R.x[e + 1];
       float v;
       if constexpr (PARABOLIC) {
         // parabolic.py:143-144   u + F*(um - 2*u + up) + (dt*beta)*u
         const float t1 = 2.0f * p;
         const float t2 = pm - t1;
         const float t3 = t2 + pp;
-        const float t4 = F * t3;
+        const float t4 = fe[e] * t3;
         const float t5 = p + t4;
         const float t7 = c[e] * p;
         v = t5 + t7;
-        if (e == 0) v = (lane == 0) ? 0.0f : v;  // parabolic.py:146  u(0,t) = 0
       } else {
         // hyperbolic.py:146-155   u + dt*((up - u)/dx + u[0]*beta)
         const float d1 = pp - p;
         const float d2 = d1 / dx;
         const float r = p0 * c[e];
         const float d3 = d2 + r;
-        const float d4 = dt * d3;
+        const float d4 = fe[e] * d3;
         v = p + d4;
         (void)pm;
       }
-      v = (j >= n - 1) ? ((j == n - 1) ? bval : 0.0f) : v;  // controlled boundary node; padding stays 0
+      if constexpr (!FAST) {
+        const int sl = s0 + e;
+        v = (sl >= ns - 1) ? ((sl == ns - 1) ? bval : 0.0f) : v;  // controlled boundary node; padding stays 0
+      }
       y[e] = v;
     }
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) x[e] = y[e];
-    ++t;
-    k = (k + 1 == S) ? 0 : k + 1;
-    if constexpr (NEUMANN) bsum += (double)fabsf(bval);
-    if (hist) {
+    for (int e = 0; e < EPL; ++e) R.x[e] = y[e];
+    if constexpr (FAST) {
+      if (s == 0) {  // the frozen boundary slot takes the new control value once (parabolic.py:148-150)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) R.x[e] = (s0 + e == ns - 1) ? bval : R.x[e];
+      }
+    }
+    R.bl = 0.0f;  // parabolic.py:146  u(0,t) = 0
+    ++R.t;
+    R.k = (R.k + 1 == S) ? 0 : R.k + 1;
+    if constexpr (NEUMANN) R.bsum += (double)fabsf(bval);
+    if constexpr (HIST) {
+      float* hrow = hist + (size_t)R.t * n;
+      if (PARABOLIC && lane == 0) hrow[0] = 0.0f;
 #pragma unroll
       for (int e = 0; e < EPL; ++e)
-        if (j0 + e < n) hist[(size_t)t * n + j0 + e] = x[e];
+        if (s0 + e < ns) hrow[J0 + s0 + e] = R.x[e];
     }
     // rows whose norm a later reward call looks back at (tuned_reward_1d.py:40): r+100 is a step end
-    if (s + 1 < nsub && (rec_all || k == 0 || t + PDEGYM_LOOKBACK == P.nt - 1)) {
-      const float nr = sqrtf(row_sumsq<EPL>(x, j0, n));
-      if (lane == 0) ring[t & (PDEGYM_RING - 1)] = nr;
+    if (s + 1 < nsub && (rec_all || R.k == 0 || R.t + PDEGYM_LOOKBACK == P.nt - 1)) {
+      const float nr = sqrtf(slots_sumsq<EPL>(R.x, s0, ns));  // node 0 is 0 after any sub-step
+      if (lane == 0) ring[R.t & (PDEGYM_RING - 1)] = nr;
     }
   }
-  if constexpr (!NEUMANN) bsum += (double)nsub * (double)fabsf(bval);
+  if constexpr (!NEUMANN) R.bsum += (double)nsub * (double)fabsf(bval);
+}
+
+template <int EPL, bool PARABOLIC>
+__device__ __forceinline__ void load_row(Row<EPL>& R, float (&beta)[EPL], const float* urow, const float* brow, int n,
+                                         int lane) {
+  constexpr int J0 = PARABOLIC ? 1 : 0;
+  const int ns = n - J0, s0 = lane * EPL;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const bool ok = s0 + e < ns;
+    R.x[e] = ok ? urow[J0 + s0 + e] : 0.f;
+    beta[e] = ok ? brow[J0 + s0 + e] : 0.f;
+  }
+  R.bl = PARABOLIC ? urow[0] : 0.f;
+}
+
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_params1d P, pdegym_bufs1d Bf, int B) {
+  constexpr int J0 = PARABOLIC ? 1 : 0;
+  constexpr bool kFast = !NEUMANN && !HIST;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (inst >= B) return;  // wave-uniform
+  const int n = P.n, ns = n - J0, s0 = lane * EPL;
+  float* urow = Bf.u + (size_t)inst * n;
+  const float* brow = Bf.beta + (size_t)inst * Bf.beta_stride;
+  float* ring = Bf.ring + (size_t)inst * PDEGYM_RING;
+  float* hist = (HIST && Bf.history) ? Bf.history + (size_t)inst * P.nt * n : nullptr;
+
+  Row<EPL> R;
+  float beta[EPL];
+  load_row<EPL, PARABOLIC>(R, beta, urow, brow, n, lane);
+  const int t_in = __builtin_amdgcn_readfirstlane(Bf.time_index[inst]);
+  const double bsum_in = Bf.bsum[inst];
+  const int S = P.substeps > 0 ? P.substeps : 1;
+  int nsub = P.nt - 1 - t_in;  // hyperbolic.py:140: while i < sample_rate and time_index < nt-1
+  nsub = nsub < P.substeps ? nsub : P.substeps;
+  nsub = nsub > 0 ? nsub : 0;
+  const float a = Bf.action[inst];
+  R.t = t_in;
+  R.k = (t_in + PDEGYM_LOOKBACK) % S;
+  R.bsum = bsum_in;
+
+  float norm_now;
+  if constexpr (kFast) {
+    run_substeps<EPL, PARABOLIC, false, true, false>(R, beta, P, nsub, a, ring, nullptr, lane);
+    norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
+    if (!(fabsf(norm_now) <= 3.4028234663852886e38f)) {
+      // inf/NaN somewhere (or a squared overflow): 0*inf may have leaked into a frozen slot -> redo exactly
+      load_row<EPL, PARABOLIC>(R, beta, urow, brow, n, lane);
+      R.t = t_in;
+      R.k = (t_in + PDEGYM_LOOKBACK) % S;
+      R.bsum = bsum_in;
+      run_substeps<EPL, PARABOLIC, false, false, false>(R, beta, P, nsub, a, ring, nullptr, lane);
+      norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
+    }
+  } else {
+    run_substeps<EPL, PARABOLIC, NEUMANN, false, HIST>(R, beta, P, nsub, a, ring, hist, lane);
+    norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
+  }
+  const int t = R.t;
 
   // ---- epilogue: norms, flags, reward, observation ------------------------------------------------
-  const float norm_now = sqrtf(row_sumsq<EPL>(x, j0, n));
-  if (nsub > 0 && (rec_all || k == 0 || t + PDEGYM_LOOKBACK == P.nt - 1)) {
+  const bool rec_all = P.nt <= PDEGYM_RING;
+  if (nsub > 0 && (rec_all || R.k == 0 || t + PDEGYM_LOOKBACK == P.nt - 1)) {
     if (lane == 0) ring[t & (PDEGYM_RING - 1)] = norm_now;
   }
   const bool terminate = t >= P.nt - 1;                                 // hyperbolic.py:171-180
@@ -169,12 +267,12 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
   if (P.reward_kind == PDEGYM_REWARD_NORM_L1) {
     float s1 = 0.f;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) s1 += (j0 + e < n) ? fabsf(x[e]) : 0.f;
-    nr_alt = wave_sum(s1);
+    for (int e = 0; e < EPL; ++e) s1 += (s0 + e < ns) ? fabsf(R.x[e]) : 0.f;
+    nr_alt = wave_sum(s1) + fabsf(R.bl);
   } else if (P.reward_kind == PDEGYM_REWARD_NORM_LINF) {
-    float m = 0.f;
+    float m = fabsf(R.bl);
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) m = fmaxf(m, (j0 + e < n) ? fabsf(x[e]) : 0.f);
+    for (int e = 0; e < EPL; ++e) m = fmaxf(m, (s0 + e < ns) ? fabsf(R.x[e]) : 0.f);
     nr_alt = wave_max(m);
   }
   // look-back row t-100 (Python negative index wraps into the zero-filled tail of the history).
@@ -188,7 +286,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
     if (!zero_row) norm_back = ring[src & (PDEGYM_RING - 1)];
     if (P.reward_kind == PDEGYM_REWARD_TUNED1D) {
       if (terminate && norm_now < 20.0f) {
-        reward = (P.terminate_reward - ((float)bsum) / 1000.0f) - norm_now;  // tuned_reward_1d.py:36-37
+        reward = (P.terminate_reward - ((float)R.bsum) / 1000.0f) - norm_now;  // tuned_reward_1d.py:36-37
       } else if (truncate) {
         reward = (float)((double)P.truncate_penalty * (double)(P.reward_nt - t));  // tuned_reward_1d.py:38-39
       } else {
@@ -203,18 +301,20 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
 
   // sensing_update (hyperbolic.py:72-116)
   const bool auto_reset = (Bf.reset_init != nullptr) && (terminate || truncate);  // wave-uniform
+  auto node = [&](int j) -> float { return (PARABOLIC && j == 0) ? R.bl : slot_get<EPL>(R.x, j - J0); };
   auto emit_obs = [&](float* obs_base) {
     if (P.sensing == PDEGYM_SENSE_FULL) {
       float* orow = obs_base + (size_t)inst * n;
+      if (PARABOLIC && lane == 0) orow[0] = R.bl;
 #pragma unroll
       for (int e = 0; e < EPL; ++e)
-        if (j0 + e < n) orow[j0 + e] = x[e];
+        if (s0 + e < ns) orow[J0 + s0 + e] = R.x[e];
     } else {
       float o;
-      if (P.sensing == PDEGYM_SENSE_LAST) o = row_get<EPL>(x, n - 1);
-      else if (P.sensing == PDEGYM_SENSE_LAST_DERIV) o = (row_get<EPL>(x, n - 1) - row_get<EPL>(x, n - 2)) / dx;
-      else if (P.sensing == PDEGYM_SENSE_FIRST_DERIV) o = (row_get<EPL>(x, 1) - row_get<EPL>(x, 0)) / dx;
-      else o = row_get<EPL>(x, 0);
+      if (P.sensing == PDEGYM_SENSE_LAST) o = node(n - 1);
+      else if (P.sensing == PDEGYM_SENSE_LAST_DERIV) o = (node(n - 1) - node(n - 2)) / P.dx;
+      else if (P.sensing == PDEGYM_SENSE_FIRST_DERIV) o = (node(1) - node(0)) / P.dx;
+      else o = node(0);
       if (lane == 0) obs_base[inst] = o;
     }
   };
@@ -227,29 +327,33 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
   }
   if (!auto_reset) {
     if (nsub > 0) {
+      if (PARABOLIC && lane == 0) urow[0] = R.bl;
 #pragma unroll
       for (int e = 0; e < EPL; ++e)
-        if (j0 + e < n) urow[j0 + e] = x[e];
+        if (s0 + e < ns) urow[J0 + s0 + e] = R.x[e];
     }
     emit_obs(Bf.obs);
     if (lane == 0) {
       Bf.time_index[inst] = t;
-      Bf.bsum[inst] = bsum;
+      Bf.bsum[inst] = R.bsum;
     }
   } else {
     // fused VecEnv auto-reset: keep the terminal observation, restart from the pool row (hyperbolic.py:214-227)
     if (Bf.final_obs) emit_obs(Bf.final_obs);
     const float* irow = Bf.reset_init + (size_t)inst * n;
+    R.bl = PARABOLIC ? irow[0] : 0.f;
+    if (PARABOLIC && lane == 0) urow[0] = R.bl;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-      x[e] = (j0 + e < n) ? irow[j0 + e] : 0.f;
-      if (j0 + e < n) urow[j0 + e] = x[e];
+      R.x[e] = (s0 + e < ns) ? irow[J0 + s0 + e] : 0.f;
+      if (s0 + e < ns) urow[J0 + s0 + e] = R.x[e];
     }
-    if (hist) {
-      for (size_t q = lane; q < (size_t)P.nt * n; q += kWave) hist[q] = (q < (size_t)n) ? irow[q] : 0.f;
+    if constexpr (HIST) {
+      if (hist)
+        for (size_t q = lane; q < (size_t)P.nt * n; q += kWave) hist[q] = (q < (size_t)n) ? irow[q] : 0.f;
     }
-    const float n0 = sqrtf(row_sumsq<EPL>(x, j0, n));
-    const float last = row_get<EPL>(x, n - 1);
+    const float n0 = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
+    const float last = node(n - 1);
     emit_obs(Bf.obs);
     if (lane == 0) {
       Bf.time_index[inst] = 0;
@@ -323,10 +427,15 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void rownorm2_kernel(const f
 template <int EPL, bool PARABOLIC>
 int launch_epl(const pdegym_params1d& P, const pdegym_bufs1d& Bf, int B, hipStream_t st) {
   const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-  if (P.control_type == PDEGYM_CONTROL_NEUMANN)
-    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, true>), grid, block, 0, st, P, Bf, B);
+  const bool neu = P.control_type == PDEGYM_CONTROL_NEUMANN, hist = Bf.history != nullptr;
+  if (neu && hist)
+    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, true, true>), grid, block, 0, st, P, Bf, B);
+  else if (neu)
+    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, true, false>), grid, block, 0, st, P, Bf, B);
+  else if (hist)
+    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, false, true>), grid, block, 0, st, P, Bf, B);
   else
-    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, false>), grid, block, 0, st, P, Bf, B);
+    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, false, false>), grid, block, 0, st, P, Bf, B);
   return pdegym::check_launch("step1d");
 }
 
@@ -342,7 +451,8 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
     return pdegym::fail(-3, "null device buffer");
   if (P.reward_kind != PDEGYM_REWARD_NONE && !buf->reward) return pdegym::fail(-3, "null reward buffer");
   hipStream_t st = (hipStream_t)stream;
-  const int epl = (P.n + kWave - 1) / kWave;
+  const int nslots = P.n - (PARABOLIC ? 1 : 0);  // parabolic node 0 lives in a wave-uniform register
+  const int epl = (nslots + kWave - 1) / kWave;
   switch (epl) {
     case 1: return launch_epl<1, PARABOLIC>(P, *buf, B, st);
     case 2: return launch_epl<2, PARABOLIC>(P, *buf, B, st);

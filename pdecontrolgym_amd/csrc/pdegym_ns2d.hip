@@ -16,6 +16,8 @@
 //                   (see DESIGN.md).  Same arithmetic, reassociated only where stated.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "pdegym.h"
 #include "pdegym_common.h"
 
@@ -28,8 +30,14 @@ struct NSConst {
 
 template <typename T>
 struct NSScal {
-  T dt, two_dx, two_dy, dxdy, nu, rho_over_dt, dt_over_rho, gamma_half, inv_unused;
+  T dt, two_dx, two_dy, dxdy, nu, rho_over_dt, dt_over_rho, gamma_half;
+  T inv_two_dx, inv_two_dy, inv_dxdy;  // float32 throughput mode multiplies by reciprocals
 };
+
+// Division by a grid constant.  double: true IEEE division (bit parity with NumPy).  float: multiply by the
+// reciprocal (rounded once on the host) -- inside the stated float32 tolerance, ~10x fewer instructions.
+__device__ __forceinline__ double div_c(double a, double c, double /*inv_c*/) { return a / c; }
+__device__ __forceinline__ float div_c(float a, float /*c*/, float inv_c) { return a * inv_c; }
 
 template <typename T>
 struct NSPtrs {
@@ -130,8 +138,8 @@ __device__ __forceinline__ void compute_rhs(const T* us, const T* vs, T* rhs, in
     T r = 0;
     if (i >= 1 && i <= ny - 2 && j >= 1 && j <= nx - 2) {
       // navier_stokes2D.py:101-103   rho/dt * (d/dx u* + d/dy v*)
-      const T dudx = (us[c + 1] - us[c - 1]) / S.two_dx;
-      const T dvdy = (vs[c + nx] - vs[c - nx]) / S.two_dy;
+      const T dudx = div_c(us[c + 1] - us[c - 1], S.two_dx, S.inv_two_dx);
+      const T dvdy = div_c(vs[c + nx] - vs[c - nx], S.two_dy, S.inv_two_dy);
       r = S.rho_over_dt * (dudx + dvdy);
     }
     rhs[c] = r;
@@ -161,10 +169,10 @@ __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, 
     if (i >= 1 && i <= ny - 2 && j >= 1 && j <= nx - 2) {
       const T uw = u[c - 1], ue = u[c + 1], usn = u[c - nx], unn = u[c + nx];
       const T vw = v[c - 1], ve = v[c + 1], vsn = v[c - nx], vnn = v[c + nx];
-      const T dudx = (ue - uw) / S.two_dx, dudy = (unn - usn) / S.two_dy;
-      const T dvdx = (ve - vw) / S.two_dx, dvdy = (vnn - vsn) / S.two_dy;
-      const T lapu = ((((uw + usn) - (T)4 * uc) + ue) + unn) / S.dxdy;
-      const T lapv = ((((vw + vsn) - (T)4 * vc) + ve) + vnn) / S.dxdy;
+      const T dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx), dudy = div_c(unn - usn, S.two_dy, S.inv_two_dy);
+      const T dvdx = div_c(ve - vw, S.two_dx, S.inv_two_dx), dvdy = div_c(vnn - vsn, S.two_dy, S.inv_two_dy);
+      const T lapu = div_c((((uw + usn) - (T)4 * uc) + ue) + unn, S.dxdy, S.inv_dxdy);
+      const T lapv = div_c((((vw + vsn) - (T)4 * vc) + ve) + vnn, S.dxdy, S.inv_dxdy);
       un = uc + S.dt * (((-uc) * dudx - vc * dudy) + S.nu * lapu);
       vn = vc + S.dt * (((-uc) * dvdx - vc * dvdy) + S.nu * lapv);
     }
@@ -192,8 +200,8 @@ __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, 
     const int i = c / nx, j = c - i * nx;
     T un = us[c], vn = vs[c];
     if (i >= 1 && i <= ny - 2 && j >= 1 && j <= nx - 2) {
-      const T dpdx = (p[c + 1] - p[c - 1]) / S.two_dx;
-      const T dpdy = (p[c + nx] - p[c - nx]) / S.two_dy;
+      const T dpdx = div_c(p[c + 1] - p[c - 1], S.two_dx, S.inv_two_dx);
+      const T dpdy = div_c(p[c + nx] - p[c - nx], S.two_dy, S.inv_two_dy);
       un = un - S.dt_over_rho * dpdx;
       vn = vn - S.dt_over_rho * dpdy;
     }
@@ -237,6 +245,308 @@ __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, 
     P.reward[b] = (((T)-0.5 * ss) / (T)nx) / (T)ny - S.gamma_half * asq;
     P.time_index[b] = t;
     P.terminated[b] = (t >= C.nt - 1) ? 1 : 0;  // navier_stokes2D.py:159-168
+  }
+}
+
+
+// ================================================================================================
+// float32 register-tiled path: grid side n = 16*PS (PS = 8 -> 128x128, PS = 4 -> 64x64).
+// 256 threads per instance, thread (ty,tx) owns the PSxPS patch at (ty*PS, tx*PS) in VGPRs.  Only patch
+// edges cross threads, through a double-buffered LDS halo area (one barrier per exchange).  p and
+// dx*dy*rhs stay in registers for all K Jacobi sweeps; u*, v* are parked in caller scratch meanwhile.
+// Arithmetic is the same expression tree as ns_generic<float>, so both paths agree bit for bit.
+// ================================================================================================
+template <int PS>
+struct TileCfg {
+  static constexpr int NP = PS / 4;                 // float4 planes per patch edge
+  static constexpr int BUF = 4 * NP * 256;          // float4 per halo buffer
+  static constexpr int LDS_BYTES = 2 * BUF * 16;    // two buffers
+};
+
+template <int PS>
+struct Halo {
+  float t[PS], b[PS], l[PS], r[PS];
+};
+
+template <int PS>
+__device__ __forceinline__ void halo_exchange(const float (&f)[PS][PS], Halo<PS>& H, float4* lds, int& xc, int tid, int ty,
+                                              int tx) {
+  constexpr int NP = TileCfg<PS>::NP;
+  float4* base = lds + (xc & 1) * TileCfg<PS>::BUF;
+  ++xc;
+  float4* eT = base;
+  float4* eB = base + NP * 256;
+  float4* eL = base + 2 * NP * 256;
+  float4* eR = base + 3 * NP * 256;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    eT[q * 256 + tid] = make_float4(f[0][4 * q], f[0][4 * q + 1], f[0][4 * q + 2], f[0][4 * q + 3]);
+    eB[q * 256 + tid] = make_float4(f[PS - 1][4 * q], f[PS - 1][4 * q + 1], f[PS - 1][4 * q + 2], f[PS - 1][4 * q + 3]);
+    eL[q * 256 + tid] = make_float4(f[4 * q][0], f[4 * q + 1][0], f[4 * q + 2][0], f[4 * q + 3][0]);
+    eR[q * 256 + tid] = make_float4(f[4 * q][PS - 1], f[4 * q + 1][PS - 1], f[4 * q + 2][PS - 1], f[4 * q + 3][PS - 1]);
+  }
+  __syncthreads();
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const float4 a = (ty > 0) ? eB[q * 256 + tid - 16] : z;   // row above = bottom edge of (ty-1, tx)
+    const float4 b = (ty < 15) ? eT[q * 256 + tid + 16] : z;  // row below = top edge of (ty+1, tx)
+    const float4 c = (tx > 0) ? eR[q * 256 + tid - 1] : z;    // column to the left = right edge of (ty, tx-1)
+    const float4 d = (tx < 15) ? eL[q * 256 + tid + 1] : z;   // column to the right = left edge of (ty, tx+1)
+    H.t[4 * q] = a.x; H.t[4 * q + 1] = a.y; H.t[4 * q + 2] = a.z; H.t[4 * q + 3] = a.w;
+    H.b[4 * q] = b.x; H.b[4 * q + 1] = b.y; H.b[4 * q + 2] = b.z; H.b[4 * q + 3] = b.w;
+    H.l[4 * q] = c.x; H.l[4 * q + 1] = c.y; H.l[4 * q + 2] = c.z; H.l[4 * q + 3] = c.w;
+    H.r[4 * q] = d.x; H.r[4 * q + 1] = d.y; H.r[4 * q + 2] = d.z; H.r[4 * q + 3] = d.w;
+  }
+}
+
+template <int PS>
+__device__ __forceinline__ void load_patch(float (&f)[PS][PS], const float* g, int n, int r0, int c0) {
+#pragma unroll
+  for (int a = 0; a < PS; ++a) {
+    const float4* row = reinterpret_cast<const float4*>(g + (size_t)(r0 + a) * n + c0);
+#pragma unroll
+    for (int q = 0; q < PS / 4; ++q) {
+      const float4 w = row[q];
+      f[a][4 * q] = w.x; f[a][4 * q + 1] = w.y; f[a][4 * q + 2] = w.z; f[a][4 * q + 3] = w.w;
+    }
+  }
+}
+
+template <int PS>
+__device__ __forceinline__ void store_patch(const float (&f)[PS][PS], float* g, int n, int r0, int c0) {
+#pragma unroll
+  for (int a = 0; a < PS; ++a) {
+    float4* row = reinterpret_cast<float4*>(g + (size_t)(r0 + a) * n + c0);
+#pragma unroll
+    for (int q = 0; q < PS / 4; ++q) row[q] = make_float4(f[a][4 * q], f[a][4 * q + 1], f[a][4 * q + 2], f[a][4 * q + 3]);
+  }
+}
+
+struct EdgeFlags {
+  bool top, bot, lef, rig;
+};
+
+// apply_boundary on a patch: the four ordered passes (lower, upper, left, right) only touch cells of edge
+// threads and only read the line next to the edge, which lives in the same patch -> no communication.
+template <int PS>
+__device__ __forceinline__ void apply_bc_patch(float (&f)[PS][PS], const EdgeFlags& E, const int (&bc)[4][2], int comp,
+                                               const float* act, int action_dim, int r0, int c0) {
+  auto aval = [&](int idx) -> float { return action_dim == 1 ? act[0] : act[idx]; };
+  if (E.top) {
+    const int c = bc[PDEGYM_EDGE_LOWER][comp];
+#pragma unroll
+    for (int b = 0; b < PS; ++b) f[0][b] = (c == PDEGYM_BC_NEUMANN) ? f[1][b] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(c0 + b));
+  }
+  if (E.bot) {
+    const int c = bc[PDEGYM_EDGE_UPPER][comp];
+#pragma unroll
+    for (int b = 0; b < PS; ++b)
+      f[PS - 1][b] = (c == PDEGYM_BC_NEUMANN) ? f[PS - 2][b] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(c0 + b));
+  }
+  if (E.lef) {
+    const int c = bc[PDEGYM_EDGE_LEFT][comp];
+#pragma unroll
+    for (int a = 0; a < PS; ++a) f[a][0] = (c == PDEGYM_BC_NEUMANN) ? f[a][1] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(r0 + a));
+  }
+  if (E.rig) {
+    const int c = bc[PDEGYM_EDGE_RIGHT][comp];
+#pragma unroll
+    for (int a = 0; a < PS; ++a)
+      f[a][PS - 1] = (c == PDEGYM_BC_NEUMANN) ? f[a][PS - 2] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(r0 + a));
+  }
+}
+
+template <int PS>
+__device__ __forceinline__ bool on_domain_edge(const EdgeFlags& E, int a, int b) {
+  return (a == 0 && E.top) || (a == PS - 1 && E.bot) || (b == 0 && E.lef) || (b == PS - 1 && E.rig);
+}
+
+template <int PS>
+__global__ __launch_bounds__(256, 2) void ns_tile_step(NSConst C, NSScal<float> S, NSPtrs<float> P, int B) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float4* lds = reinterpret_cast<float4*>(smem_raw);
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  constexpr int n = 16 * PS;
+  constexpr int ncell = n * n;
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int r0 = ty * PS, c0 = tx * PS;
+  const EdgeFlags E{ty == 0, ty == 15, tx == 0, tx == 15};
+  float* u = P.u + (size_t)b * ncell;
+  float* v = P.v + (size_t)b * ncell;
+  float* p = P.p + (size_t)b * ncell;
+  float* us = P.scratch + (size_t)b * 4 * ncell;
+  float* vs = us + ncell;
+  const float* act = P.action + (size_t)b * C.action_dim;
+  int xc = 0;
+
+  float rr[PS][PS];  // dx*dy*rhs, kept for all sweeps
+  {
+    float uf[PS][PS], vf[PS][PS];
+    load_patch<PS>(uf, u, n, r0, c0);
+    load_patch<PS>(vf, v, n, r0, c0);
+    // ---- predictor (navier_stokes2D.py:130-138) ----
+    {
+      Halo<PS> HU, HV;
+      halo_exchange<PS>(uf, HU, lds, xc, tid, ty, tx);
+      halo_exchange<PS>(vf, HV, lds, xc, tid, ty, tx);
+      float pu[PS], pv[PS];  // old row a-1
+#pragma unroll
+      for (int k = 0; k < PS; ++k) { pu[k] = HU.t[k]; pv[k] = HV.t[k]; }
+#pragma unroll
+      for (int a = 0; a < PS; ++a) {
+        float cu[PS], cv[PS];
+#pragma unroll
+        for (int k = 0; k < PS; ++k) { cu[k] = uf[a][k]; cv[k] = vf[a][k]; }
+#pragma unroll
+        for (int k = 0; k < PS; ++k) {
+          const float uc = cu[k], vc = cv[k];
+          const float uw = (k == 0) ? HU.l[a] : cu[k - 1], ue = (k == PS - 1) ? HU.r[a] : cu[k + 1];
+          const float vw = (k == 0) ? HV.l[a] : cv[k - 1], ve = (k == PS - 1) ? HV.r[a] : cv[k + 1];
+          const float usn = pu[k], vsn = pv[k];
+          const float unn = (a == PS - 1) ? HU.b[k] : uf[a + 1][k];
+          const float vnn = (a == PS - 1) ? HV.b[k] : vf[a + 1][k];
+          const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx), dudy = div_c(unn - usn, S.two_dy, S.inv_two_dy);
+          const float dvdx = div_c(ve - vw, S.two_dx, S.inv_two_dx), dvdy = div_c(vnn - vsn, S.two_dy, S.inv_two_dy);
+          const float lapu = div_c((((uw + usn) - 4.0f * uc) + ue) + unn, S.dxdy, S.inv_dxdy);
+          const float lapv = div_c((((vw + vsn) - 4.0f * vc) + ve) + vnn, S.dxdy, S.inv_dxdy);
+          const float un = uc + S.dt * (((-uc) * dudx - vc * dudy) + S.nu * lapu);
+          const float vn = vc + S.dt * (((-uc) * dvdx - vc * dvdy) + S.nu * lapv);
+          const bool edge = on_domain_edge<PS>(E, a, k);
+          uf[a][k] = edge ? uc : un;
+          vf[a][k] = edge ? vc : vn;
+        }
+#pragma unroll
+        for (int k = 0; k < PS; ++k) { pu[k] = cu[k]; pv[k] = cv[k]; }
+      }
+    }
+    // ---- apply_boundary(u*, v*) (:140) ----
+    apply_bc_patch<PS>(uf, E, C.bc, 0, act, C.action_dim, r0, c0);
+    apply_bc_patch<PS>(vf, E, C.bc, 1, act, C.action_dim, r0, c0);
+    store_patch<PS>(uf, us, n, r0, c0);
+    store_patch<PS>(vf, vs, n, r0, c0);
+    // ---- rhs (:101-103), pre-multiplied by dx*dy (:108) ----
+    {
+      Halo<PS> HU, HV;
+      halo_exchange<PS>(uf, HU, lds, xc, tid, ty, tx);
+      halo_exchange<PS>(vf, HV, lds, xc, tid, ty, tx);
+#pragma unroll
+      for (int a = 0; a < PS; ++a)
+#pragma unroll
+        for (int k = 0; k < PS; ++k) {
+          const float uw = (k == 0) ? HU.l[a] : uf[a][k - 1], ue = (k == PS - 1) ? HU.r[a] : uf[a][k + 1];
+          const float vsn = (a == 0) ? HV.t[k] : vf[a - 1][k], vnn = (a == PS - 1) ? HV.b[k] : vf[a + 1][k];
+          const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx);
+          const float dvdy = div_c(vnn - vsn, S.two_dy, S.inv_two_dy);
+          const float r = S.rho_over_dt * (dudx + dvdy);
+          rr[a][k] = on_domain_edge<PS>(E, a, k) ? 0.0f : S.dxdy * r;
+        }
+    }
+  }
+
+  // ---- K Jacobi sweeps (:104-114), p and rr in registers ----
+  float pf[PS][PS];
+  load_patch<PS>(pf, p, n, r0, c0);
+  for (int it = 0; it < C.iters; ++it) {
+    Halo<PS> H;
+    halo_exchange<PS>(pf, H, lds, xc, tid, ty, tx);
+    float prev[PS];
+#pragma unroll
+    for (int k = 0; k < PS; ++k) prev[k] = H.t[k];
+#pragma unroll
+    for (int a = 0; a < PS; ++a) {
+      float cur[PS];
+#pragma unroll
+      for (int k = 0; k < PS; ++k) cur[k] = pf[a][k];
+#pragma unroll
+      for (int k = 0; k < PS; ++k) {
+        const float w = (k == 0) ? H.l[a] : cur[k - 1], e = (k == PS - 1) ? H.r[a] : cur[k + 1];
+        const float nn = (a == PS - 1) ? H.b[k] : pf[a + 1][k];
+        const float s4 = ((w + prev[k]) + e) + nn;          // ((W + S) + E) + N
+        pf[a][k] = 0.25f * (s4 - rr[a][k]);
+      }
+#pragma unroll
+      for (int k = 0; k < PS; ++k) prev[k] = cur[k];
+    }
+    // Neumann walls (:110-113): every boundary cell = nearest interior value of THIS sweep
+    if (E.top) {
+#pragma unroll
+      for (int k = 0; k < PS; ++k) pf[0][k] = pf[1][k];
+    }
+    if (E.bot) {
+#pragma unroll
+      for (int k = 0; k < PS; ++k) pf[PS - 1][k] = pf[PS - 2][k];
+    }
+    if (E.lef) {
+#pragma unroll
+      for (int a = 0; a < PS; ++a) pf[a][0] = pf[a][1];
+    }
+    if (E.rig) {
+#pragma unroll
+      for (int a = 0; a < PS; ++a) pf[a][PS - 1] = pf[a][PS - 2];
+    }
+  }
+  store_patch<PS>(pf, p, n, r0, c0);
+
+  // ---- corrector (:143-146), observation, reward ----
+  float acc = 0.f;
+  const int t = P.time_index[b] + 1;
+  const int tr = t < C.nt_ref ? t : C.nt_ref - 1;
+  {
+    Halo<PS> H;
+    halo_exchange<PS>(pf, H, lds, xc, tid, ty, tx);
+    float uf[PS][PS], vf[PS][PS];
+    load_patch<PS>(uf, us, n, r0, c0);   // written by this same thread above
+    load_patch<PS>(vf, vs, n, r0, c0);
+#pragma unroll
+    for (int a = 0; a < PS; ++a)
+#pragma unroll
+      for (int k = 0; k < PS; ++k) {
+        const float pw = (k == 0) ? H.l[a] : pf[a][k - 1], pe = (k == PS - 1) ? H.r[a] : pf[a][k + 1];
+        const float ps = (a == 0) ? H.t[k] : pf[a - 1][k], pn = (a == PS - 1) ? H.b[k] : pf[a + 1][k];
+        const float dpdx = div_c(pe - pw, S.two_dx, S.inv_two_dx);
+        const float dpdy = div_c(pn - ps, S.two_dy, S.inv_two_dy);
+        const bool edge = on_domain_edge<PS>(E, a, k);
+        uf[a][k] = edge ? uf[a][k] : uf[a][k] - S.dt_over_rho * dpdx;
+        vf[a][k] = edge ? vf[a][k] : vf[a][k] - S.dt_over_rho * dpdy;
+      }
+    apply_bc_patch<PS>(uf, E, C.bc, 0, act, C.action_dim, r0, c0);
+    apply_bc_patch<PS>(vf, E, C.bc, 1, act, C.action_dim, r0, c0);
+    store_patch<PS>(uf, u, n, r0, c0);
+    store_patch<PS>(vf, v, n, r0, c0);
+    const float* uref = P.U_ref + (size_t)tr * ncell * 2;
+    float* obs = P.obs + (size_t)b * ncell * 2;
+#pragma unroll
+    for (int a = 0; a < PS; ++a) {
+      const size_t o = ((size_t)(r0 + a) * n + c0) * 2;
+      const float4* rrow = reinterpret_cast<const float4*>(uref + o);
+      float4* orow = reinterpret_cast<float4*>(obs + o);
+#pragma unroll
+      for (int q = 0; q < PS / 2; ++q) {
+        const float4 w = rrow[q];
+        const float a0 = uf[a][2 * q], b0 = vf[a][2 * q], a1 = uf[a][2 * q + 1], b1 = vf[a][2 * q + 1];
+        orow[q] = make_float4(a0, b0, a1, b1);
+        const float d0 = a0 - w.x, d1 = b0 - w.y, d2 = a1 - w.z, d3 = b1 - w.w;
+        acc += d0 * d0;
+        acc += d1 * d1;
+        acc += d2 * d2;
+        acc += d3 * d3;
+      }
+    }
+  }
+  float* red = reinterpret_cast<float*>(lds);   // halo buffers are idle now (block_sum syncs first)
+  const float ss = block_sum<float>(acc, red);
+  if (tid == 0) {
+    float asq = 0.f;
+    const float aref = P.action_ref[tr];
+    for (int k = 0; k < C.action_dim; ++k) {
+      const float d = act[k] - aref;
+      asq += d * d;
+    }
+    P.reward[b] = ((-0.5f * ss) / (float)n) / (float)n - S.gamma_half * asq;
+    P.time_index[b] = t;
+    P.terminated[b] = (t >= C.nt - 1) ? 1 : 0;
   }
 }
 
@@ -308,8 +618,16 @@ int fill(const pdegym_params_ns2d* prm, NSConst& C, NSScal<T>& S) {
   S.rho_over_dt = (T)(prm->density / prm->dt);
   S.dt_over_rho = (T)(prm->dt / prm->density);
   S.gamma_half = (T)(prm->gamma / 2);
-  S.inv_unused = 0;
+  S.inv_two_dx = (T)(1.0 / (2 * prm->dx));
+  S.inv_two_dy = (T)(1.0 / (2 * prm->dy));
+  S.inv_dxdy = (T)(1.0 / (prm->dx * prm->dy));
   return 0;
+}
+
+// PDEGYM_NS_GENERIC=1 in the environment routes float32 steps through ns_generic (A/B testing of the tiled path)
+inline bool pdegym_force_generic() {
+  const char* e = getenv("PDEGYM_NS_GENERIC");
+  return e && e[0] == '1';
 }
 
 inline int block_threads(int ncell) {
@@ -332,6 +650,16 @@ int ns_step(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int B, v
   C.nt_ref = buf->nt_ref;
   NSPtrs<T> P{(T*)buf->u, (T*)buf->v, (T*)buf->p, (T*)buf->scratch, (const T*)buf->action, buf->time_index,
               (const T*)buf->U_ref, (const T*)buf->action_ref, (T*)buf->obs, (T*)buf->reward, buf->terminated};
+  if constexpr (sizeof(T) == 4) {
+    // register-tiled float32 path for the square grids it is instantiated for (BASELINE config 4 is 128x128)
+    if (!pdegym_force_generic() && C.nx == C.ny && (C.nx == 128 || C.nx == 64)) {
+      if (C.nx == 128)
+        hipLaunchKernelGGL(ns_tile_step<8>, dim3(B), dim3(256), TileCfg<8>::LDS_BYTES, (hipStream_t)stream, C, S, P, B);
+      else
+        hipLaunchKernelGGL(ns_tile_step<4>, dim3(B), dim3(256), TileCfg<4>::LDS_BYTES, (hipStream_t)stream, C, S, P, B);
+      return pdegym::check_launch("ns2d_tile_step");
+    }
+  }
   hipLaunchKernelGGL(ns_generic_step<T>, dim3(B), dim3(block_threads(C.nx * C.ny)), 0, (hipStream_t)stream, C, S, P, B);
   return pdegym::check_launch("ns2d_step");
 }

@@ -196,3 +196,28 @@ def test_ns_masked_reset_and_properties_c4_size():
     ti = env.time_index.cpu()
     assert torch.equal(ti, torch.where(mask.bool(), 0, 3).int())
     assert torch.equal(env.u.cpu()[::3], u0[::3].float())
+
+
+@pytest.mark.parametrize("n", [128, 64])
+def test_ns_f32_tiled_kernel_equals_generic_kernel_bitwise(n):
+    """The register-tiled float32 kernel and the generic float32 kernel evaluate the same expression tree:
+    fields, pressure and observations must agree bit for bit over several steps (reward: summation order)."""
+    import os
+    kw, u0, v0, p0, acts = _random_case(n, 5, 50, 900 + n, BC_MIX)
+    outs = []
+    for force in ("0", "1"):
+        os.environ["PDEGYM_NS_GENERIC"] = force
+        try:
+            env = _mk(kw, 5, torch.float32)
+            env.reset(u0, v0, p0)
+            res = []
+            for a in acts:
+                obs, r, te = env.step(a)
+                res.append((obs.cpu().numpy().copy(), env.p.cpu().numpy().copy(), r.cpu().numpy().copy()))
+            outs.append(res)
+        finally:
+            os.environ["PDEGYM_NS_GENERIC"] = "0"
+    for (o1, p1, r1), (o2, p2, r2) in zip(*outs):
+        np.testing.assert_array_equal(o1, o2)
+        np.testing.assert_array_equal(p1, p2)
+        np.testing.assert_allclose(r1, r2, rtol=1e-5)
