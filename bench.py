@@ -168,11 +168,8 @@ def run_workload(wl, steps, warmup, world):
         wl.step()
     _barrier(world)
     el = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+    from pdecontrolgym_amd.sharding import max_over_ranks
+    el = max_over_ranks(el, device="cuda")      # the only communication of a multi-GPU run (no data-path collective)
     # per-launch kernel duration with HIP events on the launch stream (outside the timed region)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(extra)]
     for a, b in evs:
