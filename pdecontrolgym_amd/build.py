@@ -17,7 +17,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpdegym_hip.so")
 SOURCES = ["pdegym_abi.hip", "pdegym_1d.hip", "pdegym_ns2d.hip"]
 # -ffp-contract=off: NumPy rounds after every operation; a fused multiply-add would break bit parity.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+# -fno-slp-vectorize: v_pk_*_f32 has the same per-element issue cost as the scalar forms on gfx950 (tools/ubench_valu.hip:
+# 5.1 vs 2.8 cycles per wave-instruction at 4 waves/SIMD) and packing adjacent stencil nodes costs shuffle moves.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

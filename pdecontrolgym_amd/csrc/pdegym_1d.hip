@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "pdegym.h"
@@ -216,6 +217,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
   const int lane = threadIdx.x & (kWave - 1);
   const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (inst >= B) return;  // wave-uniform
+#ifdef PDEGYM_TIMING
+  const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+#endif
   const int n = P.n, ns = n - J0, s0 = lane * EPL;
   float* urow = Bf.u + (size_t)inst * n;
   const float* brow = Bf.beta + (size_t)inst * Bf.beta_stride;
@@ -236,6 +240,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
   R.k = (t_in + PDEGYM_LOOKBACK) % S;
   R.bsum = bsum_in;
 
+#ifdef PDEGYM_TIMING
+  const unsigned long long tm1 = __builtin_amdgcn_s_memtime() + (unsigned long long)(R.x[0] != R.x[0]);
+#endif
   float norm_now;
   if constexpr (kFast) {
     run_substeps<EPL, PARABOLIC, false, true, false>(R, beta, P, nsub, a, ring, nullptr, lane);
@@ -254,6 +261,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
     norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
   }
   const int t = R.t;
+#ifdef PDEGYM_TIMING
+  const unsigned long long tm2 = __builtin_amdgcn_s_memtime() + (unsigned long long)(norm_now != norm_now);
+#endif
 
   // ---- epilogue: norms, flags, reward, observation ------------------------------------------------
   const bool rec_all = P.nt <= PDEGYM_RING;
@@ -361,6 +371,15 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
       ring[0] = n0;
     }
   }
+#ifdef PDEGYM_TIMING
+  if (lane == 0) {
+    const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
+    unsigned int* dbg = reinterpret_cast<unsigned int*>(ring) + 116;
+    dbg[0] = (unsigned int)tm0; dbg[1] = (unsigned int)(tm0 >> 32);
+    dbg[2] = (unsigned int)(tm1 - tm0); dbg[3] = (unsigned int)(tm2 - tm1); dbg[4] = (unsigned int)(tm3 - tm2);
+    dbg[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+  }
+#endif
 }
 
 // ---- reset (state part of hyperbolic.py:214-227 / parabolic.py:208-221) -----------------------------
@@ -424,18 +443,41 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void rownorm2_kernel(const f
   if (lane == 0) out[inst] = sqrtf(ss);
 }
 
+// The dispatcher fills a CU up to its occupancy limit before moving on, so a grid of 4 blocks per CU can land as
+// 8 blocks on some CUs and none on others (measured: wave end times spread 2x, kernel 30 us vs 20 us of work).
+// Requesting an (unused) dynamic LDS slice of 160 KiB / ceil(blocks/CUs) caps the resident blocks per CU at the
+// balanced value, which spreads the grid evenly over all 256 CUs.
+inline int balance_lds_bytes(int nblocks) {
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+    }
+    return n;
+  }();
+  const char* off = getenv("PDEGYM_NO_BALANCE");
+  if (off && off[0] == '1') return 0;
+  const int per_cu = (nblocks + cus - 1) / cus;
+  if (per_cu >= 8) return 0;
+  int bytes = (160 * 1024) / per_cu;
+  bytes &= ~1023;
+  return bytes > 64 * 1024 ? 64 * 1024 : bytes;   // > 64 KiB needs a function attribute; 2 blocks/CU is close enough
+}
+
 template <int EPL, bool PARABOLIC>
 int launch_epl(const pdegym_params1d& P, const pdegym_bufs1d& Bf, int B, hipStream_t st) {
   const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
   const bool neu = P.control_type == PDEGYM_CONTROL_NEUMANN, hist = Bf.history != nullptr;
+  const int lds = balance_lds_bytes((int)grid.x);
   if (neu && hist)
-    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, true, true>), grid, block, 0, st, P, Bf, B);
+    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, true, true>), grid, block, lds, st, P, Bf, B);
   else if (neu)
-    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, true, false>), grid, block, 0, st, P, Bf, B);
+    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, true, false>), grid, block, lds, st, P, Bf, B);
   else if (hist)
-    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, false, true>), grid, block, 0, st, P, Bf, B);
+    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, false, true>), grid, block, lds, st, P, Bf, B);
   else
-    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, false, false>), grid, block, 0, st, P, Bf, B);
+    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, false, false>), grid, block, lds, st, P, Bf, B);
   return pdegym::check_launch("step1d");
 }
 

@@ -263,6 +263,10 @@ struct TileCfg {
   static constexpr int LDS_BYTES = 2 * BUF * 16;    // two buffers
 };
 
+struct EdgeFlags {
+  bool top, bot, lef, rig;
+};
+
 template <int PS>
 struct Halo {
   float t[PS], b[PS], l[PS], r[PS];
@@ -286,17 +290,124 @@ __device__ __forceinline__ void halo_exchange(const float (&f)[PS][PS], Halo<PS>
     eR[q * 256 + tid] = make_float4(f[4 * q][PS - 1], f[4 * q + 1][PS - 1], f[4 * q + 2][PS - 1], f[4 * q + 3][PS - 1]);
   }
   __syncthreads();
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Threads on the domain edge have no neighbour on that side: they re-read their own edge (a valid address) and
+  // never use the value (edge cells are overwritten by the wall / boundary rules), so every read is unconditional.
+  const int up = (ty > 0) ? tid - 16 : tid, dn = (ty < 15) ? tid + 16 : tid;
+  const int lf = (tx > 0) ? tid - 1 : tid, rt = (tx < 15) ? tid + 1 : tid;
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
-    const float4 a = (ty > 0) ? eB[q * 256 + tid - 16] : z;   // row above = bottom edge of (ty-1, tx)
-    const float4 b = (ty < 15) ? eT[q * 256 + tid + 16] : z;  // row below = top edge of (ty+1, tx)
-    const float4 c = (tx > 0) ? eR[q * 256 + tid - 1] : z;    // column to the left = right edge of (ty, tx-1)
-    const float4 d = (tx < 15) ? eL[q * 256 + tid + 1] : z;   // column to the right = left edge of (ty, tx+1)
+    const float4 a = eB[q * 256 + up];   // row above = bottom edge of (ty-1, tx)
+    const float4 b = eT[q * 256 + dn];   // row below = top edge of (ty+1, tx)
+    const float4 c = eR[q * 256 + lf];   // column to the left = right edge of (ty, tx-1)
+    const float4 d = eL[q * 256 + rt];   // column to the right = left edge of (ty, tx+1)
     H.t[4 * q] = a.x; H.t[4 * q + 1] = a.y; H.t[4 * q + 2] = a.z; H.t[4 * q + 3] = a.w;
     H.b[4 * q] = b.x; H.b[4 * q + 1] = b.y; H.b[4 * q + 2] = b.z; H.b[4 * q + 3] = b.w;
     H.l[4 * q] = c.x; H.l[4 * q + 1] = c.y; H.l[4 * q + 2] = c.z; H.l[4 * q + 3] = c.w;
     H.r[4 * q] = d.x; H.r[4 * q + 1] = d.y; H.r[4 * q + 2] = d.z; H.r[4 * q + 3] = d.w;
+  }
+}
+
+// ---- Jacobi sweep on a ROTATING register file ------------------------------------------------------------
+// ph holds PS+1 physical rows: the PS patch rows plus the row above (top halo).  The new value of row a is
+// written into the registers of OLD row a-1 (dead once row a has been computed; new row 0 goes into the halo
+// row), so a sweep needs no register copies at all; the logical->physical row map shifts by one per sweep and
+// returns to the identity after PS+1 sweeps (the sweep loop is unrolled PS+1 times over the rotation R).
+template <int PS>
+__device__ constexpr int prow(int a, int r) {
+  return (((a - r) % (PS + 1)) + (PS + 1)) % (PS + 1);
+}
+
+template <int PS, int R>
+__device__ __forceinline__ void jacobi_sweep_rot(float (&ph)[PS + 1][PS], const float (&rr)[PS][PS], const EdgeFlags& E,
+                                                 float4* lds, int& xc, int tid, int ty, int tx) {
+  constexpr int NP = TileCfg<PS>::NP;
+  float4* base = lds + (xc & 1) * TileCfg<PS>::BUF;
+  ++xc;
+  float4* eT = base;
+  float4* eB = base + NP * 256;
+  float4* eL = base + 2 * NP * 256;
+  float4* eR = base + 3 * NP * 256;
+  constexpr int r0 = prow<PS>(0, R), rl = prow<PS>(PS - 1, R);
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    eT[q * 256 + tid] = make_float4(ph[r0][4 * q], ph[r0][4 * q + 1], ph[r0][4 * q + 2], ph[r0][4 * q + 3]);
+    eB[q * 256 + tid] = make_float4(ph[rl][4 * q], ph[rl][4 * q + 1], ph[rl][4 * q + 2], ph[rl][4 * q + 3]);
+    eL[q * 256 + tid] = make_float4(ph[prow<PS>(4 * q, R)][0], ph[prow<PS>(4 * q + 1, R)][0], ph[prow<PS>(4 * q + 2, R)][0],
+                                    ph[prow<PS>(4 * q + 3, R)][0]);
+    eR[q * 256 + tid] = make_float4(ph[prow<PS>(4 * q, R)][PS - 1], ph[prow<PS>(4 * q + 1, R)][PS - 1],
+                                    ph[prow<PS>(4 * q + 2, R)][PS - 1], ph[prow<PS>(4 * q + 3, R)][PS - 1]);
+  }
+  __syncthreads();
+  const int up = (ty > 0) ? tid - 16 : tid, dn = (ty < 15) ? tid + 16 : tid;
+  const int lf = (tx > 0) ? tid - 1 : tid, rt = (tx < 15) ? tid + 1 : tid;
+  float hb[PS], hl[PS], hr[PS];
+  constexpr int rt_row = prow<PS>(-1, R);  // top halo lands in the free physical row
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const float4 a = eB[q * 256 + up];
+    const float4 b = eT[q * 256 + dn];
+    const float4 c = eR[q * 256 + lf];
+    const float4 d = eL[q * 256 + rt];
+    ph[rt_row][4 * q] = a.x; ph[rt_row][4 * q + 1] = a.y; ph[rt_row][4 * q + 2] = a.z; ph[rt_row][4 * q + 3] = a.w;
+    hb[4 * q] = b.x; hb[4 * q + 1] = b.y; hb[4 * q + 2] = b.z; hb[4 * q + 3] = b.w;
+    hl[4 * q] = c.x; hl[4 * q + 1] = c.y; hl[4 * q + 2] = c.z; hl[4 * q + 3] = c.w;
+    hr[4 * q] = d.x; hr[4 * q + 1] = d.y; hr[4 * q + 2] = d.z; hr[4 * q + 3] = d.w;
+  }
+#pragma unroll
+  for (int a = 0; a < PS; ++a) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int src = prow<PS>(a, R), dst = prow<PS>(a - 1, R), nxt = prow<PS>(a + 1, R);
+#pragma unroll
+    for (int k = 0; k < PS; ++k) {
+      const float w = (k == 0) ? hl[a] : ph[src][k - 1], e = (k == PS - 1) ? hr[a] : ph[src][k + 1];
+      const float nn = (a == PS - 1) ? hb[k] : ph[nxt][k];
+      const float s4 = ((w + ph[dst][k]) + e) + nn;          // ((W + S) + E) + N   (navier_stokes2D.py:106-108)
+      ph[dst][k] = 0.25f * (s4 - rr[a][k]);
+    }
+  }
+  // Neumann walls (:110-113) on the NEW rows (rotation R+1): every boundary cell = nearest interior value
+  constexpr int n0 = prow<PS>(0, R + 1), n1 = prow<PS>(1, R + 1), nl = prow<PS>(PS - 1, R + 1), nm = prow<PS>(PS - 2, R + 1);
+  if (E.top) {
+#pragma unroll
+    for (int k = 0; k < PS; ++k) ph[n0][k] = ph[n1][k];
+  }
+  if (E.bot) {
+#pragma unroll
+    for (int k = 0; k < PS; ++k) ph[nl][k] = ph[nm][k];
+  }
+  if (E.lef) {
+#pragma unroll
+    for (int a = 0; a < PS; ++a) ph[prow<PS>(a, R + 1)][0] = ph[prow<PS>(a, R + 1)][1];
+  }
+  if (E.rig) {
+#pragma unroll
+    for (int a = 0; a < PS; ++a) ph[prow<PS>(a, R + 1)][PS - 1] = ph[prow<PS>(a, R + 1)][PS - 2];
+  }
+}
+
+// K sweeps, unrolled over the PS+1 rotations; returns with the patch back in logical order in pf.
+template <int PS, int R>
+struct SweepChain {
+  static __device__ __forceinline__ int run(float (&ph)[PS + 1][PS], const float (&rr)[PS][PS], const EdgeFlags& E, float4* lds,
+                                            int& xc, int tid, int ty, int tx, int& it, int K) {
+    if (it >= K) return R;
+    jacobi_sweep_rot<PS, R>(ph, rr, E, lds, xc, tid, ty, tx);
+    ++it;
+    if constexpr (R == PS) return -1;  // full cycle done: identity map again
+    else return SweepChain<PS, R + 1>::run(ph, rr, E, lds, xc, tid, ty, tx, it, K);
+  }
+};
+
+template <int PS, int R>
+__device__ __forceinline__ void unrotate(const float (&ph)[PS + 1][PS], float (&pf)[PS][PS], int rot) {
+  if (rot == R) {
+#pragma unroll
+    for (int a = 0; a < PS; ++a)
+#pragma unroll
+      for (int k = 0; k < PS; ++k) pf[a][k] = ph[prow<PS>(a, R)][k];
+  } else if constexpr (R < PS) {
+    unrotate<PS, R + 1>(ph, pf, rot);
   }
 }
 
@@ -322,10 +433,6 @@ __device__ __forceinline__ void store_patch(const float (&f)[PS][PS], float* g, 
     for (int q = 0; q < PS / 4; ++q) row[q] = make_float4(f[a][4 * q], f[a][4 * q + 1], f[a][4 * q + 2], f[a][4 * q + 3]);
   }
 }
-
-struct EdgeFlags {
-  bool top, bot, lef, rig;
-};
 
 // apply_boundary on a patch: the four ordered passes (lower, upper, left, right) only touch cells of edge
 // threads and only read the line next to the edge, which lives in the same patch -> no communication.
@@ -380,6 +487,13 @@ __global__ __launch_bounds__(256, 2) void ns_tile_step(NSConst C, NSScal<float> 
   float* vs = us + ncell;
   const float* act = P.action + (size_t)b * C.action_dim;
   int xc = 0;
+#ifdef PDEGYM_TIMING
+  unsigned long long tm[8];
+  tm[0] = __builtin_amdgcn_s_memtime();
+#define PDEGYM_STAMP(i, dep) tm[i] = __builtin_amdgcn_s_memtime() + (unsigned long long)((dep) != (dep))
+#else
+#define PDEGYM_STAMP(i, dep)
+#endif
 
   float rr[PS][PS];  // dx*dy*rhs, kept for all sweeps
   {
@@ -421,6 +535,7 @@ __global__ __launch_bounds__(256, 2) void ns_tile_step(NSConst C, NSScal<float> 
         for (int k = 0; k < PS; ++k) { pu[k] = cu[k]; pv[k] = cv[k]; }
       }
     }
+    PDEGYM_STAMP(1, uf[0][0]);
     // ---- apply_boundary(u*, v*) (:140) ----
     apply_bc_patch<PS>(uf, E, C.bc, 0, act, C.action_dim, r0, c0);
     apply_bc_patch<PS>(vf, E, C.bc, 1, act, C.action_dim, r0, c0);
@@ -445,48 +560,32 @@ __global__ __launch_bounds__(256, 2) void ns_tile_step(NSConst C, NSScal<float> 
     }
   }
 
-  // ---- K Jacobi sweeps (:104-114), p and rr in registers ----
+  PDEGYM_STAMP(2, rr[0][0]);
+  // ---- K Jacobi sweeps (:104-114), p and rr in registers, rotating row map (no copies) ----
   float pf[PS][PS];
-  load_patch<PS>(pf, p, n, r0, c0);
-  for (int it = 0; it < C.iters; ++it) {
-    Halo<PS> H;
-    halo_exchange<PS>(pf, H, lds, xc, tid, ty, tx);
-    float prev[PS];
+  {
+    float ph[PS + 1][PS];
+    {
+      float tmp[PS][PS];
+      load_patch<PS>(tmp, p, n, r0, c0);
 #pragma unroll
-    for (int k = 0; k < PS; ++k) prev[k] = H.t[k];
+      for (int a = 0; a < PS; ++a)
 #pragma unroll
-    for (int a = 0; a < PS; ++a) {
-      float cur[PS];
+        for (int k = 0; k < PS; ++k) ph[a][k] = tmp[a][k];
 #pragma unroll
-      for (int k = 0; k < PS; ++k) cur[k] = pf[a][k];
-#pragma unroll
-      for (int k = 0; k < PS; ++k) {
-        const float w = (k == 0) ? H.l[a] : cur[k - 1], e = (k == PS - 1) ? H.r[a] : cur[k + 1];
-        const float nn = (a == PS - 1) ? H.b[k] : pf[a + 1][k];
-        const float s4 = ((w + prev[k]) + e) + nn;          // ((W + S) + E) + N
-        pf[a][k] = 0.25f * (s4 - rr[a][k]);
+      for (int k = 0; k < PS; ++k) ph[PS][k] = 0.f;
+    }
+    int it = 0, rot = 0;
+    while (true) {
+      const int r = SweepChain<PS, 0>::run(ph, rr, E, lds, xc, tid, ty, tx, it, C.iters);
+      if (r >= 0) {
+        rot = r;
+        break;
       }
-#pragma unroll
-      for (int k = 0; k < PS; ++k) prev[k] = cur[k];
     }
-    // Neumann walls (:110-113): every boundary cell = nearest interior value of THIS sweep
-    if (E.top) {
-#pragma unroll
-      for (int k = 0; k < PS; ++k) pf[0][k] = pf[1][k];
-    }
-    if (E.bot) {
-#pragma unroll
-      for (int k = 0; k < PS; ++k) pf[PS - 1][k] = pf[PS - 2][k];
-    }
-    if (E.lef) {
-#pragma unroll
-      for (int a = 0; a < PS; ++a) pf[a][0] = pf[a][1];
-    }
-    if (E.rig) {
-#pragma unroll
-      for (int a = 0; a < PS; ++a) pf[a][PS - 1] = pf[a][PS - 2];
-    }
+    unrotate<PS, 0>(ph, pf, rot);
   }
+  PDEGYM_STAMP(3, pf[0][0]);
   store_patch<PS>(pf, p, n, r0, c0);
 
   // ---- corrector (:143-146), observation, reward ----
@@ -535,6 +634,7 @@ __global__ __launch_bounds__(256, 2) void ns_tile_step(NSConst C, NSScal<float> 
       }
     }
   }
+  PDEGYM_STAMP(4, acc);
   float* red = reinterpret_cast<float*>(lds);   // halo buffers are idle now (block_sum syncs first)
   const float ss = block_sum<float>(acc, red);
   if (tid == 0) {
@@ -547,6 +647,11 @@ __global__ __launch_bounds__(256, 2) void ns_tile_step(NSConst C, NSScal<float> 
     P.reward[b] = ((-0.5f * ss) / (float)n) / (float)n - S.gamma_half * asq;
     P.time_index[b] = t;
     P.terminated[b] = (t >= C.nt - 1) ? 1 : 0;
+#ifdef PDEGYM_TIMING
+    tm[5] = __builtin_amdgcn_s_memtime();
+    unsigned int* dbg = reinterpret_cast<unsigned int*>(us + 2 * ncell);   // rhs quarter of the scratch is unused here
+    for (int i = 0; i < 5; ++i) dbg[i] = (unsigned int)(tm[i + 1] - tm[i]);
+#endif
   }
 }
 
