@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PDEGYM_ABI_VERSION 1
+#define PDEGYM_ABI_VERSION 2
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
 #define PDEGYM_MAX_N1D 1024      /* nodes per 1D row handled by the wave-per-instance kernels */
@@ -78,6 +78,8 @@ typedef struct pdegym_params1d {
   float max_state;          /* max_state_value */
   float truncate_penalty;   /* TunedReward1D / NormReward arguments */
   float terminate_reward;
+  double rdx;               /* 1.0/(double)(float)dx: the transport quotient (u[j+1]-u[j])/dx is formed as
+                               (float)((double)d * rdx), which equals the IEEE float32 division bit for bit */
 } pdegym_params1d;
 
 /* Per-instance device buffers of a 1D batch (B instances). */
@@ -113,6 +115,10 @@ int pdegym_parabolic_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, 
  * ring[b, 0] = ||init[b]|| , obs[b] = sensing(init[b]).  (hyperbolic.py:214-227) */
 int pdegym_reset1d_masked(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const float* init,
                           const uint8_t* mask, int32_t B, void* stream);
+
+/* Self-test of the transport quotient: counts i where (float)((double)a[i] * rdx) != a[i] / dx (IEEE division),
+ * bitwise, NaNs compared as equal.  *mismatches (device uint32) must be zeroed by the caller. */
+int pdegym_selftest_quotient(const float* a, float dx, double rdx, uint32_t* mismatches, int32_t n, void* stream);
 
 /* out[b] = ||rows[b, 0:n]||_2 */
 int pdegym_rownorm2_f32(const float* rows, float* out, int32_t n, int32_t B, void* stream);

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 RING = 128
 LOOKBACK = 100
 MAX_N1D = 1024
@@ -24,7 +24,7 @@ EDGES = ("lower", "upper", "left", "right")
 
 EXPORTS = [
     "pdegym_abi_version", "pdegym_last_error", "pdegym_transport_step", "pdegym_parabolic_step",
-    "pdegym_reset1d_masked", "pdegym_rownorm2_f32", "pdegym_ns2d_step_f32", "pdegym_ns2d_step_f64",
+    "pdegym_reset1d_masked", "pdegym_rownorm2_f32", "pdegym_selftest_quotient", "pdegym_ns2d_step_f32", "pdegym_ns2d_step_f64",
     "pdegym_ns2d_solve_pressure_f32", "pdegym_ns2d_solve_pressure_f64", "pdegym_ns2d_reset_masked_f32",
     "pdegym_ns2d_reset_masked_f64",
 ]
@@ -35,7 +35,7 @@ class Params1D(C.Structure):
                 ("normalize", C.c_int32), ("sensing", C.c_int32), ("limit_state", C.c_int32),
                 ("reward_kind", C.c_int32), ("reward_nt", C.c_int32), ("dt", C.c_float), ("dx", C.c_float),
                 ("F", C.c_float), ("max_control", C.c_float), ("max_state", C.c_float),
-                ("truncate_penalty", C.c_float), ("terminate_reward", C.c_float)]
+                ("truncate_penalty", C.c_float), ("terminate_reward", C.c_float), ("rdx", C.c_double)]
 
 
 class Bufs1D(C.Structure):
@@ -86,6 +86,8 @@ def load():
     lib.pdegym_reset1d_masked.restype = C.c_int
     lib.pdegym_rownorm2_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.pdegym_rownorm2_f32.restype = C.c_int
+    lib.pdegym_selftest_quotient.argtypes = [C.c_void_p, C.c_float, C.c_double, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.pdegym_selftest_quotient.restype = C.c_int
     for sfx in ("f32", "f64"):
         if not hasattr(lib, "pdegym_ns2d_step_" + sfx):   # TEMP until pdegym_ns2d.hip lands
             continue

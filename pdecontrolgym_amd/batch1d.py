@@ -16,7 +16,7 @@ small batches (custom reward callbacks, plotting).
 """
 from __future__ import annotations
 
-import math
+import ctypes as C
 from dataclasses import dataclass
 
 from . import _native as N
@@ -95,6 +95,7 @@ class PDEBatch1D:
         P.reward_nt = int(self.reward_spec.nt)
         P.dt, P.dx = dt, dx                       # ctypes c_float rounds the Python double to float32
         P.F = dt / (dx ** 2)                      # parabolic.py:138, computed in double then cast
+        P.rdx = 1.0 / float(C.c_float(dx).value)  # reciprocal of the float32 dx, in double (see pdegym.h)
         P.max_control = max_control_value
         P.max_state = min(max_state_value, 3.4028234663852886e38)
         P.truncate_penalty = self.reward_spec.truncate_penalty

@@ -93,6 +93,8 @@ struct Row {
   int t;          // time_index
   int k;          // (t + LOOKBACK) mod S
   double bsum;    // running sum of |u[tau,-1]|
+  int back_row;   // row index the reward of THIS call looks back at (t_end - 100), if it is produced in this call
+  float back_norm;  // its norm, captured in the loop (lane-uniform)
 };
 
 // S sub-steps of one instance.  FAST: boundary/padding slots are frozen by zero coefficients (no selects);
@@ -145,8 +147,13 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
       float v;
       if constexpr (PARABOLIC) {
         // parabolic.py:143-144   u + F*(um - 2*u + up) + (dt*beta)*u
-        const float t1 = 2.0f * p;
-        const float t2 = pm - t1;
+        float t2;
+        if constexpr (FAST) {
+          t2 = __builtin_fmaf(-2.0f, p, pm);  // == pm - RN(2p): 2p is exact unless it overflows (-> EXACT redo)
+        } else {
+          const float t1 = 2.0f * p;
+          t2 = pm - t1;
+        }
         const float t3 = t2 + pp;
         const float t4 = fe[e] * t3;
         const float t5 = p + t4;
@@ -155,7 +162,14 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
       } else {
         // hyperbolic.py:146-155   u + dt*((up - u)/dx + u[0]*beta)
         const float d1 = pp - p;
-        const float d2 = d1 / dx;
+        float d2;
+        if constexpr (FAST) {
+          // RN32(RN64(d1 * RN64(1/dx))) == RN32(d1/dx): the double product is within 2^-52 (relative) of the true
+          // quotient, while a quotient of two 24-bit floats is never closer than 2^-50 to a float rounding boundary.
+          d2 = (float)((double)d1 * P.rdx);
+        } else {
+          d2 = d1 / dx;
+        }
         const float r = p0 * c[e];
         const float d3 = d2 + r;
         const float d4 = fe[e] * d3;
@@ -191,6 +205,7 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
     if (s + 1 < nsub && (rec_all || R.k == 0 || R.t + PDEGYM_LOOKBACK == P.nt - 1)) {
       const float nr = sqrtf(slots_sumsq<EPL>(R.x, s0, ns));  // node 0 is 0 after any sub-step
       if (lane == 0) ring[R.t & (PDEGYM_RING - 1)] = nr;
+      if (R.t == R.back_row) R.back_norm = nr;                // this call's own look-back row: no memory round trip
     }
   }
   if constexpr (!NEUMANN) R.bsum += (double)nsub * (double)fabsf(bval);
@@ -239,6 +254,17 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
   R.t = t_in;
   R.k = (t_in + PDEGYM_LOOKBACK) % S;
   R.bsum = bsum_in;
+  // look-back row of this call's reward (tuned_reward_1d.py:40): t_end - 100, Python negative index wraps into the
+  // zero-filled tail of the history.  Rows that predate this call are fetched NOW (latency hidden by the loop).
+  const int t_end = t_in + nsub;
+  const int tb = t_end - PDEGYM_LOOKBACK;
+  const int src_row = tb < 0 ? P.nt + tb : tb;
+  const bool zero_row = (tb < 0 && src_row > t_end) || src_row < 0;
+  const bool from_ring = !zero_row && src_row <= t_in;
+  float norm_back_pre = 0.f;
+  if (from_ring && lane == 0) norm_back_pre = ring[src_row & (PDEGYM_RING - 1)];
+  R.back_row = (!zero_row && !from_ring) ? src_row : -1;
+  R.back_norm = 0.f;
 
 #ifdef PDEGYM_TIMING
   const unsigned long long tm1 = __builtin_amdgcn_s_memtime() + (unsigned long long)(R.x[0] != R.x[0]);
@@ -253,6 +279,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
       R.t = t_in;
       R.k = (t_in + PDEGYM_LOOKBACK) % S;
       R.bsum = bsum_in;
+      R.back_norm = 0.f;
       run_substeps<EPL, PARABOLIC, false, false, false>(R, beta, P, nsub, a, ring, nullptr, lane);
       norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
     }
@@ -285,15 +312,12 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
     for (int e = 0; e < EPL; ++e) m = fmaxf(m, (s0 + e < ns) ? fabsf(R.x[e]) : 0.f);
     nr_alt = wave_max(m);
   }
-  // look-back row t-100 (Python negative index wraps into the zero-filled tail of the history).
-  // Only lane 0 ever touches the ring, so its own earlier stores are visible to this load.
+  // look-back norm: fetched before the loop, captured inside it, the final row itself (nsub == 100 ends on it only
+  // when LOOKBACK == 0, never), or 0 for an unwritten row
   float norm_back = 0.f;
   float reward = 0.f;
   if (lane == 0) {
-    const int tb = t - PDEGYM_LOOKBACK;
-    const int src = tb < 0 ? P.nt + tb : tb;
-    const bool zero_row = (tb < 0 && src > t) || src < 0;
-    if (!zero_row) norm_back = ring[src & (PDEGYM_RING - 1)];
+    norm_back = from_ring ? norm_back_pre : ((R.back_row >= 0) ? ((R.back_row == t) ? norm_now : R.back_norm) : 0.f);
     if (P.reward_kind == PDEGYM_REWARD_TUNED1D) {
       if (terminate && norm_now < 20.0f) {
         reward = (P.terminate_reward - ((float)R.bsum) / 1000.0f) - norm_now;  // tuned_reward_1d.py:36-37
@@ -465,6 +489,17 @@ inline int balance_lds_bytes(int nblocks) {
   return bytes > 64 * 1024 ? 64 * 1024 : bytes;   // > 64 KiB needs a function attribute; 2 blocks/CU is close enough
 }
 
+__global__ void selftest_quotient_kernel(const float* a, float dx, double rdx, unsigned int* mismatches, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float x = a[i];
+    const float q_fast = (float)((double)x * rdx);
+    const float q_ieee = x / dx;
+    const bool same = (__builtin_bit_cast(unsigned int, q_fast) == __builtin_bit_cast(unsigned int, q_ieee)) ||
+                      (q_fast != q_fast && q_ieee != q_ieee);
+    if (!same) atomicAdd(mismatches, 1u);
+  }
+}
+
 template <int EPL, bool PARABOLIC>
 int launch_epl(const pdegym_params1d& P, const pdegym_bufs1d& Bf, int B, hipStream_t st) {
   const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
@@ -534,6 +569,13 @@ int pdegym_reset1d_masked(const pdegym_params1d* prm, const pdegym_bufs1d* buf, 
                        mask, B);
   }
   return pdegym::check_launch("reset1d");
+}
+
+int pdegym_selftest_quotient(const float* a, float dx, double rdx, uint32_t* mismatches, int32_t n, void* stream) {
+  if (!a || !mismatches) return pdegym::fail(-1, "null pointer");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(selftest_quotient_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, a, dx, rdx, mismatches, n);
+  return pdegym::check_launch("selftest_quotient");
 }
 
 int pdegym_rownorm2_f32(const float* rows, float* out, int32_t n, int32_t B, void* stream) {

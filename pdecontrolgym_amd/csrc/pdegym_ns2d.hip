@@ -39,6 +39,12 @@ struct NSScal {
 __device__ __forceinline__ double div_c(double a, double c, double /*inv_c*/) { return a / c; }
 __device__ __forceinline__ float div_c(float a, float /*c*/, float inv_c) { return a * inv_c; }
 
+// Jacobi update 1/4*(s4 - dx*dy*rhs) (navier_stokes2D.py:106-108).  float: the per-sweep constant q = dx*dy*rhs is
+// pre-scaled by 0.25 (exact) and the update is one fma: RN(0.25*s4 - 0.25*q) == 0.25*RN(s4 - q) because scaling by
+// a power of two commutes with rounding (outside the subnormal range) -- bit-identical, one instruction fewer.
+__device__ __forceinline__ float jacobi_rhs_term(float dxdy, float rhs) { return 0.25f * (dxdy * rhs); }
+__device__ __forceinline__ float jacobi_update(float s4, float rq) { return __builtin_fmaf(0.25f, s4, -rq); }
+
 template <typename T>
 struct NSPtrs {
   T* u;
@@ -109,7 +115,9 @@ __device__ __forceinline__ void jacobi_sweeps(T* p, T* pB, const T* rhs, int ny,
       if (i >= 1 && i <= ny - 2 && j >= 1 && j <= nx - 2) {
         // navier_stokes2D.py:106-108   1/4 * (W + S + E + N - dx*dy*rhs)
         const T s4 = ((src[c - 1] + src[c - nx]) + src[c + 1]) + src[c + nx];
-        const T val = (T)0.25 * (s4 - dxdy * rhs[c]);
+        T val;
+        if constexpr (sizeof(T) == 4) val = jacobi_update(s4, jacobi_rhs_term(dxdy, rhs[c]));
+        else val = (T)0.25 * (s4 - dxdy * rhs[c]);
         dst[c] = val;
         // navier_stokes2D.py:110-113: four Neumann copies => every boundary cell ends as its nearest interior value
         const bool top = (i == 1), bot = (i == ny - 2), lef = (j == 1), rig = (j == nx - 2);
@@ -250,236 +258,232 @@ __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, 
 
 
 // ================================================================================================
-// float32 register-tiled path: grid side n = 16*PS (PS = 8 -> 128x128, PS = 4 -> 64x64).
-// 256 threads per instance, thread (ty,tx) owns the PSxPS patch at (ty*PS, tx*PS) in VGPRs.  Only patch
-// edges cross threads, through a double-buffered LDS halo area (one barrier per exchange).  p and
-// dx*dy*rhs stay in registers for all K Jacobi sweeps; u*, v* are parked in caller scratch meanwhile.
-// Arithmetic is the same expression tree as ns_generic<float>, so both paths agree bit for bit.
+// float32 register-tiled path: 512 threads per instance, thread (ty, tx) (16 x 32) owns the PR x PC patch at
+// (ty*PR, tx*PC) in VGPRs:  (PR,PC) = (8,4) -> 128x128,  (4,2) -> 64x64.
+//   * left/right patch halos: neighbouring tx are neighbouring LANES (a wave = 2 thread rows of 32 = two full
+//     domain rows of patches), so they move with DPP wave shifts -- no LDS;
+//   * top/bottom patch halos: one PC-wide vector per thread through a double-buffered LDS area (32 KB), one
+//     barrier per exchange;
+//   * p and 0.25*dx*dy*rhs stay in registers for all K Jacobi sweeps on a ROTATING row map (no register copies);
+//     u*, v* are parked in caller scratch meanwhile (L2/MALL resident);
+//   * ~100 VGPRs -> 4 waves per SIMD, two instances per CU.
+// Same expression tree as ns_generic<float> (the fma below is exact-equivalent), so both agree bit for bit.
 // ================================================================================================
-template <int PS>
+template <int N>
+struct VecOf;
+template <>
+struct VecOf<4> { using type = float4; };
+template <>
+struct VecOf<2> { using type = float2; };
+
+template <int PC>
+__device__ __forceinline__ typename VecOf<PC>::type pack_row(const float (&r)[PC]) {
+  if constexpr (PC == 4) return make_float4(r[0], r[1], r[2], r[3]);
+  else return make_float2(r[0], r[1]);
+}
+template <int PC>
+__device__ __forceinline__ void unpack_row(const typename VecOf<PC>::type& v, float (&r)[PC]) {
+  r[0] = v.x;
+  r[1] = v.y;
+  if constexpr (PC == 4) {
+    r[2] = v.z;
+    r[3] = v.w;
+  }
+}
+
+template <int PR, int PC>
 struct TileCfg {
-  static constexpr int NP = PS / 4;                 // float4 planes per patch edge
-  static constexpr int BUF = 4 * NP * 256;          // float4 per halo buffer
-  static constexpr int LDS_BYTES = 2 * BUF * 16;    // two buffers
+  static constexpr int NT = 512;
+  static constexpr int N = 32 * PC;                      // grid side (== 16 * PR)
+  static constexpr int BUF = 2 * NT;                     // vectors per halo buffer (top edges, bottom edges)
+  static constexpr int LDS_BYTES = 2 * BUF * PC * 4;     // two buffers
+  static_assert(16 * PR == 32 * PC, "square grids only");
 };
 
 struct EdgeFlags {
   bool top, bot, lef, rig;
 };
 
-template <int PS>
+// lane i <- lane i-1 / lane i+1 (DPP wave_shr:1 / wave_shl:1); the lane without a source gets 0 (never used:
+// it is a domain-edge thread)
+__device__ __forceinline__ float lane_left(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_right(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+// top/bottom halo rows through LDS: ht = bottom row of the thread above, hb = top row of the thread below.
+// Domain-edge threads re-read their own row (valid address, value never used): every access is unconditional.
+template <int PC>
+__device__ __forceinline__ void halo_tb(const float (&top)[PC], const float (&bot)[PC], float (&ht)[PC], float (&hb)[PC],
+                                        float* lds, int& xc, int tid, int ty) {
+  using V = typename VecOf<PC>::type;
+  V* base = reinterpret_cast<V*>(lds) + (xc & 1) * (2 * 512);
+  ++xc;
+  V* eT = base;
+  V* eB = base + 512;
+  eT[tid] = pack_row<PC>(top);
+  eB[tid] = pack_row<PC>(bot);
+  __syncthreads();
+  const int up = (ty > 0) ? tid - 32 : tid, dn = (ty < 15) ? tid + 32 : tid;
+  const V a = eB[up];
+  const V b = eT[dn];
+  unpack_row<PC>(a, ht);
+  unpack_row<PC>(b, hb);
+}
+
+template <int PR, int PC>
 struct Halo {
-  float t[PS], b[PS], l[PS], r[PS];
+  float t[PC], b[PC], l[PR], r[PR];
 };
 
-template <int PS>
-__device__ __forceinline__ void halo_exchange(const float (&f)[PS][PS], Halo<PS>& H, float4* lds, int& xc, int tid, int ty,
-                                              int tx) {
-  constexpr int NP = TileCfg<PS>::NP;
-  float4* base = lds + (xc & 1) * TileCfg<PS>::BUF;
-  ++xc;
-  float4* eT = base;
-  float4* eB = base + NP * 256;
-  float4* eL = base + 2 * NP * 256;
-  float4* eR = base + 3 * NP * 256;
+template <int PR, int PC>
+__device__ __forceinline__ void halo_exchange(const float (&f)[PR][PC], Halo<PR, PC>& H, float* lds, int& xc, int tid, int ty) {
+  halo_tb<PC>(f[0], f[PR - 1], H.t, H.b, lds, xc, tid, ty);
 #pragma unroll
-  for (int q = 0; q < NP; ++q) {
-    eT[q * 256 + tid] = make_float4(f[0][4 * q], f[0][4 * q + 1], f[0][4 * q + 2], f[0][4 * q + 3]);
-    eB[q * 256 + tid] = make_float4(f[PS - 1][4 * q], f[PS - 1][4 * q + 1], f[PS - 1][4 * q + 2], f[PS - 1][4 * q + 3]);
-    eL[q * 256 + tid] = make_float4(f[4 * q][0], f[4 * q + 1][0], f[4 * q + 2][0], f[4 * q + 3][0]);
-    eR[q * 256 + tid] = make_float4(f[4 * q][PS - 1], f[4 * q + 1][PS - 1], f[4 * q + 2][PS - 1], f[4 * q + 3][PS - 1]);
-  }
-  __syncthreads();
-  // Threads on the domain edge have no neighbour on that side: they re-read their own edge (a valid address) and
-  // never use the value (edge cells are overwritten by the wall / boundary rules), so every read is unconditional.
-  const int up = (ty > 0) ? tid - 16 : tid, dn = (ty < 15) ? tid + 16 : tid;
-  const int lf = (tx > 0) ? tid - 1 : tid, rt = (tx < 15) ? tid + 1 : tid;
-#pragma unroll
-  for (int q = 0; q < NP; ++q) {
-    const float4 a = eB[q * 256 + up];   // row above = bottom edge of (ty-1, tx)
-    const float4 b = eT[q * 256 + dn];   // row below = top edge of (ty+1, tx)
-    const float4 c = eR[q * 256 + lf];   // column to the left = right edge of (ty, tx-1)
-    const float4 d = eL[q * 256 + rt];   // column to the right = left edge of (ty, tx+1)
-    H.t[4 * q] = a.x; H.t[4 * q + 1] = a.y; H.t[4 * q + 2] = a.z; H.t[4 * q + 3] = a.w;
-    H.b[4 * q] = b.x; H.b[4 * q + 1] = b.y; H.b[4 * q + 2] = b.z; H.b[4 * q + 3] = b.w;
-    H.l[4 * q] = c.x; H.l[4 * q + 1] = c.y; H.l[4 * q + 2] = c.z; H.l[4 * q + 3] = c.w;
-    H.r[4 * q] = d.x; H.r[4 * q + 1] = d.y; H.r[4 * q + 2] = d.z; H.r[4 * q + 3] = d.w;
+  for (int a = 0; a < PR; ++a) {
+    H.l[a] = lane_left(f[a][PC - 1]);
+    H.r[a] = lane_right(f[a][0]);
   }
 }
 
-// ---- Jacobi sweep on a ROTATING register file ------------------------------------------------------------
-// ph holds PS+1 physical rows: the PS patch rows plus the row above (top halo).  The new value of row a is
-// written into the registers of OLD row a-1 (dead once row a has been computed; new row 0 goes into the halo
-// row), so a sweep needs no register copies at all; the logical->physical row map shifts by one per sweep and
-// returns to the identity after PS+1 sweeps (the sweep loop is unrolled PS+1 times over the rotation R).
-template <int PS>
-__device__ constexpr int prow(int a, int r) {
-  return (((a - r) % (PS + 1)) + (PS + 1)) % (PS + 1);
+template <int PR, int PC>
+__device__ __forceinline__ void load_patch(float (&f)[PR][PC], const float* g, int n, int r0, int c0) {
+  using V = typename VecOf<PC>::type;
+#pragma unroll
+  for (int a = 0; a < PR; ++a) unpack_row<PC>(*reinterpret_cast<const V*>(g + (size_t)(r0 + a) * n + c0), f[a]);
 }
 
-template <int PS, int R>
-__device__ __forceinline__ void jacobi_sweep_rot(float (&ph)[PS + 1][PS], const float (&rr)[PS][PS], const EdgeFlags& E,
-                                                 float4* lds, int& xc, int tid, int ty, int tx) {
-  constexpr int NP = TileCfg<PS>::NP;
-  float4* base = lds + (xc & 1) * TileCfg<PS>::BUF;
-  ++xc;
-  float4* eT = base;
-  float4* eB = base + NP * 256;
-  float4* eL = base + 2 * NP * 256;
-  float4* eR = base + 3 * NP * 256;
-  constexpr int r0 = prow<PS>(0, R), rl = prow<PS>(PS - 1, R);
+template <int PR, int PC>
+__device__ __forceinline__ void store_patch(const float (&f)[PR][PC], float* g, int n, int r0, int c0) {
+  using V = typename VecOf<PC>::type;
 #pragma unroll
-  for (int q = 0; q < NP; ++q) {
-    eT[q * 256 + tid] = make_float4(ph[r0][4 * q], ph[r0][4 * q + 1], ph[r0][4 * q + 2], ph[r0][4 * q + 3]);
-    eB[q * 256 + tid] = make_float4(ph[rl][4 * q], ph[rl][4 * q + 1], ph[rl][4 * q + 2], ph[rl][4 * q + 3]);
-    eL[q * 256 + tid] = make_float4(ph[prow<PS>(4 * q, R)][0], ph[prow<PS>(4 * q + 1, R)][0], ph[prow<PS>(4 * q + 2, R)][0],
-                                    ph[prow<PS>(4 * q + 3, R)][0]);
-    eR[q * 256 + tid] = make_float4(ph[prow<PS>(4 * q, R)][PS - 1], ph[prow<PS>(4 * q + 1, R)][PS - 1],
-                                    ph[prow<PS>(4 * q + 2, R)][PS - 1], ph[prow<PS>(4 * q + 3, R)][PS - 1]);
-  }
-  __syncthreads();
-  const int up = (ty > 0) ? tid - 16 : tid, dn = (ty < 15) ? tid + 16 : tid;
-  const int lf = (tx > 0) ? tid - 1 : tid, rt = (tx < 15) ? tid + 1 : tid;
-  float hb[PS], hl[PS], hr[PS];
-  constexpr int rt_row = prow<PS>(-1, R);  // top halo lands in the free physical row
-#pragma unroll
-  for (int q = 0; q < NP; ++q) {
-    const float4 a = eB[q * 256 + up];
-    const float4 b = eT[q * 256 + dn];
-    const float4 c = eR[q * 256 + lf];
-    const float4 d = eL[q * 256 + rt];
-    ph[rt_row][4 * q] = a.x; ph[rt_row][4 * q + 1] = a.y; ph[rt_row][4 * q + 2] = a.z; ph[rt_row][4 * q + 3] = a.w;
-    hb[4 * q] = b.x; hb[4 * q + 1] = b.y; hb[4 * q + 2] = b.z; hb[4 * q + 3] = b.w;
-    hl[4 * q] = c.x; hl[4 * q + 1] = c.y; hl[4 * q + 2] = c.z; hl[4 * q + 3] = c.w;
-    hr[4 * q] = d.x; hr[4 * q + 1] = d.y; hr[4 * q + 2] = d.z; hr[4 * q + 3] = d.w;
-  }
-#pragma unroll
-  for (int a = 0; a < PS; ++a) {
-    constexpr int dummy = 0;
-    (void)dummy;
-    const int src = prow<PS>(a, R), dst = prow<PS>(a - 1, R), nxt = prow<PS>(a + 1, R);
-#pragma unroll
-    for (int k = 0; k < PS; ++k) {
-      const float w = (k == 0) ? hl[a] : ph[src][k - 1], e = (k == PS - 1) ? hr[a] : ph[src][k + 1];
-      const float nn = (a == PS - 1) ? hb[k] : ph[nxt][k];
-      const float s4 = ((w + ph[dst][k]) + e) + nn;          // ((W + S) + E) + N   (navier_stokes2D.py:106-108)
-      ph[dst][k] = 0.25f * (s4 - rr[a][k]);
-    }
-  }
-  // Neumann walls (:110-113) on the NEW rows (rotation R+1): every boundary cell = nearest interior value
-  constexpr int n0 = prow<PS>(0, R + 1), n1 = prow<PS>(1, R + 1), nl = prow<PS>(PS - 1, R + 1), nm = prow<PS>(PS - 2, R + 1);
-  if (E.top) {
-#pragma unroll
-    for (int k = 0; k < PS; ++k) ph[n0][k] = ph[n1][k];
-  }
-  if (E.bot) {
-#pragma unroll
-    for (int k = 0; k < PS; ++k) ph[nl][k] = ph[nm][k];
-  }
-  if (E.lef) {
-#pragma unroll
-    for (int a = 0; a < PS; ++a) ph[prow<PS>(a, R + 1)][0] = ph[prow<PS>(a, R + 1)][1];
-  }
-  if (E.rig) {
-#pragma unroll
-    for (int a = 0; a < PS; ++a) ph[prow<PS>(a, R + 1)][PS - 1] = ph[prow<PS>(a, R + 1)][PS - 2];
-  }
-}
-
-// K sweeps, unrolled over the PS+1 rotations; returns with the patch back in logical order in pf.
-template <int PS, int R>
-struct SweepChain {
-  static __device__ __forceinline__ int run(float (&ph)[PS + 1][PS], const float (&rr)[PS][PS], const EdgeFlags& E, float4* lds,
-                                            int& xc, int tid, int ty, int tx, int& it, int K) {
-    if (it >= K) return R;
-    jacobi_sweep_rot<PS, R>(ph, rr, E, lds, xc, tid, ty, tx);
-    ++it;
-    if constexpr (R == PS) return -1;  // full cycle done: identity map again
-    else return SweepChain<PS, R + 1>::run(ph, rr, E, lds, xc, tid, ty, tx, it, K);
-  }
-};
-
-template <int PS, int R>
-__device__ __forceinline__ void unrotate(const float (&ph)[PS + 1][PS], float (&pf)[PS][PS], int rot) {
-  if (rot == R) {
-#pragma unroll
-    for (int a = 0; a < PS; ++a)
-#pragma unroll
-      for (int k = 0; k < PS; ++k) pf[a][k] = ph[prow<PS>(a, R)][k];
-  } else if constexpr (R < PS) {
-    unrotate<PS, R + 1>(ph, pf, rot);
-  }
-}
-
-template <int PS>
-__device__ __forceinline__ void load_patch(float (&f)[PS][PS], const float* g, int n, int r0, int c0) {
-#pragma unroll
-  for (int a = 0; a < PS; ++a) {
-    const float4* row = reinterpret_cast<const float4*>(g + (size_t)(r0 + a) * n + c0);
-#pragma unroll
-    for (int q = 0; q < PS / 4; ++q) {
-      const float4 w = row[q];
-      f[a][4 * q] = w.x; f[a][4 * q + 1] = w.y; f[a][4 * q + 2] = w.z; f[a][4 * q + 3] = w.w;
-    }
-  }
-}
-
-template <int PS>
-__device__ __forceinline__ void store_patch(const float (&f)[PS][PS], float* g, int n, int r0, int c0) {
-#pragma unroll
-  for (int a = 0; a < PS; ++a) {
-    float4* row = reinterpret_cast<float4*>(g + (size_t)(r0 + a) * n + c0);
-#pragma unroll
-    for (int q = 0; q < PS / 4; ++q) row[q] = make_float4(f[a][4 * q], f[a][4 * q + 1], f[a][4 * q + 2], f[a][4 * q + 3]);
-  }
+  for (int a = 0; a < PR; ++a) *reinterpret_cast<V*>(g + (size_t)(r0 + a) * n + c0) = pack_row<PC>(f[a]);
 }
 
 // apply_boundary on a patch: the four ordered passes (lower, upper, left, right) only touch cells of edge
 // threads and only read the line next to the edge, which lives in the same patch -> no communication.
-template <int PS>
-__device__ __forceinline__ void apply_bc_patch(float (&f)[PS][PS], const EdgeFlags& E, const int (&bc)[4][2], int comp,
+template <int PR, int PC>
+__device__ __forceinline__ void apply_bc_patch(float (&f)[PR][PC], const EdgeFlags& E, const int (&bc)[4][2], int comp,
                                                const float* act, int action_dim, int r0, int c0) {
   auto aval = [&](int idx) -> float { return action_dim == 1 ? act[0] : act[idx]; };
   if (E.top) {
     const int c = bc[PDEGYM_EDGE_LOWER][comp];
 #pragma unroll
-    for (int b = 0; b < PS; ++b) f[0][b] = (c == PDEGYM_BC_NEUMANN) ? f[1][b] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(c0 + b));
+    for (int b = 0; b < PC; ++b) f[0][b] = (c == PDEGYM_BC_NEUMANN) ? f[1][b] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(c0 + b));
   }
   if (E.bot) {
     const int c = bc[PDEGYM_EDGE_UPPER][comp];
 #pragma unroll
-    for (int b = 0; b < PS; ++b)
-      f[PS - 1][b] = (c == PDEGYM_BC_NEUMANN) ? f[PS - 2][b] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(c0 + b));
+    for (int b = 0; b < PC; ++b)
+      f[PR - 1][b] = (c == PDEGYM_BC_NEUMANN) ? f[PR - 2][b] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(c0 + b));
   }
   if (E.lef) {
     const int c = bc[PDEGYM_EDGE_LEFT][comp];
 #pragma unroll
-    for (int a = 0; a < PS; ++a) f[a][0] = (c == PDEGYM_BC_NEUMANN) ? f[a][1] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(r0 + a));
+    for (int a = 0; a < PR; ++a) f[a][0] = (c == PDEGYM_BC_NEUMANN) ? f[a][1] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(r0 + a));
   }
   if (E.rig) {
     const int c = bc[PDEGYM_EDGE_RIGHT][comp];
 #pragma unroll
-    for (int a = 0; a < PS; ++a)
-      f[a][PS - 1] = (c == PDEGYM_BC_NEUMANN) ? f[a][PS - 2] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(r0 + a));
+    for (int a = 0; a < PR; ++a)
+      f[a][PC - 1] = (c == PDEGYM_BC_NEUMANN) ? f[a][PC - 2] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(r0 + a));
   }
 }
 
-template <int PS>
+template <int PR, int PC>
 __device__ __forceinline__ bool on_domain_edge(const EdgeFlags& E, int a, int b) {
-  return (a == 0 && E.top) || (a == PS - 1 && E.bot) || (b == 0 && E.lef) || (b == PS - 1 && E.rig);
+  return (a == 0 && E.top) || (a == PR - 1 && E.bot) || (b == 0 && E.lef) || (b == PC - 1 && E.rig);
 }
 
-template <int PS>
-__global__ __launch_bounds__(256, 2) void ns_tile_step(NSConst C, NSScal<float> S, NSPtrs<float> P, int B) {
+// ---- Jacobi sweep on a ROTATING register file ------------------------------------------------------------
+// ph holds PR+1 physical rows: the PR patch rows plus the row above (top halo).  The new value of row a is
+// written into the registers of OLD row a-1 (dead once row a has been computed; new row 0 goes into the halo
+// row), so a sweep needs no register copies; the logical->physical row map shifts by one per sweep and returns
+// to the identity after PR+1 sweeps (the sweep loop is unrolled PR+1 times over the rotation R).
+template <int PR>
+__device__ constexpr int prow(int a, int r) {
+  return (((a - r) % (PR + 1)) + (PR + 1)) % (PR + 1);
+}
+
+template <int PR, int PC, int R>
+__device__ __forceinline__ void jacobi_sweep_rot(float (&ph)[PR + 1][PC], const float (&rq)[PR][PC], const EdgeFlags& E,
+                                                 float* lds, int& xc, int tid, int ty) {
+  float hb[PC], hl[PR], hr[PR];
+  halo_tb<PC>(ph[prow<PR>(0, R)], ph[prow<PR>(PR - 1, R)], ph[prow<PR>(-1, R)], hb, lds, xc, tid, ty);
+#pragma unroll
+  for (int a = 0; a < PR; ++a) {
+    hl[a] = lane_left(ph[prow<PR>(a, R)][PC - 1]);
+    hr[a] = lane_right(ph[prow<PR>(a, R)][0]);
+  }
+#pragma unroll
+  for (int a = 0; a < PR; ++a) {
+    const int src = prow<PR>(a, R), dst = prow<PR>(a - 1, R), nxt = prow<PR>(a + 1, R);
+#pragma unroll
+    for (int k = 0; k < PC; ++k) {
+      const float w = (k == 0) ? hl[a] : ph[src][k - 1], e = (k == PC - 1) ? hr[a] : ph[src][k + 1];
+      const float nn = (a == PR - 1) ? hb[k] : ph[nxt][k];
+      const float s4 = ((w + ph[dst][k]) + e) + nn;          // ((W + S) + E) + N   (navier_stokes2D.py:106-108)
+      ph[dst][k] = jacobi_update(s4, rq[a][k]);
+    }
+  }
+  // Neumann walls (:110-113) on the NEW rows (rotation R+1): every boundary cell = nearest interior value
+  constexpr int n0 = prow<PR>(0, R + 1), n1 = prow<PR>(1, R + 1), nl = prow<PR>(PR - 1, R + 1), nm = prow<PR>(PR - 2, R + 1);
+  if (E.top) {
+#pragma unroll
+    for (int k = 0; k < PC; ++k) ph[n0][k] = ph[n1][k];
+  }
+  if (E.bot) {
+#pragma unroll
+    for (int k = 0; k < PC; ++k) ph[nl][k] = ph[nm][k];
+  }
+  if (E.lef) {
+#pragma unroll
+    for (int a = 0; a < PR; ++a) ph[prow<PR>(a, R + 1)][0] = ph[prow<PR>(a, R + 1)][1];
+  }
+  if (E.rig) {
+#pragma unroll
+    for (int a = 0; a < PR; ++a) ph[prow<PR>(a, R + 1)][PC - 1] = ph[prow<PR>(a, R + 1)][PC - 2];
+  }
+}
+
+// up to PR+1 sweeps, one per rotation; returns the rotation at which K was reached, or -1 after a full cycle
+template <int PR, int PC, int R>
+struct SweepChain {
+  static __device__ __forceinline__ int run(float (&ph)[PR + 1][PC], const float (&rq)[PR][PC], const EdgeFlags& E, float* lds,
+                                            int& xc, int tid, int ty, int& it, int K) {
+    if (it >= K) return R;
+    jacobi_sweep_rot<PR, PC, R>(ph, rq, E, lds, xc, tid, ty);
+    ++it;
+    if constexpr (R == PR) return -1;
+    else return SweepChain<PR, PC, R + 1>::run(ph, rq, E, lds, xc, tid, ty, it, K);
+  }
+};
+
+template <int PR, int PC, int R>
+__device__ __forceinline__ void unrotate(const float (&ph)[PR + 1][PC], float (&pf)[PR][PC], int rot) {
+  if (rot == R) {
+#pragma unroll
+    for (int a = 0; a < PR; ++a)
+#pragma unroll
+      for (int k = 0; k < PC; ++k) pf[a][k] = ph[prow<PR>(a, R)][k];
+  } else if constexpr (R < PR) {
+    unrotate<PR, PC, R + 1>(ph, pf, rot);
+  }
+}
+
+template <int PR, int PC>
+__global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> S, NSPtrs<float> P, int B) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float4* lds = reinterpret_cast<float4*>(smem_raw);
+  float* lds = reinterpret_cast<float*>(smem_raw);
   const int b = blockIdx.x;
   if (b >= B) return;
-  constexpr int n = 16 * PS;
+  constexpr int n = TileCfg<PR, PC>::N;
   constexpr int ncell = n * n;
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const int r0 = ty * PS, c0 = tx * PS;
-  const EdgeFlags E{ty == 0, ty == 15, tx == 0, tx == 15};
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  const int r0 = ty * PR, c0 = tx * PC;
+  const EdgeFlags E{ty == 0, ty == 15, tx == 0, tx == 31};
   float* u = P.u + (size_t)b * ncell;
   float* v = P.v + (size_t)b * ncell;
   float* p = P.p + (size_t)b * ncell;
@@ -495,134 +499,134 @@ __global__ __launch_bounds__(256, 2) void ns_tile_step(NSConst C, NSScal<float> 
 #define PDEGYM_STAMP(i, dep)
 #endif
 
-  float rr[PS][PS];  // dx*dy*rhs, kept for all sweeps
+  float rq[PR][PC];  // 0.25*dx*dy*rhs, kept for all sweeps
   {
-    float uf[PS][PS], vf[PS][PS];
-    load_patch<PS>(uf, u, n, r0, c0);
-    load_patch<PS>(vf, v, n, r0, c0);
+    float uf[PR][PC], vf[PR][PC];
+    load_patch<PR, PC>(uf, u, n, r0, c0);
+    load_patch<PR, PC>(vf, v, n, r0, c0);
     // ---- predictor (navier_stokes2D.py:130-138) ----
     {
-      Halo<PS> HU, HV;
-      halo_exchange<PS>(uf, HU, lds, xc, tid, ty, tx);
-      halo_exchange<PS>(vf, HV, lds, xc, tid, ty, tx);
-      float pu[PS], pv[PS];  // old row a-1
+      Halo<PR, PC> HU, HV;
+      halo_exchange<PR, PC>(uf, HU, lds, xc, tid, ty);
+      halo_exchange<PR, PC>(vf, HV, lds, xc, tid, ty);
+      float pu[PC], pv[PC];  // old row a-1
 #pragma unroll
-      for (int k = 0; k < PS; ++k) { pu[k] = HU.t[k]; pv[k] = HV.t[k]; }
+      for (int k = 0; k < PC; ++k) { pu[k] = HU.t[k]; pv[k] = HV.t[k]; }
 #pragma unroll
-      for (int a = 0; a < PS; ++a) {
-        float cu[PS], cv[PS];
+      for (int a = 0; a < PR; ++a) {
+        float cu[PC], cv[PC];
 #pragma unroll
-        for (int k = 0; k < PS; ++k) { cu[k] = uf[a][k]; cv[k] = vf[a][k]; }
+        for (int k = 0; k < PC; ++k) { cu[k] = uf[a][k]; cv[k] = vf[a][k]; }
 #pragma unroll
-        for (int k = 0; k < PS; ++k) {
+        for (int k = 0; k < PC; ++k) {
           const float uc = cu[k], vc = cv[k];
-          const float uw = (k == 0) ? HU.l[a] : cu[k - 1], ue = (k == PS - 1) ? HU.r[a] : cu[k + 1];
-          const float vw = (k == 0) ? HV.l[a] : cv[k - 1], ve = (k == PS - 1) ? HV.r[a] : cv[k + 1];
+          const float uw = (k == 0) ? HU.l[a] : cu[k - 1], ue = (k == PC - 1) ? HU.r[a] : cu[k + 1];
+          const float vw = (k == 0) ? HV.l[a] : cv[k - 1], ve = (k == PC - 1) ? HV.r[a] : cv[k + 1];
           const float usn = pu[k], vsn = pv[k];
-          const float unn = (a == PS - 1) ? HU.b[k] : uf[a + 1][k];
-          const float vnn = (a == PS - 1) ? HV.b[k] : vf[a + 1][k];
+          const float unn = (a == PR - 1) ? HU.b[k] : uf[a + 1][k];
+          const float vnn = (a == PR - 1) ? HV.b[k] : vf[a + 1][k];
           const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx), dudy = div_c(unn - usn, S.two_dy, S.inv_two_dy);
           const float dvdx = div_c(ve - vw, S.two_dx, S.inv_two_dx), dvdy = div_c(vnn - vsn, S.two_dy, S.inv_two_dy);
           const float lapu = div_c((((uw + usn) - 4.0f * uc) + ue) + unn, S.dxdy, S.inv_dxdy);
           const float lapv = div_c((((vw + vsn) - 4.0f * vc) + ve) + vnn, S.dxdy, S.inv_dxdy);
           const float un = uc + S.dt * (((-uc) * dudx - vc * dudy) + S.nu * lapu);
           const float vn = vc + S.dt * (((-uc) * dvdx - vc * dvdy) + S.nu * lapv);
-          const bool edge = on_domain_edge<PS>(E, a, k);
+          const bool edge = on_domain_edge<PR, PC>(E, a, k);
           uf[a][k] = edge ? uc : un;
           vf[a][k] = edge ? vc : vn;
         }
 #pragma unroll
-        for (int k = 0; k < PS; ++k) { pu[k] = cu[k]; pv[k] = cv[k]; }
+        for (int k = 0; k < PC; ++k) { pu[k] = cu[k]; pv[k] = cv[k]; }
       }
     }
     PDEGYM_STAMP(1, uf[0][0]);
     // ---- apply_boundary(u*, v*) (:140) ----
-    apply_bc_patch<PS>(uf, E, C.bc, 0, act, C.action_dim, r0, c0);
-    apply_bc_patch<PS>(vf, E, C.bc, 1, act, C.action_dim, r0, c0);
-    store_patch<PS>(uf, us, n, r0, c0);
-    store_patch<PS>(vf, vs, n, r0, c0);
-    // ---- rhs (:101-103), pre-multiplied by dx*dy (:108) ----
+    apply_bc_patch<PR, PC>(uf, E, C.bc, 0, act, C.action_dim, r0, c0);
+    apply_bc_patch<PR, PC>(vf, E, C.bc, 1, act, C.action_dim, r0, c0);
+    store_patch<PR, PC>(uf, us, n, r0, c0);
+    store_patch<PR, PC>(vf, vs, n, r0, c0);
+    // ---- rhs (:101-103), pre-multiplied by 0.25*dx*dy (:108) ----
     {
-      Halo<PS> HU, HV;
-      halo_exchange<PS>(uf, HU, lds, xc, tid, ty, tx);
-      halo_exchange<PS>(vf, HV, lds, xc, tid, ty, tx);
+      Halo<PR, PC> HU, HV;
+      halo_exchange<PR, PC>(uf, HU, lds, xc, tid, ty);
+      halo_exchange<PR, PC>(vf, HV, lds, xc, tid, ty);
 #pragma unroll
-      for (int a = 0; a < PS; ++a)
+      for (int a = 0; a < PR; ++a)
 #pragma unroll
-        for (int k = 0; k < PS; ++k) {
-          const float uw = (k == 0) ? HU.l[a] : uf[a][k - 1], ue = (k == PS - 1) ? HU.r[a] : uf[a][k + 1];
-          const float vsn = (a == 0) ? HV.t[k] : vf[a - 1][k], vnn = (a == PS - 1) ? HV.b[k] : vf[a + 1][k];
+        for (int k = 0; k < PC; ++k) {
+          const float uw = (k == 0) ? HU.l[a] : uf[a][k - 1], ue = (k == PC - 1) ? HU.r[a] : uf[a][k + 1];
+          const float vsn = (a == 0) ? HV.t[k] : vf[a - 1][k], vnn = (a == PR - 1) ? HV.b[k] : vf[a + 1][k];
           const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx);
           const float dvdy = div_c(vnn - vsn, S.two_dy, S.inv_two_dy);
           const float r = S.rho_over_dt * (dudx + dvdy);
-          rr[a][k] = on_domain_edge<PS>(E, a, k) ? 0.0f : S.dxdy * r;
+          rq[a][k] = on_domain_edge<PR, PC>(E, a, k) ? 0.0f : jacobi_rhs_term(S.dxdy, r);
         }
     }
   }
+  PDEGYM_STAMP(2, rq[0][0]);
 
-  PDEGYM_STAMP(2, rr[0][0]);
-  // ---- K Jacobi sweeps (:104-114), p and rr in registers, rotating row map (no copies) ----
-  float pf[PS][PS];
+  // ---- K Jacobi sweeps (:104-114), p and rq in registers, rotating row map (no copies) ----
+  float pf[PR][PC];
   {
-    float ph[PS + 1][PS];
+    float ph[PR + 1][PC];
     {
-      float tmp[PS][PS];
-      load_patch<PS>(tmp, p, n, r0, c0);
+      float tmp[PR][PC];
+      load_patch<PR, PC>(tmp, p, n, r0, c0);
 #pragma unroll
-      for (int a = 0; a < PS; ++a)
+      for (int a = 0; a < PR; ++a)
 #pragma unroll
-        for (int k = 0; k < PS; ++k) ph[a][k] = tmp[a][k];
+        for (int k = 0; k < PC; ++k) ph[a][k] = tmp[a][k];
 #pragma unroll
-      for (int k = 0; k < PS; ++k) ph[PS][k] = 0.f;
+      for (int k = 0; k < PC; ++k) ph[PR][k] = 0.f;
     }
     int it = 0, rot = 0;
     while (true) {
-      const int r = SweepChain<PS, 0>::run(ph, rr, E, lds, xc, tid, ty, tx, it, C.iters);
+      const int r = SweepChain<PR, PC, 0>::run(ph, rq, E, lds, xc, tid, ty, it, C.iters);
       if (r >= 0) {
         rot = r;
         break;
       }
     }
-    unrotate<PS, 0>(ph, pf, rot);
+    unrotate<PR, PC, 0>(ph, pf, rot);
   }
   PDEGYM_STAMP(3, pf[0][0]);
-  store_patch<PS>(pf, p, n, r0, c0);
+  store_patch<PR, PC>(pf, p, n, r0, c0);
 
   // ---- corrector (:143-146), observation, reward ----
   float acc = 0.f;
   const int t = P.time_index[b] + 1;
   const int tr = t < C.nt_ref ? t : C.nt_ref - 1;
   {
-    Halo<PS> H;
-    halo_exchange<PS>(pf, H, lds, xc, tid, ty, tx);
-    float uf[PS][PS], vf[PS][PS];
-    load_patch<PS>(uf, us, n, r0, c0);   // written by this same thread above
-    load_patch<PS>(vf, vs, n, r0, c0);
+    Halo<PR, PC> H;
+    halo_exchange<PR, PC>(pf, H, lds, xc, tid, ty);
+    float uf[PR][PC], vf[PR][PC];
+    load_patch<PR, PC>(uf, us, n, r0, c0);   // written by this same thread above
+    load_patch<PR, PC>(vf, vs, n, r0, c0);
 #pragma unroll
-    for (int a = 0; a < PS; ++a)
+    for (int a = 0; a < PR; ++a)
 #pragma unroll
-      for (int k = 0; k < PS; ++k) {
-        const float pw = (k == 0) ? H.l[a] : pf[a][k - 1], pe = (k == PS - 1) ? H.r[a] : pf[a][k + 1];
-        const float ps = (a == 0) ? H.t[k] : pf[a - 1][k], pn = (a == PS - 1) ? H.b[k] : pf[a + 1][k];
+      for (int k = 0; k < PC; ++k) {
+        const float pw = (k == 0) ? H.l[a] : pf[a][k - 1], pe = (k == PC - 1) ? H.r[a] : pf[a][k + 1];
+        const float ps = (a == 0) ? H.t[k] : pf[a - 1][k], pn = (a == PR - 1) ? H.b[k] : pf[a + 1][k];
         const float dpdx = div_c(pe - pw, S.two_dx, S.inv_two_dx);
         const float dpdy = div_c(pn - ps, S.two_dy, S.inv_two_dy);
-        const bool edge = on_domain_edge<PS>(E, a, k);
+        const bool edge = on_domain_edge<PR, PC>(E, a, k);
         uf[a][k] = edge ? uf[a][k] : uf[a][k] - S.dt_over_rho * dpdx;
         vf[a][k] = edge ? vf[a][k] : vf[a][k] - S.dt_over_rho * dpdy;
       }
-    apply_bc_patch<PS>(uf, E, C.bc, 0, act, C.action_dim, r0, c0);
-    apply_bc_patch<PS>(vf, E, C.bc, 1, act, C.action_dim, r0, c0);
-    store_patch<PS>(uf, u, n, r0, c0);
-    store_patch<PS>(vf, v, n, r0, c0);
+    apply_bc_patch<PR, PC>(uf, E, C.bc, 0, act, C.action_dim, r0, c0);
+    apply_bc_patch<PR, PC>(vf, E, C.bc, 1, act, C.action_dim, r0, c0);
+    store_patch<PR, PC>(uf, u, n, r0, c0);
+    store_patch<PR, PC>(vf, v, n, r0, c0);
     const float* uref = P.U_ref + (size_t)tr * ncell * 2;
     float* obs = P.obs + (size_t)b * ncell * 2;
 #pragma unroll
-    for (int a = 0; a < PS; ++a) {
+    for (int a = 0; a < PR; ++a) {
       const size_t o = ((size_t)(r0 + a) * n + c0) * 2;
       const float4* rrow = reinterpret_cast<const float4*>(uref + o);
       float4* orow = reinterpret_cast<float4*>(obs + o);
 #pragma unroll
-      for (int q = 0; q < PS / 2; ++q) {
+      for (int q = 0; q < PC / 2; ++q) {
         const float4 w = rrow[q];
         const float a0 = uf[a][2 * q], b0 = vf[a][2 * q], a1 = uf[a][2 * q + 1], b1 = vf[a][2 * q + 1];
         orow[q] = make_float4(a0, b0, a1, b1);
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void ns_tile_step(NSConst C, NSScal<float> 
     }
   }
   PDEGYM_STAMP(4, acc);
-  float* red = reinterpret_cast<float*>(lds);   // halo buffers are idle now (block_sum syncs first)
+  float* red = lds;   // halo buffers are idle now (block_sum syncs first)
   const float ss = block_sum<float>(acc, red);
   if (tid == 0) {
     float asq = 0.f;
@@ -758,10 +762,11 @@ int ns_step(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int B, v
   if constexpr (sizeof(T) == 4) {
     // register-tiled float32 path for the square grids it is instantiated for (BASELINE config 4 is 128x128)
     if (!pdegym_force_generic() && C.nx == C.ny && (C.nx == 128 || C.nx == 64)) {
+      constexpr int lds128 = TileCfg<8, 4>::LDS_BYTES, lds64 = TileCfg<4, 2>::LDS_BYTES;
       if (C.nx == 128)
-        hipLaunchKernelGGL(ns_tile_step<8>, dim3(B), dim3(256), TileCfg<8>::LDS_BYTES, (hipStream_t)stream, C, S, P, B);
+        hipLaunchKernelGGL((ns_tile_step<8, 4>), dim3(B), dim3(512), lds128, (hipStream_t)stream, C, S, P, B);
       else
-        hipLaunchKernelGGL(ns_tile_step<4>, dim3(B), dim3(256), TileCfg<4>::LDS_BYTES, (hipStream_t)stream, C, S, P, B);
+        hipLaunchKernelGGL((ns_tile_step<4, 2>), dim3(B), dim3(512), lds64, (hipStream_t)stream, C, S, P, B);
       return pdegym::check_launch("ns2d_tile_step");
     }
   }

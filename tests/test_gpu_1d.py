@@ -241,3 +241,26 @@ def test_fused_auto_reset():
         o, r, te, tr = env.step(torch.tensor(a))
         np.testing.assert_array_equal(o.cpu().numpy(), o_ref)
         np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-6, atol=1e-4)
+
+
+@pytest.mark.parametrize("dx", [1e-2, 1.0 / 512, 1.0 / 3, 0.1, 5e-3, 1.0 / 100, 0.999999, 1.9999999, 3.0e-5, 7.0])
+def test_transport_quotient_equals_ieee_division(dx):
+    """(float)((double)d * (1/(double)dx)) == d / dx for every float32 d: 64 M random bit patterns (all exponents,
+    subnormals, infinities, NaNs) + structured values, per dx."""
+    import ctypes as C
+    from pdecontrolgym_amd import _native as N
+    lib = N.load()
+    dx32 = float(C.c_float(dx).value)
+    n = 1 << 26
+    g = torch.Generator(device="cuda").manual_seed(int(dx * 1e6) % 100003)
+    bits = torch.randint(-2**31, 2**31 - 1, (n,), generator=g, device="cuda", dtype=torch.int32)
+    a = bits.view(torch.float32)
+    # structured: exact multiples of dx, powers of two, boundaries
+    k = torch.arange(-4096, 4096, device="cuda", dtype=torch.float32)
+    extra = torch.cat([k * dx32, k * dx32 * (1 + 2.0 ** -23), 2.0 ** torch.arange(-149, 128, device="cuda", dtype=torch.float32),
+                       torch.tensor([0.0, -0.0, float("inf"), -float("inf"), float("nan"), 3.4028234663852886e38, 1.1754944e-38, 1e-45], device="cuda")])
+    for arr in (a, extra.contiguous()):
+        mism = torch.zeros(1, dtype=torch.int32, device="cuda")
+        rc = lib.pdegym_selftest_quotient(arr.data_ptr(), dx32, 1.0 / dx32, mism.data_ptr(), arr.numel(), N.current_stream_ptr())
+        assert rc == 0
+        assert int(mism.item()) == 0
