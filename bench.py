@@ -155,19 +155,58 @@ except Exception:  # pragma: no cover - NS workload is optional at import time
     pass
 
 
-def run_workload(wl, steps, warmup, world):
-    """Returns (seconds for `steps` steps [max over ranks], avg kernel ms from per-launch HIP events)."""
+def measured_traffic(workload_key):
+    """HBM bytes per launch from the last committed PMC collection (tools/profile_round.sh -> profiles/traffic_latest.json);
+    bench.py itself never runs under the profiler."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        return d["bytes_per_launch"].get(workload_key), d.get("source")
+    except Exception:
+        return None, None
+
+
+def run_workload(wl, steps, warmup, world, graph=False):
+    """Returns (seconds for `steps` steps [max over ranks], average launch duration in ms from HIP events bracketing
+    the timed region on the launch stream, median duration of isolated launches timed one by one afterwards).
+    graph=True: the `steps` launches are captured once into a hipGraph and replayed (no Python between launches)."""
     import torch
     extra = min(steps, 50)
-    wl.prepare(warmup + steps + extra)
+    wl.prepare(warmup + (2 * steps if graph else steps) + extra)
     for _ in range(warmup):
         wl.step()
-    _barrier(world)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        wl.step()
-    _barrier(world)
-    el = time.perf_counter() - t0
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if graph:
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            wl.step()                       # warm the side stream
+            wl.i -= 1
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(steps):
+                    wl.step()
+        torch.cuda.current_stream().wait_stream(side)
+        g.replay()                          # untimed first replay (graph upload)
+        _barrier(world)
+        t0 = time.perf_counter()
+        ev0.record()
+        g.replay()
+        ev1.record()
+        _barrier(world)
+        el = time.perf_counter() - t0
+    else:
+        _barrier(world)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            wl.step()
+        ev1.record()
+        _barrier(world)
+        el = time.perf_counter() - t0
+    region_ms = ev0.elapsed_time(ev1) / steps      # HIP events on the launch stream, over the timed region
     from pdecontrolgym_amd.sharding import max_over_ranks
     el = max_over_ranks(el, device="cuda")      # the only communication of a multi-GPU run (no data-path collective)
     # per-launch kernel duration with HIP events on the launch stream (outside the timed region)
@@ -178,8 +217,7 @@ def run_workload(wl, steps, warmup, world):
         b.record()
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b) for a, b in evs)
-    kernel_ms = sum(ms) / len(ms)
-    return el, kernel_ms, ms[len(ms) // 2]
+    return el, region_ms, ms[len(ms) // 2]
 
 
 def main():
@@ -193,6 +231,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads in the default run")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--eager", action="store_true",
+                    help="one Python call per launch instead of replaying the K timed launches from one captured hipGraph")
     args = ap.parse_args()
 
     import torch
@@ -206,7 +246,17 @@ def main():
     if args.substeps:
         kw["S"] = args.substeps
     wl = WORKLOADS[args.workload](device, 1234 + rank, **kw)
-    el, kernel_ms, kernel_ms_med = run_workload(wl, args.steps, args.warmup, world)
+    use_graph = not args.eager
+    try:
+        el, kernel_ms, kernel_ms_med = run_workload(wl, args.steps, args.warmup, world, graph=use_graph)
+    except Exception as ex:                 # capture unsupported in this environment -> time the eager loop instead
+        if not use_graph:
+            raise
+        sys.stderr.write(f"hipGraph capture failed ({ex!r}); falling back to the eager loop\n")
+        use_graph = False
+        torch.cuda.synchronize()
+        wl = WORKLOADS[args.workload](device, 1234 + rank, **kw)
+        el, kernel_ms, kernel_ms_med = run_workload(wl, args.steps, args.warmup, world, graph=False)
     value = wl.units_per_step() * args.steps * world / el
     alg = wl.algorithmic_bytes_per_step()
     achieved = alg / (kernel_ms * 1e-3) / 1e9
@@ -214,15 +264,19 @@ def main():
         "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
-        "config": wl.config(),
+        "config": dict(wl.config(), launch="hipGraph replay of the K timed launches" if use_graph else "eager (one Python call per launch)"),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel_ms_avg": kernel_ms, "kernel_ms_median": kernel_ms_med,
+                     "kernel_ms_avg": kernel_ms, "kernel_ms_isolated_median": kernel_ms_med,
                      "algorithmic_bytes_per_launch": alg, "compulsory_bytes_per_launch": wl.compulsory_bytes_per_step(),
                      "note": "achieved = streaming-model algorithmic bytes / kernel time; the fused kernel keeps state "
                              "on-chip across sub-steps, so this is an EFFECTIVE bandwidth and may exceed the HBM peak "
                              "(real HBM traffic ~ compulsory bytes; see DESIGN.md)"},
     }
+    tb, tsrc = measured_traffic(args.workload)
+    if tb and not args.batch and not args.substeps:
+        out["roofline"]["traffic"] = tb
+        out["roofline"]["traffic_source"] = tsrc
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
     if rank == 0 and world == 1 and not args.no_also and args.workload == "parabolic_c2" and not args.batch:
@@ -232,7 +286,7 @@ def main():
                 continue
             try:
                 w2 = cls(device, 99)
-                e2, k2, k2m = run_workload(w2, max(20, args.steps // 4), max(5, args.warmup // 2), 1)
+                e2, k2, k2m = run_workload(w2, max(20, args.steps // 4), max(5, args.warmup // 2), 1, graph=use_graph)
                 n2 = max(20, args.steps // 4)
                 a2 = w2.algorithmic_bytes_per_step() / (k2 * 1e-3) / 1e9
                 also[name] = {"value": w2.units_per_step() * n2 / e2, "unit": "env-steps/s", "ms_per_step": e2 / n2 * 1e3,

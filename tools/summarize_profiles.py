@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Distil gpurun_out/<tag>/ (rocprofv3 CSVs written by tools/profile_round.sh) into the small files committed under
+profiles/: per-workload kernel stats, per-launch HBM traffic (PMC), and SQ counters of the dominant kernels.
+
+HBM traffic follows MI355X_MICROARCH.md section HBM: bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 per launch
+(gfx950's FETCH_SIZE tallies 128-byte fabric reads at 64 bytes, hence the factor 2 on the read side; WRITE_SIZE is
+taken as is).  Check: the parabolic kernel's known compulsory traffic (row + beta in, row + obs out) is reproduced."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+DOM = {"parabolic_c2": "step1d_kernel", "transport_c3": "step1d_kernel", "ns2d_c4": "ns_tile_step"}
+summary = {"tag": tag, "units": "bytes per launch of the dominant kernel", "workloads": {}}
+
+
+def counter_avg(path, kernel_sub):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if kernel_sub in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
+
+
+for wl, ksub in DOM.items():
+    st = os.path.join(src, f"stats_{wl}", "p_kernel_stats.csv")
+    entry = {}
+    if os.path.exists(st):
+        shutil.copy(st, os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv"))
+        for r in csv.DictReader(open(st)):
+            if ksub in r["Name"]:
+                entry["kernel"] = r["Name"].split("(")[0][-60:]
+                entry["calls"] = int(r["Calls"])
+                entry["avg_ns"] = float(r["AverageNs"])
+                entry["min_ns"] = float(r["MinNs"])
+                entry["max_ns"] = float(r["MaxNs"])
+                break
+        bj = os.path.join(src, f"stats_{wl}.json")
+        if os.path.exists(bj):
+            try:
+                entry["bench_line_under_profiler"] = json.loads(open(bj).read().strip().splitlines()[-1])
+            except Exception:
+                pass
+    tr = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = os.path.join(src, f"pmc_{wl}_{c}", "p_counter_collection.csv")
+        if os.path.exists(f):
+            avg, n = counter_avg(f, ksub)
+            if c in avg:
+                tr[c + "_KB"] = avg[c]
+                tr["launches_" + c] = n[c]
+    if "FETCH_SIZE_KB" in tr and "WRITE_SIZE_KB" in tr:
+        tr["hbm_read_bytes"] = tr["FETCH_SIZE_KB"] * 1024 * 2
+        tr["hbm_write_bytes"] = tr["WRITE_SIZE_KB"] * 1024
+        tr["hbm_bytes"] = tr["hbm_read_bytes"] + tr["hbm_write_bytes"]
+    entry["traffic"] = tr
+    summary["workloads"][wl] = entry
+for name, ksub in (("pmc_sq_parabolic_c2", "step1d_kernel"), ("pmc_sq_ns2d_c4", "ns_tile_step")):
+    f = os.path.join(src, name, "p_counter_collection.csv")
+    if os.path.exists(f):
+        avg, n = counter_avg(f, ksub)
+        summary.setdefault("sq_counters", {})[name] = {"per_launch_avg": avg, "launches": max(n.values()) if n else 0}
+with open(os.path.join(dst, f"{tag}_summary.json"), "w") as fh:
+    json.dump(summary, fh, indent=1)
+with open(os.path.join(dst, "traffic_latest.json"), "w") as fh:
+    json.dump({"source": f"profiles/{tag}_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; read side x2 per "
+                         "MI355X_MICROARCH.md)",
+               "bytes_per_launch": {wl: e.get("traffic", {}).get("hbm_bytes") for wl, e in summary["workloads"].items()}}, fh, indent=1)
+print(json.dumps({wl: {"avg_us": e.get("avg_ns", 0) / 1e3, "hbm_MB": (e.get("traffic", {}).get("hbm_bytes") or 0) / 1e6}
+                  for wl, e in summary["workloads"].items()}, indent=1))
