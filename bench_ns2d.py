@@ -1,6 +1,7 @@
 """NS2D workload of bench.py: BASELINE configs[3] (NavierStokes2D 128x128, 50 Jacobi sweeps/step, batch 512, fp32)."""
 from __future__ import annotations
 
+import os
 import platform
 import time
 
@@ -26,7 +27,8 @@ class NavierStokesC4:
         self.device = device
         U_ref = torch.zeros(self.nt, n, n, 2, dtype=torch.float32, device=device)
         a_ref = 2.0 * torch.ones(self.nt, dtype=torch.float32, device=device)
-        self.env = NSBatch2D(U_ref=U_ref, action_ref=a_ref, num_envs=self.B, device=device, dtype=torch.float32, **self.kw)
+        self.env = NSBatch2D(U_ref=U_ref, action_ref=a_ref, num_envs=self.B, device=device, dtype=torch.float32,
+                             interleaved_state=os.environ.get("PDEGYM_NS_SEPARATE_UV", "0") != "1", **self.kw)
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.gen = g
         c = torch.rand(self.B, 3, generator=g) * 10 - 5

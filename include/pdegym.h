@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PDEGYM_ABI_VERSION 2
+#define PDEGYM_ABI_VERSION 3
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
 #define PDEGYM_MAX_N1D 1024      /* nodes per 1D row handled by the wave-per-instance kernels */
@@ -143,7 +143,7 @@ typedef struct pdegym_params_ns2d {
 
 /* T = float (f32 entry points) or double (f64 entry points). Fields are [B, ny, nx], row = y, col = x. */
 typedef struct pdegym_bufs_ns2d {
-  void* u;                  /* [B, ny, nx] in/out                                                             */
+  void* u;                  /* [B, ny, nx] in/out; may be NULL (together with v) when state_in is given        */
   void* v;                  /* [B, ny, nx] in/out                                                             */
   void* p;                  /* [B, ny, nx] in/out (warm start of the next step, navier_stokes2D.py:115)        */
   void* scratch;            /* [B, 4, ny, nx] work space (u*, v*, rhs, p')                                    */
@@ -155,6 +155,9 @@ typedef struct pdegym_bufs_ns2d {
   void* obs;                /* [B, ny, nx, 2] out (u,v interleaved; base_env_2d.py:50)                         */
   void* reward;             /* [B] out                                                                        */
   uint8_t* terminated;      /* [B] out; truncated is always False in the reference (navier_stokes2D.py:155)    */
+  const void* state_in;     /* optional [B, ny, nx, 2]: the observation written by the PREVIOUS call.  When non-NULL the
+                               velocity state is read from it and written only to obs (the reference's obs is the state,
+                               navier_stokes2D.py:147-154), which saves one write of u and v per step; must not alias obs */
 } pdegym_bufs_ns2d;
 
 int pdegym_ns2d_step_f32(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int32_t B, void* stream);

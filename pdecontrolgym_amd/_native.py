@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 RING = 128
 LOOKBACK = 100
 MAX_N1D = 1024
@@ -56,7 +56,7 @@ class BufsNS2D(C.Structure):
     _fields_ = [("u", C.c_void_p), ("v", C.c_void_p), ("p", C.c_void_p), ("scratch", C.c_void_p),
                 ("action", C.c_void_p), ("time_index", C.c_void_p), ("U_ref", C.c_void_p),
                 ("action_ref", C.c_void_p), ("nt_ref", C.c_int32), ("obs", C.c_void_p), ("reward", C.c_void_p),
-                ("terminated", C.c_void_p)]
+                ("terminated", C.c_void_p), ("state_in", C.c_void_p)]
 
 
 class NativeError(RuntimeError):

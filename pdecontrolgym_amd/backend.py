@@ -65,8 +65,10 @@ class HipBackend:
     def _bufs_ns(T, dtype) -> N.BufsNS2D:
         import torch
         b = N.BufsNS2D()
-        for k in ("u", "v", "p", "scratch", "action", "U_ref", "action_ref", "obs", "reward"):
+        for k in ("p", "scratch", "action", "U_ref", "action_ref", "obs", "reward"):
             setattr(b, k, N.dptr(T[k], dtype))
+        for k in ("u", "v", "state_in"):
+            setattr(b, k, N.dptr(T[k], dtype) if T.get(k) is not None else None)
         b.time_index = N.dptr(T["time_index"], torch.int32)
         b.terminated = N.dptr(T["terminated"], torch.uint8)
         b.nt_ref = int(min(T["U_ref"].shape[0], T["action_ref"].shape[0]))
@@ -78,19 +80,19 @@ class HipBackend:
         return "f32" if dtype == torch.float32 else "f64"
 
     def ns2d_step(self, P: N.ParamsNS2D, T: dict, B: int):
-        dtype = T["u"].dtype
+        dtype = T["p"].dtype
         bufs = self._bufs_ns(T, dtype)
         fn = getattr(self.lib, "pdegym_ns2d_step_" + self._sfx(dtype))
-        N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["u"].device)), "pdegym_ns2d_step")
+        N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["p"].device)), "pdegym_ns2d_step")
 
     def ns2d_reset(self, P: N.ParamsNS2D, T: dict, u0, v0, p0, mask, B: int):
         import torch
-        dtype = T["u"].dtype
+        dtype = T["p"].dtype
         bufs = self._bufs_ns(T, dtype)
         fn = getattr(self.lib, "pdegym_ns2d_reset_masked_" + self._sfx(dtype))
         m = N.dptr(mask, torch.uint8) if mask is not None else None
         N.check(fn(C.byref(P), C.byref(bufs), N.dptr(u0, dtype), N.dptr(v0, dtype), N.dptr(p0, dtype), m, B,
-                   N.current_stream_ptr(T["u"].device)), "pdegym_ns2d_reset_masked")
+                   N.current_stream_ptr(T["p"].device)), "pdegym_ns2d_reset_masked")
 
     def ns2d_solve_pressure(self, P: N.ParamsNS2D, u, v, p_in, p_out, scratch, B: int):
         dtype = u.dtype

@@ -34,7 +34,7 @@ class NSBatch2D:
     def __init__(self, T: float, dt: float, X: float, dx: float, Y: float, dy: float, boundary_condition: dict,
                  U_ref, action_ref, action_dim: int = 1, gamma: float = 0.1, viscosity: float = 0.1,
                  density: float = 1.0, maximum_pressure_iteration: int = 2000, stable_factor: float = 0.5,
-                 num_envs: int = 1, device="cuda", dtype=None, backend=None):
+                 num_envs: int = 1, device="cuda", dtype=None, backend=None, interleaved_state: bool = True):
         import torch
         self.nt = int(round(T / dt))
         self.nx = int(round(X / dx + 1))
@@ -71,9 +71,13 @@ class NSBatch2D:
         if U_ref.dim() != 4 or U_ref.shape[1:] != (ny, nx, 2):
             raise ValueError(f"U_ref must be [nt, {ny}, {nx}, 2], got {tuple(U_ref.shape)}")
         a_ref = torch.as_tensor(action_ref, dtype=dt_, device=dev).reshape(-1).contiguous()
+        # interleaved_state: the velocity state lives only in the (double-buffered) observation tensors
+        # [B, ny, nx, 2] -- like the reference, whose obs U[t] IS the state -- which saves writing u and v separately
+        self.interleaved_state = bool(interleaved_state)
         self.t = {
-            "u": torch.zeros(B, ny, nx, dtype=dt_, device=dev),
-            "v": torch.zeros(B, ny, nx, dtype=dt_, device=dev),
+            "u": None if self.interleaved_state else torch.zeros(B, ny, nx, dtype=dt_, device=dev),
+            "v": None if self.interleaved_state else torch.zeros(B, ny, nx, dtype=dt_, device=dev),
+            "state_in": None,
             "p": torch.zeros(B, ny, nx, dtype=dt_, device=dev),
             "scratch": torch.zeros(B, 4, ny, nx, dtype=dt_, device=dev),
             "action": torch.zeros(B, self.action_dim, dtype=dt_, device=dev),
@@ -90,11 +94,12 @@ class NSBatch2D:
 
     @property
     def u(self):
-        return self.t["u"]
+        """Current u field [B, ny, nx] (a strided view of the observation tensor in interleaved mode)."""
+        return self.t["obs"][..., 0] if self.interleaved_state else self.t["u"]
 
     @property
     def v(self):
-        return self.t["v"]
+        return self.t["obs"][..., 1] if self.interleaved_state else self.t["v"]
 
     @property
     def p(self):
@@ -105,6 +110,8 @@ class NSBatch2D:
         return self.t["time_index"]
 
     def _next_obs(self):
+        if self.interleaved_state:
+            self.t["state_in"] = self.t["obs"]      # the observation just produced is the next call's input state
         self._flip ^= 1
         self.t["obs"] = self._obs[self._flip]
 
@@ -114,8 +121,7 @@ class NSBatch2D:
         u0, v0, p0 = cvt(u0), cvt(v0), cvt(p0)
         if mask is not None:
             mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
-        else:
-            self._next_obs()
+        # a reset writes the (new) state into the CURRENT observation buffer: untouched instances keep theirs
         self.backend.ns2d_reset(self.params, self.t, u0, v0, p0, mask, self.num_envs)
         return self.t["obs"]
 

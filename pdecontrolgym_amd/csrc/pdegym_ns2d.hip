@@ -58,6 +58,7 @@ struct NSPtrs {
   T* obs;
   T* reward;
   uint8_t* terminated;
+  const T* state_in;  // optional [B, ny, nx, 2]: (u, v) of the previous call's observation; then u, v may be NULL
 };
 
 // Value of boundary cell (i,j) after apply_boundary's four ordered passes (navier_stokes2D.py:76-90), as a
@@ -160,23 +161,27 @@ __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, 
   const int b = blockIdx.x;
   if (b >= B) return;
   const int nx = C.nx, ny = C.ny, ncell = nx * ny;
-  T* u = P.u + (size_t)b * ncell;
-  T* v = P.v + (size_t)b * ncell;
+  T* u = (P.u && !P.state_in) ? P.u + (size_t)b * ncell : nullptr;
+  T* v = (P.v && !P.state_in) ? P.v + (size_t)b * ncell : nullptr;
   T* p = P.p + (size_t)b * ncell;
   T* us = P.scratch + (size_t)b * 4 * ncell;
   T* vs = us + ncell;
   T* rhs = vs + ncell;
   T* pB = rhs + ncell;
   const T* act = P.action + (size_t)b * C.action_dim;
+  // state: separate u, v fields, or the interleaved observation of the previous call
+  const T* sin = P.state_in ? P.state_in + (size_t)b * ncell * 2 : nullptr;
+  auto U = [&](int c) -> T { return sin ? sin[2 * (size_t)c] : u[c]; };
+  auto V = [&](int c) -> T { return sin ? sin[2 * (size_t)c + 1] : v[c]; };
 
   // ---- predictor (navier_stokes2D.py:130-138); boundary derivatives are zero so u* = u there (:9-22) ----
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
     const int i = c / nx, j = c - i * nx;
-    const T uc = u[c], vc = v[c];
+    const T uc = U(c), vc = V(c);
     T un = uc, vn = vc;
     if (i >= 1 && i <= ny - 2 && j >= 1 && j <= nx - 2) {
-      const T uw = u[c - 1], ue = u[c + 1], usn = u[c - nx], unn = u[c + nx];
-      const T vw = v[c - 1], ve = v[c + 1], vsn = v[c - nx], vnn = v[c + nx];
+      const T uw = U(c - 1), ue = U(c + 1), usn = U(c - nx), unn = U(c + nx);
+      const T vw = V(c - 1), ve = V(c + 1), vsn = V(c - nx), vnn = V(c + nx);
       const T dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx), dudy = div_c(unn - usn, S.two_dy, S.inv_two_dy);
       const T dvdx = div_c(ve - vw, S.two_dx, S.inv_two_dx), dvdy = div_c(vnn - vsn, S.two_dy, S.inv_two_dy);
       const T lapu = div_c((((uw + usn) - (T)4 * uc) + ue) + unn, S.dxdy, S.inv_dxdy);
@@ -213,8 +218,8 @@ __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, 
       un = un - S.dt_over_rho * dpdx;
       vn = vn - S.dt_over_rho * dpdy;
     }
-    u[c] = un;
-    v[c] = vn;
+    us[c] = un;  // in place: each thread reads only its own u*, v* and neighbours of p
+    vs[c] = vn;
   }
   __syncthreads();
   // ---- apply_boundary(u, v, action) (:146), observation (:147-149,:154), reward (ns_reward.py:28) ----
@@ -227,13 +232,15 @@ __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, 
     const int i = c / nx, j = c - i * nx;
     T un, vn;
     if (i == 0 || i == ny - 1 || j == 0 || j == nx - 1) {
-      un = bc_value<T>(u, i, j, ny, nx, C.bc, 0, act, C.action_dim);
-      vn = bc_value<T>(v, i, j, ny, nx, C.bc, 1, act, C.action_dim);
+      un = bc_value<T>(us, i, j, ny, nx, C.bc, 0, act, C.action_dim);   // reads interior cells only
+      vn = bc_value<T>(vs, i, j, ny, nx, C.bc, 1, act, C.action_dim);
+    } else {
+      un = us[c];
+      vn = vs[c];
+    }
+    if (u) {
       u[c] = un;
       v[c] = vn;
-    } else {
-      un = u[c];
-      vn = v[c];
     }
     obs[2 * (size_t)c] = un;
     obs[2 * (size_t)c + 1] = vn;
@@ -307,10 +314,23 @@ struct EdgeFlags {
 // lane i <- lane i-1 / lane i+1 (DPP wave_shr:1 / wave_shl:1); the lane without a source gets 0 (never used:
 // it is a domain-edge thread)
 __device__ __forceinline__ float lane_left(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float lane_right(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+// y + (value of x in the lane to the left / right): the DPP shift rides on the add itself (hipcc keeps a separate
+// v_mov_b32_dpp otherwise).  s_nop 1 covers the VALU-write -> DPP-read hazard for operands hipcc cannot see into.
+__device__ __forceinline__ float add_lane_left(float x, float y) {
+  float r;
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ float add_lane_right(float x, float y) {
+  float r;
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(x), "v"(y));
+  return r;
 }
 
 // top/bottom halo rows through LDS: ht = bottom row of the thread above, hb = top row of the thread below.
@@ -352,14 +372,14 @@ template <int PR, int PC>
 __device__ __forceinline__ void load_patch(float (&f)[PR][PC], const float* g, int n, int r0, int c0) {
   using V = typename VecOf<PC>::type;
 #pragma unroll
-  for (int a = 0; a < PR; ++a) unpack_row<PC>(*reinterpret_cast<const V*>(g + (size_t)(r0 + a) * n + c0), f[a]);
+  for (int a = 0; a < PR; ++a) unpack_row<PC>(*reinterpret_cast<const V*>(g + ((r0 + a) * n + c0)), f[a]);
 }
 
 template <int PR, int PC>
 __device__ __forceinline__ void store_patch(const float (&f)[PR][PC], float* g, int n, int r0, int c0) {
   using V = typename VecOf<PC>::type;
 #pragma unroll
-  for (int a = 0; a < PR; ++a) *reinterpret_cast<V*>(g + (size_t)(r0 + a) * n + c0) = pack_row<PC>(f[a]);
+  for (int a = 0; a < PR; ++a) *reinterpret_cast<V*>(g + ((r0 + a) * n + c0)) = pack_row<PC>(f[a]);
 }
 
 // apply_boundary on a patch: the four ordered passes (lower, upper, left, right) only touch cells of edge
@@ -410,23 +430,24 @@ __device__ constexpr int prow(int a, int r) {
 template <int PR, int PC, int R>
 __device__ __forceinline__ void jacobi_sweep_rot(float (&ph)[PR + 1][PC], const float (&rq)[PR][PC], const EdgeFlags& E,
                                                  float* lds, int& xc, int tid, int ty) {
-  float hb[PC], hl[PR], hr[PR];
+  float hb[PC];
   halo_tb<PC>(ph[prow<PR>(0, R)], ph[prow<PR>(PR - 1, R)], ph[prow<PR>(-1, R)], hb, lds, xc, tid, ty);
-#pragma unroll
-  for (int a = 0; a < PR; ++a) {
-    hl[a] = lane_left(ph[prow<PR>(a, R)][PC - 1]);
-    hr[a] = lane_right(ph[prow<PR>(a, R)][0]);
-  }
+  // The new row a overwrites the registers of old row a-1, but the RIGHT neighbour lane still needs this lane's old
+  // first column of row a (and the left one its last column) -> sample the edge columns before the row is updated.
 #pragma unroll
   for (int a = 0; a < PR; ++a) {
     const int src = prow<PR>(a, R), dst = prow<PR>(a - 1, R), nxt = prow<PR>(a + 1, R);
+    float nv[PC];
 #pragma unroll
     for (int k = 0; k < PC; ++k) {
-      const float w = (k == 0) ? hl[a] : ph[src][k - 1], e = (k == PC - 1) ? hr[a] : ph[src][k + 1];
       const float nn = (a == PR - 1) ? hb[k] : ph[nxt][k];
-      const float s4 = ((w + ph[dst][k]) + e) + nn;          // ((W + S) + E) + N   (navier_stokes2D.py:106-108)
-      ph[dst][k] = jacobi_update(s4, rq[a][k]);
+      // ((W + S) + E) + N   (navier_stokes2D.py:106-108); W / E of the edge columns come from the neighbour lanes
+      float t = (k == 0) ? add_lane_left(ph[src][PC - 1], ph[dst][k]) : (ph[src][k - 1] + ph[dst][k]);
+      t = (k == PC - 1) ? add_lane_right(ph[src][0], t) : (t + ph[src][k + 1]);
+      nv[k] = jacobi_update(t + nn, rq[a][k]);
     }
+#pragma unroll
+    for (int k = 0; k < PC; ++k) ph[dst][k] = nv[k];
   }
   // Neumann walls (:110-113) on the NEW rows (rotation R+1): every boundary cell = nearest interior value
   constexpr int n0 = prow<PR>(0, R + 1), n1 = prow<PR>(1, R + 1), nl = prow<PR>(PR - 1, R + 1), nm = prow<PR>(PR - 2, R + 1);
@@ -473,7 +494,7 @@ __device__ __forceinline__ void unrotate(const float (&ph)[PR + 1][PC], float (&
   }
 }
 
-template <int PR, int PC>
+template <int PR, int PC, bool INTERLEAVED>
 __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> S, NSPtrs<float> P, int B) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* lds = reinterpret_cast<float*>(smem_raw);
@@ -484,12 +505,13 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
   const int r0 = ty * PR, c0 = tx * PC;
   const EdgeFlags E{ty == 0, ty == 15, tx == 0, tx == 31};
-  float* u = P.u + (size_t)b * ncell;
-  float* v = P.v + (size_t)b * ncell;
+  float* u = INTERLEAVED ? nullptr : P.u + (size_t)b * ncell;
+  float* v = INTERLEAVED ? nullptr : P.v + (size_t)b * ncell;
   float* p = P.p + (size_t)b * ncell;
   float* us = P.scratch + (size_t)b * 4 * ncell;
   float* vs = us + ncell;
   const float* act = P.action + (size_t)b * C.action_dim;
+  const float* sin = INTERLEAVED ? P.state_in + (size_t)b * ncell * 2 : nullptr;
   int xc = 0;
 #ifdef PDEGYM_TIMING
   unsigned long long tm[8];
@@ -502,29 +524,46 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
   float rq[PR][PC];  // 0.25*dx*dy*rhs, kept for all sweeps
   {
     float uf[PR][PC], vf[PR][PC];
-    load_patch<PR, PC>(uf, u, n, r0, c0);
-    load_patch<PR, PC>(vf, v, n, r0, c0);
+    if constexpr (INTERLEAVED) {  // (u, v) interleaved: the previous call's observation IS the state
+#pragma unroll
+      for (int a = 0; a < PR; ++a) {
+        const float4* row = reinterpret_cast<const float4*>(sin + ((r0 + a) * n + c0) * 2);
+#pragma unroll
+        for (int q = 0; q < PC / 2; ++q) {
+          const float4 w = row[q];
+          uf[a][2 * q] = w.x; vf[a][2 * q] = w.y; uf[a][2 * q + 1] = w.z; vf[a][2 * q + 1] = w.w;
+        }
+      }
+    } else {
+      load_patch<PR, PC>(uf, u, n, r0, c0);
+      load_patch<PR, PC>(vf, v, n, r0, c0);
+    }
     // ---- predictor (navier_stokes2D.py:130-138) ----
+    // Only the top/bottom halo rows are kept; left/right neighbours are fetched per row with DPP right before the
+    // row is overwritten in place (all lanes of a wave update the same row in lockstep, so the neighbour lane still
+    // holds its OLD row) -- this keeps the phase inside the 128-VGPR budget.
     {
-      Halo<PR, PC> HU, HV;
-      halo_exchange<PR, PC>(uf, HU, lds, xc, tid, ty);
-      halo_exchange<PR, PC>(vf, HV, lds, xc, tid, ty);
+      float ut[PC], ub[PC], vt[PC], vb[PC];
+      halo_tb<PC>(uf[0], uf[PR - 1], ut, ub, lds, xc, tid, ty);
+      halo_tb<PC>(vf[0], vf[PR - 1], vt, vb, lds, xc, tid, ty);
       float pu[PC], pv[PC];  // old row a-1
 #pragma unroll
-      for (int k = 0; k < PC; ++k) { pu[k] = HU.t[k]; pv[k] = HV.t[k]; }
+      for (int k = 0; k < PC; ++k) { pu[k] = ut[k]; pv[k] = vt[k]; }
 #pragma unroll
       for (int a = 0; a < PR; ++a) {
         float cu[PC], cv[PC];
 #pragma unroll
         for (int k = 0; k < PC; ++k) { cu[k] = uf[a][k]; cv[k] = vf[a][k]; }
+        const float ul = lane_left(cu[PC - 1]), ur = lane_right(cu[0]);
+        const float vl = lane_left(cv[PC - 1]), vr = lane_right(cv[0]);
 #pragma unroll
         for (int k = 0; k < PC; ++k) {
           const float uc = cu[k], vc = cv[k];
-          const float uw = (k == 0) ? HU.l[a] : cu[k - 1], ue = (k == PC - 1) ? HU.r[a] : cu[k + 1];
-          const float vw = (k == 0) ? HV.l[a] : cv[k - 1], ve = (k == PC - 1) ? HV.r[a] : cv[k + 1];
+          const float uw = (k == 0) ? ul : cu[k - 1], ue = (k == PC - 1) ? ur : cu[k + 1];
+          const float vw = (k == 0) ? vl : cv[k - 1], ve = (k == PC - 1) ? vr : cv[k + 1];
           const float usn = pu[k], vsn = pv[k];
-          const float unn = (a == PR - 1) ? HU.b[k] : uf[a + 1][k];
-          const float vnn = (a == PR - 1) ? HV.b[k] : vf[a + 1][k];
+          const float unn = (a == PR - 1) ? ub[k] : uf[a + 1][k];
+          const float vnn = (a == PR - 1) ? vb[k] : vf[a + 1][k];
           const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx), dudy = div_c(unn - usn, S.two_dy, S.inv_two_dy);
           const float dvdx = div_c(ve - vw, S.two_dx, S.inv_two_dx), dvdy = div_c(vnn - vsn, S.two_dy, S.inv_two_dy);
           const float lapu = div_c((((uw + usn) - 4.0f * uc) + ue) + unn, S.dxdy, S.inv_dxdy);
@@ -547,20 +586,23 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
     store_patch<PR, PC>(vf, vs, n, r0, c0);
     // ---- rhs (:101-103), pre-multiplied by 0.25*dx*dy (:108) ----
     {
-      Halo<PR, PC> HU, HV;
-      halo_exchange<PR, PC>(uf, HU, lds, xc, tid, ty);
-      halo_exchange<PR, PC>(vf, HV, lds, xc, tid, ty);
+      float vt[PC], vb[PC], dummy_t[PC], dummy_b[PC];
+      (void)dummy_t;
+      (void)dummy_b;
+      halo_tb<PC>(vf[0], vf[PR - 1], vt, vb, lds, xc, tid, ty);   // d/dy v* needs the rows above / below
 #pragma unroll
-      for (int a = 0; a < PR; ++a)
+      for (int a = 0; a < PR; ++a) {
+        const float ul = lane_left(uf[a][PC - 1]), ur = lane_right(uf[a][0]);   // d/dx u* needs the lanes left / right
 #pragma unroll
         for (int k = 0; k < PC; ++k) {
-          const float uw = (k == 0) ? HU.l[a] : uf[a][k - 1], ue = (k == PC - 1) ? HU.r[a] : uf[a][k + 1];
-          const float vsn = (a == 0) ? HV.t[k] : vf[a - 1][k], vnn = (a == PR - 1) ? HV.b[k] : vf[a + 1][k];
+          const float uw = (k == 0) ? ul : uf[a][k - 1], ue = (k == PC - 1) ? ur : uf[a][k + 1];
+          const float vsn = (a == 0) ? vt[k] : vf[a - 1][k], vnn = (a == PR - 1) ? vb[k] : vf[a + 1][k];
           const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx);
           const float dvdy = div_c(vnn - vsn, S.two_dy, S.inv_two_dy);
           const float r = S.rho_over_dt * (dudx + dvdy);
           rq[a][k] = on_domain_edge<PR, PC>(E, a, k) ? 0.0f : jacobi_rhs_term(S.dxdy, r);
         }
+      }
     }
   }
   PDEGYM_STAMP(2, rq[0][0]);
@@ -616,13 +658,15 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
       }
     apply_bc_patch<PR, PC>(uf, E, C.bc, 0, act, C.action_dim, r0, c0);
     apply_bc_patch<PR, PC>(vf, E, C.bc, 1, act, C.action_dim, r0, c0);
-    store_patch<PR, PC>(uf, u, n, r0, c0);
-    store_patch<PR, PC>(vf, v, n, r0, c0);
+    if constexpr (!INTERLEAVED) {
+      store_patch<PR, PC>(uf, u, n, r0, c0);
+      store_patch<PR, PC>(vf, v, n, r0, c0);
+    }
     const float* uref = P.U_ref + (size_t)tr * ncell * 2;
     float* obs = P.obs + (size_t)b * ncell * 2;
 #pragma unroll
     for (int a = 0; a < PR; ++a) {
-      const size_t o = ((size_t)(r0 + a) * n + c0) * 2;
+      const int o = ((r0 + a) * n + c0) * 2;
       const float4* rrow = reinterpret_cast<const float4*>(uref + o);
       float4* orow = reinterpret_cast<float4*>(obs + o);
 #pragma unroll
@@ -688,8 +732,10 @@ __global__ void ns_reset_kernel(NSConst C, NSPtrs<T> P, const T* u0, const T* v0
   const size_t off = (size_t)b * ncell;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += gridDim.x * blockDim.x) {
     const T a = u0[off + c], bb = v0[off + c];
-    P.u[off + c] = a;
-    P.v[off + c] = bb;
+    if (P.u) {
+      P.u[off + c] = a;
+      P.v[off + c] = bb;
+    }
     P.p[off + c] = p0[off + c];
     P.obs[2 * (off + c)] = a;
     P.obs[2 * (off + c) + 1] = bb;
@@ -752,21 +798,32 @@ int ns_step(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int B, v
   if (int rc = fill<T>(prm, C, S)) return rc;
   if (!buf) return pdegym::fail(-1, "null bufs");
   if (B <= 0) return 0;
-  if (!buf->u || !buf->v || !buf->p || !buf->scratch || !buf->action || !buf->time_index || !buf->U_ref ||
-      !buf->action_ref || !buf->obs || !buf->reward || !buf->terminated)
+  if (!buf->p || !buf->scratch || !buf->action || !buf->time_index || !buf->U_ref || !buf->action_ref || !buf->obs ||
+      !buf->reward || !buf->terminated)
     return pdegym::fail(-3, "null device buffer");
+  if (!buf->state_in && (!buf->u || !buf->v)) return pdegym::fail(-3, "either state_in or both u and v must be given");
+  if ((buf->u == nullptr) != (buf->v == nullptr)) return pdegym::fail(-3, "u and v must be given together");
+  if (buf->state_in == buf->obs) return pdegym::fail(-3, "state_in must not alias obs (double-buffer the observations)");
   if (buf->nt_ref < 1) return pdegym::fail(-2, "nt_ref must be >= 1");
   C.nt_ref = buf->nt_ref;
   NSPtrs<T> P{(T*)buf->u, (T*)buf->v, (T*)buf->p, (T*)buf->scratch, (const T*)buf->action, buf->time_index,
-              (const T*)buf->U_ref, (const T*)buf->action_ref, (T*)buf->obs, (T*)buf->reward, buf->terminated};
+              (const T*)buf->U_ref, (const T*)buf->action_ref, (T*)buf->obs, (T*)buf->reward, buf->terminated,
+              (const T*)buf->state_in};
   if constexpr (sizeof(T) == 4) {
     // register-tiled float32 path for the square grids it is instantiated for (BASELINE config 4 is 128x128)
     if (!pdegym_force_generic() && C.nx == C.ny && (C.nx == 128 || C.nx == 64)) {
       constexpr int lds128 = TileCfg<8, 4>::LDS_BYTES, lds64 = TileCfg<4, 2>::LDS_BYTES;
-      if (C.nx == 128)
-        hipLaunchKernelGGL((ns_tile_step<8, 4>), dim3(B), dim3(512), lds128, (hipStream_t)stream, C, S, P, B);
+      // state_in given -> the velocity state is the previous observation and u, v are not written (if the caller
+      // also passed u, v they are simply left untouched)
+      const bool inter = buf->state_in != nullptr;
+      if (C.nx == 128 && inter)
+        hipLaunchKernelGGL((ns_tile_step<8, 4, true>), dim3(B), dim3(512), lds128, (hipStream_t)stream, C, S, P, B);
+      else if (C.nx == 128)
+        hipLaunchKernelGGL((ns_tile_step<8, 4, false>), dim3(B), dim3(512), lds128, (hipStream_t)stream, C, S, P, B);
+      else if (inter)
+        hipLaunchKernelGGL((ns_tile_step<4, 2, true>), dim3(B), dim3(512), lds64, (hipStream_t)stream, C, S, P, B);
       else
-        hipLaunchKernelGGL((ns_tile_step<4, 2>), dim3(B), dim3(512), lds64, (hipStream_t)stream, C, S, P, B);
+        hipLaunchKernelGGL((ns_tile_step<4, 2, false>), dim3(B), dim3(512), lds64, (hipStream_t)stream, C, S, P, B);
       return pdegym::check_launch("ns2d_tile_step");
     }
   }
@@ -798,7 +855,7 @@ int ns_reset(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, const v
   if (B <= 0) return 0;
   C.nt_ref = 1;
   NSPtrs<T> P{(T*)buf->u, (T*)buf->v, (T*)buf->p, (T*)buf->scratch, (const T*)buf->action, buf->time_index,
-              (const T*)buf->U_ref, (const T*)buf->action_ref, (T*)buf->obs, (T*)buf->reward, buf->terminated};
+              (const T*)buf->U_ref, (const T*)buf->action_ref, (T*)buf->obs, (T*)buf->reward, buf->terminated, nullptr};
   const int ncell = C.nx * C.ny;
   const int gx = (ncell + 255) / 256 > 64 ? 64 : (ncell + 255) / 256;
   hipLaunchKernelGGL(ns_reset_kernel<T>, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, C, P, (const T*)u0, (const T*)v0,

@@ -105,29 +105,35 @@ class FakeBackend:
     # ---- NS2D -----------------------------------------------------------------------------------
     def _orc_ns(self, T):
         c = self.core
-        np_dt = np.float64 if T["u"].dtype == torch.float64 else np.float32
+        np_dt = np.float64 if T["p"].dtype == torch.float64 else np.float32
         kw = dict(c.ctor)
         return po.NavierStokesOracle(U_ref=T["U_ref"].numpy(), action_ref=T["action_ref"].numpy(), dtype=np_dt, **kw)
 
     def ns2d_step(self, P, T, B):
         orc = self._orc_ns(T)
-        orc.reset(T["u"].numpy(), T["v"].numpy(), T["p"].numpy())
+        if T.get("state_in") is not None:
+            st = T["state_in"].numpy()
+            orc.reset(st[..., 0], st[..., 1], T["p"].numpy())
+        else:
+            orc.reset(T["u"].numpy(), T["v"].numpy(), T["p"].numpy())
         orc.time_index = T["time_index"].numpy().astype(np.int64)
         obs, r, te, _ = orc.step(T["action"].numpy())
         for k, a in (("u", orc.u), ("v", orc.v), ("p", orc.p), ("obs", obs), ("reward", r)):
-            T[k].copy_(torch.from_numpy(np.ascontiguousarray(a)).to(T[k].dtype))
+            if T.get(k) is not None:
+                T[k].copy_(torch.from_numpy(np.ascontiguousarray(a)).to(T[k].dtype))
         T["time_index"].copy_(torch.from_numpy(orc.time_index.astype(np.int32)))
         T["terminated"].copy_(torch.from_numpy(te.astype(np.uint8)))
 
     def ns2d_reset(self, P, T, u0, v0, p0, mask, B):
         m = torch.ones(B, dtype=torch.bool) if mask is None else mask.bool()
-        T["u"][m] = u0[m]
-        T["v"][m] = v0[m]
+        if T.get("u") is not None:
+            T["u"][m] = u0[m]
+            T["v"][m] = v0[m]
         T["p"][m] = p0[m]
         T["obs"][m] = torch.stack([u0[m], v0[m]], dim=-1)
         T["time_index"][m] = 0
         T["terminated"][m] = 0
 
     def ns2d_solve_pressure(self, P, u, v, p_in, p_out, scratch, B):
-        orc = self._orc_ns({"u": u, "U_ref": torch.zeros(1, self.core.ny, self.core.nx, 2), "action_ref": torch.zeros(1)})
+        orc = self._orc_ns({"u": u, "p": p_in, "U_ref": torch.zeros(1, self.core.ny, self.core.nx, 2), "action_ref": torch.zeros(1)})
         p_out.copy_(torch.from_numpy(orc.solve_pressure(u.numpy(), v.numpy(), p_in.numpy())))

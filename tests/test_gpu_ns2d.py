@@ -221,3 +221,31 @@ def test_ns_f32_tiled_kernel_equals_generic_kernel_bitwise(n):
         np.testing.assert_array_equal(o1, o2)
         np.testing.assert_array_equal(p1, p2)
         np.testing.assert_allclose(r1, r2, rtol=1e-5)
+
+
+@pytest.mark.parametrize("n,dtype", [(128, "float32"), (40, "float32"), (21, "float64")])
+def test_ns_interleaved_state_equals_separate_fields(n, dtype):
+    """interleaved_state=True (state lives in the double-buffered obs tensors) == separate u, v fields, bitwise."""
+    from pdecontrolgym_amd.batch2d import NSBatch2D
+    td = getattr(torch, dtype)
+    kw, u0, v0, p0, acts = _random_case(n, 3, 30, 31 + n, BC_MIX)
+    outs = []
+    for inter in (True, False):
+        env = NSBatch2D(num_envs=3, device="cuda", dtype=td, interleaved_state=inter, **kw)
+        assert (env.t["u"] is None) == inter
+        env.reset(u0, v0, p0)
+        res = []
+        for a in acts:
+            obs, r, te = env.step(a)
+            res.append((obs.cpu().numpy().copy(), env.u.cpu().numpy().copy(), env.v.cpu().numpy().copy(),
+                        env.p.cpu().numpy().copy(), r.cpu().numpy().copy()))
+        # masked reset keeps the other instances' state
+        m = torch.tensor([1, 0, 1], dtype=torch.uint8)
+        env.reset(u0 * 0 + 1.5, v0 * 0 - 0.5, p0 * 0, mask=m)
+        obs, r, te = env.step(acts[0])
+        res.append((obs.cpu().numpy().copy(), env.u.cpu().numpy().copy(), env.v.cpu().numpy().copy(), env.p.cpu().numpy().copy(),
+                    r.cpu().numpy().copy()))
+        outs.append(res)
+    for x, y in zip(*outs):
+        for a, b in zip(x, y):
+            np.testing.assert_array_equal(a, b)
