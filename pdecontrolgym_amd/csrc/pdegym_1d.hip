@@ -139,6 +139,48 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
       bval = normalize_ctrl(cdx + slot_get<EPL>(R.x, ns - 2), P.max_control, P.normalize);
     }
     float y[EPL];
+    if constexpr (FAST && PARABOLIC) {
+      // Stage-major form of the same expression tree: the EPL independent chains advance together, so consecutive
+      // instructions of a wave do not depend on each other (in-order issue stalls on back-to-back dependent VALU ops).
+      // parabolic.py:143-144   u + F*(um - 2*u + up) + (dt*beta)*u
+      float t2[EPL], t3[EPL], t4[EPL], t5[EPL], t7[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) t2[e] = __builtin_fmaf(-2.0f, R.x[e], (e == 0) ? xl : R.x[e - 1]);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) t3[e] = t2[e] + ((e == EPL - 1) ? xr : R.x[e + 1]);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) t7[e] = c[e] * R.x[e];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) t4[e] = fe[e] * t3[e];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) t5[e] = R.x[e] + t4[e];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) y[e] = t5[e] + t7[e];
+    } else if constexpr (FAST && !PARABOLIC) {
+      // hyperbolic.py:146-155   u + dt*((up - u)/dx + u[0]*beta), stage-major like the parabolic form above.
+      // Quotient: RN32(RN64(d1 * RN64(1/dx))) == RN32(d1/dx): the double product is within 2^-52 (relative) of the
+      // true quotient, while a quotient of two 24-bit floats is never closer than 2^-50 to a float rounding boundary
+      // (checked on the device by pdegym_selftest_quotient).
+      float d1[EPL], d2[EPL], r[EPL], d3[EPL], d4[EPL];
+      double q[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) d1[e] = ((e == EPL - 1) ? xr : R.x[e + 1]) - R.x[e];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) r[e] = p0 * c[e];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) q[e] = (double)d1[e];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) q[e] = q[e] * P.rdx;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) d2[e] = (float)q[e];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) d3[e] = d2[e] + r[e];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) d4[e] = fe[e] * d3[e];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) y[e] = R.x[e] + d4[e];
+      (void)xl;
+    } else {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
       const float p = R.x[e];
@@ -181,6 +223,7 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
         v = (sl >= ns - 1) ? ((sl == ns - 1) ? bval : 0.0f) : v;  // controlled boundary node; padding stays 0
       }
       y[e] = v;
+    }
     }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) R.x[e] = y[e];
@@ -401,7 +444,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
     unsigned int* dbg = reinterpret_cast<unsigned int*>(ring) + 116;
     dbg[0] = (unsigned int)tm0; dbg[1] = (unsigned int)(tm0 >> 32);
     dbg[2] = (unsigned int)(tm1 - tm0); dbg[3] = (unsigned int)(tm2 - tm1); dbg[4] = (unsigned int)(tm3 - tm2);
-    dbg[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+    dbg[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+    dbg[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
   }
 #endif
 }

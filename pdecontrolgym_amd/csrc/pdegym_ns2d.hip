@@ -437,15 +437,18 @@ __device__ __forceinline__ void jacobi_sweep_rot(float (&ph)[PR + 1][PC], const 
 #pragma unroll
   for (int a = 0; a < PR; ++a) {
     const int src = prow<PR>(a, R), dst = prow<PR>(a - 1, R), nxt = prow<PR>(a + 1, R);
+    // ((W + S) + E) + N   (navier_stokes2D.py:106-108), stage-major over the PC independent cells of the row so that
+    // consecutive instructions do not depend on each other; W / E of the edge columns ride in on the DPP adds
     float nv[PC];
 #pragma unroll
-    for (int k = 0; k < PC; ++k) {
-      const float nn = (a == PR - 1) ? hb[k] : ph[nxt][k];
-      // ((W + S) + E) + N   (navier_stokes2D.py:106-108); W / E of the edge columns come from the neighbour lanes
-      float t = (k == 0) ? add_lane_left(ph[src][PC - 1], ph[dst][k]) : (ph[src][k - 1] + ph[dst][k]);
-      t = (k == PC - 1) ? add_lane_right(ph[src][0], t) : (t + ph[src][k + 1]);
-      nv[k] = jacobi_update(t + nn, rq[a][k]);
-    }
+    for (int k = 0; k < PC; ++k)
+      nv[k] = (k == 0) ? add_lane_left(ph[src][PC - 1], ph[dst][k]) : (ph[src][k - 1] + ph[dst][k]);
+#pragma unroll
+    for (int k = 0; k < PC; ++k) nv[k] = (k == PC - 1) ? add_lane_right(ph[src][0], nv[k]) : (nv[k] + ph[src][k + 1]);
+#pragma unroll
+    for (int k = 0; k < PC; ++k) nv[k] = nv[k] + ((a == PR - 1) ? hb[k] : ph[nxt][k]);
+#pragma unroll
+    for (int k = 0; k < PC; ++k) nv[k] = jacobi_update(nv[k], rq[a][k]);
 #pragma unroll
     for (int k = 0; k < PC; ++k) ph[dst][k] = nv[k];
   }

@@ -58,7 +58,7 @@ void run(const char* name, int waves_per_simd, int ninstr) {
 }
 
 int main() {
-  for (int w : {1, 2, 4}) {
+  for (int w : {1, 2, 4, 6, 8}) {
     run<0>("v_add_f32 x8", w, 8);
     run<1>("v_pk_add_f32 x8", w, 8);
     run<2>("v_mul_f32 x8", w, 8);
