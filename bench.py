@@ -114,37 +114,86 @@ class Parabolic1D:
                 "nx": self.nx, "nodes": self.env.n, "batch_per_gpu": self.B, "substeps_per_env_step": self.S,
                 "reward": "TunedReward1D", "auto_reset": "fused", "parallelism": "independent instances, no collective"}
 
-    # ---- CPU baseline: the NumPy restatement run like the reference (one instance, Python loop) ----
-    def cpu_baseline(self, seconds=10.0):
-        import numpy as np
-        from oracle import pde_oracle as po
-        cls = po.ParabolicOracle if self.kind == "parabolic" else po.TransportOracle
-        okw = {k: self.kw[k] for k in ("T", "dt", "X", "dx", "control_sample_rate", "control_type", "sensing_loc",
-                                       "sensing_type", "normalize", "max_control_value", "limit_pde_state_size", "max_state_value")}
-        env = cls(reward=po.TunedReward1DOracle(*self.reward_args), keep_history=False, **okw)
-        init = self.init[:1].cpu().numpy()
-        beta = self.beta[:1].cpu().numpy()
-        env.reset(init, beta)
-        acts = self.actions[:, :1].cpu().numpy()
-        n, t0 = 0, time.perf_counter()
-        with np.errstate(all="ignore"):
-            while time.perf_counter() - t0 < seconds:
-                _, _, te, tr = env.step(acts[n % len(acts)])
-                n += 1
-                if te[0] or tr[0]:
-                    env.reset(init, beta)
-        el = time.perf_counter() - t0
-        return {"value": n / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
-                "sample": f"{n} env-steps of ONE instance ({self.S} sub-steps each) in a Python loop over the NumPy oracle, "
-                          f"{el:.1f} s on {platform.processor() or platform.machine()}; batching B instances on one core keeps "
-                          "the same aggregate rate (SURVEY.md section 6)"}
-
 
 class Transport1D(Parabolic1D):
     """BASELINE config 3 shape: TransportPDE1D nx=512, dt=0.5dx, S=100, B=16384/GPU (the reference has no
     Burgers env)."""
     name = "TransportPDE1D nx=512 B=16384 S=100 (BASELINE configs[2] shape)"
     kind, nx, B, S, amp, glo, ghi = "transport", 512, 16384, 100, 5.0, 7.0, 7.7
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the NumPy oracle run like the reference (ONE instance, Python loop over sub-steps).  NumPy only --
+# it runs before this process touches the GPU, and the all-cores figure uses plain child processes.
+# ------------------------------------------------------------------------------------------------
+def cpu_port_rate(workload_key, seconds, seed=0):
+    import numpy as np
+    from oracle import pde_oracle as po
+    rng = np.random.default_rng(seed)
+    if workload_key in ("parabolic_c2", "transport_c3"):
+        cls = Parabolic1D if workload_key == "parabolic_c2" else Transport1D
+        nx, S = cls.nx, cls.S
+        dx = 1.0 / nx
+        dt = 0.25 * dx * dx if cls.kind == "parabolic" else 0.5 * dx
+        okw = dict(T=1000 * S * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type="Dirchilet", sensing_loc="full",
+                   sensing_type=None, normalize=True, max_control_value=20, limit_pde_state_size=True, max_state_value=1e10)
+        ocl = po.ParabolicOracle if cls.kind == "parabolic" else po.TransportOracle
+        env = ocl(reward=po.TunedReward1DOracle(int(round(okw["T"] / dt)), -1e3, 3e2), keep_history=False, **okw)
+        n = nx + (cls.kind == "parabolic")
+        init = (rng.uniform(1, 10) * np.ones((1, n))).astype(np.float32)
+        beta = (cls.amp * np.cos(rng.uniform(cls.glo, cls.ghi) * np.arccos(np.linspace(0, 1, n))))[None].astype(np.float32)
+        acts = rng.uniform(-1, 1, (256, 1)).astype(np.float32)
+        reset = lambda: env.reset(init, beta)
+        done = lambda out: bool(out[2][0] or out[3][0])
+        what = f"{S} sub-steps each"
+    else:
+        from bench_ns2d import NavierStokesC4 as W
+        nn, K, nt = W.n, W.K, 1000
+        dx = 1.0 / (nn - 1)
+        dt = 0.2 * 0.5 * dx * dx / 0.1
+        env = po.NavierStokesOracle(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=W.BC, U_ref=np.zeros((nt, nn, nn, 2)),
+                                    action_ref=2.0 * np.ones(nt), gamma=0.1, maximum_pressure_iteration=K)
+        ic = [rng.uniform(-5, 5) * np.ones((1, nn, nn)) for _ in range(3)]
+        acts = rng.uniform(2, 4, (256, 1))
+        reset = lambda: env.reset(*ic)
+        done = lambda out: bool(env.time_index[0] >= nt - 2)
+        what = f"float64, {K} Jacobi sweeps each"
+    reset()
+    with np.errstate(all="ignore"):
+        for i in range(10):                      # warm-up (also skips the CPU denormal slow start of NS, SURVEY.md section 6)
+            env.step(acts[i])
+        k, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            out = env.step(acts[k % len(acts)])
+            k += 1
+            if done(out):
+                reset()
+    el = time.perf_counter() - t0
+    return k / el, k, el, what
+
+
+def cpu_baseline_report(workload_key, seconds):
+    """Single-process figure (what a user of the reference gets) + all-cores figure (P independent worker processes)."""
+    import subprocess
+    rate, k, el, what = cpu_port_rate(workload_key, seconds)
+    rep = {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": "port",
+           "sample": f"{k} env-steps of ONE instance ({what}) in a Python loop over the NumPy oracle, {el:.1f} s on "
+                     f"{platform.processor() or platform.machine()}; B instances on one core run at the same aggregate rate"}
+    try:
+        P = len(os.sched_getaffinity(0))
+        sec = min(seconds, 8.0)
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", workload_key, "--cpu-seconds", str(sec),
+                                   "--seed", str(100 + i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+                 for i in range(P)]
+        tot = 0.0
+        for pr in procs:
+            o, _ = pr.communicate(timeout=sec * 4 + 120)
+            tot += float(o.decode().strip().splitlines()[-1])
+        rep["all_cores"] = {"value": tot, "cores": P, "sample": f"{P} independent worker processes x {sec:.0f} s, one instance each"}
+    except Exception as ex:
+        rep["all_cores"] = {"error": repr(ex)}
+    return rep
 
 
 WORKLOADS = {"parabolic_c2": Parabolic1D, "transport_c3": Transport1D}
@@ -233,7 +282,16 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--eager", action="store_true",
                     help="one Python call per launch instead of replaying the K timed launches from one captured hipGraph")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--seed", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:                      # child of cpu_baseline_report: NumPy only, prints env-steps/s
+        print(cpu_port_rate(args.cpu_worker, args.cpu_seconds, args.seed)[0])
+        return
+    # CPU baseline first: it must run (and fork its workers) before this process initialises the GPU
+    cpu_rep = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        cpu_rep = cpu_baseline_report(args.workload, args.cpu_seconds)
 
     import torch
     if not torch.cuda.is_available():
@@ -277,8 +335,8 @@ def main():
     if tb and not args.batch and not args.substeps:
         out["roofline"]["traffic"] = tb
         out["roofline"]["traffic_source"] = tsrc
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = wl.cpu_baseline(args.cpu_seconds)
+    if cpu_rep is not None:
+        out["cpu_baseline"] = cpu_rep
     if rank == 0 and world == 1 and not args.no_also and args.workload == "parabolic_c2" and not args.batch:
         also = {}
         for name, cls in WORKLOADS.items():

@@ -59,24 +59,3 @@ class NavierStokesC4:
         return {"workload": self.name, "env": "PDEControlGym-NavierStokes2D", "nx": self.n, "ny": self.n,
                 "batch_per_gpu": self.B, "jacobi_sweeps_per_step": self.K, "reward": "NSReward(0.1)",
                 "parallelism": "independent instances, no collective"}
-
-    def cpu_baseline(self, seconds=10.0):
-        import numpy as np
-        from oracle import pde_oracle as po
-        n = self.n
-        env = po.NavierStokesOracle(U_ref=np.zeros((self.nt, n, n, 2)), action_ref=2.0 * np.ones(self.nt), **self.kw)
-        ic = [x[:1].cpu().numpy().astype(np.float64) for x in self.ic]
-        env.reset(*ic)
-        acts = self.actions[:, :1].cpu().numpy().astype(np.float64)
-        for i in range(10):                      # skip the denormal slow start
-            env.step(acts[i % len(acts)])
-        k, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < seconds:
-            env.step(acts[k % len(acts)])
-            k += 1
-            if env.time_index[0] >= self.nt - 2:
-                env.reset(*ic)
-        el = time.perf_counter() - t0
-        return {"value": k / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
-                "sample": f"{k} env-steps of ONE float64 instance ({self.K} Jacobi sweeps each) over the NumPy oracle, "
-                          f"{el:.1f} s on {platform.processor() or platform.machine()}"}
