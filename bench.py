@@ -147,7 +147,8 @@ def cpu_port_rate(workload_key, seconds, seed=0):
         done = lambda out: bool(out[2][0] or out[3][0])
         what = f"{S} sub-steps each"
     else:
-        from bench_ns2d import NavierStokesC4 as W
+        from bench_ns2d import NavierStokesC4, NavierStokesC5
+        W = NavierStokesC5 if workload_key == "ns2d_c5" else NavierStokesC4
         nn, K, nt = W.n, W.K, 1000
         dx = 1.0 / (nn - 1)
         dt = 0.2 * 0.5 * dx * dx / 0.1
@@ -197,11 +198,9 @@ def cpu_baseline_report(workload_key, seconds):
 
 
 WORKLOADS = {"parabolic_c2": Parabolic1D, "transport_c3": Transport1D}
-try:
-    from bench_ns2d import NavierStokesC4  # noqa: E402
-    WORKLOADS["ns2d_c4"] = NavierStokesC4
-except Exception:  # pragma: no cover - NS workload is optional at import time
-    pass
+from bench_ns2d import NavierStokesC4, NavierStokesC5  # noqa: E402
+WORKLOADS["ns2d_c4"] = NavierStokesC4
+WORKLOADS["ns2d_c5"] = NavierStokesC5
 
 
 def measured_traffic(workload_key):
@@ -340,7 +339,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_also and args.workload == "parabolic_c2" and not args.batch:
         also = {}
         for name, cls in WORKLOADS.items():
-            if name == args.workload:
+            if name == args.workload or name == "ns2d_c5":      # C5 is the 8-GPU config: run it explicitly with --workload
                 continue
             try:
                 w2 = cls(device, 99)

@@ -59,3 +59,9 @@ class NavierStokesC4:
         return {"workload": self.name, "env": "PDEControlGym-NavierStokes2D", "nx": self.n, "ny": self.n,
                 "batch_per_gpu": self.B, "jacobi_sweeps_per_step": self.K, "reward": "NSReward(0.1)",
                 "parallelism": "independent instances, no collective"}
+
+
+class NavierStokesC5(NavierStokesC4):
+    """BASELINE configs[4] per-GPU shard: NavierStokes2D 256x256, 50 Jacobi sweeps/step, 512 instances per GPU, fp32."""
+    name = "NavierStokes2D 256x256 K=50 B=512/GPU fp32 (BASELINE configs[4] shard)"
+    n, B, K = 256, 512, 50

@@ -1,0 +1,67 @@
+"""On-device rollout loop: policy inference and environment stepping never leave the GPU.
+
+The reference trains with SB3, which steps ONE environment per Python call (``DummyVecEnv(n=1)``,
+examples/transportPDE/transport1Dppo.py:77-90).  With thousands of instances per launch the per-step host work
+(Python, launch latency) becomes the bottleneck at small sub-step counts, so ``DeviceRollout`` records the whole
+T-step rollout -- policy forward pass (any torch module), action clamp, environment step with fused auto-reset,
+writes into the [T, B, ...] rollout buffers -- into ONE hipGraph and replays it: zero host work per step.
+"""
+from __future__ import annotations
+
+
+class DeviceRollout:
+    """``policy``: callable mapping an observation tensor [B, obs_dim] to actions [B] (or [B, 1]) on the same device.
+    Buffers: ``obs[T+1, B, D]``, ``actions[T, B]``, ``rewards[T, B]``, ``terminated[T, B]``, ``truncated[T, B]``."""
+
+    def __init__(self, venv, policy, n_steps: int, use_graph: bool = True, action_low: float = -1.0, action_high: float = 1.0):
+        import torch
+        if venv.kind == "ns2d":
+            raise NotImplementedError("DeviceRollout drives the 1D environments")
+        self.venv, self.policy, self.T = venv, policy, int(n_steps)
+        self.lo, self.hi = float(action_low), float(action_high)
+        core = venv.core
+        B, D, dev = core.num_envs, core.obs_dim, core.device
+        self.obs = torch.zeros(self.T + 1, B, D, dtype=torch.float32, device=dev)
+        self.actions = torch.zeros(self.T, B, dtype=torch.float32, device=dev)
+        self.rewards = torch.zeros(self.T, B, dtype=torch.float32, device=dev)
+        self.terminated = torch.zeros(self.T, B, dtype=torch.uint8, device=dev)
+        self.truncated = torch.zeros(self.T, B, dtype=torch.uint8, device=dev)
+        self.use_graph = bool(use_graph) and dev.type == "cuda"
+        self._graph = None
+
+    def _body(self):
+        import torch
+        core = self.venv.core
+        for t in range(self.T):
+            with torch.no_grad():
+                a = self.policy(self.obs[t]).reshape(core.num_envs).clamp(self.lo, self.hi)
+            self.actions[t].copy_(a)
+            # the step kernel writes observation / reward / flags straight into slot t of the rollout buffers
+            core.step(self.actions[t], out_obs=self.obs[t + 1], out_reward=self.rewards[t],
+                      out_terminated=self.terminated[t], out_truncated=self.truncated[t])
+
+    def run(self, first_obs=None):
+        """Roll T steps from ``first_obs`` (default: the environment's current observation). Returns self."""
+        import torch
+        core = self.venv.core
+        self.obs[0].copy_(core.t["obs"] if first_obs is None else first_obs)
+        if not self.use_graph:
+            self._body()
+            return self
+        if self._graph is None:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            snapshot = {k: core.t[k].clone() for k in ("u", "time_index", "bsum", "ring")}
+            with torch.cuda.stream(side):
+                self._body()                               # warm-up on the side stream (allocator, lazy init)
+                for k, v in snapshot.items():
+                    core.t[k].copy_(v)                     # ... then rewind the environment state
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph, stream=side):
+                    self._body()
+            torch.cuda.current_stream().wait_stream(side)
+            for k, v in snapshot.items():
+                core.t[k].copy_(v)
+        self._graph.replay()
+        return self

@@ -181,13 +181,20 @@ class PDEBatch1D:
         self.t["reset_init"] = None
         self.t["final_obs"] = None
 
-    def step(self, action):
+    def step(self, action, out_obs=None, out_reward=None, out_terminated=None, out_truncated=None):
         """Advance every instance by one env-step (S sub-steps). action: [B] float32 tensor.
-        Returns (obs, reward, terminated, truncated) device tensors (uint8 flags)."""
+        Returns (obs, reward, terminated, truncated) device tensors (uint8 flags).  The ``out_*`` tensors, when given,
+        receive the outputs directly (contiguous, right dtype/shape) -- e.g. slot t of a rollout buffer."""
         import torch
         a = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs).contiguous()
         self.t["action"] = a
-        self._next_obs()
+        if out_obs is not None:
+            self.t["obs"] = out_obs.view(self.num_envs, self.obs_dim)
+        else:
+            self._next_obs()
+        for key, out in (("reward", out_reward), ("terminated", out_terminated), ("truncated", out_truncated)):
+            if out is not None:
+                self.t[key] = out
         self.backend.step1d(self.kind, self.params, self.t, self.num_envs)
         return self.t["obs"], self.t["reward"], self.t["terminated"], self.t["truncated"]
 

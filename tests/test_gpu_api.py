@@ -108,3 +108,32 @@ def test_ns_public_api_on_gpu(golden_ns):
     from pde_control_gym.src.environments2d.navier_stokes2D import central_difference
     pr = env.solve_pressure(env.u, env.v, np.zeros((21, 21)))
     assert np.isfinite(central_difference(pr, "x", 0.05)).all()
+
+
+def test_device_rollout_graph_equals_eager_on_gpu():
+    """The hipGraph-captured rollout (policy MLP + fused env step, zero host work per step) reproduces the eager loop
+    bit for bit, across an episode boundary (fused auto-reset)."""
+    import pde_control_gym
+    from pde_control_gym import DeviceRollout
+    from pde_control_gym.src import TunedReward1D
+    B, T = 64, 20                                   # nt=401, S=30 -> episodes end every 14 steps
+    torch.manual_seed(0)
+    pol = torch.nn.Sequential(torch.nn.Linear(100, 32), torch.nn.Tanh(), torch.nn.Linear(32, 1), torch.nn.Tanh()).cuda()
+    outs = []
+    for graph in (False, True):
+        p = _transport_params(T=0.0400, dt=1e-4, control_sample_rate=30e-4, reward_class=TunedReward1D(400, -1e3, 3e2))
+        rng = np.random.default_rng(5)
+        p["reset_init_condition_func"] = lambda nx: np.ones(nx) * rng.uniform(1, 3)
+        venv = pde_control_gym.make_vec("PDEControlGym-TransportPDE1D", num_envs=B, **p)
+        venv.reset_tensor()
+        venv.enable_fused_auto_reset()
+        ro = DeviceRollout(venv, pol, T, use_graph=graph).run()
+        torch.cuda.synchronize()
+        outs.append([x.cpu().numpy().copy() for x in (ro.obs, ro.actions, ro.rewards, ro.terminated, ro.truncated)])
+        if graph:                                    # a second replay continues from the rollout's last observation
+            ro.run()
+            torch.cuda.synchronize()
+            assert np.isfinite(ro.rewards.cpu().numpy()).all()
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    assert outs[0][3][13].all() and not outs[0][3][12].any()      # every instance terminates at step 14 and restarts

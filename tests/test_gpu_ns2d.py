@@ -249,3 +249,28 @@ def test_ns_interleaved_state_equals_separate_fields(n, dtype):
     for x, y in zip(*outs):
         for a, b in zip(x, y):
             np.testing.assert_array_equal(a, b)
+
+
+def test_ns_c5_grid_256_parity():
+    """BASELINE config 5 grid (256x256, K=50): float64 bit-exact vs the oracle, float32 within the stated tolerance."""
+    from oracle import pde_oracle as po
+    kw, u0, v0, p0, acts = _random_case(256, 2, 50, 256, NS_BC)
+    orc = po.NavierStokesOracle(**kw)
+    env = _mk(kw, 2, torch.float64)
+    orc.reset(u0, v0, p0)
+    env.reset(u0, v0, p0)
+    for a in acts[:2]:
+        o_ref, r_ref, _, _ = orc.step(a)
+        obs, r, te = env.step(a)
+        np.testing.assert_array_equal(obs.cpu().numpy(), o_ref)
+        np.testing.assert_array_equal(env.p.cpu().numpy(), orc.p)
+        np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-12)
+    env32 = _mk(kw, 2, torch.float32)
+    u32, v32, p32 = (x.astype(np.float32) for x in (u0, v0, p0))
+    orc.reset(u32.astype(np.float64), v32.astype(np.float64), p32.astype(np.float64))
+    env32.reset(u32, v32, p32)
+    a32 = acts[0].astype(np.float32)
+    o_ref, r_ref, _, _ = orc.step(a32.astype(np.float64))
+    obs, r, te = env32.step(a32)
+    np.testing.assert_allclose(obs.cpu().numpy().astype(np.float64), o_ref, rtol=1e-5, atol=2e-6 * np.abs(o_ref).max())
+    np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-4)

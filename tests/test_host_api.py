@@ -319,3 +319,25 @@ def test_reward_classes_host_definitions():
     assert NormReward(10, "inf").reward(u, 3, False, False) == -np.abs(u[3]).max()
     with pytest.raises(Exception):
         NormReward()
+
+
+def test_device_rollout_eager_matches_manual_loop():
+    """DeviceRollout (eager path on the CPU test double) == stepping by hand with the same policy."""
+    import torch
+    from pde_control_gym import DeviceRollout
+    B, T = 3, 6
+    torch.manual_seed(0)
+    pol = torch.nn.Sequential(torch.nn.Linear(100, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1), torch.nn.Tanh())
+    env = _vec(B)
+    env.reset_tensor()
+    ro = DeviceRollout(env, pol, T, use_graph=False).run()
+    env2 = _vec(B)
+    obs = env2.reset_tensor()
+    np.testing.assert_array_equal(ro.obs[0].numpy(), obs.numpy())
+    for t in range(T):
+        with torch.no_grad():
+            a = pol(obs).reshape(B).clamp(-1, 1)
+        obs, r, te, tr = env2.step_tensor(a)
+        np.testing.assert_array_equal(ro.obs[t + 1].numpy(), obs.numpy())
+        np.testing.assert_array_equal(ro.rewards[t].numpy(), r.numpy())
+        np.testing.assert_array_equal(ro.actions[t].numpy(), a.numpy())
