@@ -46,3 +46,8 @@ def golden_kat():
 @pytest.fixture(scope="session")
 def golden_ns():
     return load_golden("ns2d")
+
+
+@pytest.fixture(scope="session")
+def golden_traffic():
+    return load_golden("traffic")

@@ -363,12 +363,52 @@ def gen_ns(src):
     np.savez_compressed(os.path.join(OUT, "ns2d.npz"), **store)
 
 
+def gen_traffic(src):
+    """TrafficPDE1D (environments1d/traffic_arz_env.py) with TrafficARZReward: the shipped notebook configuration
+    (examples/TrafficPDE1D/*.ipynb cell 3: T=240, dt=0.25, dx=10, X=500, tau=60, v_max=40, ro_max=0.16)."""
+    import contextlib
+    import io
+    import random
+    store = {}
+    rng = np.random.default_rng(77)
+    for name, sim, cf, nact, nsteps, limit in [("inlet", "inlet", 1, 1, 60, True), ("outlet", "outlet", 1, 1, 60, True),
+                                               ("both", "both", 1, 2, 60, True), ("train", "outlet-train", 2, 1, 60, True),
+                                               ("outlet_cf3", "outlet", 3, 1, 40, False), ("long", "inlet", 1, 1, 1000, True)]:
+        kw = dict(T=240, dt=0.25, X=500, dx=10, reward_class=src.TrafficARZReward(), simulation_type=sim, v_steady=10,
+                  ro_steady=0.12, v_max=40, ro_max=0.16, tau=60, limit_pde_state_size=limit, control_freq=cf)
+        random.seed(11)
+        with contextlib.redirect_stdout(io.StringIO()):
+            env = src.TrafficPDE1D(**kw)
+            qs_clip = env.qs
+            random.seed(13)
+            obs0, _ = env.reset()
+        acts = rng.uniform(0.7, 1.3, (nsteps, nact)) * env.qs
+        obs, rew, done, trunc, tim = [np.array(obs0)], [], [], [], []
+        for a in acts:
+            with contextlib.redirect_stdout(io.StringIO()):
+                o, r, d, t, _ = env.step(a)
+            obs.append(np.array(o))
+            rew.append(r)
+            done.append(bool(d))
+            trunc.append(bool(t))
+            tim.append(env.time_index)
+        obs = np.stack(obs)
+        if name == "long":      # keep the file small: every 50th observation
+            keep = np.arange(0, nsteps + 1, 50)
+            obs = obs[keep]
+            store[f"{name}/keep"] = keep
+        pack(name, dict(obs=obs, reward=np.array(rew), done=np.array(done), trunc=np.array(trunc), time=np.array(tim),
+                        actions=acts, rs=np.float64(env.rs), qs_clip=np.float64(qs_clip), control_freq=np.int64(cf),
+                        limit=np.bool_(limit), sim=np.array(sim)), store)
+    np.savez_compressed(os.path.join(OUT, "traffic.npz"), **store)
+
+
 if __name__ == "__main__":
     src = import_reference()
-    which = sys.argv[1:] or ["transport", "parabolic", "kat", "ns"]
+    which = sys.argv[1:] or ["transport", "parabolic", "kat", "ns", "traffic"]
     store_meta = dict(numpy=np.__version__)
     for w in which:
-        {"transport": gen_transport, "parabolic": gen_parabolic, "kat": gen_kat, "ns": gen_ns}[w](src)
+        {"transport": gen_transport, "parabolic": gen_parabolic, "kat": gen_kat, "ns": gen_ns, "traffic": gen_traffic}[w](src)
         print("wrote", w)
     with open(os.path.join(OUT, "VERSIONS.txt"), "w") as f:
         f.write(f"numpy {np.__version__}\nreference snapshot 2026-01-09 (lukebhan/PDEControlGym)\n")

@@ -193,3 +193,29 @@ def test_batched_oracle_equals_per_instance():
         for i, a in enumerate(acts):
             e1.step(a[b:b + 1])
             np.testing.assert_array_equal(e1.row[0], rows[i][b])
+
+
+# ---- Traffic ARZ ----------------------------------------------------------------
+TRAFFIC_CASES = ["inlet", "outlet", "both", "train", "outlet_cf3", "long"]
+
+
+def traffic_oracle_for(g):
+    return po.TrafficOracle(240, 0.25, 500, 10, str(g.sim), 40, 0.16, 60, bool(g.limit), int(g.control_freq))
+
+
+@pytest.mark.parametrize("case", TRAFFIC_CASES)
+def test_traffic_oracle_matches_reference(golden_traffic, case):
+    """float64, bit-exact observations / rewards / flags / time against the reference's own TrafficPDE1D."""
+    g = golden_traffic[case]
+    orc = traffic_oracle_for(g)
+    o = orc.reset([float(g.rs)], [float(g.qs_clip)])
+    keep = {int(k): i for i, k in enumerate(g.keep)} if "keep" in g else None
+    np.testing.assert_array_equal(o[0], g.obs[0])
+    for k, a in enumerate(g.actions):
+        o, r, d, t = orc.step(a[None])
+        if keep is None:
+            np.testing.assert_array_equal(o[0], g.obs[k + 1], err_msg=f"step {k}")
+        elif (k + 1) in keep:
+            np.testing.assert_array_equal(o[0], g.obs[keep[k + 1]], err_msg=f"step {k}")
+        assert r[0] == g.reward[k] and bool(d[0]) == bool(g.done[k]) and bool(t[0]) == bool(g.trunc[k])
+        assert orc.time_index[0] == g.time[k]
