@@ -130,7 +130,15 @@ def cpu_port_rate(workload_key, seconds, seed=0):
     import numpy as np
     from oracle import pde_oracle as po
     rng = np.random.default_rng(seed)
-    if workload_key in ("parabolic_c2", "transport_c3"):
+    if workload_key == "traffic_arz":
+        env = po.TrafficOracle(240, 0.25, 500, 10, "outlet", 40, 0.16, 60, True, TrafficARZ.S)
+        rs = [0.12]
+        qs = 0.12 * 40 * (1 - 0.12 / 0.16)
+        acts = rng.uniform(0.8, 1.2, (256, 1, 1)) * qs
+        reset = lambda: env.reset(rs)
+        done = lambda out: bool(out[2][0] or out[3][0] or env.time_index[0] >= 239)
+        what = f"float64, {TrafficARZ.S} sub-steps each"
+    elif workload_key in ("parabolic_c2", "transport_c3"):
         cls = Parabolic1D if workload_key == "parabolic_c2" else Transport1D
         nx, S = cls.nx, cls.S
         dx = 1.0 / nx
@@ -198,9 +206,57 @@ def cpu_baseline_report(workload_key, seconds):
 
 
 WORKLOADS = {"parabolic_c2": Parabolic1D, "transport_c3": Transport1D}
+class TrafficARZ:
+    """TrafficPDE1D (reference notebook configuration T=240, dt=0.25, dx=10, X=500, M=51 nodes,
+    float64), 'outlet' control, control_freq=2 sub-steps per env-step, B=16384 instances."""
+    name = "TrafficPDE1D M=51 f64 B=16384 control_freq=2 (reference notebook configuration)"
+    dtype = "f64"
+    B, S = 16384, 2
+
+    def __init__(self, device, seed, B=None, S=None):
+        import torch
+        from pdecontrolgym_amd.batch_traffic import TrafficBatch
+        self.B, self.S = B or self.B, S or self.S
+        self.device = device
+        self.env = TrafficBatch(240, 0.25, 500, 10, "outlet", 40, 0.16, 60, True, self.S, num_envs=self.B, device=device)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.gen = g
+        self.rs = torch.tensor([0.115, 0.12, 0.125], dtype=torch.float64)[torch.randint(0, 3, (self.B,), generator=g)]
+        self.qs = self.rs * (40 * (1 - self.rs / 0.16))
+        self.env.set_action_bounds(self.qs)
+
+    def prepare(self, total_steps):
+        import torch
+        a = (torch.rand(total_steps, self.B, 1, generator=self.gen, dtype=torch.float64) * 0.4 + 0.8) * self.qs.reshape(1, -1, 1)
+        self.actions = torch.cat([a, torch.zeros_like(a)], dim=2).to(self.device).contiguous()
+        self.env.reset(self.rs)
+        self.i = 0
+
+    def step(self):
+        out = self.env.step(self.actions[self.i])
+        self.i += 1
+        return out
+
+    def units_per_step(self):
+        return self.B
+
+    def algorithmic_bytes_per_step(self):      # streaming model: r, y read + written per sub-step (f64), obs (r, v), scalars
+        M = self.env.M
+        return (self.S * 32 * M + 16 * M + 48) * self.B
+
+    def compulsory_bytes_per_step(self):
+        M = self.env.M
+        return (2 * 16 * M + 16 * M + 64) * self.B
+
+    def config(self):
+        return {"workload": self.name, "env": "PDEControlGym-TrafficPDE1D", "nodes": self.env.M, "batch_per_gpu": self.B,
+                "substeps_per_env_step": self.S, "reward": "TrafficARZReward", "parallelism": "independent instances, no collective"}
+
+
 from bench_ns2d import NavierStokesC4, NavierStokesC5  # noqa: E402
 WORKLOADS["ns2d_c4"] = NavierStokesC4
 WORKLOADS["ns2d_c5"] = NavierStokesC5
+WORKLOADS["traffic_arz"] = TrafficARZ
 
 
 def measured_traffic(workload_key):

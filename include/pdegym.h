@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PDEGYM_ABI_VERSION 3
+#define PDEGYM_ABI_VERSION 4
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
 #define PDEGYM_MAX_N1D 1024      /* nodes per 1D row handled by the wave-per-instance kernels */
@@ -175,6 +175,44 @@ int pdegym_ns2d_reset_masked_f32(const pdegym_params_ns2d* prm, const pdegym_buf
                                  const void* v0, const void* p0, const uint8_t* mask, int32_t B, void* stream);
 int pdegym_ns2d_reset_masked_f64(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, const void* u0,
                                  const void* v0, const void* p0, const uint8_t* mask, int32_t B, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Traffic ARZ 1D: Aw-Rascle-Zhang freeway model in (r, y), float64,
+ * two-step Lax-Wendroff with relaxation, flux boundary control.
+ *   pdegym_traffic_step          replaces TrafficPDE1D.step + terminate/truncate   environments1d/traffic_arz_env.py:103-233
+ *                                + TrafficARZReward.reward                          rewards/traffic_arz_reward.py:12-22
+ *   pdegym_traffic_reset_masked  replaces the state part of TrafficPDE1D.reset     traffic_arz_env.py:245-260
+ * ------------------------------------------------------------------------------------------------ */
+enum { PDEGYM_TRAFFIC_INLET = 0, PDEGYM_TRAFFIC_OUTLET = 1, PDEGYM_TRAFFIC_BOTH = 2, PDEGYM_TRAFFIC_OUTLET_TRAIN = 3 };
+#define PDEGYM_TRAFFIC_MAX_M 64  /* nodes handled by the wave-per-instance kernel (the reference uses 51) */
+
+typedef struct pdegym_params_traffic {
+  int32_t M;               /* len(np.arange(0, X+dx, dx))                                   traffic_arz_env.py:77-79 */
+  int32_t control_freq;    /* PDE sub-steps per step() call                                  :41-42 */
+  int32_t sim;             /* PDEGYM_TRAFFIC_*  (simulation_type)                            :44-57 */
+  int32_t limit;           /* limit_pde_state_size                                           :124 */
+  double dt, dx, T;        /* T in seconds; time advances by dt per step() (not per sub-step) :146 */
+  double vm, rm, tau;      /* v_max, ro_max, relaxation time */
+} pdegym_params_traffic;
+
+typedef struct pdegym_bufs_traffic {
+  double* r;               /* [B, M] density (in/out)                                                       */
+  double* y;               /* [B, M] relative flow y = r (v - Veq(r)) (in/out)                              */
+  const double* action;    /* [B, 2] inlet / outlet flux command; column 1 is used by 'both' only           */
+  double* time;            /* [B] simulated seconds ("time_index" of the reference) in/out                  */
+  const double* rs;        /* [B] steady-state density of each instance (vs, qs follow the equilibrium law) */
+  const double* qs_clip;   /* [B] qs the action bounds [0.8 qs, 1.2 qs] were built from (:97-100)           */
+  double* obs;             /* [B, 2M] out: (r, v), or ((r-rs)/rs, (v-vs)/vs) for outlet-train (:227-230)    */
+  double* reward;          /* [B] out                                                                       */
+  uint8_t* done;           /* [B] out: terminate() or reward > -0.00023 (:230)                              */
+  uint8_t* truncated;      /* [B] out                                                                       */
+} pdegym_bufs_traffic;
+
+int pdegym_traffic_step(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf, int32_t B, void* stream);
+/* Where mask[b] != 0 (or mask == NULL): rs[b] is taken as given, r = rs*profile, y = qs - vm r + vm/rm r^2, time = 0,
+ * obs = (r, v).  profile[M] = sin(3 x/L pi)*0.1 + 1 is computed by the caller in NumPy (libm sin, bit parity). */
+int pdegym_traffic_reset_masked(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf, const double* profile,
+                                const uint8_t* mask, int32_t B, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,4 @@
-"""Environments of the reference that are outside this build's hot-path scope (SURVEY.md section 8f, ranks 2-3).
+"""Environments of the reference that are outside this build's hot-path scope (SURVEY.md section 8f, rank 3).
 
 The names exist so ``from pde_control_gym.src import TrafficPDE1D`` keeps importing; constructing one fails loudly
 instead of silently running something else.
@@ -12,10 +12,6 @@ class _NotBuilt:
         raise NotImplementedError(
             f"{self._what} is not part of the MI355X hot-path build yet (SURVEY.md section 8f); "
             "TransportPDE1D, ReactionDiffusionPDE1D and NavierStokes2D are.")
-
-
-class TrafficPDE1D(_NotBuilt):
-    _what = "TrafficPDE1D (Aw-Rascle-Zhang traffic env, reference environments1d/traffic_arz_env.py)"
 
 
 class BrainTumor1D(_NotBuilt):

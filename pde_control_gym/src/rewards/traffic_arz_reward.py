@@ -1,11 +1,13 @@
-"""TrafficARZReward belongs to the TrafficPDE1D environment, which is outside this build's hot-path scope
-(SURVEY.md section 8f rank 2).  The name is kept importable; using it fails loudly."""
+"""TrafficARZReward (reference rewards/traffic_arz_reward.py:5-22): minus the relative L2 deviation of velocity and
+density from the desired steady state.  ``TrafficPDE1D.step`` evaluates it inside the step kernel; ``reward()`` is the
+host-side definition for caller-held arrays."""
+import numpy as np
+
 from pde_control_gym.src.rewards.base_reward import BaseReward
 
 
 class TrafficARZReward(BaseReward):
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("TrafficARZReward / TrafficPDE1D are not part of the MI355X hot-path build yet")
-
-    def reward(self, *args, **kwargs):  # pragma: no cover
-        raise NotImplementedError
+    def reward(self, v_desired: float, r_desired: float, v: np.ndarray, r: np.ndarray):
+        dev_v = np.linalg.norm(v - v_desired, ord=None) / v_desired
+        dev_r = np.linalg.norm(r - r_desired, ord=None) / r_desired
+        return -(dev_v + dev_r)

@@ -23,6 +23,7 @@ _KINDS = {
     "PDEControlGym-TransportPDE1D": "transport", "transport": "transport", "TransportPDE1D": "transport",
     "PDEControlGym-ReactionDiffusionPDE1D": "parabolic", "parabolic": "parabolic", "ReactionDiffusionPDE1D": "parabolic",
     "PDEControlGym-NavierStokes2D": "ns2d", "ns2d": "ns2d", "NavierStokes2D": "ns2d",
+    "PDEControlGym-TrafficPDE1D": "traffic", "traffic": "traffic", "TrafficPDE1D": "traffic",
 }
 _RESET_ERR = ("Please pass both an initial condition and a recirculation function in the parameters dictionary. "
               "See documentation for more details")
@@ -46,6 +47,8 @@ class PDEVecEnv:
         self._fused_reset = False
         if self.kind == "ns2d":
             self._init_ns(kw, backend, dtype)
+        elif self.kind == "traffic":
+            self._init_traffic(kw, backend)
         else:
             self._init_1d(kw, backend)
 
@@ -98,6 +101,29 @@ class PDEVecEnv:
                                             np.full((self.nx, self.ny, 2), np.inf, dtype="float32"))
         self.action_space = spaces.Box(low=-1.0, high=1.0, shape=(kw.get("action_dim", 1),), dtype=np.float32)
 
+    def _init_traffic(self, kw, backend):
+        import random
+        from pdecontrolgym_amd.batch_traffic import TrafficBatch
+        from pde_control_gym.src.rewards import TrafficARZReward
+        if type(self.reward_class) is not TrafficARZReward:
+            raise NotImplementedError("PDEVecEnv(TrafficPDE1D) evaluates TrafficARZReward inside the step kernel")
+        sim = kw.get("simulation_type", "inlet")
+        self.core = TrafficBatch(kw["T"], kw["dt"], kw["X"], kw["dx"], sim, kw.get("v_max", 40), kw.get("ro_max", 0.16),
+                                 kw.get("tau", 60), kw.get("limit_pde_state_size", False), kw.get("control_freq", 1),
+                                 num_envs=self.num_envs, device=self.device, backend=backend)
+        self._traffic_train = sim == "outlet-train"
+        self._rs_fixed = kw.get("ro_steady", 0.12)
+        self._draw_rs = lambda k: (np.array([{0: 0.115, 1: 0.12, 2: 0.125}[random.randint(0, 2)] for _ in range(k)])
+                                   if self._traffic_train else np.full(k, self._rs_fixed))
+        rs0 = self._draw_rs(self.num_envs)                 # construction-time draw fixes the action bounds (:97-100)
+        self.core.set_action_bounds(rs0 * self.core.Veq(rs0))
+        M = self.core.M
+        lo, hi = (-10, 10) if self._traffic_train else (0, 40)
+        self.observation_space = spaces.Box(low=lo, high=hi, shape=(2 * M,), dtype=np.float64)
+        qs = float(rs0[0] * self.core.Veq(rs0[0]))
+        self.action_space = spaces.Box(dtype=np.float64, low=qs * 0.8, high=1.2 * qs, shape=(self.core.action_dim,))
+        self.nx, self.nt = M, int(round(kw["T"] / kw["dt"]))
+
     # ---- initial conditions --------------------------------------------------------------------------
     def _sample_1d(self, idx):
         """Initial condition and beta rows for the instances in ``idx`` (user callbacks, reference semantics)."""
@@ -137,6 +163,8 @@ class PDEVecEnv:
     # ---- torch-native face ---------------------------------------------------------------------------
     def reset_tensor(self):
         idx = np.arange(self.num_envs)
+        if self.kind == "traffic":
+            return self.core.reset(self._draw_rs(self.num_envs))
         if self.kind == "ns2d":
             u, v, p = self._sample_ns(idx)
             return self.core.reset(u, v, p)
@@ -166,7 +194,7 @@ class PDEVecEnv:
         if self.kind == "ns2d":
             obs, r, te = self.core.step(actions)
             return obs, r, te, torch.zeros_like(te)
-        return self.core.step(actions)
+        return self.core.step(actions)      # 1D envs and traffic: (obs, reward, terminated|done, truncated)
 
     # ---- SB3 VecEnv face -----------------------------------------------------------------------------
     def _noise(self, obs):
@@ -175,7 +203,7 @@ class PDEVecEnv:
 
     def _obs_np(self, obs):
         o = obs.cpu().numpy()
-        return o.astype(np.float32, copy=False)
+        return o if self.kind == "traffic" else o.astype(np.float32, copy=False)   # the traffic env observes in float64
 
     def reset(self):
         return self._noise(self._obs_np(self.reset_tensor()))
@@ -186,10 +214,10 @@ class PDEVecEnv:
     def step_wait(self):
         import torch
         a = torch.as_tensor(np.asarray(self._actions), device=self.device)
-        if self.kind != "ns2d":
+        if self.kind not in ("ns2d", "traffic"):
             a = a.reshape(self.num_envs)
         obs_t, r_t, te_t, tr_t = self.step_tensor(a)
-        obs = self._obs_np(obs_t).copy()
+        obs = (obs_t.cpu().numpy() if self.kind == "traffic" else self._obs_np(obs_t)).copy()
         rew = r_t.cpu().numpy().astype(np.float32)
         te = te_t.cpu().numpy().astype(bool)
         tr = tr_t.cpu().numpy().astype(bool)
@@ -204,7 +232,12 @@ class PDEVecEnv:
                 infos[i]["TimeLimit.truncated"] = bool(tr[i] and not te[i])
             if not self._fused_reset:
                 mask = torch.as_tensor(dones.astype(np.uint8), device=self.device)
-                if self.kind == "ns2d":
+                if self.kind == "traffic":
+                    rs = self.core.t["rs"].cpu().numpy().copy()
+                    rs[idx] = self._draw_rs(len(idx))
+                    new = self.core.reset(rs, mask=mask)
+                    obs[idx] = new.cpu().numpy()[idx]
+                elif self.kind == "ns2d":
                     u, v, p = self._sample_ns(idx)
                     shp = (self.ny, self.nx)
                     new = self.core.reset(self._scatter(u, idx, shp), self._scatter(v, idx, shp), self._scatter(p, idx, shp), mask=mask)
@@ -214,7 +247,8 @@ class PDEVecEnv:
                         self.core.t["beta"][torch.as_tensor(idx, device=self.device)] = torch.as_tensor(
                             beta, dtype=torch.float32, device=self.device)
                     new = self.core.reset(self._scatter(init, idx, (self.core.n,)), mask=mask)
-                obs[idx] = self._obs_np(new)[idx]
+                if self.kind != "traffic":
+                    obs[idx] = self._obs_np(new)[idx]
         return self._noise(obs), rew, dones, infos
 
     def step(self, actions):

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 RING = 128
 LOOKBACK = 100
 MAX_N1D = 1024
@@ -26,7 +26,7 @@ EXPORTS = [
     "pdegym_abi_version", "pdegym_last_error", "pdegym_transport_step", "pdegym_parabolic_step",
     "pdegym_reset1d_masked", "pdegym_rownorm2_f32", "pdegym_selftest_quotient", "pdegym_ns2d_step_f32", "pdegym_ns2d_step_f64",
     "pdegym_ns2d_solve_pressure_f32", "pdegym_ns2d_solve_pressure_f64", "pdegym_ns2d_reset_masked_f32",
-    "pdegym_ns2d_reset_masked_f64",
+    "pdegym_ns2d_reset_masked_f64", "pdegym_traffic_step", "pdegym_traffic_reset_masked",
 ]
 
 
@@ -57,6 +57,21 @@ class BufsNS2D(C.Structure):
                 ("action", C.c_void_p), ("time_index", C.c_void_p), ("U_ref", C.c_void_p),
                 ("action_ref", C.c_void_p), ("nt_ref", C.c_int32), ("obs", C.c_void_p), ("reward", C.c_void_p),
                 ("terminated", C.c_void_p), ("state_in", C.c_void_p)]
+
+
+TRAFFIC_SIM = {"inlet": 0, "outlet": 1, "both": 2, "outlet-train": 3}
+
+
+class ParamsTraffic(C.Structure):
+    _fields_ = [("M", C.c_int32), ("control_freq", C.c_int32), ("sim", C.c_int32), ("limit", C.c_int32),
+                ("dt", C.c_double), ("dx", C.c_double), ("T", C.c_double), ("vm", C.c_double), ("rm", C.c_double),
+                ("tau", C.c_double)]
+
+
+class BufsTraffic(C.Structure):
+    _fields_ = [("r", C.c_void_p), ("y", C.c_void_p), ("action", C.c_void_p), ("time", C.c_void_p), ("rs", C.c_void_p),
+                ("qs_clip", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
+                ("truncated", C.c_void_p)]
 
 
 class NativeError(RuntimeError):
@@ -100,6 +115,11 @@ def load():
         f = getattr(lib, "pdegym_ns2d_reset_masked_" + sfx)
         f.argtypes = [C.POINTER(ParamsNS2D), C.POINTER(BufsNS2D), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         f.restype = C.c_int
+    lib.pdegym_traffic_step.argtypes = [C.POINTER(ParamsTraffic), C.POINTER(BufsTraffic), C.c_int32, C.c_void_p]
+    lib.pdegym_traffic_step.restype = C.c_int
+    lib.pdegym_traffic_reset_masked.argtypes = [C.POINTER(ParamsTraffic), C.POINTER(BufsTraffic), C.c_void_p, C.c_void_p,
+                                                C.c_int32, C.c_void_p]
+    lib.pdegym_traffic_reset_masked.restype = C.c_int
     if lib.pdegym_abi_version() != ABI_VERSION:
         raise NativeError(f"ABI mismatch: library {lib.pdegym_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

@@ -101,6 +101,30 @@ class HipBackend:
                    N.dptr(scratch, dtype), B, N.current_stream_ptr(u.device)), "pdegym_ns2d_solve_pressure")
 
 
+    # ---- Traffic ARZ ---------------------------------------------------------------------------
+    @staticmethod
+    def _bufs_traffic(T) -> N.BufsTraffic:
+        import torch
+        b = N.BufsTraffic()
+        for k in ("r", "y", "action", "time", "rs", "qs_clip", "obs", "reward"):
+            setattr(b, k, N.dptr(T[k], torch.float64))
+        b.done = N.dptr(T["done"], torch.uint8)
+        b.truncated = N.dptr(T["truncated"], torch.uint8)
+        return b
+
+    def traffic_step(self, P: N.ParamsTraffic, T: dict, B: int):
+        bufs = self._bufs_traffic(T)
+        N.check(self.lib.pdegym_traffic_step(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["r"].device)),
+                "pdegym_traffic_step")
+
+    def traffic_reset(self, P: N.ParamsTraffic, T: dict, profile, mask, B: int):
+        import torch
+        bufs = self._bufs_traffic(T)
+        m = N.dptr(mask, torch.uint8) if mask is not None else None
+        N.check(self.lib.pdegym_traffic_reset_masked(C.byref(P), C.byref(bufs), N.dptr(profile, torch.float64), m, B,
+                                                     N.current_stream_ptr(T["r"].device)), "pdegym_traffic_reset_masked")
+
+
 _default = None
 
 

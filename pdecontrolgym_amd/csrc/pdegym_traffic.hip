@@ -1,0 +1,164 @@
+// pdegym_traffic.hip -- gfx950 kernel for the Aw-Rascle-Zhang traffic environment (float64).
+//
+// One 64-lane wavefront owns one freeway instance, lane j holds node j (the reference's M = 51 nodes), both fields
+// (r, y) stay in registers for the control_freq sub-steps of a step() call.  Neighbour values cross lanes with
+// wave shuffles; the "minus" midpoint of node j IS the "plus" midpoint of node j-1 (same floating-point expression,
+// addition is commutative), so each lane evaluates one midpoint flux and the other arrives from lane j-1.
+// Operation order follows environments1d/traffic_arz_env.py:172-227 exactly (-ffp-contract=off, IEEE division):
+// fields are bit-identical to NumPy; the reward norms are wave reductions (rtol 1e-14 vs BLAS ddot).
+#include <hip/hip_runtime.h>
+
+#include "pdegym.h"
+#include "pdegym_common.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ double Veq(double vm, double rm, double rho) { return vm * (1 - rho / rm); }  // :270-272
+__device__ __forceinline__ double F_r(double vm, double rm, double rho, double y) { return y + rho * Veq(vm, rm, rho); }
+__device__ __forceinline__ double F_y(double vm, double rm, double rho, double y) { return y * (y / rho + Veq(vm, rm, rho)); }
+
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pdegym_params_traffic P, pdegym_bufs_traffic Bf, int B) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (inst >= B) return;
+  const int M = P.M;
+  const bool in = lane < M;
+  const double vm = P.vm, rm = P.rm, dt = P.dt, dx = P.dx;
+  double r = in ? Bf.r[(size_t)inst * M + lane] : 1.0;
+  double y = in ? Bf.y[(size_t)inst * M + lane] : 0.0;
+  const double rs = Bf.rs[inst];
+  const double vs = Veq(vm, rm, rs);              // :66-72
+  const double qs = rs * vs;
+  const double qc = Bf.qs_clip[inst];
+  // action clip (:151-156) -- np.clip(a, low, high) = min(max(a, low), high)
+  double a0 = Bf.action[(size_t)inst * 2], a1 = Bf.action[(size_t)inst * 2 + 1];
+  const double lo = qc * 0.8, hi = 1.2 * qc;
+  a0 = fmin(fmax(a0, lo), hi);
+  a1 = fmin(fmax(a1, lo), hi);
+  double q_in, q_out;
+  if (P.sim == PDEGYM_TRAFFIC_BOTH) { q_in = a0; q_out = a1; }
+  else if (P.sim == PDEGYM_TRAFFIC_INLET) { q_in = a0; q_out = qs; }
+  else { q_in = qs; q_out = a0; }
+
+  double time = Bf.time[inst] + dt;               // :146
+  // Python evaluates these scalar sub-expressions before they meet an array (:201-222)
+  const double c1 = dt / (2 * dx), c2 = 0.25 * dt / P.tau, c3 = dt / dx, c4 = 0.5 * dt / P.tau;
+  if (time < P.T) {                               // :172  (time does not change inside the loop)
+    for (int s = 0; s < P.control_freq; ++s) {
+      // boundary conditions :174-190
+      const double r1 = __shfl(r, 1), rm2 = __shfl(r, M - 2);
+      if (lane == 0) { r = r1; y = q_in - r * Veq(vm, rm, r); }
+      if (lane == M - 1) { r = rm2; y = q_out - r * Veq(vm, rm, r); }
+      // nodal fluxes and the "plus" midpoint (:201-216)
+      const double fr = F_r(vm, rm, r, y), fy = F_y(vm, rm, r, y);
+      const double r_p = __shfl_down(r, 1), y_p = __shfl_down(y, 1), fr_p = __shfl_down(fr, 1), fy_p = __shfl_down(fy, 1);
+      const double r_pm = 0.5 * (r_p + r) - c1 * (fr_p - fr);
+      const double y_pm = (0.5 * (y_p + y) - c1 * (fy_p - fy)) - c2 * (y_p + y);
+      const double Frp = F_r(vm, rm, r_pm, y_pm), Fyp = F_y(vm, rm, r_pm, y_pm);
+      // the "minus" midpoint of node j is the "plus" midpoint of node j-1
+      const double Frm = __shfl_up(Frp, 1), Fym = __shfl_up(Fyp, 1), y_mm = __shfl_up(y_pm, 1);
+      if (lane >= 1 && lane <= M - 2) {           // inner update :219-223
+        r = r - c3 * (Frp - Frm);
+        y = y - (c3 * (Fyp - Fym) + c4 * (y_pm + y_mm));
+      }
+    }
+  }
+  const double v = y / r + Veq(vm, rm, r);         // :227
+  // reward (traffic_arz_reward.py:22)
+  const double dv = in ? v - vs : 0.0, dr = in ? r - rs : 0.0;
+  const double nv = sqrt(wave_sum_d(dv * dv)), nr = sqrt(wave_sum_d(dr * dr));
+  const double reward = -(nv / vs + nr / rs);
+  const bool term = time >= P.T / dt;              // :106 (seconds compared with a step count -- kept)
+  if (term) time = 0.0;
+  bool trunc = false;
+  if (P.limit) trunc = __any(in && (v > vm || r > rm));
+  trunc = trunc || !__any(in && (dr != 0.0 || dv != 0.0));   // exact steady state (:127-128)
+  const bool done = (P.sim == PDEGYM_TRAFFIC_OUTLET_TRAIN) ? term : (term || reward > -0.00023);
+  if (in) {
+    Bf.r[(size_t)inst * M + lane] = r;
+    Bf.y[(size_t)inst * M + lane] = y;
+    double* o = Bf.obs + (size_t)inst * 2 * M;
+    if (P.sim == PDEGYM_TRAFFIC_OUTLET_TRAIN) {
+      o[lane] = (r - rs) / rs;
+      o[M + lane] = (v - vs) / vs;
+    } else {
+      o[lane] = r;
+      o[M + lane] = v;
+    }
+  }
+  if (lane == 0) {
+    Bf.time[inst] = time;
+    Bf.reward[inst] = reward;
+    Bf.done[inst] = done ? 1 : 0;
+    Bf.truncated[inst] = trunc ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_reset_kernel(pdegym_params_traffic P, pdegym_bufs_traffic Bf,
+                                                                               const double* profile, const uint8_t* mask, int B) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (inst >= B || (mask && !mask[inst])) return;
+  const int M = P.M;
+  if (lane < M) {
+    const double rs = Bf.rs[inst];
+    const double vs = Veq(P.vm, P.rm, rs), qs = rs * vs;
+    // :256-258   r = rs*(sin(3x/L pi)*0.1 + 1) ; y = qs - vm r + vm/rm r^2 ; v = y/r + Veq(r)
+    const double r = rs * profile[lane];
+    const double y = (qs * 1.0 - P.vm * r) + (P.vm / P.rm) * (r * r);
+    const double v = y / r + Veq(P.vm, P.rm, r);
+    Bf.r[(size_t)inst * M + lane] = r;
+    Bf.y[(size_t)inst * M + lane] = y;
+    Bf.obs[(size_t)inst * 2 * M + lane] = r;
+    Bf.obs[(size_t)inst * 2 * M + M + lane] = v;
+  }
+  if (lane == 0) {
+    Bf.time[inst] = 0.0;
+    Bf.done[inst] = 0;
+    Bf.truncated[inst] = 0;
+  }
+}
+
+int check(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf) {
+  if (!prm || !buf) return pdegym::fail(-1, "null params/bufs");
+  if (prm->M < 4 || prm->M > PDEGYM_TRAFFIC_MAX_M) return pdegym::fail(-2, "M must be in [4, 64] for the wave-per-instance traffic kernel");
+  if (prm->control_freq < 1) return pdegym::fail(-2, "control_freq must be >= 1");
+  if (prm->sim < 0 || prm->sim > 3) return pdegym::fail(-2, "bad simulation type");
+  if (!buf->r || !buf->y || !buf->time || !buf->rs || !buf->qs_clip || !buf->obs || !buf->done || !buf->truncated)
+    return pdegym::fail(-3, "null device buffer");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pdegym_traffic_step(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf, int32_t B, void* stream) {
+  if (int rc = check(prm, buf)) return rc;
+  if (!buf->action || !buf->reward) return pdegym::fail(-3, "null device buffer");
+  if (B <= 0) return 0;
+  const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+  hipLaunchKernelGGL(traffic_step_kernel, grid, block, 0, (hipStream_t)stream, *prm, *buf, B);
+  return pdegym::check_launch("traffic_step");
+}
+
+int pdegym_traffic_reset_masked(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf, const double* profile,
+                                const uint8_t* mask, int32_t B, void* stream) {
+  if (int rc = check(prm, buf)) return rc;
+  if (!profile) return pdegym::fail(-1, "null profile");
+  if (B <= 0) return 0;
+  const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+  hipLaunchKernelGGL(traffic_reset_kernel, grid, block, 0, (hipStream_t)stream, *prm, *buf, profile, mask, B);
+  return pdegym::check_launch("traffic_reset");
+}
+
+}  // extern "C"

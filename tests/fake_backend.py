@@ -137,3 +137,32 @@ class FakeBackend:
     def ns2d_solve_pressure(self, P, u, v, p_in, p_out, scratch, B):
         orc = self._orc_ns({"u": u, "p": p_in, "U_ref": torch.zeros(1, self.core.ny, self.core.nx, 2), "action_ref": torch.zeros(1)})
         p_out.copy_(torch.from_numpy(orc.solve_pressure(u.numpy(), v.numpy(), p_in.numpy())))
+
+
+    # ---- Traffic ARZ ----------------------------------------------------------------------------
+    def _orc_traffic(self):
+        c = self.core
+        return po.TrafficOracle(c.T, c.dt, c.X, c.dx, c.simulation_type, c.vm, c.rm, c.tau, c.limit, c.control_freq)
+
+    def traffic_step(self, P, T, B):
+        orc = self._orc_traffic()
+        orc.reset(T["rs"].numpy(), T["qs_clip"].numpy())
+        orc.r, orc.y = T["r"].numpy().copy(), T["y"].numpy().copy()
+        orc.time_index = T["time"].numpy().copy()
+        a = T["action"].numpy()
+        obs, r, d, t = orc.step(a if self.core.action_dim == 2 else a[:, :1])
+        for k, v in (("r", orc.r), ("y", orc.y), ("time", orc.time_index), ("obs", obs), ("reward", r)):
+            T[k].copy_(torch.from_numpy(np.ascontiguousarray(v)))
+        T["done"].copy_(torch.from_numpy(d.astype(np.uint8)))
+        T["truncated"].copy_(torch.from_numpy(t.astype(np.uint8)))
+
+    def traffic_reset(self, P, T, profile, mask, B):
+        orc = self._orc_traffic()
+        obs = orc.reset(T["rs"].numpy())
+        m = torch.ones(B, dtype=torch.bool) if mask is None else mask.bool()
+        T["r"][m] = torch.from_numpy(orc.r)[m]
+        T["y"][m] = torch.from_numpy(orc.y)[m]
+        T["obs"][m] = torch.from_numpy(obs)[m]
+        T["time"][m] = 0
+        T["done"][m] = 0
+        T["truncated"][m] = 0

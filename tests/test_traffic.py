@@ -1,0 +1,122 @@
+"""TrafficPDE1D: host API on the CPU test double, and GPU parity through the C ABI.
+
+GPU bars: r, y, v and observations BIT-EXACT float64 vs the reference's golden vectors and vs the oracle; rewards rtol
+1e-13 (wave butterfly vs BLAS ddot order); flags equal."""
+import contextlib
+import io
+import random
+
+import numpy as np
+import pytest
+
+from tests.fake_backend import FakeBackend
+from tests.test_oracle_golden import TRAFFIC_CASES
+
+torch = pytest.importorskip("torch")
+BASE = dict(T=240, dt=0.25, X=500, dx=10, v_steady=10, ro_steady=0.12, v_max=40, ro_max=0.16, tau=60)
+
+
+def _single(g, **extra):
+    from pde_control_gym.src import TrafficARZReward, TrafficPDE1D
+    random.seed(11)
+    env = TrafficPDE1D(reward_class=TrafficARZReward(), simulation_type=str(g.sim), limit_pde_state_size=bool(g.limit),
+                       control_freq=int(g.control_freq), **BASE, **extra)
+    random.seed(13)
+    return env
+
+
+def _check_single(env, g):
+    obs, info = env.reset()
+    assert info == {} and obs.shape == (102,) and obs.dtype == np.float64
+    np.testing.assert_array_equal(obs, g.obs[0])
+    assert env.rs == float(g.rs)
+    keep = {int(k): i for i, k in enumerate(g.keep)} if "keep" in g else None
+    for k, a in enumerate(g.actions):
+        obs, r, d, t, info = env.step(a)
+        assert isinstance(d, bool) and isinstance(t, bool)
+        if keep is None:
+            np.testing.assert_array_equal(obs, g.obs[k + 1], err_msg=f"step {k}")
+        elif (k + 1) in keep:
+            np.testing.assert_array_equal(obs, g.obs[keep[k + 1]], err_msg=f"step {k}")
+        np.testing.assert_allclose(r, g.reward[k], rtol=1e-13)
+        assert d == bool(g.done[k]) and t == bool(g.trunc[k]) and env.time_index == g.time[k]
+    assert env.r.shape == (51, 1) and env.v.shape == (51, 1)
+
+
+@pytest.mark.parametrize("case", TRAFFIC_CASES)
+def test_traffic_public_api_on_test_double(golden_traffic, case):
+    _check_single(_single(golden_traffic[case], device="cpu", backend=FakeBackend()), golden_traffic[case])
+
+
+def test_traffic_constructor_errors():
+    from pde_control_gym.src import TrafficARZReward, TrafficPDE1D
+    kw = dict(reward_class=TrafficARZReward(), device="cpu", backend=FakeBackend(), **BASE)
+    with pytest.raises(ValueError, match="Invalid simulation type"):
+        TrafficPDE1D(simulation_type="sideways", **kw)
+    with pytest.raises(ValueError, match="equilibrium condition"):
+        TrafficPDE1D(simulation_type="inlet", **dict(kw, v_steady=11))
+    with pytest.raises(AssertionError, match="control_freq must be a positive integer"):
+        TrafficPDE1D(simulation_type="inlet", control_freq=0, **kw)
+    env = TrafficPDE1D(simulation_type="both", **kw)
+    assert env.action_space.shape == (2,) and env.observation_space.shape == (102,) and env.M == 51
+    assert env.action_space.low[0] == env.qs * 0.8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", TRAFFIC_CASES)
+def test_traffic_hip_matches_reference_golden(golden_traffic, case):
+    _check_single(_single(golden_traffic[case]), golden_traffic[case])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sim,cf,B", [("inlet", 1, 37), ("outlet", 2, 64), ("both", 1, 5), ("outlet-train", 3, 130)])
+def test_traffic_hip_matches_oracle_batched(sim, cf, B):
+    """Per-instance steady states / actions, masked reset mid-run: every field bit-exact vs the oracle."""
+    from oracle import pde_oracle as po
+    from pdecontrolgym_amd.batch_traffic import TrafficBatch
+    rng = np.random.default_rng(B)
+    rs = rng.choice([0.115, 0.12, 0.125], B)
+    orc = po.TrafficOracle(240, 0.25, 500, 10, sim, 40, 0.16, 60, True, cf)
+    env = TrafficBatch(240, 0.25, 500, 10, sim, 40, 0.16, 60, True, cf, num_envs=B, device="cuda")
+    qclip = rng.choice([0.115, 0.12, 0.125], B)
+    qclip = qclip * (40 * (1 - qclip / 0.16))
+    env.set_action_bounds(qclip)
+    o_ref = orc.reset(rs, qclip)
+    o = env.reset(rs)
+    np.testing.assert_array_equal(o.cpu().numpy(), o_ref)
+    nact = 2 if sim == "both" else 1
+    for k in range(25):
+        a = rng.uniform(0.7, 1.3, (B, nact)) * orc.qs[:, None]
+        o_ref, r_ref, d_ref, t_ref = orc.step(a)
+        o, r, d, t = env.step(a)
+        np.testing.assert_array_equal(o.cpu().numpy(), o_ref, err_msg=f"step {k}")
+        np.testing.assert_array_equal(env.t["r"].cpu().numpy(), orc.r)
+        np.testing.assert_array_equal(env.t["y"].cpu().numpy(), orc.y)
+        np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-13)
+        np.testing.assert_array_equal(d.cpu().numpy().astype(bool), d_ref)
+        np.testing.assert_array_equal(t.cpu().numpy().astype(bool), t_ref)
+        np.testing.assert_array_equal(env.t["time"].cpu().numpy(), orc.time_index)
+    # masked reset: only the selected instances restart (with a new steady state)
+    mask = (np.arange(B) % 3 == 0)
+    rs2 = np.where(mask, 0.125, rs)
+    env.reset(rs2, mask=torch.tensor(mask.astype(np.uint8)))
+    fresh = po.TrafficOracle(240, 0.25, 500, 10, sim, 40, 0.16, 60, True, cf)
+    fresh.reset(rs2, qclip)
+    np.testing.assert_array_equal(env.t["r"].cpu().numpy()[mask], fresh.r[mask])
+    np.testing.assert_array_equal(env.t["r"].cpu().numpy()[~mask], orc.r[~mask])
+    assert (env.t["time"].cpu().numpy()[mask] == 0).all() and (env.t["time"].cpu().numpy()[~mask] > 0).all()
+
+
+def test_traffic_vecenv_on_test_double():
+    import pde_control_gym
+    from pde_control_gym.src import TrafficARZReward
+    random.seed(0)
+    venv = pde_control_gym.make_vec("PDEControlGym-TrafficPDE1D", num_envs=5, device="cpu", backend=FakeBackend(),
+                                    reward_class=TrafficARZReward(), simulation_type="outlet-train", limit_pde_state_size=True,
+                                    control_freq=2, **BASE)
+    obs = venv.reset()
+    assert obs.shape == (5, 102) and obs.dtype == np.float64
+    qs = venv.core.t["qs_clip"].numpy()
+    obs, rew, dones, infos = venv.step(qs[:, None] * 1.05)
+    assert obs.shape == (5, 102) and rew.shape == (5,) and not dones.any()
+    assert venv.observation_space.shape == (102,) and venv.action_space.shape == (1,)
