@@ -155,19 +155,16 @@ __device__ __forceinline__ void compute_rhs(const T* us, const T* vs, T* rhs, in
   }
 }
 
+// ---- the phases of one step around the pressure solve, for one instance owned by one workgroup --------------
+// front: predictor -> apply_boundary -> rhs      (u*, v*, rhs left in the instance's scratch quarters 0, 1, 2)
 template <typename T>
-__global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, NSPtrs<T> P, int B) {
-  __shared__ T red[16];
-  const int b = blockIdx.x;
-  if (b >= B) return;
+__device__ __forceinline__ void gen_front(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int b) {
   const int nx = C.nx, ny = C.ny, ncell = nx * ny;
-  T* u = (P.u && !P.state_in) ? P.u + (size_t)b * ncell : nullptr;
-  T* v = (P.v && !P.state_in) ? P.v + (size_t)b * ncell : nullptr;
-  T* p = P.p + (size_t)b * ncell;
+  const T* u = (P.u && !P.state_in) ? P.u + (size_t)b * ncell : nullptr;
+  const T* v = (P.v && !P.state_in) ? P.v + (size_t)b * ncell : nullptr;
   T* us = P.scratch + (size_t)b * 4 * ncell;
   T* vs = us + ncell;
   T* rhs = vs + ncell;
-  T* pB = rhs + ncell;
   const T* act = P.action + (size_t)b * C.action_dim;
   // state: separate u, v fields, or the interleaved observation of the previous call
   const T* sin = P.state_in ? P.state_in + (size_t)b * ncell * 2 : nullptr;
@@ -204,22 +201,33 @@ __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, 
     }
   }
   __syncthreads();
-  // ---- pressure Poisson (:142, :94-116) ----
+  // ---- rhs of the pressure Poisson problem (:101-103) ----
   compute_rhs<T>(us, vs, rhs, ny, nx, S);
-  __syncthreads();
-  jacobi_sweeps<T>(p, pB, rhs, ny, nx, C.iters, S.dxdy);
+}
+
+// back: corrector (with the solved pressure pfin) -> apply_boundary -> observation, reward, flags
+template <typename T>
+__device__ __forceinline__ void gen_back(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int b, const T* pfin, T* red) {
+  const int nx = C.nx, ny = C.ny, ncell = nx * ny;
+  T* u = (P.u && !P.state_in) ? P.u + (size_t)b * ncell : nullptr;
+  T* v = (P.v && !P.state_in) ? P.v + (size_t)b * ncell : nullptr;
+  T* pdst = P.p + (size_t)b * ncell;
+  T* us = P.scratch + (size_t)b * 4 * ncell;
+  T* vs = us + ncell;
+  const T* act = P.action + (size_t)b * C.action_dim;
   // ---- corrector (:143-145): interior; the boundary keeps u* (zero pressure derivative) until the BC pass ----
   for (int c = threadIdx.x; c < ncell; c += blockDim.x) {
     const int i = c / nx, j = c - i * nx;
     T un = us[c], vn = vs[c];
     if (i >= 1 && i <= ny - 2 && j >= 1 && j <= nx - 2) {
-      const T dpdx = div_c(p[c + 1] - p[c - 1], S.two_dx, S.inv_two_dx);
-      const T dpdy = div_c(p[c + nx] - p[c - nx], S.two_dy, S.inv_two_dy);
+      const T dpdx = div_c(pfin[c + 1] - pfin[c - 1], S.two_dx, S.inv_two_dx);
+      const T dpdy = div_c(pfin[c + nx] - pfin[c - nx], S.two_dy, S.inv_two_dy);
       un = un - S.dt_over_rho * dpdx;
       vn = vn - S.dt_over_rho * dpdy;
     }
     us[c] = un;  // in place: each thread reads only its own u*, v* and neighbours of p
     vs[c] = vn;
+    if (pfin != pdst) pdst[c] = pfin[c];  // the split pipeline may finish in the ping-pong buffer: p is the warm start
   }
   __syncthreads();
   // ---- apply_boundary(u, v, action) (:146), observation (:147-149,:154), reward (ns_reward.py:28) ----
@@ -261,6 +269,41 @@ __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, 
     P.time_index[b] = t;
     P.terminated[b] = (t >= C.nt - 1) ? 1 : 0;  // navier_stokes2D.py:159-168
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, NSPtrs<T> P, int B) {
+  __shared__ T red[16];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int ncell = C.nx * C.ny;
+  T* p = P.p + (size_t)b * ncell;
+  T* rhs = P.scratch + (size_t)b * 4 * ncell + 2 * (size_t)ncell;
+  T* pB = rhs + ncell;
+  gen_front<T>(C, S, P, b);
+  __syncthreads();
+  jacobi_sweeps<T>(p, pB, rhs, C.ny, C.nx, C.iters, S.dxdy);   // pressure Poisson (:142, :94-116), result in p
+  gen_back<T>(C, S, P, b, p, red);
+}
+
+// ---- split pipeline for grids whose p + rhs do not fit one CU (256x256 float32) --------------------------------
+// ns_front_kernel -> ns_slab_jacobi x ceil(K/H) -> ns_back_kernel ; each a separate launch, so no workgroup ever
+// waits for another one (the slab passes ping-pong p between the p field and scratch quarter 3).
+template <typename T>
+__global__ __launch_bounds__(1024) void ns_front_kernel(NSConst C, NSScal<T> S, NSPtrs<T> P, int B) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  gen_front<T>(C, S, P, b);
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void ns_back_kernel(NSConst C, NSScal<T> S, NSPtrs<T> P, int final_in_scratch, int B) {
+  __shared__ T red[16];
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int ncell = C.nx * C.ny;
+  const T* pfin = final_in_scratch ? P.scratch + (size_t)b * 4 * ncell + 3 * (size_t)ncell : P.p + (size_t)b * ncell;
+  gen_back<T>(C, S, P, b, pfin, red);
 }
 
 
@@ -335,18 +378,18 @@ __device__ __forceinline__ float add_lane_right(float x, float y) {
 
 // top/bottom halo rows through LDS: ht = bottom row of the thread above, hb = top row of the thread below.
 // Domain-edge threads re-read their own row (valid address, value never used): every access is unconditional.
-template <int PC>
+template <int PC, int NT = 512, int RS = 32>
 __device__ __forceinline__ void halo_tb(const float (&top)[PC], const float (&bot)[PC], float (&ht)[PC], float (&hb)[PC],
                                         float* lds, int& xc, int tid, int ty) {
   using V = typename VecOf<PC>::type;
-  V* base = reinterpret_cast<V*>(lds) + (xc & 1) * (2 * 512);
+  V* base = reinterpret_cast<V*>(lds) + (xc & 1) * (2 * NT);
   ++xc;
   V* eT = base;
-  V* eB = base + 512;
+  V* eB = base + NT;
   eT[tid] = pack_row<PC>(top);
   eB[tid] = pack_row<PC>(bot);
   __syncthreads();
-  const int up = (ty > 0) ? tid - 32 : tid, dn = (ty < 15) ? tid + 32 : tid;
+  const int up = (ty > 0) ? tid - RS : tid, dn = (ty < NT / RS - 1) ? tid + RS : tid;
   const V a = eB[up];
   const V b = eT[dn];
   unpack_row<PC>(a, ht);
@@ -427,11 +470,11 @@ __device__ constexpr int prow(int a, int r) {
   return (((a - r) % (PR + 1)) + (PR + 1)) % (PR + 1);
 }
 
-template <int PR, int PC, int R>
+template <int PR, int PC, int R, int NT = 512, int RS = 32>
 __device__ __forceinline__ void jacobi_sweep_rot(float (&ph)[PR + 1][PC], const float (&rq)[PR][PC], const EdgeFlags& E,
                                                  float* lds, int& xc, int tid, int ty) {
   float hb[PC];
-  halo_tb<PC>(ph[prow<PR>(0, R)], ph[prow<PR>(PR - 1, R)], ph[prow<PR>(-1, R)], hb, lds, xc, tid, ty);
+  halo_tb<PC, NT, RS>(ph[prow<PR>(0, R)], ph[prow<PR>(PR - 1, R)], ph[prow<PR>(-1, R)], hb, lds, xc, tid, ty);
   // The new row a overwrites the registers of old row a-1, but the RIGHT neighbour lane still needs this lane's old
   // first column of row a (and the left one its last column) -> sample the edge columns before the row is updated.
 #pragma unroll
@@ -473,15 +516,32 @@ __device__ __forceinline__ void jacobi_sweep_rot(float (&ph)[PR + 1][PC], const 
 }
 
 // up to PR+1 sweeps, one per rotation; returns the rotation at which K was reached, or -1 after a full cycle
-template <int PR, int PC, int R>
+// RC = sweeps per cycle.  RC == PR+1 closes the rotation by itself; a shorter cycle copies the rows back to the identity
+// map after RC sweeps (PR*PC moves per RC sweeps) -- used where the fully unrolled cycle is too large for the compiler
+// to keep the rotating array in registers.
+template <int PR, int PC, int R, int NT = 512, int RS = 32, int RC = PR + 1>
 struct SweepChain {
   static __device__ __forceinline__ int run(float (&ph)[PR + 1][PC], const float (&rq)[PR][PC], const EdgeFlags& E, float* lds,
                                             int& xc, int tid, int ty, int& it, int K) {
     if (it >= K) return R;
-    jacobi_sweep_rot<PR, PC, R>(ph, rq, E, lds, xc, tid, ty);
+    jacobi_sweep_rot<PR, PC, R, NT, RS>(ph, rq, E, lds, xc, tid, ty);
     ++it;
-    if constexpr (R == PR) return -1;
-    else return SweepChain<PR, PC, R + 1>::run(ph, rq, E, lds, xc, tid, ty, it, K);
+    if constexpr (R == RC - 1) {
+      if constexpr (RC != PR + 1) {
+        float tmp[PR][PC];
+#pragma unroll
+        for (int a = 0; a < PR; ++a)
+#pragma unroll
+          for (int k = 0; k < PC; ++k) tmp[a][k] = ph[prow<PR>(a, RC)][k];
+#pragma unroll
+        for (int a = 0; a < PR; ++a)
+#pragma unroll
+          for (int k = 0; k < PC; ++k) ph[a][k] = tmp[a][k];
+      }
+      return -1;
+    } else {
+      return SweepChain<PR, PC, R + 1, NT, RS, RC>::run(ph, rq, E, lds, xc, tid, ty, it, K);
+    }
   }
 };
 
@@ -706,6 +766,61 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
   }
 }
 
+// ================================================================================================
+// Slab Jacobi pass for 256x256 float32 (BASELINE config 5): p + rhs of one instance (512 KB) exceed one CU's
+// registers, so an instance is cut into two slabs of 128 rows; each slab is swept by its own workgroup together with
+// H = 32 halo rows of the other slab (rows next to the cut go stale by one row per sweep, so after H sweeps the
+// slab's own rows are still exact).  A pass does up to H sweeps entirely in registers (patch PR x 4 per thread, a wave
+// = one full 256-wide row of patches -> left/right halos are DPP lane shifts, top/bottom halos cross waves through
+// LDS), then stores its own rows; passes ping-pong between two global copies of p, so no workgroup waits for another.
+// Redundant work: (128+32)/128 = 1.25x.  Same update expression as ns_generic<float>: bit-identical results.
+// ================================================================================================
+template <int PR, int H>
+__global__ __launch_bounds__(1024, 4) void ns_slab_jacobi(NSScal<float> S, const float* p_src, size_t src_stride, float* p_dst,
+                                                         size_t dst_stride, const float* rhs, size_t rhs_stride, int nsweeps,
+                                                         int B) {
+  constexpr int n = 256, PC = 4, NT = 1024, RS = 64, OWN = 128;
+  static_assert(16 * PR == OWN + H, "16 thread rows must cover the slab plus its halo rows");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* lds = reinterpret_cast<float*>(smem_raw);
+  const int b = blockIdx.x >> 1, slab = blockIdx.x & 1;
+  if (b >= B) return;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int c0 = tx * PC, lr0 = ty * PR;
+  const int g0 = (slab == 0 ? 0 : n - (OWN + H)) + lr0;          // global row of this thread's first patch row
+  const EdgeFlags E{slab == 0 && ty == 0, slab == 1 && ty == 15, tx == 0, tx == 63};
+  const float* ps = p_src + (size_t)b * src_stride;
+  float* pd = p_dst + (size_t)b * dst_stride;
+  const float* rh = rhs + (size_t)b * rhs_stride;
+  float ph[PR + 1][PC], rq[PR][PC];
+#pragma unroll
+  for (int a = 0; a < PR; ++a) {
+    const float4 w = *reinterpret_cast<const float4*>(ps + (g0 + a) * n + c0);
+    const float4 q = *reinterpret_cast<const float4*>(rh + (g0 + a) * n + c0);
+    ph[a][0] = w.x; ph[a][1] = w.y; ph[a][2] = w.z; ph[a][3] = w.w;
+    rq[a][0] = jacobi_rhs_term(S.dxdy, q.x); rq[a][1] = jacobi_rhs_term(S.dxdy, q.y);
+    rq[a][2] = jacobi_rhs_term(S.dxdy, q.z); rq[a][3] = jacobi_rhs_term(S.dxdy, q.w);
+  }
+#pragma unroll
+  for (int k = 0; k < PC; ++k) ph[PR][k] = 0.f;
+  int xc = 0, it = 0, rot = 0;
+  while (true) {
+    const int r = SweepChain<PR, PC, 0, NT, RS, 4>::run(ph, rq, E, lds, xc, tid, ty, it, nsweeps);
+    if (r >= 0) {
+      rot = r;
+      break;
+    }
+  }
+  float pf[PR][PC];
+  unrotate<PR, PC, 0>(ph, pf, rot);
+#pragma unroll
+  for (int a = 0; a < PR; ++a) {
+    const int g = g0 + a;
+    const bool own = slab == 0 ? (g < OWN) : (g >= n - OWN);       // wave-uniform
+    if (own) *reinterpret_cast<float4*>(pd + g * n + c0) = make_float4(pf[a][0], pf[a][1], pf[a][2], pf[a][3]);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void ns_generic_pressure(NSConst C, NSScal<T> S, const T* ug, const T* vg, const T* p_in,
                                                              T* p_out, T* scratch, int B) {
@@ -828,6 +943,26 @@ int ns_step(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int B, v
       else
         hipLaunchKernelGGL((ns_tile_step<4, 2, false>), dim3(B), dim3(512), lds64, (hipStream_t)stream, C, S, P, B);
       return pdegym::check_launch("ns2d_tile_step");
+    }
+  }
+  if constexpr (sizeof(T) == 4) {
+    // 256x256 float32 (BASELINE config 5): front kernel -> slab Jacobi passes -> back kernel
+    if (!pdegym_force_generic() && C.nx == 256 && C.ny == 256) {
+      constexpr int kH = 32, kPR = 10;
+      const size_t ncell = (size_t)C.nx * C.ny;
+      hipStream_t st = (hipStream_t)stream;
+      hipLaunchKernelGGL(ns_front_kernel<float>, dim3(B), dim3(1024), 0, st, C, S, P, B);
+      float* bufs[2] = {P.p, P.scratch + 3 * ncell};
+      const size_t strides[2] = {ncell, 4 * ncell};
+      int cur = 0;
+      for (int left = C.iters; left > 0; left -= kH) {
+        const int nsw = left < kH ? left : kH;
+        hipLaunchKernelGGL((ns_slab_jacobi<kPR, kH>), dim3(2 * B), dim3(1024), 2 * 2 * 1024 * 16, st, S, bufs[cur], strides[cur],
+                           bufs[cur ^ 1], strides[cur ^ 1], P.scratch + 2 * ncell, 4 * ncell, nsw, B);
+        cur ^= 1;
+      }
+      hipLaunchKernelGGL(ns_back_kernel<float>, dim3(B), dim3(1024), 0, st, C, S, P, cur, B);
+      return pdegym::check_launch("ns2d_slab_step");
     }
   }
   hipLaunchKernelGGL(ns_generic_step<T>, dim3(B), dim3(block_threads(C.nx * C.ny)), 0, (hipStream_t)stream, C, S, P, B);
