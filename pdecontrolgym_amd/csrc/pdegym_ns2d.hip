@@ -777,8 +777,8 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
 // ================================================================================================
 template <int PR, int H>
 __global__ __launch_bounds__(1024, 4) void ns_slab_jacobi(NSScal<float> S, const float* p_src, size_t src_stride, float* p_dst,
-                                                         size_t dst_stride, const float* rhs, size_t rhs_stride, int nsweeps,
-                                                         int B) {
+                                                         size_t dst_stride, const float* us_base, const float* vs_base,
+                                                         size_t uv_stride, int nsweeps, int B) {
   constexpr int n = 256, PC = 4, NT = 1024, RS = 64, OWN = 128;
   static_assert(16 * PR == OWN + H, "16 thread rows must cover the slab plus its halo rows");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -791,15 +791,41 @@ __global__ __launch_bounds__(1024, 4) void ns_slab_jacobi(NSScal<float> S, const
   const EdgeFlags E{slab == 0 && ty == 0, slab == 1 && ty == 15, tx == 0, tx == 63};
   const float* ps = p_src + (size_t)b * src_stride;
   float* pd = p_dst + (size_t)b * dst_stride;
-  const float* rh = rhs + (size_t)b * rhs_stride;
+  const float* us = us_base + (size_t)b * uv_stride;
+  const float* vs = vs_base + (size_t)b * uv_stride;
   float ph[PR + 1][PC], rq[PR][PC];
+  // 0.25*dx*dy*rhs with rhs = rho/dt (d/dx u* + d/dy v*) (navier_stokes2D.py:101-103) straight from u*, v*: the
+  // left/right u* neighbours are the neighbouring lanes (DPP), the v* rows above/below are two more row loads
+  {
+    auto vrow = [&](int g, float (&r)[PC]) {
+      const int gg = g < 0 ? 0 : (g > n - 1 ? n - 1 : g);     // clamped rows feed domain-edge cells only (rq = 0 there)
+      const float4 w = *reinterpret_cast<const float4*>(vs + gg * n + c0);
+      r[0] = w.x; r[1] = w.y; r[2] = w.z; r[3] = w.w;
+    };
+    float vprev[PC], vcur[PC], vnext[PC];
+    vrow(g0 - 1, vprev);
+    vrow(g0, vcur);
 #pragma unroll
-  for (int a = 0; a < PR; ++a) {
-    const float4 w = *reinterpret_cast<const float4*>(ps + (g0 + a) * n + c0);
-    const float4 q = *reinterpret_cast<const float4*>(rh + (g0 + a) * n + c0);
-    ph[a][0] = w.x; ph[a][1] = w.y; ph[a][2] = w.z; ph[a][3] = w.w;
-    rq[a][0] = jacobi_rhs_term(S.dxdy, q.x); rq[a][1] = jacobi_rhs_term(S.dxdy, q.y);
-    rq[a][2] = jacobi_rhs_term(S.dxdy, q.z); rq[a][3] = jacobi_rhs_term(S.dxdy, q.w);
+    for (int a = 0; a < PR; ++a) {
+      const int g = g0 + a;
+      vrow(g + 1, vnext);
+      const float4 w = *reinterpret_cast<const float4*>(ps + g * n + c0);
+      ph[a][0] = w.x; ph[a][1] = w.y; ph[a][2] = w.z; ph[a][3] = w.w;
+      const float4 uu = *reinterpret_cast<const float4*>(us + g * n + c0);
+      const float ur[PC] = {uu.x, uu.y, uu.z, uu.w};
+      const float ul = lane_left(ur[PC - 1]), urr = lane_right(ur[0]);
+#pragma unroll
+      for (int k = 0; k < PC; ++k) {
+        const float uw = (k == 0) ? ul : ur[k - 1], ue = (k == PC - 1) ? urr : ur[k + 1];
+        const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx);
+        const float dvdy = div_c(vnext[k] - vprev[k], S.two_dy, S.inv_two_dy);
+        const float r = S.rho_over_dt * (dudx + dvdy);
+        const bool edge = (g == 0) || (g == n - 1) || (tx == 0 && k == 0) || (tx == 63 && k == PC - 1);
+        rq[a][k] = edge ? 0.0f : jacobi_rhs_term(S.dxdy, r);
+      }
+#pragma unroll
+      for (int k = 0; k < PC; ++k) { vprev[k] = vcur[k]; vcur[k] = vnext[k]; }
+    }
   }
 #pragma unroll
   for (int k = 0; k < PC; ++k) ph[PR][k] = 0.f;
@@ -819,6 +845,176 @@ __global__ __launch_bounds__(1024, 4) void ns_slab_jacobi(NSScal<float> S, const
     const bool own = slab == 0 ? (g < OWN) : (g >= n - OWN);       // wave-uniform
     if (own) *reinterpret_cast<float4*>(pd + g * n + c0) = make_float4(pf[a][0], pf[a][1], pf[a][2], pf[a][3]);
   }
+}
+
+// ---- row-wave kernels of the 256x256 split pipeline: one 64-lane wave per grid row (4 cells per lane, float4 I/O,
+// left/right neighbours by DPP), 16 rows per workgroup; only the first / last workgroup of an instance touch the lower /
+// upper wall, and they hold the row next to it themselves (exchanged through LDS).
+template <int NROW>
+__device__ __forceinline__ void bc_rows_256(float (&fu)[4], float (&fv)[4], int i, int lane, int w, const float* lds_u,
+                                            const float* lds_v, const int (&bc)[4][2], const float* act, int action_dim) {
+  constexpr int n = 256;
+  const int c0 = 4 * lane;
+  auto aval = [&](int idx) -> float { return action_dim == 1 ? act[0] : act[idx]; };
+#pragma unroll
+  for (int comp = 0; comp < 2; ++comp) {
+    float (&f)[4] = comp == 0 ? fu : fv;
+    const float* lds = comp == 0 ? lds_u : lds_v;
+    if (i == 0 || i == n - 1) {               // lower / upper pass over the whole row (navier_stokes2D.py:76-90)
+      const int c = bc[i == 0 ? PDEGYM_EDGE_LOWER : PDEGYM_EDGE_UPPER][comp];
+      const int wr = (i == 0) ? w + 1 : w - 1;  // the row next to the wall lives in the neighbouring wave of this workgroup
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        f[k] = (c == PDEGYM_BC_NEUMANN) ? lds[wr * n + c0 + k] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(c0 + k));
+    }
+    if (lane == 0) {                          // left pass
+      const int c = bc[PDEGYM_EDGE_LEFT][comp];
+      f[0] = (c == PDEGYM_BC_NEUMANN) ? f[1] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(i));
+    }
+    if (lane == 63) {                         // right pass
+      const int c = bc[PDEGYM_EDGE_RIGHT][comp];
+      f[3] = (c == PDEGYM_BC_NEUMANN) ? f[2] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(i));
+    }
+  }
+}
+
+template <bool INTERLEAVED>
+__global__ __launch_bounds__(1024) void ns256_front(NSConst C, NSScal<float> S, NSPtrs<float> P, int B) {
+  constexpr int n = 256, ncell = n * n;
+  __shared__ __attribute__((aligned(16))) float lds_u[16 * n], lds_v[16 * n];
+  const int b = blockIdx.x >> 4, rb = blockIdx.x & 15;
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = rb * 16 + w, c0 = 4 * lane;
+  float* us = P.scratch + (size_t)b * 4 * ncell;
+  float* vs = us + ncell;
+  const float* act = P.action + (size_t)b * C.action_dim;
+  auto load_uv = [&](int row, float (&fu)[4], float (&fv)[4]) {
+    const int r = row < 0 ? 0 : (row > n - 1 ? n - 1 : row);
+    if constexpr (INTERLEAVED) {
+      const float4* q = reinterpret_cast<const float4*>(P.state_in + (size_t)b * ncell * 2 + (r * n + c0) * 2);
+      const float4 a = q[0], d = q[1];
+      fu[0] = a.x; fv[0] = a.y; fu[1] = a.z; fv[1] = a.w; fu[2] = d.x; fv[2] = d.y; fu[3] = d.z; fv[3] = d.w;
+    } else {
+      const float4 a = *reinterpret_cast<const float4*>(P.u + (size_t)b * ncell + r * n + c0);
+      const float4 d = *reinterpret_cast<const float4*>(P.v + (size_t)b * ncell + r * n + c0);
+      fu[0] = a.x; fu[1] = a.y; fu[2] = a.z; fu[3] = a.w; fv[0] = d.x; fv[1] = d.y; fv[2] = d.z; fv[3] = d.w;
+    }
+  };
+  float uc[4], vc[4], uu[4], vu[4], ud[4], vd[4];
+  load_uv(i, uc, vc);
+  load_uv(i - 1, uu, vu);
+  load_uv(i + 1, ud, vd);
+  const float ul = lane_left(uc[3]), ur = lane_right(uc[0]), vl = lane_left(vc[3]), vr = lane_right(vc[0]);
+  float un[4], vn[4];
+  // ---- predictor (navier_stokes2D.py:130-138) ----
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float uw = (k == 0) ? ul : uc[k - 1], ue = (k == 3) ? ur : uc[k + 1];
+    const float vw = (k == 0) ? vl : vc[k - 1], ve = (k == 3) ? vr : vc[k + 1];
+    const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx), dudy = div_c(ud[k] - uu[k], S.two_dy, S.inv_two_dy);
+    const float dvdx = div_c(ve - vw, S.two_dx, S.inv_two_dx), dvdy = div_c(vd[k] - vu[k], S.two_dy, S.inv_two_dy);
+    const float lapu = div_c((((uw + uu[k]) - 4.0f * uc[k]) + ue) + ud[k], S.dxdy, S.inv_dxdy);
+    const float lapv = div_c((((vw + vu[k]) - 4.0f * vc[k]) + ve) + vd[k], S.dxdy, S.inv_dxdy);
+    const float a = uc[k] + S.dt * (((-uc[k]) * dudx - vc[k] * dudy) + S.nu * lapu);
+    const float d = vc[k] + S.dt * (((-uc[k]) * dvdx - vc[k] * dvdy) + S.nu * lapv);
+    const bool edge = (i == 0) || (i == n - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
+    un[k] = edge ? uc[k] : a;
+    vn[k] = edge ? vc[k] : d;
+  }
+  // ---- apply_boundary(u*, v*) (:140) ----
+  *reinterpret_cast<float4*>(lds_u + w * n + c0) = make_float4(un[0], un[1], un[2], un[3]);
+  *reinterpret_cast<float4*>(lds_v + w * n + c0) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+  __syncthreads();
+  bc_rows_256<16>(un, vn, i, lane, w, lds_u, lds_v, C.bc, act, C.action_dim);
+  *reinterpret_cast<float4*>(us + i * n + c0) = make_float4(un[0], un[1], un[2], un[3]);
+  *reinterpret_cast<float4*>(vs + i * n + c0) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+}
+
+template <bool INTERLEAVED>
+__global__ __launch_bounds__(1024) void ns256_back(NSConst C, NSScal<float> S, NSPtrs<float> P, int final_in_scratch, int B) {
+  constexpr int n = 256, ncell = n * n;
+  __shared__ __attribute__((aligned(16))) float lds_u[16 * n], lds_v[16 * n];
+  __shared__ float red[16];
+  const int b = blockIdx.x >> 4, rb = blockIdx.x & 15;
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = rb * 16 + w, c0 = 4 * lane;
+  float* sc = P.scratch + (size_t)b * 4 * ncell;
+  const float* us = sc;
+  const float* vs = sc + ncell;
+  const float* pfin = final_in_scratch ? sc + 3 * ncell : P.p + (size_t)b * ncell;
+  const float* act = P.action + (size_t)b * C.action_dim;
+  auto row4 = [&](const float* base, int row, float (&f)[4]) {
+    const int r = row < 0 ? 0 : (row > n - 1 ? n - 1 : row);
+    const float4 a = *reinterpret_cast<const float4*>(base + r * n + c0);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
+  };
+  float pc[4], pu[4], pd[4], un[4], vn[4];
+  row4(pfin, i, pc);
+  row4(pfin, i - 1, pu);
+  row4(pfin, i + 1, pd);
+  row4(us, i, un);
+  row4(vs, i, vn);
+  if (final_in_scratch) *reinterpret_cast<float4*>(P.p + (size_t)b * ncell + i * n + c0) = make_float4(pc[0], pc[1], pc[2], pc[3]);
+  const float pl = lane_left(pc[3]), pr = lane_right(pc[0]);
+  // ---- corrector (:143-145) ----
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float pw = (k == 0) ? pl : pc[k - 1], pe = (k == 3) ? pr : pc[k + 1];
+    const float dpdx = div_c(pe - pw, S.two_dx, S.inv_two_dx);
+    const float dpdy = div_c(pd[k] - pu[k], S.two_dy, S.inv_two_dy);
+    const bool edge = (i == 0) || (i == n - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
+    un[k] = edge ? un[k] : un[k] - S.dt_over_rho * dpdx;
+    vn[k] = edge ? vn[k] : vn[k] - S.dt_over_rho * dpdy;
+  }
+  // ---- apply_boundary(u, v) (:146) ----
+  *reinterpret_cast<float4*>(lds_u + w * n + c0) = make_float4(un[0], un[1], un[2], un[3]);
+  *reinterpret_cast<float4*>(lds_v + w * n + c0) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+  __syncthreads();
+  bc_rows_256<16>(un, vn, i, lane, w, lds_u, lds_v, C.bc, act, C.action_dim);
+  if constexpr (!INTERLEAVED) {
+    *reinterpret_cast<float4*>(P.u + (size_t)b * ncell + i * n + c0) = make_float4(un[0], un[1], un[2], un[3]);
+    *reinterpret_cast<float4*>(P.v + (size_t)b * ncell + i * n + c0) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+  }
+  // ---- observation (:147-154) and the reward's squared distance to the reference frame (ns_reward.py:28) ----
+  const int t = P.time_index[b] + 1;
+  const int tr = t < C.nt_ref ? t : C.nt_ref - 1;
+  const float4* rr = reinterpret_cast<const float4*>(P.U_ref + (size_t)tr * ncell * 2 + (i * n + c0) * 2);
+  float4* oo = reinterpret_cast<float4*>(P.obs + (size_t)b * ncell * 2 + (i * n + c0) * 2);
+  float acc = 0.f;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float4 r4 = rr[q];
+    const float a0 = un[2 * q], b0 = vn[2 * q], a1 = un[2 * q + 1], b1 = vn[2 * q + 1];
+    oo[q] = make_float4(a0, b0, a1, b1);
+    const float d0 = a0 - r4.x, d1 = b0 - r4.y, d2 = a1 - r4.z, d3 = b1 - r4.w;
+    acc += d0 * d0;
+    acc += d1 * d1;
+    acc += d2 * d2;
+    acc += d3 * d3;
+  }
+  const float ss = block_sum<float>(acc, red);
+  if (threadIdx.x == 0) sc[2 * ncell + rb] = ss;   // partial sum of this 16-row band (the rhs quarter is free here)
+}
+
+__global__ void ns256_finish(NSConst C, NSScal<float> S, NSPtrs<float> P, int B) {
+  constexpr int n = 256, ncell = n * n;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* part = P.scratch + (size_t)b * 4 * ncell + 2 * ncell;
+  float ss = 0.f;
+  for (int k = 0; k < 16; ++k) ss += part[k];          // fixed order: deterministic
+  const int t = P.time_index[b] + 1;
+  const int tr = t < C.nt_ref ? t : C.nt_ref - 1;
+  const float* act = P.action + (size_t)b * C.action_dim;
+  float asq = 0.f;
+  const float aref = P.action_ref[tr];
+  for (int k = 0; k < C.action_dim; ++k) {
+    const float d = act[k] - aref;
+    asq += d * d;
+  }
+  P.reward[b] = ((-0.5f * ss) / (float)n) / (float)n - S.gamma_half * asq;
+  P.time_index[b] = t;
+  P.terminated[b] = (t >= C.nt - 1) ? 1 : 0;
 }
 
 template <typename T>
@@ -951,17 +1147,25 @@ int ns_step(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int B, v
       constexpr int kH = 32, kPR = 10;
       const size_t ncell = (size_t)C.nx * C.ny;
       hipStream_t st = (hipStream_t)stream;
-      hipLaunchKernelGGL(ns_front_kernel<float>, dim3(B), dim3(1024), 0, st, C, S, P, B);
+      const bool inter = buf->state_in != nullptr;
+      if (inter)
+        hipLaunchKernelGGL(ns256_front<true>, dim3(16 * B), dim3(1024), 0, st, C, S, P, B);
+      else
+        hipLaunchKernelGGL(ns256_front<false>, dim3(16 * B), dim3(1024), 0, st, C, S, P, B);
       float* bufs[2] = {P.p, P.scratch + 3 * ncell};
       const size_t strides[2] = {ncell, 4 * ncell};
       int cur = 0;
       for (int left = C.iters; left > 0; left -= kH) {
         const int nsw = left < kH ? left : kH;
         hipLaunchKernelGGL((ns_slab_jacobi<kPR, kH>), dim3(2 * B), dim3(1024), 2 * 2 * 1024 * 16, st, S, bufs[cur], strides[cur],
-                           bufs[cur ^ 1], strides[cur ^ 1], P.scratch + 2 * ncell, 4 * ncell, nsw, B);
+                           bufs[cur ^ 1], strides[cur ^ 1], P.scratch, P.scratch + ncell, 4 * ncell, nsw, B);
         cur ^= 1;
       }
-      hipLaunchKernelGGL(ns_back_kernel<float>, dim3(B), dim3(1024), 0, st, C, S, P, cur, B);
+      if (inter)
+        hipLaunchKernelGGL(ns256_back<true>, dim3(16 * B), dim3(1024), 0, st, C, S, P, cur, B);
+      else
+        hipLaunchKernelGGL(ns256_back<false>, dim3(16 * B), dim3(1024), 0, st, C, S, P, cur, B);
+      hipLaunchKernelGGL(ns256_finish, dim3((B + 255) / 256), dim3(256), 0, st, C, S, P, B);
       return pdegym::check_launch("ns2d_slab_step");
     }
   }
