@@ -35,11 +35,27 @@ def _dist_setup(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("PDEGYM_BENCH_SHARE_GPU") == "1":      # test hook: several ranks on one GPU (exercises the N>1 code path)
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # The step path has no collective; the process group only carries the timing barrier and one MAX all-reduce.
+        # RCCL ("nccl") first, gloo as a fallback so a fabric hiccup cannot lose the measurement.
+        try:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+            t = torch.zeros(1, device="cuda")
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+        except Exception as ex:
+            sys.stderr.write(f"rank {rank}: RCCL process group failed ({ex!r}); using gloo for the timing barrier\n")
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+            dist.init_process_group(backend="gloo")
     return rank, local, world
 
 

@@ -19,6 +19,8 @@ def max_over_ranks(value: float, device=None) -> float:
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
