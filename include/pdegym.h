@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PDEGYM_ABI_VERSION 4
+#define PDEGYM_ABI_VERSION 5
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
 #define PDEGYM_MAX_N1D 1024      /* nodes per 1D row handled by the wave-per-instance kernels */
@@ -213,6 +213,58 @@ int pdegym_traffic_step(const pdegym_params_traffic* prm, const pdegym_bufs_traf
  * obs = (r, v).  profile[M] = sin(3 x/L pi)*0.1 + 1 is computed by the caller in NumPy (libm sin, bit parity). */
 int pdegym_traffic_reset_masked(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf, const double* profile,
                                 const uint8_t* mask, int32_t B, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Brain tumour 1D (float64) -- SURVEY.md section 8f rank 3
+ *
+ *   pdegym_tumor_step          replaces BrainTumor1D.step + _update_fd + _compute_radiation_field + getTumorRadius
+ *                              + terminate/truncate                               environments1d/brain_tumor_env.py:106-352
+ *                              + BrainTumorReward.reward                          rewards/brain_tumor_reward.py:30-73
+ *   pdegym_tumor_reset_masked  replaces the state part of BrainTumor1D.reset      brain_tumor_env.py:354-384
+ * ------------------------------------------------------------------------------------------------------------------ */
+enum { PDEGYM_TUMOR_GROWTH = 0, PDEGYM_TUMOR_THERAPY = 1, PDEGYM_TUMOR_POST = 2 };   /* "Growth" / "Therapy" / "Post-Therapy" */
+enum { PDEGYM_TUMOR_DAY_GROWTH = 0, PDEGYM_TUMOR_DAY_THERAPY = 1, PDEGYM_TUMOR_DAY_POST = 2, PDEGYM_TUMOR_DAY_SIM = 3,
+       PDEGYM_TUMOR_DAY_DEATH = 4, PDEGYM_TUMOR_DAYS = 5 };
+enum { PDEGYM_TUMOR_OUT_T1 = 0, PDEGYM_TUMOR_OUT_T2 = 1, PDEGYM_TUMOR_OUT_TREAT = 2, PDEGYM_TUMOR_OUT_DOSE = 3,
+       PDEGYM_TUMOR_OUTS = 4 };
+
+typedef struct pdegym_params_tumor {
+  int32_t nx;              /* int(round(X/dx)+1)                                             brain_tumor_env.py:51 */
+  int32_t nt;              /* int(round(T/dt)+1)                                             base_env_1d.py:23 */
+  double dt, dx, dx2;      /* dx2 = dx**2 as the caller's Python evaluates it                :226 */
+  double D, rho, alpha, alpha_beta_ratio, k;
+  double thr_t1, thr_t2;   /* detection_threshold * k  (caller's double product)             :114 */
+  double detect_radius;    /* t1_detection_radius: Growth -> Therapy                          :151 */
+  double death_radius;     /* t1_death_radius: truncation                                    :327 */
+  double total_dosage, dose_end;   /* total_dosage, dosage_termination_threshold             :159, :171 */
+  double margin;           /* 25 (mm) added to the T2 radius for the treated region          :257 */
+} pdegym_params_tumor;
+
+typedef struct pdegym_bufs_tumor {
+  double* u;               /* [B, nx] live density row, updated in place (it IS the observation)               */
+  const double* xscale;    /* [nx] np.linspace(0, X, nx) from the caller                                  :56 */
+  const double* control;   /* [B] proportion of total_dosage requested this day (used in Therapy only)         */
+  const double* kill;      /* [B] or NULL: 1 - exp(-alpha*BED) precomputed by the caller (bit parity with
+                              NumPy's exp); NULL = the kernel evaluates exp itself (<= 1 ulp apart)   :260-262 */
+  int32_t* time_index;     /* [B] in/out                                                                       */
+  int32_t* stage;          /* [B] in/out PDEGYM_TUMOR_*                                                        */
+  double* remaining;       /* [B] in/out remaining_dosage                                                      */
+  int32_t* days;           /* [B, 5] in/out growthDays, therapyDays, postTherapyDays, simulationDays, cDeathDay (-1 = None) */
+  const double* t_benchmark; /* [B] NaN = not set (reward 0)                                                   */
+  double* reward;          /* [B] out                                                                          */
+  uint8_t* terminated;     /* [B] out                                                                          */
+  uint8_t* truncated;      /* [B] out                                                                          */
+  double* out;             /* [B, 4] out: T1 radius and T2 radius of the new row (NaN = invisible), treatment radius and
+                              applied dose of this step (0 outside Therapy)                                    */
+} pdegym_bufs_tumor;
+
+/* One day per call.  Instances with time_index >= nt-1 are left untouched (reward 0, flags 0).  LDS: 4*nx*8 bytes,
+ * nx <= 4096. */
+int pdegym_tumor_step(const pdegym_params_tumor* prm, const pdegym_bufs_tumor* buf, int32_t B, void* stream);
+/* Where mask[b] != 0 (or mask == NULL): u = init (init_stride = 0 broadcasts one row), time_index = 0, stage = Growth,
+ * remaining = total_dosage, days = (0,0,0,0,-1). */
+int pdegym_tumor_reset_masked(const pdegym_params_tumor* prm, const pdegym_bufs_tumor* buf, const double* init,
+                              int64_t init_stride, const uint8_t* mask, int32_t B, void* stream);
 
 #ifdef __cplusplus
 }

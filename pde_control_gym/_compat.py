@@ -68,6 +68,34 @@ class _Env:
         return None
 
 
+class _Wrapper(_Env):
+    """Subset of gymnasium.Wrapper: holds ``env``, forwards reset/step/attributes, ``unwrapped`` reaches the base env."""
+
+    def __init__(self, env):
+        self.env = env
+
+    @property
+    def unwrapped(self):
+        return self.env.unwrapped
+
+    @property
+    def action_space(self):
+        return self.env.action_space
+
+    @property
+    def observation_space(self):
+        return self.env.observation_space
+
+    def reset(self, **kwargs):
+        return self.env.reset(**kwargs)
+
+    def step(self, action):
+        return self.env.step(action)
+
+    def close(self):
+        return self.env.close()
+
+
 class _Spaces:
     Box = _Box
 
@@ -90,6 +118,6 @@ def _fallback_make(id, **kwargs):
 
 
 if HAVE_GYMNASIUM:  # pragma: no cover
-    Env, spaces, register, make = _gym.Env, _spaces, _register, _gym.make
+    Env, spaces, register, make, Wrapper = _gym.Env, _spaces, _register, _gym.make, _gym.Wrapper
 else:
-    Env, spaces, register, make = _Env, _Spaces, _fallback_register, _fallback_make
+    Env, spaces, register, make, Wrapper = _Env, _Spaces, _fallback_register, _fallback_make, _Wrapper

@@ -1,0 +1,241 @@
+"""BrainTumor1D and TherapyWrapper -- 1D reaction-diffusion glioma growth under radiotherapy (interface of the
+reference's environments1d/brain_tumor_env.py:10-505).
+
+The density row lives on the GPU in float64; one ``step`` is one simulated day in one kernel launch
+(pdecontrolgym_amd/csrc/pdegym_tumor.hip): finite-difference update with the radiation kill term, T1/T2 MRI radii,
+the Growth -> Therapy -> Post-Therapy stage machine, its day counters, terminate/truncate.  The host keeps what the
+reference keeps as Python attributes (``stage``, ``remaining_dosage``, the ``*Days`` counters, ``t_benchmark``,
+``t1_radius_idx_vs_time``, ``dosage_vs_time``) by reading the handful of scalars the kernel returns.  Bit parity with
+the reference: the kill fraction ``1 - exp(-alpha*BED)`` and the toxicity reward's powers are evaluated on the host with
+the same NumPy / Python calls the reference makes, everything else is IEEE arithmetic in the reference's order.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from pde_control_gym._compat import Wrapper, spaces
+from pde_control_gym.src.environments1d.base_env_1d import PDEEnv1D
+
+_STAGES = ("Growth", "Therapy", "Post-Therapy")
+
+
+class BrainTumor1D(PDEEnv1D):
+    """:param t1_detection_threshold, t2_detection_threshold: fraction of ``k`` visible on T1Gd / T2 MRI.
+    :param dosage_termination_threshold: therapy ends once less than this many Gy remain.
+    :param D, rho: diffusion (mm^2/day) and proliferation (1/day).  :param alpha, alpha_beta_ratio: radiosensitivity.
+    :param k: carrying capacity (cells/mm).  :param t1_detection_radius, t1_death_radius: mm.
+    :param reset_init_condition_func: ``f(X, nx) -> row``.  :param total_dosage: Gy.  :param verbose: print progress.
+    Extra: ``device``, ``record_history`` (default True: keeps ``env.u[nt, nx]`` on the host like the reference)."""
+
+    u = None        # plain attribute here (the trajectory array), not the base class's device view
+
+    def __init__(self, t1_detection_threshold: float = 0.8, t2_detection_threshold: float = 0.16,
+                 dosage_termination_threshold: float = 0.1, D: float = 0.2, rho: float = 0.03, alpha: float = 0.04,
+                 alpha_beta_ratio: int = 10, k: float = 1e5, t1_detection_radius: int = 15, t1_death_radius: int = 35,
+                 reset_init_condition_func=None, total_dosage=None, verbose=True, device="cuda", backend=None,
+                 record_history=True, **kwargs):
+        super().__init__(**kwargs)
+        from pdecontrolgym_amd.batch_tumor import TumorBatch
+        self.verbose = verbose
+        self.nx = int(round(self.X / self.dx) + 1)
+        self._core = TumorBatch(self.T, self.dt, self.X, self.dx, total_dosage, t1_detection_threshold,
+                                t2_detection_threshold, dosage_termination_threshold, D, rho, alpha, alpha_beta_ratio, k,
+                                t1_detection_radius, t1_death_radius, num_envs=1, device=device, backend=backend)
+        self._record = bool(record_history)
+        self.u = np.zeros((self.nt, self.nx)) if self._record else np.zeros((1, self.nx))
+        self.t1_radius_idx_vs_time = np.zeros(self.nt)
+        self.t1_radius_idx_vs_time[0] = np.nan
+        self.dosage_vs_time = np.zeros(self.nt)
+        self.xScale = self._core.xScale
+        if self.verbose:
+            print(f"nx: {self.nx}, nt: {self.nt}")
+            print(f"u.shape: {self.u.shape}")
+        self.action_space = spaces.Box(np.full(1, 0, dtype="float32"), np.full(1, 1, dtype="float32"))
+        self.observation_space = spaces.Box(np.full(self.nx, 0, dtype="float64"), np.full(self.nx, k, dtype="float64"),
+                                            dtype=np.float64)
+        self.t1_detection_threshold, self.t2_detection_threshold = t1_detection_threshold, t2_detection_threshold
+        self.dosage_termination_threshold = dosage_termination_threshold
+        self.reset_init_condition_func = reset_init_condition_func
+        self.D, self.rho, self.alpha, self.alphaBetaRatio, self.k = D, rho, alpha, alpha_beta_ratio, k
+        self.t1_detection_radius, self.t1_death_radius = t1_detection_radius, t1_death_radius
+        self.total_dosage = float(total_dosage)
+        self.remaining_dosage = float(total_dosage)
+        self.stage = "Growth"
+        self.simulationDays = self.growthDays = self.therapyDays = self.postTherapyDays = 0
+        self.firstTherapyDay = self.firstPostTherapyDay = self.cDeathDay = None
+        self.t_benchmark = None
+        self._terminated = self._truncated = False
+
+    # ---- reference helpers ------------------------------------------------------------------------------------
+    def getTumorRadius(self, time_index, detectionRatio):
+        """Radius (mm) of the rightmost node at or above ``detectionRatio * k`` in row ``time_index`` (None if
+        invisible).  Needs ``record_history`` for rows other than the live one."""
+        densities = self.u[time_index if self._record else 0]
+        binaryMask = densities >= detectionRatio * self.k
+        if not binaryMask.any():
+            return None
+        return (binaryMask.size - 1 - np.argmax(binaryMask[::-1])) * self.dx
+
+    def terminate(self):
+        return bool(self._terminated)
+
+    def truncate(self):
+        return bool(self._truncated)
+
+    def _pull(self):
+        """One device->host read of the scalars a step produced."""
+        t = self._core.t
+        self.time_index = int(t["time_index"][0])
+        days = t["days"][0].tolist()
+        self.growthDays, self.therapyDays, self.postTherapyDays, self.simulationDays = days[:4]
+        self.cDeathDay = None if days[4] < 0 else days[4]
+        self.remaining_dosage = float(t["remaining"][0])
+        self._terminated, self._truncated = bool(t["terminated"][0]), bool(t["truncated"][0])
+        return int(t["stage"][0]), t["out"][0].tolist()
+
+    def step(self, control: float):
+        """One simulated day.  ``control`` = proportion of ``total_dosage`` to apply (used in the Therapy stage)."""
+        if self.verbose:
+            print(f"\tEnvironment: Call step(). Perform dimensionalized finite differencing for time_index={self.time_index+1}")
+        if not (self.time_index < self.nt - 1):
+            return None                                  # the reference's step falls through without a return here
+        stage_before = self.stage
+        kill = None
+        if stage_before == "Therapy":
+            control = float(np.asarray(control).squeeze())
+            applied = min(control * self.total_dosage, self.remaining_dosage)
+            dArray = np.array([applied])
+            BED = dArray + ((dArray ** 2) / (self.alphaBetaRatio))          # brain_tumor_env.py:260-262
+            kill = 1.0 - np.exp(-self.alpha * BED)
+            ctl = [control]
+        else:
+            ctl = [0.0]
+        self._core.set_benchmark(float("nan") if self.t_benchmark is None else float(self.t_benchmark))
+        u, *_ = self._core.step(ctl, kill=kill)
+        row = u[0].cpu().numpy()
+        stage_i, (T1, T2, treatmentRadius, applied_dosage) = self._pull()
+        self.stage = _STAGES[stage_i]
+        if self._record:
+            self.u[self.time_index] = row
+            obs = self.u[self.time_index]
+        else:
+            self.u[0] = row
+            obs = self.u[0]
+        T1 = None if np.isnan(T1) else T1
+        self.t1_radius_idx_vs_time[self.time_index] = np.nan if T1 is None else T1 / self.dx
+        if self.verbose:
+            t1r = float("nan") if T1 is None else T1
+            print(f"\t{stage_before:<15} {self.time_index:<5} {t1r:<15.2f} {T2:<15.2f}\n")
+        if stage_before == "Growth" and self.stage == "Therapy":
+            self.firstTherapyDay = self.time_index + 1
+        if stage_before == "Therapy":
+            self.dosage_vs_time[self.time_index] = applied_dosage
+            if self.stage == "Post-Therapy":
+                self.firstPostTherapyDay = self.time_index + 1
+            reward = self.reward_class.reward(
+                uVec=self.u, time_index=self.time_index, terminate=self._terminated, truncate=self._truncated,
+                action=control, verbose=self.verbose, t_benchmark=self.t_benchmark, tumor_radius=T1,
+                treatment_radius=treatmentRadius, applied_dosage=applied_dosage, total_dosage=self.total_dosage)
+        elif self.stage == "Post-Therapy" and (self._terminated or self._truncated):
+            reward = self.reward_class.reward(
+                uVec=self.u, time_index=self.time_index, terminate=self._terminated, truncate=self._truncated,
+                action=control, verbose=self.verbose, t_benchmark=self.t_benchmark)
+        else:
+            reward = 0.0
+        return obs, reward, self._terminated, self._truncated, {"stage": self.stage}
+
+    def reset(self, seed: Optional[int] = None, options: Optional[dict] = None):
+        try:
+            init_condition = self.reset_init_condition_func(self.X, self.nx)
+        except:  # noqa: E722 - the reference converts any failure into this message (brain_tumor_env.py:363-368)
+            raise Exception("Please pass an initial condition function")
+        self.u = np.zeros((self.nt, self.nx)) if self._record else np.zeros((1, self.nx))
+        self.dosage_vs_time = np.zeros(self.nt)
+        self.u[0] = init_condition
+        self._core.reset(self.u[0].copy())
+        self.time_index = 0
+        self.stage = "Growth"
+        self.remaining_dosage = self.total_dosage
+        self.simulationDays = self.growthDays = self.therapyDays = self.postTherapyDays = 0
+        self.firstTherapyDay = self.firstPostTherapyDay = self.cDeathDay = None
+        self._terminated = self._truncated = False
+        return self.u[0], {}
+
+
+class TherapyWrapper(Wrapper):
+    """Hides the Growth and Post-Therapy stages: ``reset`` runs the growth stage, ``step`` applies one treatment day
+    (plus forced two-day breaks after five consecutive treatment days if ``weekends``), and once therapy is over one
+    ``step`` simulates until death or the time limit (reference brain_tumor_env.py:385-505)."""
+
+    def __init__(self, env: BrainTumor1D, weekends=False, verbose=True):
+        super().__init__(env)
+        self.verbose, self.weekends = verbose, weekends
+        self.treatment_calls = 0
+        self.soft_constraint_violations = 0
+        self.consecutive_treatment_days = 0
+
+    def reset(self, seed: Optional[int] = None, options: Optional[dict] = None):
+        if self.verbose:
+            print("Wrapper: Reset environment")
+        self.consecutive_treatment_days = 0
+        obs, info = self.env.reset()
+        if self.verbose:
+            print("Wrapper: Start Growth Stage")
+        while self.env.unwrapped.stage == "Growth":
+            obs, _, terminated, truncated, info = self.env.step(0)
+            if terminated or truncated:
+                break
+        if self.verbose:
+            print("Wrapper: End Growth Stage\n")
+        return obs, info
+
+    def step(self, control: float):
+        if self.env.unwrapped.stage == "Post-Therapy":
+            if self.verbose:
+                print("Wrapper: Post-Therapy step()")
+            terminated, truncated = False, False
+            while not (terminated or truncated):
+                obs, reward, terminated, truncated, info = self.env.step(0)
+            if self.verbose:
+                print(f"[Episode Reward] {reward}\n")
+                print(f"Soft constraint violation rate: {(self.soft_constraint_violations / self.treatment_calls) * 100}%")
+            return obs, reward, terminated, truncated, info
+        if self.verbose:
+            print("Wrapper: Therapy step()")
+        obs, reward, terminated, truncated, info = self.env.step(control)
+        self.treatment_calls += 1
+        if reward < 0.0:
+            self.soft_constraint_violations += 1
+        if self.weekends:
+            if control > 0:
+                self.consecutive_treatment_days += 1
+            else:
+                self.consecutive_treatment_days = 0
+        if self.weekends and self.consecutive_treatment_days >= 5:
+            self.consecutive_treatment_days = 0
+            if self.verbose:
+                print("Wrapper: Force weekend")
+            for _ in range(2):
+                _ = self.env.step(0)
+                if terminated or truncated:      # flags of the treatment step, as in the reference (:476-479)
+                    return obs, reward, terminated, truncated, info
+        if self.verbose:
+            print(f"[Therapy Reward] {reward}\n")
+        return obs, reward, terminated, truncated, info
+
+    def benchmark(self):
+        """Open-loop episode without treatment; stores the survival days as ``t_benchmark`` and resets."""
+        obs, info = self.env.reset()
+        if self.verbose:
+            print("Wrapper: Benchmark (episode run with no action and no reward):")
+        terminated = truncated = False
+        while not (terminated or truncated):
+            obs, _, terminated, truncated, info = self.env.step(0)
+        t_benchmark = self.env.unwrapped.simulationDays
+        self.env.unwrapped.t_benchmark = t_benchmark
+        if self.verbose:
+            print(f"Set t_benchmark = {t_benchmark}\n\n\n")
+        obs, info = self.env.reset()
+        return t_benchmark

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 RING = 128
 LOOKBACK = 100
 MAX_N1D = 1024
@@ -27,6 +27,7 @@ EXPORTS = [
     "pdegym_reset1d_masked", "pdegym_rownorm2_f32", "pdegym_selftest_quotient", "pdegym_ns2d_step_f32", "pdegym_ns2d_step_f64",
     "pdegym_ns2d_solve_pressure_f32", "pdegym_ns2d_solve_pressure_f64", "pdegym_ns2d_reset_masked_f32",
     "pdegym_ns2d_reset_masked_f64", "pdegym_traffic_step", "pdegym_traffic_reset_masked",
+    "pdegym_tumor_step", "pdegym_tumor_reset_masked",
 ]
 
 
@@ -72,6 +73,21 @@ class BufsTraffic(C.Structure):
     _fields_ = [("r", C.c_void_p), ("y", C.c_void_p), ("action", C.c_void_p), ("time", C.c_void_p), ("rs", C.c_void_p),
                 ("qs_clip", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
                 ("truncated", C.c_void_p)]
+
+
+TUMOR_GROWTH, TUMOR_THERAPY, TUMOR_POST = range(3)
+TUMOR_STAGE_NAMES = ("Growth", "Therapy", "Post-Therapy")
+
+
+class ParamsTumor(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("nt", C.c_int32)] + [(k, C.c_double) for k in (
+        "dt", "dx", "dx2", "D", "rho", "alpha", "alpha_beta_ratio", "k", "thr_t1", "thr_t2", "detect_radius",
+        "death_radius", "total_dosage", "dose_end", "margin")]
+
+
+class BufsTumor(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("u", "xscale", "control", "kill", "time_index", "stage", "remaining", "days",
+                                          "t_benchmark", "reward", "terminated", "truncated", "out")]
 
 
 class NativeError(RuntimeError):
@@ -120,6 +136,11 @@ def load():
     lib.pdegym_traffic_reset_masked.argtypes = [C.POINTER(ParamsTraffic), C.POINTER(BufsTraffic), C.c_void_p, C.c_void_p,
                                                 C.c_int32, C.c_void_p]
     lib.pdegym_traffic_reset_masked.restype = C.c_int
+    lib.pdegym_tumor_step.argtypes = [C.POINTER(ParamsTumor), C.POINTER(BufsTumor), C.c_int32, C.c_void_p]
+    lib.pdegym_tumor_step.restype = C.c_int
+    lib.pdegym_tumor_reset_masked.argtypes = [C.POINTER(ParamsTumor), C.POINTER(BufsTumor), C.c_void_p, C.c_int64, C.c_void_p,
+                                              C.c_int32, C.c_void_p]
+    lib.pdegym_tumor_reset_masked.restype = C.c_int
     if lib.pdegym_abi_version() != ABI_VERSION:
         raise NativeError(f"ABI mismatch: library {lib.pdegym_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

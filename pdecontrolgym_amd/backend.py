@@ -124,6 +124,33 @@ class HipBackend:
         N.check(self.lib.pdegym_traffic_reset_masked(C.byref(P), C.byref(bufs), N.dptr(profile, torch.float64), m, B,
                                                      N.current_stream_ptr(T["r"].device)), "pdegym_traffic_reset_masked")
 
+    # ---- Brain tumour --------------------------------------------------------------------------
+    @staticmethod
+    def _bufs_tumor(T) -> N.BufsTumor:
+        import torch
+        b = N.BufsTumor()
+        for k in ("u", "xscale", "control", "remaining", "t_benchmark", "reward", "out"):
+            setattr(b, k, N.dptr(T[k], torch.float64))
+        b.kill = N.dptr(T.get("kill"), torch.float64) if T.get("kill") is not None else None
+        for k in ("time_index", "stage", "days"):
+            setattr(b, k, N.dptr(T[k], torch.int32))
+        b.terminated = N.dptr(T["terminated"], torch.uint8)
+        b.truncated = N.dptr(T["truncated"], torch.uint8)
+        return b
+
+    def tumor_step(self, P: N.ParamsTumor, T: dict, B: int):
+        bufs = self._bufs_tumor(T)
+        N.check(self.lib.pdegym_tumor_step(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["u"].device)),
+                "pdegym_tumor_step")
+
+    def tumor_reset(self, P: N.ParamsTumor, T: dict, init, mask, B: int):
+        import torch
+        bufs = self._bufs_tumor(T)
+        m = N.dptr(mask, torch.uint8) if mask is not None else None
+        stride = 0 if init.dim() == 1 else init.shape[-1]
+        N.check(self.lib.pdegym_tumor_reset_masked(C.byref(P), C.byref(bufs), N.dptr(init, torch.float64), stride, m, B,
+                                                   N.current_stream_ptr(T["u"].device)), "pdegym_tumor_reset_masked")
+
 
 _default = None
 

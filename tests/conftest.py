@@ -51,3 +51,8 @@ def golden_ns():
 @pytest.fixture(scope="session")
 def golden_traffic():
     return load_golden("traffic")
+
+
+@pytest.fixture(scope="session")
+def golden_tumor():
+    return load_golden("tumor")

@@ -166,3 +166,42 @@ class FakeBackend:
         T["time"][m] = 0
         T["done"][m] = 0
         T["truncated"][m] = 0
+
+    # ---- Brain tumour ---------------------------------------------------------------------------
+    def _orc_tumor(self, P):
+        return po.BrainTumorOracle(self.core.T, self.core.dt, self.core.X, self.core.dx, P.total_dosage,
+                                   P.thr_t1 / P.k, P.thr_t2 / P.k, P.dose_end, P.D, P.rho, P.alpha, P.alpha_beta_ratio, P.k,
+                                   P.detect_radius, P.death_radius)
+
+    def tumor_step(self, P, T, B):
+        orc = self._orc_tumor(P)
+        orc.thr1, orc.thr2 = P.thr_t1, P.thr_t2
+        orc.reset(T["u"].numpy(), T["t_benchmark"].numpy())
+        orc.time_index = T["time_index"].numpy().astype(np.int64)
+        orc.stage = T["stage"].numpy().astype(np.int64)
+        orc.remaining = T["remaining"].numpy().copy()
+        d = T["days"].numpy().astype(np.int64)
+        orc.growthDays, orc.therapyDays, orc.postDays, orc.simulationDays, orc.cDeathDay = (d[:, i].copy() for i in range(5))
+        live = orc.time_index < orc.nt - 1
+        obs, r, te, tr = orc.step(T["control"].numpy())
+        T["u"].copy_(torch.from_numpy(obs))
+        T["time_index"].copy_(torch.from_numpy(orc.time_index.astype(np.int32)))
+        T["stage"].copy_(torch.from_numpy(orc.stage.astype(np.int32)))
+        T["remaining"].copy_(torch.from_numpy(orc.remaining))
+        T["days"].copy_(torch.from_numpy(np.stack([orc.growthDays, orc.therapyDays, orc.postDays, orc.simulationDays,
+                                                   orc.cDeathDay], axis=1).astype(np.int32)))
+        T["reward"].copy_(torch.from_numpy(r))
+        T["terminated"].copy_(torch.from_numpy(te.astype(np.uint8)))
+        T["truncated"].copy_(torch.from_numpy(tr.astype(np.uint8)))
+        out = np.stack([orc.T1, orc.radius_abs(orc.u, orc.thr2), orc.treat_r, orc.applied], axis=1)
+        keep = torch.from_numpy(live)
+        T["out"][keep] = torch.from_numpy(out)[keep]
+
+    def tumor_reset(self, P, T, init, mask, B):
+        m = torch.ones(B, dtype=torch.bool) if mask is None else mask.bool()
+        src = init.expand(B, -1) if init.dim() == 1 else init
+        T["u"][m] = src[m]
+        T["time_index"][m] = 0
+        T["stage"][m] = 0
+        T["remaining"][m] = P.total_dosage
+        T["days"][m] = torch.tensor([0, 0, 0, 0, -1], dtype=torch.int32)

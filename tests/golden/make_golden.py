@@ -34,9 +34,17 @@ def import_reference():
         def __init__(self):
             pass
 
+        @property
+        def unwrapped(self):
+            return self
+
     class Wrapper(Env):
         def __init__(self, env):
             self.env = env
+
+        @property
+        def unwrapped(self):
+            return self.env.unwrapped
 
     class Box:
         def __init__(self, low, high, shape=None, dtype=np.float32):
@@ -403,12 +411,84 @@ def gen_traffic(src):
     np.savez_compressed(os.path.join(OUT, "traffic.npz"), **store)
 
 
+def tumor_ic(X, nx):
+    """examples/BrainTumor1D notebook: 0.8 k exp(-0.25 x^2)."""
+    xs = np.linspace(0, X, nx)
+    return 0.8 * 1e5 * np.exp(-0.25 * (xs ** 2))
+
+
+TUMOR_KW = dict(X=200, dt=1, dx=1, normalize=True, dosage_termination_threshold=0.1, t1_detection_threshold=0.8,
+                t2_detection_threshold=0.16, D=0.2, rho=0.03, alpha=0.04, alpha_beta_ratio=10, k=1e5,
+                t1_detection_radius=15, t1_death_radius=35, total_dosage=61.2, verbose=False)
+
+
+def gen_tumor(src):
+    """BrainTumor1D + BrainTumorReward + TherapyWrapper (environments1d/brain_tumor_env.py, rewards/brain_tumor_reward.py)
+    on the shipped notebook configuration (examples/BrainTumor1D: T=600, X=200, dt=dx=1, total_dosage=61.2)."""
+    import importlib
+    bt = importlib.import_module("pde_control_gym.src.environments1d.brain_tumor_env")
+    br = importlib.import_module("pde_control_gym.src.rewards.brain_tumor_reward")
+    store = {}
+    rng = np.random.default_rng(2024)
+    # ---- raw environment episodes: (name, T, t_benchmark, dose range)
+    for name, T, tb, hi in [("raw", 600, 300, 0.08), ("toxic", 600, 250, 0.3), ("nobench", 600, None, 0.1),
+                            ("term_therapy", 230, 200, 0.004), ("term_post", 300, 200, 0.25)]:
+        env = bt.BrainTumor1D(T=T, reward_class=br.BrainTumorReward(), reset_init_condition_func=tumor_ic, **TUMOR_KW)
+        env.t_benchmark = tb
+        obs0, _ = env.reset()
+        acts, rew, term, trunc, stage = [], [], [], [], []
+        while True:
+            a = float(rng.uniform(0, hi))
+            o, r, te, tr, info = env.step(a)
+            acts.append(a)
+            rew.append(float(r))
+            term.append(bool(te))
+            trunc.append(bool(tr))
+            stage.append({"Growth": 0, "Therapy": 1, "Post-Therapy": 2}[info["stage"]])
+            if te or tr:
+                break
+        n = len(acts)
+        keep = np.unique(np.concatenate([np.arange(0, n + 1, 16), [n]]))
+        pack(name, dict(T=np.int64(T), t_benchmark=np.float64(np.nan if tb is None else tb), actions=np.array(acts),
+                        reward=np.array(rew), term=np.array(term), trunc=np.array(trunc), stage=np.array(stage),
+                        keep=keep, rows=env.u[keep].copy(), t1_idx=env.t1_radius_idx_vs_time[: n + 1].copy(),
+                        dosage=env.dosage_vs_time[: n + 1].copy(),
+                        days=np.array([env.growthDays, env.therapyDays, env.postTherapyDays, env.simulationDays,
+                                       -1 if env.cDeathDay is None else env.cDeathDay]),
+                        first=np.array([-1 if env.firstTherapyDay is None else env.firstTherapyDay,
+                                        -1 if env.firstPostTherapyDay is None else env.firstPostTherapyDay]),
+                        remaining=np.float64(env.remaining_dosage)), store)
+    # ---- wrapper flows: benchmark(), reset() through the growth stage, constant daily fraction
+    for name, weekends, frac in [("wrap_week", True, 2.0 / 61.2), ("wrap_daily", False, 1.8 / 61.2), ("wrap_hypo", True, 0.2)]:
+        env = bt.BrainTumor1D(T=600, reward_class=br.BrainTumorReward(), reset_init_condition_func=tumor_ic, **TUMOR_KW)
+        w = bt.TherapyWrapper(env, weekends=weekends, verbose=False)
+        tb = w.benchmark()
+        obs, _ = w.reset()
+        rows, rew, term, trunc, tidx = [np.array(obs)], [], [], [], [env.time_index]
+        while True:
+            o, r, te, tr, info = w.step(frac)
+            rows.append(np.array(o))
+            rew.append(float(r))
+            term.append(bool(te))
+            trunc.append(bool(tr))
+            tidx.append(env.time_index)
+            if te or tr:
+                break
+        pack(name, dict(weekends=np.bool_(weekends), frac=np.float64(frac), t_benchmark=np.int64(tb), rows=np.stack(rows),
+                        reward=np.array(rew), term=np.array(term), trunc=np.array(trunc), time_index=np.array(tidx),
+                        days=np.array([env.growthDays, env.therapyDays, env.postTherapyDays, env.simulationDays,
+                                       -1 if env.cDeathDay is None else env.cDeathDay]),
+                        calls=np.int64(w.treatment_calls), violations=np.int64(w.soft_constraint_violations),
+                        dosage=env.dosage_vs_time.copy(), t1_idx=env.t1_radius_idx_vs_time.copy()), store)
+    np.savez_compressed(os.path.join(OUT, "tumor.npz"), **store)
+
+
 if __name__ == "__main__":
     src = import_reference()
-    which = sys.argv[1:] or ["transport", "parabolic", "kat", "ns", "traffic"]
+    which = sys.argv[1:] or ["transport", "parabolic", "kat", "ns", "traffic", "tumor"]
     store_meta = dict(numpy=np.__version__)
     for w in which:
-        {"transport": gen_transport, "parabolic": gen_parabolic, "kat": gen_kat, "ns": gen_ns, "traffic": gen_traffic}[w](src)
+        {"transport": gen_transport, "parabolic": gen_parabolic, "kat": gen_kat, "ns": gen_ns, "traffic": gen_traffic, "tumor": gen_tumor}[w](src)
         print("wrote", w)
     with open(os.path.join(OUT, "VERSIONS.txt"), "w") as f:
         f.write(f"numpy {np.__version__}\nreference snapshot 2026-01-09 (lukebhan/PDEControlGym)\n")

@@ -81,9 +81,9 @@ def test_import_surface_and_registration():
     for i in ("PDEControlGym-TransportPDE1D", "PDEControlGym-ReactionDiffusionPDE1D", "PDEControlGym-NavierStokes2D",
               "PDEControlGym-BrainTumor1D", "PDEControlGym-TrafficPDE1D"):
         assert i in pde_control_gym._IDS
-    from pde_control_gym.src import BrainTumor1D
-    with pytest.raises(NotImplementedError):
-        BrainTumor1D()
+    from pde_control_gym.src import BrainTumor1D, BrainTumorReward, TherapyWrapper  # noqa: F401
+    from pde_control_gym.src.environments1d.brain_tumor_env import TherapyWrapper as W2
+    assert W2 is TherapyWrapper
     f = np.arange(25.0).reshape(5, 5) ** 2
     d = central_difference(f, "x", 0.5)
     assert d[0].sum() == 0 and d[2, 2] == (f[2, 3] - f[2, 1]) / 1.0
