@@ -154,6 +154,14 @@ def cpu_port_rate(workload_key, seconds, seed=0):
         reset = lambda: env.reset(rs)
         done = lambda out: bool(out[2][0] or out[3][0] or env.time_index[0] >= 239)
         what = f"float64, {TrafficARZ.S} sub-steps each"
+    elif workload_key == "brain_tumor":
+        env = po.BrainTumorOracle(600, 1, 200, 1, 61.2)
+        xs = np.linspace(0, 200, 201)
+        ic = (0.8 * 1e5 * np.exp(-0.25 * (xs ** 2)))[None]
+        acts = rng.uniform(0, 0.05, (256, 1))
+        reset = lambda: env.reset(ic, [363.0])
+        done = lambda out: bool(out[2][0] or out[3][0])
+        what = "float64, one simulated day each"
     elif workload_key in ("parabolic_c2", "transport_c3"):
         cls = Parabolic1D if workload_key == "parabolic_c2" else Transport1D
         nx, S = cls.nx, cls.S
@@ -269,10 +277,56 @@ class TrafficARZ:
                 "substeps_per_env_step": self.S, "reward": "TrafficARZReward", "parallelism": "independent instances, no collective"}
 
 
+class BrainTumor:
+    """BrainTumor1D (reference notebook configuration T=600, X=200, dt=dx=1, nx=201, float64,
+    total_dosage=61.2), one simulated day per env-step, B=65536 patients with individual daily doses."""
+    name = "BrainTumor1D nx=201 f64 B=65536 (reference notebook configuration)"
+    dtype = "f64"
+    B, S = 65536, 1
+
+    def __init__(self, device, seed, B=None, S=None):
+        import numpy as np
+        import torch
+        from pdecontrolgym_amd.batch_tumor import TumorBatch
+        self.B = B or self.B
+        self.device = device
+        self.env = TumorBatch(600, 1, 200, 1, 61.2, num_envs=self.B, device=device)
+        self.gen = torch.Generator(device="cpu").manual_seed(seed)
+        xs = np.linspace(0, 200, 201)
+        self.init = torch.as_tensor(0.8 * 1e5 * np.exp(-0.25 * (xs ** 2)), dtype=torch.float64, device=device)
+        self.env.set_benchmark(363.0)
+
+    def prepare(self, total_steps):
+        import torch
+        self.actions = (torch.rand(min(total_steps, 64), self.B, generator=self.gen, dtype=torch.float64) * 0.05).to(self.device)
+        self.env.reset(self.init)
+        self.i = 0
+
+    def step(self):
+        if self.i and self.i % 599 == 0:           # every patient has reached day T: start the next cohort
+            self.env.reset(self.init)
+        out = self.env.step(self.actions[self.i % self.actions.shape[0]])
+        self.i += 1
+        return out
+
+    def units_per_step(self):
+        return self.B
+
+    def algorithmic_bytes_per_step(self):      # row read + written (f64) + per-patient scalars
+        return (16 * self.env.nx + 96) * self.B
+
+    compulsory_bytes_per_step = algorithmic_bytes_per_step
+
+    def config(self):
+        return {"workload": self.name, "env": "PDEControlGym-BrainTumor1D", "nodes": self.env.nx, "batch_per_gpu": self.B,
+                "substeps_per_env_step": 1, "reward": "BrainTumorReward", "parallelism": "independent instances, no collective"}
+
+
 from bench_ns2d import NavierStokesC4, NavierStokesC5  # noqa: E402
 WORKLOADS["ns2d_c4"] = NavierStokesC4
 WORKLOADS["ns2d_c5"] = NavierStokesC5
 WORKLOADS["traffic_arz"] = TrafficARZ
+WORKLOADS["brain_tumor"] = BrainTumor
 
 
 def measured_traffic(workload_key):

@@ -28,7 +28,9 @@ __device__ __forceinline__ int wave_max_i(int v) {
 
 // brain_tumor_env.py:221-245, one interior node.
 __device__ __forceinline__ double fd_node(const pdegym_params_tumor& P, double ul, double uc, double ur, double R, bool rad) {
-  const double diffusion = P.D * (((ur - 2.0 * uc) + ul) / P.dx2);
+  double lap = (ur - 2.0 * uc) + ul;
+  if (P.dx2 != 1.0) lap = lap / P.dx2;                                 // x / 1.0 == x: skip the f64 division when dx = 1
+  const double diffusion = P.D * lap;
   const double logistic = 1.0 - (uc / P.k);
   const double proliferation = (P.rho * uc) * logistic;
   double s = diffusion + proliferation;
