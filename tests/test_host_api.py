@@ -170,6 +170,29 @@ def test_sensing_modes_and_scalar_observations(golden_transport):
         assert obs == g.obs[i + 1][0]
 
 
+def test_export_1d_trajectory(golden_transport, tmp_path):
+    import pde_control_gym
+    from pde_control_gym import export
+    g = golden_transport["H1"]
+    env = pde_control_gym.make("PDEControlGym-TransportPDE1D", device="cpu", backend=FakeBackend(), record_history=True,
+                               **_transport_params()).unwrapped
+    env.reset()
+    acts, rews = [], []
+    for a in g.actions[:3]:
+        _, r, *_ = env.step(np.array([a], dtype=np.float32))
+        acts.append(a)
+        rews.append(r)
+    export.save_trajectory_1d(tmp_path / "traj.npz", env, acts, rews)
+    z = np.load(tmp_path / "traj.npz")
+    assert z["u"].shape == (env.nt, 100) and int(z["time_index"]) == env.time_index and len(z["rewards"]) == 3
+    np.testing.assert_array_equal(z["u"][env.time_index], g.rows[2])
+    env2 = pde_control_gym.make("PDEControlGym-TransportPDE1D", device="cpu", backend=FakeBackend(), record_history=False,
+                                **_transport_params()).unwrapped
+    env2.reset()
+    with pytest.raises(ValueError, match="record_history"):
+        export.save_trajectory_1d(tmp_path / "no.npz", env2)
+
+
 def test_custom_reward_class_gets_a_trajectory_view(golden_transport):
     """A user BaseReward subclass (docs/source/utils/customrewards.rst) is called with (uVec, t, term, trunc, action)."""
     from pde_control_gym.src import BaseReward, TransportPDE1D
@@ -229,6 +252,20 @@ def test_ns_single_env_public_api_reproduces_target_frames(golden_ns):
     np.testing.assert_array_equal(env.u, g["u2"])
     pr = env.solve_pressure(env.u, env.v, np.zeros((21, 21)))
     assert pr.shape == (21, 21) and np.isfinite(pr).all()
+    # export in the reference's on-disk layouts (target.npz keys u, v; NS_optmization.npz keys U, V, desired_*, actions)
+    import tempfile, os
+    from pde_control_gym import export
+    with tempfile.TemporaryDirectory() as d:
+        export.save_ns_target(os.path.join(d, "target.npz"), env)
+        z = np.load(os.path.join(d, "target.npz"))
+        assert sorted(z.files) == ["u", "v"] and z["u"].shape == (200, 21, 21) and z["u"].dtype == np.float64
+        np.testing.assert_array_equal(z["u"][2], g["u2"])
+        np.testing.assert_array_equal(export.load_ns_target(os.path.join(d, "target.npz")), env.U)
+        export.save_ns_optimization(os.path.join(d, "res.npz"), env, Uref[..., 0], Uref[..., 1], list(g.actions[:2]))
+        z = np.load(os.path.join(d, "res.npz"))
+        assert sorted(z.files) == ["U", "V", "actions", "desired_U", "desired_V"] and z["V"].shape == (200, 21, 21)
+        with pytest.raises(ValueError):
+            export.save_ns_target(os.path.join(d, "x.npz"), np.zeros((3, 3)))
 
 
 # ---- batched VecEnv ------------------------------------------------------------------------------------
