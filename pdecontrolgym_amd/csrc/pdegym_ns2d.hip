@@ -139,6 +139,73 @@ __device__ __forceinline__ void jacobi_sweeps(T* p, T* pB, const T* rhs, int ny,
   }
 }
 
+// Same sweeps for grids of at most kLdsCells cells: p ping-pongs between two LDS copies and each thread keeps the
+// right-hand-side term of its (up to kLdsCPT) cells in registers, so a sweep costs LDS latency + one barrier instead of
+// an L2 round trip (the shipped 21x21, K = 2000 example: 2000 dependent sweeps per env-step).  Identical arithmetic.
+constexpr int kLdsCells = 4096;
+constexpr int kLdsCPT = 4;
+
+template <typename T>
+__device__ __forceinline__ void jacobi_sweeps_lds(T* p, const T* rhs, T* sh, int ny, int nx, int K, T dxdy) {
+  const int ncell = ny * nx;
+  T* src = sh;
+  T* dst = sh + ncell;
+  T rq[kLdsCPT];
+  int flag[kLdsCPT];   // bit0 interior, bit1 top, bit2 bottom, bit3 left, bit4 right
+#pragma unroll
+  for (int k = 0; k < kLdsCPT; ++k) {
+    const int c = threadIdx.x + k * blockDim.x;
+    flag[k] = 0;
+    rq[k] = 0;
+    if (c < ncell) {
+      const T pv = p[c];
+      src[c] = pv;
+      dst[c] = pv;
+      const int i = c / nx, j = c - i * nx;
+      if (i >= 1 && i <= ny - 2 && j >= 1 && j <= nx - 2) {
+        flag[k] = 1 | ((i == 1) << 1) | ((i == ny - 2) << 2) | ((j == 1) << 3) | ((j == nx - 2) << 4);
+        if constexpr (sizeof(T) == 4) rq[k] = jacobi_rhs_term(dxdy, rhs[c]);
+        else rq[k] = dxdy * rhs[c];
+      }
+    }
+  }
+  __syncthreads();
+  for (int it = 0; it < K; ++it) {
+#pragma unroll
+    for (int k = 0; k < kLdsCPT; ++k) {
+      const int f = flag[k];
+      if (f) {
+        const int c = threadIdx.x + k * blockDim.x;
+        const T s4 = ((src[c - 1] + src[c - nx]) + src[c + 1]) + src[c + nx];
+        T val;
+        if constexpr (sizeof(T) == 4) val = jacobi_update(s4, rq[k]);
+        else val = (T)0.25 * (s4 - rq[k]);
+        dst[c] = val;
+        if (f != 1) {
+          const bool top = f & 2, bot = f & 4, lef = f & 8, rig = f & 16;
+          if (top) dst[c - nx] = val;
+          if (bot) dst[c + nx] = val;
+          if (lef) dst[c - 1] = val;
+          if (rig) dst[c + 1] = val;
+          if (top && lef) dst[c - nx - 1] = val;
+          if (top && rig) dst[c - nx + 1] = val;
+          if (bot && lef) dst[c + nx - 1] = val;
+          if (bot && rig) dst[c + nx + 1] = val;
+        }
+      }
+    }
+    __syncthreads();
+    T* t = src;
+    src = dst;
+    dst = t;
+  }
+#pragma unroll
+  for (int k = 0; k < kLdsCPT; ++k) {
+    const int c = threadIdx.x + k * blockDim.x;
+    if (c < ncell) p[c] = src[c];
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ void compute_rhs(const T* us, const T* vs, T* rhs, int ny, int nx, const NSScal<T>& S) {
   const int ncell = ny * nx;
@@ -271,9 +338,10 @@ __device__ __forceinline__ void gen_back(const NSConst& C, const NSScal<T>& S, c
   }
 }
 
-template <typename T>
+template <typename T, bool LDSJ>
 __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, NSPtrs<T> P, int B) {
   __shared__ T red[16];
+  extern __shared__ double ns_dyn_lds[];
   const int b = blockIdx.x;
   if (b >= B) return;
   const int ncell = C.nx * C.ny;
@@ -282,7 +350,13 @@ __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, 
   T* pB = rhs + ncell;
   gen_front<T>(C, S, P, b);
   __syncthreads();
-  jacobi_sweeps<T>(p, pB, rhs, C.ny, C.nx, C.iters, S.dxdy);   // pressure Poisson (:142, :94-116), result in p
+  // pressure Poisson (:142, :94-116), result in p
+  if constexpr (LDSJ) {
+    jacobi_sweeps_lds<T>(p, rhs, reinterpret_cast<T*>(ns_dyn_lds), C.ny, C.nx, C.iters, S.dxdy);
+    __syncthreads();
+  } else {
+    jacobi_sweeps<T>(p, pB, rhs, C.ny, C.nx, C.iters, S.dxdy);
+  }
   gen_back<T>(C, S, P, b, p, red);
 }
 
@@ -1017,9 +1091,10 @@ __global__ void ns256_finish(NSConst C, NSScal<float> S, NSPtrs<float> P, int B)
   P.terminated[b] = (t >= C.nt - 1) ? 1 : 0;
 }
 
-template <typename T>
+template <typename T, bool LDSJ>
 __global__ __launch_bounds__(1024) void ns_generic_pressure(NSConst C, NSScal<T> S, const T* ug, const T* vg, const T* p_in,
                                                              T* p_out, T* scratch, int B) {
+  extern __shared__ double ns_dyn_lds[];
   const int b = blockIdx.x;
   if (b >= B) return;
   const int nx = C.nx, ny = C.ny, ncell = nx * ny;
@@ -1034,7 +1109,8 @@ __global__ __launch_bounds__(1024) void ns_generic_pressure(NSConst C, NSScal<T>
     for (int c = threadIdx.x; c < ncell; c += blockDim.x) po[c] = pi[c];
   }
   __syncthreads();
-  jacobi_sweeps<T>(po, pB, rhs, ny, nx, C.iters, S.dxdy);
+  if constexpr (LDSJ) jacobi_sweeps_lds<T>(po, rhs, reinterpret_cast<T*>(ns_dyn_lds), ny, nx, C.iters, S.dxdy);
+  else jacobi_sweeps<T>(po, pB, rhs, ny, nx, C.iters, S.dxdy);
 }
 
 template <typename T>
@@ -1096,6 +1172,18 @@ int fill(const pdegym_params_ns2d* prm, NSConst& C, NSScal<T>& S) {
 // PDEGYM_NS_GENERIC=1 in the environment routes float32 steps through ns_generic (A/B testing of the tiled path)
 inline bool pdegym_force_generic() {
   const char* e = getenv("PDEGYM_NS_GENERIC");
+  return e && e[0] == '1';
+}
+
+// LDS-resident Jacobi: every thread owns at most kLdsCPT cells
+inline int lds_block_threads(int ncell) {
+  if (ncell <= 1024) return 256;
+  if (ncell <= 2048) return 512;
+  return 1024;
+}
+
+inline bool pdegym_no_lds_jacobi() {
+  const char* e = getenv("PDEGYM_NS_NO_LDS_JACOBI");
   return e && e[0] == '1';
 }
 
@@ -1169,7 +1257,12 @@ int ns_step(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int B, v
       return pdegym::check_launch("ns2d_slab_step");
     }
   }
-  hipLaunchKernelGGL(ns_generic_step<T>, dim3(B), dim3(block_threads(C.nx * C.ny)), 0, (hipStream_t)stream, C, S, P, B);
+  const int ncell = C.nx * C.ny;
+  if (ncell <= kLdsCells && !pdegym_no_lds_jacobi())
+    hipLaunchKernelGGL((ns_generic_step<T, true>), dim3(B), dim3(lds_block_threads(ncell)), 2 * (size_t)ncell * sizeof(T),
+                       (hipStream_t)stream, C, S, P, B);
+  else
+    hipLaunchKernelGGL((ns_generic_step<T, false>), dim3(B), dim3(block_threads(ncell)), 0, (hipStream_t)stream, C, S, P, B);
   return pdegym::check_launch("ns2d_step");
 }
 
@@ -1182,8 +1275,13 @@ int ns_pressure(const pdegym_params_ns2d* prm, const void* u, const void* v, con
   if (B <= 0) return 0;
   if (!u || !v || !p_in || !p_out || !scratch) return pdegym::fail(-3, "null device buffer");
   C.nt_ref = 1;
-  hipLaunchKernelGGL(ns_generic_pressure<T>, dim3(B), dim3(block_threads(C.nx * C.ny)), 0, (hipStream_t)stream, C, S,
-                     (const T*)u, (const T*)v, (const T*)p_in, (T*)p_out, (T*)scratch, B);
+  const int ncell = C.nx * C.ny;
+  if (ncell <= kLdsCells && !pdegym_no_lds_jacobi())
+    hipLaunchKernelGGL((ns_generic_pressure<T, true>), dim3(B), dim3(lds_block_threads(ncell)), 2 * (size_t)ncell * sizeof(T),
+                       (hipStream_t)stream, C, S, (const T*)u, (const T*)v, (const T*)p_in, (T*)p_out, (T*)scratch, B);
+  else
+    hipLaunchKernelGGL((ns_generic_pressure<T, false>), dim3(B), dim3(block_threads(ncell)), 0, (hipStream_t)stream, C, S,
+                       (const T*)u, (const T*)v, (const T*)p_in, (T*)p_out, (T*)scratch, B);
   return pdegym::check_launch("ns2d_solve_pressure");
 }
 

@@ -223,6 +223,35 @@ def test_ns_f32_tiled_kernel_equals_generic_kernel_bitwise(n):
         np.testing.assert_allclose(r1, r2, rtol=1e-5)
 
 
+@pytest.mark.parametrize("n,dtype,K", [(21, "float64", 200), (21, "float64", 7), (33, "float32", 50), (64, "float64", 31),
+                                       (64, "float32", 50), (5, "float64", 12)])
+def test_ns_lds_resident_jacobi_equals_global_memory_jacobi_bitwise(n, dtype, K):
+    """Grids of <= 4096 cells keep p in LDS during the sweeps; same arithmetic as the global-memory loop -> identical
+    fields, pressure (incl. the public solve_pressure) and rewards.  Odd and even K, both dtypes."""
+    import os
+    td = getattr(torch, dtype)
+    kw, u0, v0, p0, acts = _random_case(n, 3, K, 77 + n + K, BC_MIX)
+    outs = []
+    for no_lds in ("0", "1"):
+        os.environ["PDEGYM_NS_NO_LDS_JACOBI"] = no_lds
+        os.environ["PDEGYM_NS_GENERIC"] = "1"
+        try:
+            env = _mk(kw, 3, td)
+            env.reset(u0, v0, p0)
+            res = []
+            for a in acts:
+                obs, r, te = env.step(a)
+                res.append((obs.cpu().numpy().copy(), env.p.cpu().numpy().copy(), r.cpu().numpy().copy()))
+            res.append((env.solve_pressure(u0, v0, p0).cpu().numpy().copy(),))
+            outs.append(res)
+        finally:
+            os.environ["PDEGYM_NS_NO_LDS_JACOBI"] = "0"
+            os.environ["PDEGYM_NS_GENERIC"] = "0"
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+
+
 @pytest.mark.parametrize("n,dtype", [(128, "float32"), (40, "float32"), (21, "float64")])
 def test_ns_interleaved_state_equals_separate_fields(n, dtype):
     """interleaved_state=True (state lives in the double-buffered obs tensors) == separate u, v fields, bitwise."""
