@@ -39,7 +39,7 @@ extern "C" {
 #define PDEGYM_ABI_VERSION 5
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
-#define PDEGYM_MAX_N1D 1024      /* nodes per 1D row handled by the wave-per-instance kernels */
+#define PDEGYM_MAX_N1D 2048      /* nodes per 1D row handled by the wave-per-instance kernels */
 
 /* control_type (hyperbolic.py:66-124): the reference's (mis)spelling "Dirchilet" is kept in the Python layer */
 enum { PDEGYM_CONTROL_DIRICHLET = 0, PDEGYM_CONTROL_NEUMANN = 1 };

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 ABI_VERSION = 5
 RING = 128
 LOOKBACK = 100
-MAX_N1D = 1024
+MAX_N1D = 2048
 
 CONTROL = {"Dirchilet": 0, "Neumann": 1}
 SENSE_FULL, SENSE_LAST, SENSE_LAST_DERIV, SENSE_FIRST_DERIV, SENSE_FIRST = range(5)

@@ -565,7 +565,7 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
   if (!prm || !buf) return pdegym::fail(-1, "null params/bufs");
   if (B <= 0) return 0;
   const pdegym_params1d& P = *prm;
-  if (P.n < 3 || P.n > PDEGYM_MAX_N1D) return pdegym::fail(-2, "n must be in [3, 1024] for the wave-per-instance 1D kernels");
+  if (P.n < 3 || P.n > PDEGYM_MAX_N1D) return pdegym::fail(-2, "n must be in [3, 2048] for the wave-per-instance 1D kernels");
   if (P.nt < 2) return pdegym::fail(-2, "nt must be >= 2");
   if (!buf->u || !buf->beta || !buf->action || !buf->time_index || !buf->bsum || !buf->ring || !buf->obs ||
       !buf->norm_now || !buf->norm_back || !buf->terminated || !buf->truncated)
@@ -583,7 +583,9 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
     case 6: return launch_epl<6, PARABOLIC>(P, *buf, B, st);
     case 7: case 8: return launch_epl<8, PARABOLIC>(P, *buf, B, st);
     case 9: case 10: case 11: case 12: return launch_epl<12, PARABOLIC>(P, *buf, B, st);
-    default: return launch_epl<16, PARABOLIC>(P, *buf, B, st);
+    case 13: case 14: case 15: case 16: return launch_epl<16, PARABOLIC>(P, *buf, B, st);
+    case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: return launch_epl<24, PARABOLIC>(P, *buf, B, st);
+    default: return launch_epl<32, PARABOLIC>(P, *buf, B, st);
   }
 }
 

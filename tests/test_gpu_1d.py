@@ -69,6 +69,8 @@ def _oracle_kwargs(kw):
     ("transport", 512, 100, 64, "Dirchilet"), ("transport", 100, 50, 17, "Neumann"), ("transport", 64, 10, 8, "Dirchilet"),
     ("transport", 65, 10, 8, "Dirchilet"), ("transport", 300, 25, 6, "Dirchilet"), ("transport", 1024, 12, 4, "Dirchilet"),
     ("transport", 31, 12, 5, "Dirchilet"), ("parabolic", 2, 3, 4, "Dirchilet"),
+    ("transport", 1500, 9, 3, "Dirchilet"), ("parabolic", 2047, 4, 3, "Dirchilet"), ("transport", 2048, 5, 2, "Neumann"),
+    ("parabolic", 1300, 6, 2, "Neumann"),
 ])
 def test_hip_matches_oracle_random_batches(kind, nx, S, B, ctrl):
     """Seeded random per-instance IC / beta / actions: every row bit-exact vs the oracle."""
@@ -205,7 +207,7 @@ def test_abi_rejects_bad_arguments():
     from pdecontrolgym_amd import _native as N
     from pdecontrolgym_amd.batch1d import PDEBatch1D
     with pytest.raises(N.NativeError):
-        env = PDEBatch1D("transport", 1, 1e-3, 1, 1.0 / 2000, 0.01, num_envs=2, device="cuda")   # n = 2000 > 1024
+        env = PDEBatch1D("transport", 1, 1e-3, 1, 1.0 / 2100, 0.01, num_envs=2, device="cuda")   # n = 2100 > 2048
         env.step(torch.zeros(2))
 
 
