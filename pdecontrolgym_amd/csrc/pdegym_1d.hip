@@ -20,6 +20,8 @@
 //       reward     rewards/tuned_reward_1d.py:25-40 (streaming form)
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -112,6 +114,9 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
   // control_update (hyperbolic.py:68,95). Transport/Neumann reads u[t][-2] of the NEW row, which is still zero
   // (hyperbolic.py:144), so its boundary value is constant over the sub-steps.
   const float cdx = a * dx;
+  const float rdxf = 1.0f / dx;   // exact when dx is a power of two (the only case it is used in)
+  const bool pow2_dx = !PARABOLIC && dx > 0.0f && (__float_as_uint(dx) & 0x7fffffu) == 0u && rdxf * dx == 1.0f &&
+                       rdxf < 3.0e38f;
   float bval = NEUMANN ? normalize_ctrl(cdx + 0.0f, P.max_control, P.normalize) : normalize_ctrl(a, P.max_control, P.normalize);
 
   // per-slot coefficients: parabolic c = dt*beta (parabolic.py:144 forms dt*beta first), transport c = beta
@@ -129,8 +134,13 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
     }
   }
 
-  for (int s = 0; s < nsub; ++s) {
-    const float xl = PARABOLIC ? from_left_lane(R.x[EPL - 1], R.bl) : 0.0f;  // p[first slot - 1]
+  // one PDE sub-step on the register-resident row (no bookkeeping).  GENERAL_EDGE: node 0 may be non-zero (first
+  // sub-step after a reset) and, on the fast path, the frozen boundary slot takes the new control value.
+  auto pde_substep = [&](auto general_edge, auto pow2_tag) {
+    constexpr bool GENERAL_EDGE = decltype(general_edge)::value;
+    constexpr bool POW2_DX = decltype(pow2_tag)::value;
+    // p[first slot - 1]; after the first sub-step node 0 is identically 0, so the shift needs no fill operand
+    const float xl = PARABOLIC ? from_left_lane(R.x[EPL - 1], GENERAL_EDGE ? R.bl : 0.0f) : 0.0f;
     const float xr = from_right_lane(R.x[0], 0.0f);                          // p[last slot + 1]
     float p0 = 0.f;
     if constexpr (!PARABOLIC) p0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, R.x[0])));
@@ -145,7 +155,12 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
       // parabolic.py:143-144   u + F*(um - 2*u + up) + (dt*beta)*u
       float t2[EPL], t3[EPL], t4[EPL], t5[EPL], t7[EPL];
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) t2[e] = __builtin_fmaf(-2.0f, R.x[e], (e == 0) ? xl : R.x[e - 1]);
+      for (int e = 0; e < EPL; ++e) {
+        // pm - 2p: 2p is exact, so fma(-2, p, pm) == pm + (-2p).  The first slot takes the product form so that the
+        // lane shift folds into the add (v_add_f32_dpp); VOP3 fma cannot carry a DPP operand.
+        if (e == 0 && !GENERAL_EDGE) t2[e] = xl + (-2.0f * R.x[e]);
+        else t2[e] = __builtin_fmaf(-2.0f, R.x[e], (e == 0) ? xl : R.x[e - 1]);
+      }
 #pragma unroll
       for (int e = 0; e < EPL; ++e) t3[e] = t2[e] + ((e == EPL - 1) ? xr : R.x[e + 1]);
 #pragma unroll
@@ -167,12 +182,19 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
       for (int e = 0; e < EPL; ++e) d1[e] = ((e == EPL - 1) ? xr : R.x[e + 1]) - R.x[e];
 #pragma unroll
       for (int e = 0; e < EPL; ++e) r[e] = p0 * c[e];
+      if constexpr (POW2_DX) {
+        // dx = 2^k: d/dx == d * 2^-k exactly (same rounding into the denormal range, same overflow), one multiply
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) q[e] = (double)d1[e];
+        for (int e = 0; e < EPL; ++e) d2[e] = d1[e] * rdxf;
+        (void)q;
+      } else {
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) q[e] = q[e] * P.rdx;
+        for (int e = 0; e < EPL; ++e) q[e] = (double)d1[e];
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) d2[e] = (float)q[e];
+        for (int e = 0; e < EPL; ++e) q[e] = q[e] * P.rdx;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) d2[e] = (float)q[e];
+      }
 #pragma unroll
       for (int e = 0; e < EPL; ++e) d3[e] = d2[e] + r[e];
 #pragma unroll
@@ -227,28 +249,67 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
     }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) R.x[e] = y[e];
-    if constexpr (FAST) {
-      if (s == 0) {  // the frozen boundary slot takes the new control value once (parabolic.py:148-150)
+    if constexpr (FAST && GENERAL_EDGE) {  // the frozen boundary slot takes the new control value once (parabolic.py:148-150)
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) R.x[e] = (s0 + e == ns - 1) ? bval : R.x[e];
-      }
+      for (int e = 0; e < EPL; ++e) R.x[e] = (s0 + e == ns - 1) ? bval : R.x[e];
     }
     R.bl = 0.0f;  // parabolic.py:146  u(0,t) = 0
-    ++R.t;
-    R.k = (R.k + 1 == S) ? 0 : R.k + 1;
-    if constexpr (NEUMANN) R.bsum += (double)fabsf(bval);
-    if constexpr (HIST) {
-      float* hrow = hist + (size_t)R.t * n;
-      if (PARABOLIC && lane == 0) hrow[0] = 0.0f;
-#pragma unroll
-      for (int e = 0; e < EPL; ++e)
-        if (s0 + e < ns) hrow[J0 + s0 + e] = R.x[e];
-    }
-    // rows whose norm a later reward call looks back at (tuned_reward_1d.py:40): r+100 is a step end
-    if (s + 1 < nsub && (rec_all || R.k == 0 || R.t + PDEGYM_LOOKBACK == P.nt - 1)) {
+  };
+  // rows whose norm a later reward call looks back at (tuned_reward_1d.py:40): r+100 is a step end
+  auto record_norm = [&](int done) {
+    if (done < nsub && (rec_all || R.k == 0 || R.t + PDEGYM_LOOKBACK == P.nt - 1)) {
       const float nr = sqrtf(slots_sumsq<EPL>(R.x, s0, ns));  // node 0 is 0 after any sub-step
       if (lane == 0) ring[R.t & (PDEGYM_RING - 1)] = nr;
       if (R.t == R.back_row) R.back_norm = nr;                // this call's own look-back row: no memory round trip
+    }
+  };
+  if constexpr (FAST) {
+    // Every instruction of the loop -- scalar bookkeeping included -- takes an issue slot of the SIMD (about one per
+    // 2.8 cycles with four resident waves), so the sub-steps between two norm records run in a bare inner loop and the
+    // time index / phase counters advance once per run.
+    int s = 0;
+    if (nsub > 0) {
+      pde_substep(std::true_type{}, std::false_type{});
+      ++R.t;
+      R.k = (R.k + 1 == S) ? 0 : R.k + 1;
+      s = 1;
+      record_norm(s);
+    }
+    while (s < nsub) {
+      int run = nsub - s;
+      if (rec_all) {
+        run = 1;
+      } else {
+        const int to_phase0 = S - R.k;                                   // sub-steps until R.k wraps to 0
+        const int to_lookback = (P.nt - 1 - PDEGYM_LOOKBACK) - R.t;      // ... until R.t + LOOKBACK == nt - 1
+        run = run < to_phase0 ? run : to_phase0;
+        if (to_lookback > 0) run = run < to_lookback ? run : to_lookback;
+      }
+      if (pow2_dx) {
+        for (int i = 0; i < run; ++i) pde_substep(std::false_type{}, std::true_type{});
+      } else {
+        for (int i = 0; i < run; ++i) pde_substep(std::false_type{}, std::false_type{});
+      }
+      R.t += run;
+      R.k += run;
+      if (R.k >= S) R.k -= S;
+      s += run;
+      record_norm(s);
+    }
+  } else {
+    for (int s = 0; s < nsub; ++s) {
+      pde_substep(std::true_type{}, std::false_type{});
+      ++R.t;
+      R.k = (R.k + 1 == S) ? 0 : R.k + 1;
+      if constexpr (NEUMANN) R.bsum += (double)fabsf(bval);
+      if constexpr (HIST) {
+        float* hrow = hist + (size_t)R.t * n;
+        if (PARABOLIC && lane == 0) hrow[0] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+          if (s0 + e < ns) hrow[J0 + s0 + e] = R.x[e];
+      }
+      record_norm(s + 1);
     }
   }
   if constexpr (!NEUMANN) R.bsum += (double)nsub * (double)fabsf(bval);
