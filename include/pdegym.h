@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PDEGYM_ABI_VERSION 5
+#define PDEGYM_ABI_VERSION 6
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
 #define PDEGYM_MAX_N1D 2048      /* nodes per 1D row handled by the wave-per-instance kernels */
@@ -256,11 +256,26 @@ typedef struct pdegym_bufs_tumor {
   uint8_t* truncated;      /* [B] out                                                                          */
   double* out;             /* [B, 4] out: T1 radius and T2 radius of the new row (NaN = invisible), treatment radius and
                               applied dose of this step (0 outside Therapy)                                    */
+  const uint8_t* active;   /* [B] or NULL: instances with active[b] == 0 are left untouched (no output is written)    */
+  double* history;         /* [B, nt, nx] or NULL: the row of every simulated day t is stored at [b, t] (env.u)   :143 */
+  double* t1_log;          /* [B, nt] or NULL: T1 radius / dx of every simulated day (t1_radius_idx_vs_time) :271-273  */
 } pdegym_bufs_tumor;
 
-/* One day per call.  Instances with time_index >= nt-1 are left untouched (reward 0, flags 0).  LDS: 4*nx*8 bytes,
- * nx <= 4096. */
+/* Runs of days inside one launch (the loops of TherapyWrapper, brain_tumor_env.py:385-505) */
+enum {
+  PDEGYM_TUMOR_RUN_ONE_DAY = 0, /* == pdegym_tumor_step                                                                 */
+  PDEGYM_TUMOR_RUN_GROWTH = 1,  /* instances in Growth: step(0) until the stage changes or the episode ends  :409-428   */
+  PDEGYM_TUMOR_RUN_POST = 2,    /* instances in Post-Therapy: step(0) until terminated or truncated          :437-446   */
+  PDEGYM_TUMOR_RUN_TO_END = 3   /* every live instance: step(0) until terminated or truncated (benchmark())  :488-503   */
+};
+
+/* One day per call.  Instances with time_index >= nt-1 are left untouched (reward 0, flags 0).  nx <= 4096. */
 int pdegym_tumor_step(const pdegym_params_tumor* prm, const pdegym_bufs_tumor* buf, int32_t B, void* stream);
+/* Up to max_days days per participating instance inside ONE launch (row and stage machine stay on chip between days);
+ * control is 0 on every day of modes 1-3; reward / flags / out are those of the LAST simulated day; instances that do not
+ * take part (wrong stage, inactive, or past nt-1) are left untouched.  kill is only honoured by RUN_ONE_DAY. */
+int pdegym_tumor_advance(const pdegym_params_tumor* prm, const pdegym_bufs_tumor* buf, int32_t mode, int32_t max_days,
+                         int32_t B, void* stream);
 /* Where mask[b] != 0 (or mask == NULL): u = init (init_stride = 0 broadcasts one row), time_index = 0, stage = Growth,
  * remaining = total_dosage, days = (0,0,0,0,-1). */
 int pdegym_tumor_reset_masked(const pdegym_params_tumor* prm, const pdegym_bufs_tumor* buf, const double* init,

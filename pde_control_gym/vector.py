@@ -291,7 +291,10 @@ class PDEVecEnv:
         return self
 
 
-def make_vec(env_id: str, num_envs: int, **kwargs) -> PDEVecEnv:
+def make_vec(env_id: str, num_envs: int, **kwargs):
     """``make_vec("PDEControlGym-ReactionDiffusionPDE1D", num_envs=4096, **params)`` -- the batched sibling of
     ``gym.make(id, **params)`` taking the same parameter dictionary."""
+    if env_id == "PDEControlGym-BrainTumor1D":
+        from pde_control_gym.vector_tumor import TumorVecEnv
+        return TumorVecEnv(num_envs, **kwargs)
     return PDEVecEnv(env_id, num_envs, **kwargs)

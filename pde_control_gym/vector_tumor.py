@@ -1,0 +1,136 @@
+"""TumorVecEnv -- a batch of ``TherapyWrapper(BrainTumor1D)`` patients behind one VecEnv-style object.
+
+What the reference offers one patient at a time (examples/BrainTumor1D: ``TherapyWrapper(gym.make("PDEControlGym-BrainTumor1D",
+**params))`` driven by SAC/PPO) happens here for ``num_envs`` patients with a handful of launches per step and no host
+synchronisation: the agent only sees treatment days; growth (at reset) and post-therapy (after the last dose) run as
+in-kernel day loops (``pdegym_tumor_advance``), finished patients restart inside the same ``step`` (SB3 auto-reset
+semantics: ``infos[i]["terminal_observation"]``).  Per-patient semantics follow brain_tumor_env.py:385-505 including
+the ``weekends`` option (two untreated days after five consecutive treatment days).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from pde_control_gym._compat import spaces
+
+
+class TumorVecEnv:
+    metadata = {"render_modes": []}
+    render_mode = None
+
+    def __init__(self, num_envs: int, weekends: bool = False, device="cuda", backend=None, t_benchmark=None, **kw):
+        import torch
+        from pdecontrolgym_amd.batch_tumor import TumorBatch
+        from pdecontrolgym_amd import _native as N
+        self._N = N
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        self.weekends = bool(weekends)
+        self.reward_class = kw.pop("reward_class", None)
+        kw.pop("normalize", None)
+        kw.pop("verbose", None)
+        self.reset_init_condition_func = kw.pop("reset_init_condition_func")
+        self.core = TumorBatch(num_envs=self.num_envs, device=device, backend=backend, **kw)
+        c = self.core
+        self.observation_space = spaces.Box(np.full(c.nx, 0, dtype="float64"), np.full(c.nx, c.k, dtype="float64"), dtype=np.float64)
+        self.action_space = spaces.Box(np.full(1, 0, dtype="float32"), np.full(1, 1, dtype="float32"))
+        self._init_rows = torch.as_tensor(np.asarray(self.reset_init_condition_func(c.X, c.nx), dtype=np.float64), device=self.device)
+        self._consecutive = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        self.treatment_calls = torch.zeros(self.num_envs, dtype=torch.int64, device=self.device)
+        self.soft_constraint_violations = torch.zeros(self.num_envs, dtype=torch.int64, device=self.device)
+        self.t_benchmark = None
+        if t_benchmark is not None:
+            self.t_benchmark = t_benchmark
+            c.set_benchmark(t_benchmark)
+        self._actions = None
+
+    # ---- TherapyWrapper.benchmark / reset -------------------------------------------------------------------------
+    def benchmark(self):
+        """Open-loop survival days of every patient (no treatment); stored as ``t_benchmark`` (brain_tumor_env.py:488-503)."""
+        import torch
+        c = self.core
+        c.set_benchmark(float("nan"))
+        c.reset(self._init_rows)
+        c.advance(self._N.TUMOR_RUN_TO_END)
+        tb = c.t["days"][:, 3].to(torch.float64).clone()
+        self.t_benchmark = tb
+        c.set_benchmark(tb)
+        self.reset_tensor()
+        return tb
+
+    def reset_tensor(self, mask=None):
+        """Restart (``mask``: only those patients) and run the growth stage: the first observation is the first treatment day."""
+        c = self.core
+        c.reset(self._init_rows, mask=mask)
+        c.advance(self._N.TUMOR_RUN_GROWTH, active=mask)
+        if mask is None:
+            self._consecutive.zero_()
+        else:
+            self._consecutive.masked_fill_(mask.bool(), 0)
+        return c.t["u"]
+
+    def reset(self, seed=None, options=None):
+        return self.reset_tensor().cpu().numpy().copy()
+
+    # ---- TherapyWrapper.step for every patient ------------------------------------------------------------------------
+    def step_tensor(self, actions):
+        """actions [B] (or [B, 1]) = fraction of total_dosage for today's treatment.  Returns device tensors
+        (obs [B, nx], reward [B], terminated [B] bool, truncated [B] bool); finished patients have already been restarted
+        and their last observation is kept in ``self.terminal_obs``."""
+        import torch
+        N, c = self._N, self.core
+        a = torch.as_tensor(actions, dtype=torch.float64, device=self.device).reshape(self.num_envs)
+        stage = c.t["stage"]
+        in_post = stage == N.TUMOR_POST
+        in_therapy = stage == N.TUMOR_THERAPY                       # Growth cannot be observed here (reset runs it)
+        # Case 1 (:437-446): patients whose therapy is over run to the end of their episode inside one launch
+        c.advance(N.TUMOR_RUN_POST, active=in_post)
+        # Case 2 (:452-456): one treatment day for the others
+        c.step(a, active=in_therapy)
+        rew, term, trunc = c.t["reward"], c.t["terminated"].bool(), c.t["truncated"].bool()
+        self.treatment_calls += in_therapy
+        self.soft_constraint_violations += in_therapy & (rew < 0.0)
+        if self.weekends:                                            # :458-472
+            self._consecutive = torch.where(in_therapy, torch.where(a > 0, self._consecutive + 1, torch.zeros_like(self._consecutive)),
+                                            self._consecutive)
+            rest = in_therapy & (self._consecutive >= 5) & ~(term | trunc)
+            self._consecutive = torch.where(rest, torch.zeros_like(self._consecutive), self._consecutive)
+            keep = (rew.clone(), c.t["terminated"].clone(), c.t["truncated"].clone())
+            seen = c.t["u"].clone()                                  # the wrapper returns the TREATMENT day's row (:456, :481)
+            zero = torch.zeros_like(a)
+            for _ in range(2):                                       # two untreated days; their outputs are discarded
+                c.step(zero, active=rest)
+            for dst, src in zip((c.t["reward"], c.t["terminated"], c.t["truncated"]), keep):
+                dst.copy_(src)
+            rew = c.t["reward"]
+        done = term | trunc
+        rewards = rew.clone()
+        self.terminal_obs = c.t["u"].clone()
+        self.reset_tensor(mask=done)
+        obs = c.t["u"]
+        if self.weekends:
+            obs = torch.where((rest & ~done)[:, None], seen, obs)
+        return obs, rewards, term, trunc
+
+    # ---- SB3 VecEnv face ------------------------------------------------------------------------------------------------
+    def step_async(self, actions):
+        self._actions = actions
+
+    def step_wait(self):
+        obs, rew, term, trunc = self.step_tensor(np.asarray(self._actions, dtype=np.float64).reshape(self.num_envs))
+        done = (term | trunc).cpu().numpy()
+        tr = trunc.cpu().numpy()
+        infos = [{} for _ in range(self.num_envs)]
+        if done.any():
+            tob = self.terminal_obs.cpu().numpy()
+            for i in np.nonzero(done)[0]:
+                infos[i]["terminal_observation"] = tob[i].copy()
+                infos[i]["TimeLimit.truncated"] = bool(tr[i] and not term[i])
+        return obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), done, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        pass

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 RING = 128
 LOOKBACK = 100
 MAX_N1D = 2048
@@ -27,7 +27,7 @@ EXPORTS = [
     "pdegym_reset1d_masked", "pdegym_rownorm2_f32", "pdegym_selftest_quotient", "pdegym_ns2d_step_f32", "pdegym_ns2d_step_f64",
     "pdegym_ns2d_solve_pressure_f32", "pdegym_ns2d_solve_pressure_f64", "pdegym_ns2d_reset_masked_f32",
     "pdegym_ns2d_reset_masked_f64", "pdegym_traffic_step", "pdegym_traffic_reset_masked",
-    "pdegym_tumor_step", "pdegym_tumor_reset_masked",
+    "pdegym_tumor_step", "pdegym_tumor_advance", "pdegym_tumor_reset_masked",
 ]
 
 
@@ -77,6 +77,7 @@ class BufsTraffic(C.Structure):
 
 TUMOR_GROWTH, TUMOR_THERAPY, TUMOR_POST = range(3)
 TUMOR_STAGE_NAMES = ("Growth", "Therapy", "Post-Therapy")
+TUMOR_RUN_ONE_DAY, TUMOR_RUN_GROWTH, TUMOR_RUN_POST, TUMOR_RUN_TO_END = range(4)
 
 
 class ParamsTumor(C.Structure):
@@ -87,7 +88,8 @@ class ParamsTumor(C.Structure):
 
 class BufsTumor(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("u", "xscale", "control", "kill", "time_index", "stage", "remaining", "days",
-                                          "t_benchmark", "reward", "terminated", "truncated", "out")]
+                                          "t_benchmark", "reward", "terminated", "truncated", "out", "active", "history",
+                                          "t1_log")]
 
 
 class NativeError(RuntimeError):
@@ -138,6 +140,8 @@ def load():
     lib.pdegym_traffic_reset_masked.restype = C.c_int
     lib.pdegym_tumor_step.argtypes = [C.POINTER(ParamsTumor), C.POINTER(BufsTumor), C.c_int32, C.c_void_p]
     lib.pdegym_tumor_step.restype = C.c_int
+    lib.pdegym_tumor_advance.argtypes = [C.POINTER(ParamsTumor), C.POINTER(BufsTumor), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.pdegym_tumor_advance.restype = C.c_int
     lib.pdegym_tumor_reset_masked.argtypes = [C.POINTER(ParamsTumor), C.POINTER(BufsTumor), C.c_void_p, C.c_int64, C.c_void_p,
                                               C.c_int32, C.c_void_p]
     lib.pdegym_tumor_reset_masked.restype = C.c_int

@@ -136,7 +136,15 @@ class HipBackend:
             setattr(b, k, N.dptr(T[k], torch.int32))
         b.terminated = N.dptr(T["terminated"], torch.uint8)
         b.truncated = N.dptr(T["truncated"], torch.uint8)
+        b.active = N.dptr(T.get("active"), torch.uint8) if T.get("active") is not None else None
+        b.history = N.dptr(T.get("history"), torch.float64) if T.get("history") is not None else None
+        b.t1_log = N.dptr(T.get("t1_log"), torch.float64) if T.get("t1_log") is not None else None
         return b
+
+    def tumor_advance(self, P: N.ParamsTumor, T: dict, mode: int, max_days: int, B: int):
+        bufs = self._bufs_tumor(T)
+        N.check(self.lib.pdegym_tumor_advance(C.byref(P), C.byref(bufs), mode, max_days, B, N.current_stream_ptr(T["u"].device)),
+                "pdegym_tumor_advance")
 
     def tumor_step(self, P: N.ParamsTumor, T: dict, B: int):
         bufs = self._bufs_tumor(T)

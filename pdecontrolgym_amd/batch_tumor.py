@@ -18,7 +18,7 @@ class TumorBatch:
                  t1_detection_threshold: float = 0.8, t2_detection_threshold: float = 0.16,
                  dosage_termination_threshold: float = 0.1, D: float = 0.2, rho: float = 0.03, alpha: float = 0.04,
                  alpha_beta_ratio: float = 10, k: float = 1e5, t1_detection_radius: float = 15,
-                 t1_death_radius: float = 35, num_envs: int = 1, device="cuda", backend=None):
+                 t1_death_radius: float = 35, num_envs: int = 1, device="cuda", backend=None, record_history: bool = False):
         import torch
         self.T, self.dt, self.X, self.dx = T, dt, X, dx
         self.nt = int(round(T / dt) + 1)
@@ -53,6 +53,10 @@ class TumorBatch:
             "terminated": torch.zeros(B, dtype=torch.uint8, device=dev),
             "truncated": torch.zeros(B, dtype=torch.uint8, device=dev),
             "out": torch.zeros(B, 4, dtype=f64, device=dev),
+            "active": None,
+            # optional trajectory on the device: history[b, t] = row of day t, t1_log[b, t] = T1 radius / dx (NaN = invisible)
+            "history": torch.zeros(B, self.nt, self.nx, dtype=f64, device=dev) if record_history else None,
+            "t1_log": torch.full((B, self.nt), float("nan"), dtype=f64, device=dev) if record_history else None,
         }
         self.t["days"][:, 4] = -1
 
@@ -73,9 +77,28 @@ class TumorBatch:
         if mask is not None:
             mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
         self.backend.tumor_reset(self.params, self.t, init, mask, self.num_envs)
+        if self.t["history"] is not None:
+            sel = slice(None) if mask is None else mask.bool()
+            self.t["history"][sel] = 0
+            self.t["history"][sel, 0] = self.t["u"][sel]
+            self.t["t1_log"][sel] = float("nan")
         return self.t["u"]
 
-    def step(self, control, kill=None):
+    def _set_active(self, active):
+        import torch
+        self.t["active"] = None if active is None else \
+            torch.as_tensor(active, device=self.device).to(torch.uint8).reshape(self.num_envs).contiguous()
+
+    def advance(self, mode: int, max_days: int = None, active=None):
+        """Run whole stretches of days inside ONE launch (control 0 every day): ``N.TUMOR_RUN_GROWTH`` -- patients in Growth
+        until their stage changes; ``N.TUMOR_RUN_POST`` -- patients in Post-Therapy until death or the time limit;
+        ``N.TUMOR_RUN_TO_END`` -- everybody until death or the time limit (the open-loop benchmark).  Outputs
+        (reward, flags, ``out``) are those of each patient's last simulated day; others are left untouched."""
+        self._set_active(active)
+        self.backend.tumor_advance(self.params, self.t, int(mode), int(self.nt if max_days is None else max_days), self.num_envs)
+        return self.t["u"], self.t["reward"], self.t["terminated"], self.t["truncated"]
+
+    def step(self, control, kill=None, active=None):
         """control [B]: proportion of total_dosage requested today.  ``kill`` [B] optionally carries
         ``1 - exp(-alpha*BED)`` evaluated by the caller (NumPy bit parity); by default the kernel evaluates it.
         Returns (u [B,nx] -- the live state, updated in place --, reward, terminated, truncated)."""
@@ -83,5 +106,6 @@ class TumorBatch:
         self.t["control"] = torch.as_tensor(control, dtype=torch.float64, device=self.device).reshape(self.num_envs).contiguous()
         self.t["kill"] = None if kill is None else \
             torch.as_tensor(kill, dtype=torch.float64, device=self.device).reshape(self.num_envs).contiguous()
+        self._set_active(active)
         self.backend.tumor_step(self.params, self.t, self.num_envs)
         return self.t["u"], self.t["reward"], self.t["terminated"], self.t["truncated"]

@@ -173,7 +173,8 @@ class FakeBackend:
                                    P.thr_t1 / P.k, P.thr_t2 / P.k, P.dose_end, P.D, P.rho, P.alpha, P.alpha_beta_ratio, P.k,
                                    P.detect_radius, P.death_radius)
 
-    def tumor_step(self, P, T, B):
+    def _tumor_day(self, P, T, B, part, control, use_kill):
+        """One oracle day for the instances in ``part`` (bool [B]); everything else is left untouched."""
         orc = self._orc_tumor(P)
         orc.thr1, orc.thr2 = P.thr_t1, P.thr_t2
         orc.reset(T["u"].numpy(), T["t_benchmark"].numpy())
@@ -183,19 +184,49 @@ class FakeBackend:
         d = T["days"].numpy().astype(np.int64)
         orc.growthDays, orc.therapyDays, orc.postDays, orc.simulationDays, orc.cDeathDay = (d[:, i].copy() for i in range(5))
         live = orc.time_index < orc.nt - 1
-        obs, r, te, tr = orc.step(T["control"].numpy())
-        T["u"].copy_(torch.from_numpy(obs))
-        T["time_index"].copy_(torch.from_numpy(orc.time_index.astype(np.int32)))
-        T["stage"].copy_(torch.from_numpy(orc.stage.astype(np.int32)))
-        T["remaining"].copy_(torch.from_numpy(orc.remaining))
-        T["days"].copy_(torch.from_numpy(np.stack([orc.growthDays, orc.therapyDays, orc.postDays, orc.simulationDays,
-                                                   orc.cDeathDay], axis=1).astype(np.int32)))
-        T["reward"].copy_(torch.from_numpy(r))
-        T["terminated"].copy_(torch.from_numpy(te.astype(np.uint8)))
-        T["truncated"].copy_(torch.from_numpy(tr.astype(np.uint8)))
+        obs, r, te, tr = orc.step(control)
         out = np.stack([orc.T1, orc.radius_abs(orc.u, orc.thr2), orc.treat_r, orc.applied], axis=1)
-        keep = torch.from_numpy(live)
-        T["out"][keep] = torch.from_numpy(out)[keep]
+        days = np.stack([orc.growthDays, orc.therapyDays, orc.postDays, orc.simulationDays, orc.cDeathDay], axis=1).astype(np.int32)
+        m = torch.from_numpy(part)
+        upd = torch.from_numpy(part & live)
+        T["u"][upd] = torch.from_numpy(obs)[upd]
+        T["time_index"][upd] = torch.from_numpy(orc.time_index.astype(np.int32))[upd]
+        T["stage"][upd] = torch.from_numpy(orc.stage.astype(np.int32))[upd]
+        T["remaining"][upd] = torch.from_numpy(orc.remaining)[upd]
+        T["days"][upd] = torch.from_numpy(days)[upd]
+        T["out"][upd] = torch.from_numpy(out)[upd]
+        if T.get("history") is not None:
+            for b_ in np.nonzero(part & live)[0]:
+                T["history"][b_, int(orc.time_index[b_])] = torch.from_numpy(obs[b_])
+                T["t1_log"][b_, int(orc.time_index[b_])] = float(orc.T1[b_] / self.core.dx)
+        return m, upd, r, te, tr
+
+    def tumor_step(self, P, T, B):
+        part = np.ones(B, bool) if T.get("active") is None else T["active"].numpy().astype(bool)
+        m, upd, r, te, tr = self._tumor_day(P, T, B, part, T["control"].numpy(), True)
+        T["reward"][m] = torch.from_numpy(r)[m]
+        T["terminated"][m] = torch.from_numpy(te.astype(np.uint8))[m]
+        T["truncated"][m] = torch.from_numpy(tr.astype(np.uint8))[m]
+
+    def tumor_advance(self, P, T, mode, max_days, B):
+        if mode == 0:
+            return self.tumor_step(P, T, B)
+        act = np.ones(B, bool) if T.get("active") is None else T["active"].numpy().astype(bool)
+        stage = T["stage"].numpy()
+        live = T["time_index"].numpy() < self.core.nt - 1
+        part = act & live & {1: stage == 0, 2: stage == 2, 3: np.ones(B, bool)}[mode]
+        zero = np.zeros(B)
+        for _ in range(max_days):
+            if not part.any():
+                break
+            m, upd, r, te, tr = self._tumor_day(P, T, B, part, zero, False)
+            T["reward"][m] = torch.from_numpy(r)[m]
+            T["terminated"][m] = torch.from_numpy(te.astype(np.uint8))[m]
+            T["truncated"][m] = torch.from_numpy(tr.astype(np.uint8))[m]
+            done = te | tr
+            part = part & ~done
+            if mode == 1:
+                part = part & (T["stage"].numpy() == 0)
 
     def tumor_reset(self, P, T, init, mask, B):
         m = torch.ones(B, dtype=torch.bool) if mask is None else mask.bool()

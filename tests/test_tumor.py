@@ -195,3 +195,77 @@ def test_tumor_batch_vs_oracle_gpu(B):
     d = eng.t["days"].cpu().numpy()
     np.testing.assert_array_equal(d, np.stack([orc.growthDays, orc.therapyDays, orc.postDays, orc.simulationDays,
                                                orc.cDeathDay], axis=1))
+
+
+# ---- batched TherapyWrapper semantics ----------------------------------------------------------------------------------
+def _vec_vs_singles(B, weekends, device, backend_factory, nsteps, rtol):
+    """TumorVecEnv == B independent TherapyWrapper(BrainTumor1D) episodes (incl. auto-reset) fed the same doses."""
+    import pde_control_gym
+    from pde_control_gym.src import BrainTumorReward, TherapyWrapper
+    kw = dict(T=600, reward_class=BrainTumorReward(), reset_init_condition_func=tumor_ic, **KW)
+    venv = pde_control_gym.make_vec("PDEControlGym-BrainTumor1D", num_envs=B, weekends=weekends, device=device,
+                                    backend=backend_factory(), **kw)
+    tb = venv.benchmark().cpu().numpy()
+    singles = []
+    for i in range(B):
+        w = TherapyWrapper(_env(device=device, backend=backend_factory()), weekends=weekends, verbose=False)
+        assert w.benchmark() == tb[i]
+        singles.append(w)
+    obs = venv.reset()
+    sob = np.stack([w.reset()[0] for w in singles])
+    np.testing.assert_array_equal(obs, sob)
+    rng = np.random.default_rng(5)
+    hi = np.linspace(0.03, 0.3, B)
+    n_done = 0
+    for k in range(nsteps):
+        a = rng.uniform(0, 1, B) * hi
+        obs, rew, done, infos = venv.step(a)
+        for i, w in enumerate(singles):
+            o, r, te, tr, info = w.step(float(a[i]))
+            assert bool(done[i]) == (te or tr), (k, i)
+            np.testing.assert_allclose(rew[i], r, rtol=rtol, atol=0, err_msg=f"step {k} env {i}")
+            if te or tr:
+                n_done += 1
+                np.testing.assert_allclose(infos[i]["terminal_observation"], o, rtol=rtol, atol=0)
+                o = w.reset()[0]
+            np.testing.assert_allclose(obs[i], o, rtol=rtol, atol=0, err_msg=f"obs step {k} env {i}")
+    assert n_done >= 1
+    calls = venv.treatment_calls.cpu().numpy()
+    np.testing.assert_array_equal(calls, [w.treatment_calls for w in singles])
+    np.testing.assert_array_equal(venv.soft_constraint_violations.cpu().numpy(), [w.soft_constraint_violations for w in singles])
+
+
+@pytest.mark.parametrize("weekends", [False, True])
+def test_tumor_vecenv_equals_single_wrappers_on_test_double(weekends):
+    _vec_vs_singles(3, weekends, "cpu", FakeBackend, 30, 1e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weekends", [False, True])
+def test_tumor_vecenv_equals_single_wrappers_gpu(weekends):
+    _vec_vs_singles(5, weekends, "cuda", lambda: None, 45, 1e-11)
+
+
+@pytest.mark.gpu
+def test_tumor_run_days_equals_daily_steps_gpu(golden_tumor):
+    """The in-kernel day loops (growth / post-therapy / open-loop benchmark) are bit-identical to daily step(0) calls:
+    wrapper flows with fused loops reproduce the reference's vectors, and env.u / the radius log are filled the same."""
+    from pde_control_gym.src import TherapyWrapper
+    g = golden_tumor["wrap_daily"]
+    a, b = _env(), _env()
+    wa, wb = TherapyWrapper(a, verbose=False, fused_loops=True), TherapyWrapper(b, verbose=False, fused_loops=False)
+    assert wa.benchmark() == wb.benchmark() == int(g.t_benchmark)
+    np.testing.assert_array_equal(wa.reset()[0], wb.reset()[0])
+    assert a.time_index == b.time_index and a.growthDays == b.growthDays and a.firstTherapyDay == b.firstTherapyDay
+    np.testing.assert_array_equal(a.u, b.u)
+    np.testing.assert_array_equal(a.t1_radius_idx_vs_time, b.t1_radius_idx_vs_time)
+    while True:
+        ra, rb = wa.step(float(g.frac)), wb.step(float(g.frac))
+        np.testing.assert_array_equal(ra[0], rb[0])
+        assert ra[1:4] == rb[1:4]
+        if ra[2] or ra[3]:
+            break
+    np.testing.assert_array_equal(a.u, b.u)
+    np.testing.assert_array_equal(a.t1_radius_idx_vs_time, b.t1_radius_idx_vs_time)
+    assert (a.growthDays, a.therapyDays, a.postTherapyDays, a.simulationDays, a.cDeathDay) == \
+           (b.growthDays, b.therapyDays, b.postTherapyDays, b.simulationDays, b.cDeathDay)
