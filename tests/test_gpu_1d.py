@@ -108,6 +108,49 @@ def test_hip_matches_oracle_random_batches(kind, nx, S, B, ctrl):
         np.testing.assert_allclose(r_gpu.cpu().numpy(), r_ref, rtol=1e-6, atol=2e-6 * float(np.max(orc.norm_now)))
 
 
+@pytest.mark.parametrize("kind,nx,S", [("parabolic", 256, 100), ("parabolic", 100, 40), ("transport", 128, 50), ("transport", 100, 30)])
+def test_denormal_and_compact_support_states_match_numpy_bitwise(kind, nx, S):
+    """float32 denormals are kept, not flushed: (a) a compactly supported initial condition whose diffusion front decays
+    through the denormal range to zero, (b) rows that live entirely in the denormal range, (c) zero actions / zero beta
+    entries.  NumPy on the CPU honours denormals; every row must still be bit-identical."""
+    from oracle import pde_oracle as po
+    rng = np.random.default_rng(nx + S)
+    dx = 1.0 / nx
+    dt = 0.25 * dx * dx if kind == "parabolic" else 0.5 * dx
+    nsteps, B = 4, 6
+    kw = dict(T=nsteps * S * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type="Dirchilet",
+              sensing_loc="full", sensing_type=None, normalize=False, max_control_value=20,
+              limit_pde_state_size=True, max_state_value=1e10)
+    n = nx + (1 if kind == "parabolic" else 0)
+    init = np.zeros((B, n), dtype=np.float32)
+    init[0, n // 2 - 2: n // 2 + 2] = 3.0                                   # compact support: the front underflows
+    init[1, : n // 3] = rng.uniform(1, 2, n // 3)
+    init[2] = (rng.uniform(-1, 1, n) * 1e-39).astype(np.float32)            # everything denormal
+    init[3] = (rng.uniform(0.5, 1, n) * 2.0 ** -120).astype(np.float32)     # just above the denormal range, decaying into it
+    init[4, ::7] = np.float32(1e-44)
+    init[5] = rng.uniform(1, 2, n)
+    assert (np.abs(init[2][init[2] != 0]) < 1.2e-38).all()
+    beta = np.zeros((B, n), dtype=np.float32)
+    beta[5] = rng.uniform(-1, 1, n)
+    beta[3] = -30.0 if kind == "parabolic" else 0.0
+    rargs = (int(round(kw["T"] / dt)), -1e3, 3e2)
+    cls = po.ParabolicOracle if kind == "parabolic" else po.TransportOracle
+    orc = cls(reward=po.TunedReward1DOracle(*rargs), keep_history=False, **_oracle_kwargs(kw))
+    env = _mk(kind, kw, rargs, B)
+    orc.reset(init, beta)
+    env.reset(torch.tensor(init), torch.tensor(beta))
+    saw_denormal = False
+    for i in range(nsteps):
+        a = np.array([0.0, 0.0, 1e-40, 0.0, 0.0, 0.3], dtype=np.float32)
+        with np.errstate(all="ignore"):
+            orc.step(a)
+        env.step(torch.tensor(a))
+        row = orc.row
+        saw_denormal |= bool(((np.abs(row) < 1.17e-38) & (row != 0)).any())
+        np.testing.assert_array_equal(env.u.cpu().numpy().view(np.uint32), row.view(np.uint32), err_msg=f"step {i}")
+    assert saw_denormal
+
+
 def test_history_recording_matches_oracle():
     from oracle import pde_oracle as po
     kw = dict(PARABOLIC_CASES["P2_s1"])
