@@ -75,6 +75,7 @@ class Parabolic1D:
     name = "ReactionDiffusionPDE1D nx=256 B=4096 S=100 (BASELINE configs[1])"
     kind, nx, B, S, amp, glo, ghi = "parabolic", 256, 4096, 100, 50.0, 7.5, 8.5
     dtype = "f32"
+    flux, max_control, ic_lo, ic_hi, act_lo = "linear", 20, 1.0, 10.0, -1.0
 
     def __init__(self, device, seed, B=None, S=None):
         import torch
@@ -86,27 +87,27 @@ class Parabolic1D:
         dx = 1.0 / nx
         dt = 0.25 * dx * dx if self.kind == "parabolic" else 0.5 * dx
         self.kw = dict(T=1000 * self.S * dt, dt=dt, X=1, dx=dx, control_sample_rate=self.S * dt, control_type="Dirchilet",
-                       sensing_loc="full", sensing_type=None, normalize=True, max_control_value=20,
+                       sensing_loc="full", sensing_type=None, normalize=True, max_control_value=self.max_control,
                        limit_pde_state_size=True, max_state_value=1e10)
         nt1 = int(round(self.kw["T"] / dt))
         self.reward_args = (nt1, -1e3, 3e2)
         self.env = PDEBatch1D(self.kind, reward=RewardSpec(N.REWARD_TUNED1D, *self.reward_args), num_envs=self.B,
-                              device=device, **self.kw)
+                              device=device, flux=self.flux, **self.kw)
         n = self.env.n
         g = torch.Generator(device="cpu").manual_seed(seed)
         x = torch.linspace(0, 1, n, dtype=torch.float64)
         gam = torch.rand(self.B, 1, generator=g, dtype=torch.float64) * (self.ghi - self.glo) + self.glo
         self.beta = (self.amp * torch.cos(gam * torch.acos(x))).float().to(device)
-        c = torch.rand(self.B, 1, generator=g) * 9 + 1
+        c = torch.rand(self.B, 1, generator=g) * (self.ic_hi - self.ic_lo) + self.ic_lo
         self.init = (c * torch.ones(1, n)).float().to(device)
-        c2 = torch.rand(self.B, 1, generator=g) * 9 + 1
+        c2 = torch.rand(self.B, 1, generator=g) * (self.ic_hi - self.ic_lo) + self.ic_lo
         self.pool = (c2 * torch.ones(1, n)).float().to(device)
         self.gen = g
         self.device = device
 
     def prepare(self, total_steps):
         import torch
-        self.actions = (torch.rand(total_steps, self.B, generator=self.gen) * 2 - 1).float().to(self.device)
+        self.actions = (torch.rand(total_steps, self.B, generator=self.gen) * (1 - self.act_lo) + self.act_lo).float().to(self.device)
         self.env.reset(self.init, self.beta)
         self.env.enable_auto_reset(self.pool, keep_final_obs=True)
         self.i = 0
@@ -126,7 +127,8 @@ class Parabolic1D:
         return self.env.compulsory_bytes_per_env_step() * self.B
 
     def config(self):
-        return {"workload": self.name, "env": "PDEControlGym-ReactionDiffusionPDE1D" if self.kind == "parabolic" else "PDEControlGym-TransportPDE1D",
+        return {"workload": self.name, "env": "PDEControlGym-ReactionDiffusionPDE1D" if self.kind == "parabolic" else
+                ("PDEControlGym-BurgersPDE1D (extension)" if self.flux == "burgers" else "PDEControlGym-TransportPDE1D"),
                 "nx": self.nx, "nodes": self.env.n, "batch_per_gpu": self.B, "substeps_per_env_step": self.S,
                 "reward": "TunedReward1D", "auto_reset": "fused", "parallelism": "independent instances, no collective"}
 
@@ -136,6 +138,13 @@ class Transport1D(Parabolic1D):
     Burgers env)."""
     name = "TransportPDE1D nx=512 B=16384 S=100 (BASELINE configs[2] shape)"
     kind, nx, B, S, amp, glo, ghi = "transport", 512, 16384, 100, 5.0, 7.0, 7.7
+
+
+class Burgers1D(Transport1D):
+    """EXTENSION (not in the reference, parity unpinned): BASELINE config 3 as worded -- nonlinear flux u u_x on the
+    transport kernel, nx=512, S=100, B=16384; amplitudes keep dt*max|u|/dx <= 1."""
+    name = "BurgersPDE1D (extension, not in the reference) nx=512 B=16384 S=100 (BASELINE configs[2] wording)"
+    flux, max_control, ic_lo, ic_hi, amp, act_lo = "burgers", 1.0, 0.1, 1.0, 0.0, 0.1     # u stays in (0, 1]: monotone upwind
 
 
 # ------------------------------------------------------------------------------------------------
@@ -162,19 +171,19 @@ def cpu_port_rate(workload_key, seconds, seed=0):
         reset = lambda: env.reset(ic, [363.0])
         done = lambda out: bool(out[2][0] or out[3][0])
         what = "float64, one simulated day each"
-    elif workload_key in ("parabolic_c2", "transport_c3"):
-        cls = Parabolic1D if workload_key == "parabolic_c2" else Transport1D
+    elif workload_key in ("parabolic_c2", "transport_c3", "burgers_c3"):
+        cls = {"parabolic_c2": Parabolic1D, "transport_c3": Transport1D, "burgers_c3": Burgers1D}[workload_key]
         nx, S = cls.nx, cls.S
         dx = 1.0 / nx
         dt = 0.25 * dx * dx if cls.kind == "parabolic" else 0.5 * dx
         okw = dict(T=1000 * S * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type="Dirchilet", sensing_loc="full",
-                   sensing_type=None, normalize=True, max_control_value=20, limit_pde_state_size=True, max_state_value=1e10)
-        ocl = po.ParabolicOracle if cls.kind == "parabolic" else po.TransportOracle
+                   sensing_type=None, normalize=True, max_control_value=cls.max_control, limit_pde_state_size=True, max_state_value=1e10)
+        ocl = po.ParabolicOracle if cls.kind == "parabolic" else (po.BurgersOracle if cls.flux == "burgers" else po.TransportOracle)
         env = ocl(reward=po.TunedReward1DOracle(int(round(okw["T"] / dt)), -1e3, 3e2), keep_history=False, **okw)
         n = nx + (cls.kind == "parabolic")
-        init = (rng.uniform(1, 10) * np.ones((1, n))).astype(np.float32)
+        init = (rng.uniform(cls.ic_lo, cls.ic_hi) * np.ones((1, n))).astype(np.float32)
         beta = (cls.amp * np.cos(rng.uniform(cls.glo, cls.ghi) * np.arccos(np.linspace(0, 1, n))))[None].astype(np.float32)
-        acts = rng.uniform(-1, 1, (256, 1)).astype(np.float32)
+        acts = rng.uniform(cls.act_lo, 1, (256, 1)).astype(np.float32)
         reset = lambda: env.reset(init, beta)
         done = lambda out: bool(out[2][0] or out[3][0])
         what = f"{S} sub-steps each"
@@ -229,7 +238,7 @@ def cpu_baseline_report(workload_key, seconds):
     return rep
 
 
-WORKLOADS = {"parabolic_c2": Parabolic1D, "transport_c3": Transport1D}
+WORKLOADS = {"parabolic_c2": Parabolic1D, "transport_c3": Transport1D, "burgers_c3": Burgers1D}
 class TrafficARZ:
     """TrafficPDE1D (reference notebook configuration T=240, dt=0.25, dx=10, X=500, M=51 nodes,
     float64), 'outlet' control, control_freq=2 sub-steps per env-step, B=16384 instances."""

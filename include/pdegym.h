@@ -36,13 +36,14 @@
 extern "C" {
 #endif
 
-#define PDEGYM_ABI_VERSION 6
+#define PDEGYM_ABI_VERSION 7
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
 #define PDEGYM_MAX_N1D 2048      /* nodes per 1D row handled by the wave-per-instance kernels */
 
 /* control_type (hyperbolic.py:66-124): the reference's (mis)spelling "Dirchilet" is kept in the Python layer */
 enum { PDEGYM_CONTROL_DIRICHLET = 0, PDEGYM_CONTROL_NEUMANN = 1 };
+enum { PDEGYM_FLUX_LINEAR = 0, PDEGYM_FLUX_BURGERS = 1 };   /* transport kernels only */
 /* sensing_update variants (hyperbolic.py:72-116, parabolic.py:72-116) */
 enum {
   PDEGYM_SENSE_FULL = 0,        /* obs = row                              obs_dim = n */
@@ -80,6 +81,9 @@ typedef struct pdegym_params1d {
   float terminate_reward;
   double rdx;               /* 1.0/(double)(float)dx: the transport quotient (u[j+1]-u[j])/dx is formed as
                                (float)((double)d * rdx), which equals the IEEE float32 division bit for bit */
+  int32_t flux;             /* PDEGYM_FLUX_LINEAR = the reference's transport term; PDEGYM_FLUX_BURGERS = extension,
+                               NOT in the reference (parity unpinned): n[j] = p[j] + dt*(p[j]*((p[j+1]-p[j])/dx) + (p[0]*beta)[j]) */
+  int32_t reserved_;        /* keeps sizeof a multiple of 8 */
 } pdegym_params1d;
 
 /* Per-instance device buffers of a 1D batch (B instances). */

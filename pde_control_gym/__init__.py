@@ -13,6 +13,8 @@ _IDS = {
     "PDEControlGym-BrainTumor1D": "pde_control_gym.src:BrainTumor1D",
     "PDEControlGym-TrafficPDE1D": "pde_control_gym.src:TrafficPDE1D",
     "PDEControlGym-NavierStokes2D": "pde_control_gym.src:NavierStokes2D",
+    # extension, not in the reference (parity unpinned): nonlinear sibling of TransportPDE1D
+    "PDEControlGym-BurgersPDE1D": "pde_control_gym.src.environments1d.burgers:BurgersPDE1D",
 }
 
 for _id, _entry in _IDS.items():

@@ -63,6 +63,7 @@ class PDEEnv1D(Env):
     neighbour value, as in the reference)."""
 
     _kind = None  # "transport" | "parabolic"
+    _flux = "linear"   # "burgers" only in the BurgersPDE1D extension
 
     def __init__(self, T: float, dt: float, X: float, dx: float, reward_class: BaseReward, normalize: bool = False):
         super().__init__()
@@ -91,7 +92,7 @@ class PDEEnv1D(Env):
                                 max_control_value=self.max_control_value,
                                 limit_pde_state_size=self.limit_pde_state_size, max_state_value=self.max_state_value,
                                 reward=spec, num_envs=1, device=device, backend=backend,
-                                record_history=record_history)
+                                record_history=record_history, flux=self._flux)
         self._terminated = False
         self._truncated = False
 

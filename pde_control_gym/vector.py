@@ -21,6 +21,7 @@ from pde_control_gym._compat import spaces
 
 _KINDS = {
     "PDEControlGym-TransportPDE1D": "transport", "transport": "transport", "TransportPDE1D": "transport",
+    "PDEControlGym-BurgersPDE1D": "burgers", "burgers": "burgers", "BurgersPDE1D": "burgers",
     "PDEControlGym-ReactionDiffusionPDE1D": "parabolic", "parabolic": "parabolic", "ReactionDiffusionPDE1D": "parabolic",
     "PDEControlGym-NavierStokes2D": "ns2d", "ns2d": "ns2d", "NavierStokes2D": "ns2d",
     "PDEControlGym-TrafficPDE1D": "traffic", "traffic": "traffic", "TrafficPDE1D": "traffic",
@@ -39,6 +40,9 @@ class PDEVecEnv:
         if env_id not in _KINDS:
             raise KeyError(f"No registered env with id: {env_id}")
         self.kind = _KINDS[env_id]
+        self._flux = "linear"
+        if self.kind == "burgers":              # extension (not in the reference): transport kernel with the u u_x flux
+            self.kind, self._flux = "transport", "burgers"
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
         self.batched_reset_func = batched_reset_func
@@ -71,7 +75,7 @@ class PDEVecEnv:
                                max_control_value=kw.get("max_control_value", 20),
                                limit_pde_state_size=kw.get("limit_pde_state_size", False),
                                max_state_value=kw.get("max_state_value", 1e10), reward=spec, num_envs=self.num_envs,
-                               device=self.device, backend=backend)
+                               device=self.device, backend=backend, flux=self._flux)
         self.nx, self.nt = self.core.nx, self.core.nt
         msv = kw.get("max_state_value", 1e10)
         d = self.core.obs_dim

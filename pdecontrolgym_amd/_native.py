@@ -11,12 +11,13 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 RING = 128
 LOOKBACK = 100
 MAX_N1D = 2048
 
 CONTROL = {"Dirchilet": 0, "Neumann": 1}
+FLUX_LINEAR, FLUX_BURGERS = 0, 1
 SENSE_FULL, SENSE_LAST, SENSE_LAST_DERIV, SENSE_FIRST_DERIV, SENSE_FIRST = range(5)
 REWARD_NONE, REWARD_TUNED1D, REWARD_NORM_L1, REWARD_NORM_L2, REWARD_NORM_LINF = range(5)
 BC = {"Neumann": 0, "Dirchilet": 1, "Controllable": 2}
@@ -36,7 +37,8 @@ class Params1D(C.Structure):
                 ("normalize", C.c_int32), ("sensing", C.c_int32), ("limit_state", C.c_int32),
                 ("reward_kind", C.c_int32), ("reward_nt", C.c_int32), ("dt", C.c_float), ("dx", C.c_float),
                 ("F", C.c_float), ("max_control", C.c_float), ("max_state", C.c_float),
-                ("truncate_penalty", C.c_float), ("terminate_reward", C.c_float), ("rdx", C.c_double)]
+                ("truncate_penalty", C.c_float), ("terminate_reward", C.c_float), ("rdx", C.c_double),
+                ("flux", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class Bufs1D(C.Structure):

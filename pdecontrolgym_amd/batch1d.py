@@ -62,10 +62,12 @@ class PDEBatch1D:
                  control_type: str = "Dirchilet", sensing_loc: str = "full", sensing_type="Dirchilet",
                  normalize: bool = False, max_control_value: float = 20, limit_pde_state_size: bool = False,
                  max_state_value: float = 1e10, reward: RewardSpec | None = None, num_envs: int = 1,
-                 device="cuda", backend=None, record_history: bool = False):
+                 device="cuda", backend=None, record_history: bool = False, flux: str = "linear"):
         import torch
         assert kind in ("transport", "parabolic")
-        self.kind = kind
+        if flux not in ("linear", "burgers") or (flux == "burgers" and kind != "transport"):
+            raise ValueError("flux must be 'linear' (the reference's transport term) or 'burgers' (extension, transport only)")
+        self.kind, self.flux = kind, flux
         self.T, self.dt, self.X, self.dx = T, dt, X, dx
         self.nt = int(round(T / dt) + 1)
         self.nx = int(round(X / dx))
@@ -98,6 +100,7 @@ class PDEBatch1D:
         P.rdx = 1.0 / float(C.c_float(dx).value)  # reciprocal of the float32 dx, in double (see pdegym.h)
         P.max_control = max_control_value
         P.max_state = min(max_state_value, 3.4028234663852886e38)
+        P.flux = N.FLUX_BURGERS if flux == "burgers" else N.FLUX_LINEAR
         P.truncate_penalty = self.reward_spec.truncate_penalty
         P.terminate_reward = self.reward_spec.terminate_reward
         self.params = P

@@ -102,7 +102,7 @@ struct Row {
 // S sub-steps of one instance.  FAST: boundary/padding slots are frozen by zero coefficients (no selects);
 // otherwise explicit selects (exact for non-finite states, and required when the boundary value changes every
 // sub-step, i.e. parabolic Neumann control).
-template <int EPL, bool PARABOLIC, bool NEUMANN, bool FAST, bool HIST>
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool FAST, bool HIST, bool BURGERS = false>
 __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EPL], const pdegym_params1d& P, int nsub,
                                              float a, float* ring, float* hist, int lane) {
   static_assert(!(FAST && (NEUMANN || HIST)), "fast mode is the Dirichlet, history-free path");
@@ -195,6 +195,10 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
 #pragma unroll
         for (int e = 0; e < EPL; ++e) d2[e] = (float)q[e];
       }
+      if constexpr (BURGERS) {   // extension: u_t = u u_x + beta(x) u(0,t)  ->  p*((pp - p)/dx) replaces (pp - p)/dx
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) d2[e] = R.x[e] * d2[e];
+      }
 #pragma unroll
       for (int e = 0; e < EPL; ++e) d3[e] = d2[e] + r[e];
 #pragma unroll
@@ -235,7 +239,7 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
           d2 = d1 / dx;
         }
         const float r = p0 * c[e];
-        const float d3 = d2 + r;
+        const float d3 = (BURGERS ? p * d2 : d2) + r;
         const float d4 = fe[e] * d3;
         v = p + d4;
         (void)pm;
@@ -329,7 +333,7 @@ __device__ __forceinline__ void load_row(Row<EPL>& R, float (&beta)[EPL], const 
   R.bl = PARABOLIC ? urow[0] : 0.f;
 }
 
-template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST>
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_params1d P, pdegym_bufs1d Bf, int B) {
   constexpr int J0 = PARABOLIC ? 1 : 0;
   constexpr bool kFast = !NEUMANN && !HIST;
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
 #endif
   float norm_now;
   if constexpr (kFast) {
-    run_substeps<EPL, PARABOLIC, false, true, false>(R, beta, P, nsub, a, ring, nullptr, lane);
+    run_substeps<EPL, PARABOLIC, false, true, false, BURGERS>(R, beta, P, nsub, a, ring, nullptr, lane);
     norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
     if (!(fabsf(norm_now) <= 3.4028234663852886e38f)) {
       // inf/NaN somewhere (or a squared overflow): 0*inf may have leaked into a frozen slot -> redo exactly
@@ -384,11 +388,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
       R.k = (t_in + PDEGYM_LOOKBACK) % S;
       R.bsum = bsum_in;
       R.back_norm = 0.f;
-      run_substeps<EPL, PARABOLIC, false, false, false>(R, beta, P, nsub, a, ring, nullptr, lane);
+      run_substeps<EPL, PARABOLIC, false, false, false, BURGERS>(R, beta, P, nsub, a, ring, nullptr, lane);
       norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
     }
   } else {
-    run_substeps<EPL, PARABOLIC, NEUMANN, false, HIST>(R, beta, P, nsub, a, ring, hist, lane);
+    run_substeps<EPL, PARABOLIC, NEUMANN, false, HIST, BURGERS>(R, beta, P, nsub, a, ring, hist, lane);
     norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
   }
   const int t = R.t;
@@ -605,23 +609,23 @@ __global__ void selftest_quotient_kernel(const float* a, float dx, double rdx, u
   }
 }
 
-template <int EPL, bool PARABOLIC>
+template <int EPL, bool PARABOLIC, bool BURGERS = false>
 int launch_epl(const pdegym_params1d& P, const pdegym_bufs1d& Bf, int B, hipStream_t st) {
   const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
   const bool neu = P.control_type == PDEGYM_CONTROL_NEUMANN, hist = Bf.history != nullptr;
   const int lds = balance_lds_bytes((int)grid.x);
   if (neu && hist)
-    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, true, true>), grid, block, lds, st, P, Bf, B);
+    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, true, true, BURGERS>), grid, block, lds, st, P, Bf, B);
   else if (neu)
-    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, true, false>), grid, block, lds, st, P, Bf, B);
+    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, true, false, BURGERS>), grid, block, lds, st, P, Bf, B);
   else if (hist)
-    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, false, true>), grid, block, lds, st, P, Bf, B);
+    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, false, true, BURGERS>), grid, block, lds, st, P, Bf, B);
   else
-    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, false, false>), grid, block, lds, st, P, Bf, B);
+    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, false, false, BURGERS>), grid, block, lds, st, P, Bf, B);
   return pdegym::check_launch("step1d");
 }
 
-template <bool PARABOLIC>
+template <bool PARABOLIC, bool BURGERS = false>
 int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, void* stream) {
   if (!prm || !buf) return pdegym::fail(-1, "null params/bufs");
   if (B <= 0) return 0;
@@ -636,17 +640,17 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
   const int nslots = P.n - (PARABOLIC ? 1 : 0);  // parabolic node 0 lives in a wave-uniform register
   const int epl = (nslots + kWave - 1) / kWave;
   switch (epl) {
-    case 1: return launch_epl<1, PARABOLIC>(P, *buf, B, st);
-    case 2: return launch_epl<2, PARABOLIC>(P, *buf, B, st);
-    case 3: return launch_epl<3, PARABOLIC>(P, *buf, B, st);
-    case 4: return launch_epl<4, PARABOLIC>(P, *buf, B, st);
-    case 5: return launch_epl<5, PARABOLIC>(P, *buf, B, st);
-    case 6: return launch_epl<6, PARABOLIC>(P, *buf, B, st);
-    case 7: case 8: return launch_epl<8, PARABOLIC>(P, *buf, B, st);
-    case 9: case 10: case 11: case 12: return launch_epl<12, PARABOLIC>(P, *buf, B, st);
-    case 13: case 14: case 15: case 16: return launch_epl<16, PARABOLIC>(P, *buf, B, st);
-    case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: return launch_epl<24, PARABOLIC>(P, *buf, B, st);
-    default: return launch_epl<32, PARABOLIC>(P, *buf, B, st);
+    case 1: return launch_epl<1, PARABOLIC, BURGERS>(P, *buf, B, st);
+    case 2: return launch_epl<2, PARABOLIC, BURGERS>(P, *buf, B, st);
+    case 3: return launch_epl<3, PARABOLIC, BURGERS>(P, *buf, B, st);
+    case 4: return launch_epl<4, PARABOLIC, BURGERS>(P, *buf, B, st);
+    case 5: return launch_epl<5, PARABOLIC, BURGERS>(P, *buf, B, st);
+    case 6: return launch_epl<6, PARABOLIC, BURGERS>(P, *buf, B, st);
+    case 7: case 8: return launch_epl<8, PARABOLIC, BURGERS>(P, *buf, B, st);
+    case 9: case 10: case 11: case 12: return launch_epl<12, PARABOLIC, BURGERS>(P, *buf, B, st);
+    case 13: case 14: case 15: case 16: return launch_epl<16, PARABOLIC, BURGERS>(P, *buf, B, st);
+    case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: return launch_epl<24, PARABOLIC, BURGERS>(P, *buf, B, st);
+    default: return launch_epl<32, PARABOLIC, BURGERS>(P, *buf, B, st);
   }
 }
 
@@ -655,7 +659,9 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
 extern "C" {
 
 int pdegym_transport_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int32_t B, void* stream) {
-  return launch_step<false>(prm, buf, B, stream);
+  // flux = PDEGYM_FLUX_BURGERS is an extension that the reference does not have
+  if (prm && prm->flux == PDEGYM_FLUX_BURGERS) return launch_step<false, true>(prm, buf, B, stream);
+  return launch_step<false, false>(prm, buf, B, stream);
 }
 
 int pdegym_parabolic_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int32_t B, void* stream) {

@@ -29,7 +29,7 @@ class FakeBackend:
             rw = po.NormRewardOracle(P.reward_nt, {2: "1", 3: "2", 4: "inf"}[P.reward_kind], P.truncate_penalty, P.terminate_reward)
         else:
             rw = None
-        cls = po.ParabolicOracle if c.kind == "parabolic" else po.TransportOracle
+        cls = po.ParabolicOracle if c.kind == "parabolic" else (po.BurgersOracle if getattr(c, "flux", "linear") == "burgers" else po.TransportOracle)
         return cls(c.T, c.dt, c.X, c.dx, c.control_sample_rate, control_type=c.control_type, sensing_loc=c.sensing_loc,
                    sensing_type=c.sensing_type, normalize=c.normalize, max_control_value=c.max_control_value,
                    limit_pde_state_size=c.limit_pde_state_size, max_state_value=c.max_state_value, reward=rw,

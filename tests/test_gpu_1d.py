@@ -151,6 +151,45 @@ def test_denormal_and_compact_support_states_match_numpy_bitwise(kind, nx, S):
     assert saw_denormal
 
 
+@pytest.mark.parametrize("nx,S,B,ctrl", [(512, 100, 16, "Dirchilet"), (100, 25, 7, "Neumann"), (65, 30, 5, "Dirchilet"), (1500, 30, 2, "Dirchilet")])
+def test_burgers_extension_matches_own_restatement(nx, S, B, ctrl):
+    """EXTENSION, parity unpinned (the reference has no Burgers environment): the u u_x flux mode of the transport kernel
+    against this repository's NumPy restatement, bit for bit; power-of-two and other dx, both control types, history."""
+    from oracle import pde_oracle as po
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
+    rng = np.random.default_rng(nx + S)
+    dx = 1.0 / nx
+    dt = 0.5 * dx
+    nsteps = 5
+    kw = dict(T=nsteps * S * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type=ctrl, sensing_loc="full",
+              sensing_type=None, normalize=False, max_control_value=20, limit_pde_state_size=True, max_state_value=1e10)
+    x = np.linspace(0, 1, nx)
+    init = (rng.uniform(0.2, 1.0, (B, 1)) * (1 + 0.3 * np.sin(2 * np.pi * x * rng.uniform(0.5, 3, (B, 1))))).astype(np.float32)
+    beta = (0.2 * (1 + np.cos(rng.uniform(2, 4, (B, 1)) * x))).astype(np.float32)          # non-negative: u stays positive
+    rargs = (int(round(kw["T"] / dt)), -1e3, 3e2)
+    orc = po.BurgersOracle(reward=po.TunedReward1DOracle(*rargs), keep_history=True, **_oracle_kwargs(kw))
+    env = PDEBatch1D("transport", reward=RewardSpec(N.REWARD_TUNED1D, *rargs), num_envs=B, device="cuda", record_history=(nx == 65),
+                     flux="burgers", **{k: kw[k] for k in kw})
+    lin = PDEBatch1D("transport", reward=RewardSpec(N.REWARD_TUNED1D, *rargs), num_envs=B, device="cuda", **{k: kw[k] for k in kw})
+    orc.reset(init, beta)
+    env.reset(torch.tensor(init), torch.tensor(beta))
+    lin.reset(torch.tensor(init), torch.tensor(beta))
+    for i in range(nsteps):
+        a = rng.uniform(0, 1, B).astype(np.float32)
+        with np.errstate(all="ignore"):
+            o_ref, r_ref, te_ref, tr_ref = orc.step(a)
+        o_gpu, r_gpu, te_gpu, tr_gpu = env.step(torch.tensor(a))
+        lin.step(torch.tensor(a))
+        np.testing.assert_array_equal(env.u.cpu().numpy().view(np.uint32), orc.row.view(np.uint32), err_msg=f"step {i}")
+        assert np.isfinite(orc.row).all()
+        np.testing.assert_allclose(r_gpu.cpu().numpy(), r_ref, rtol=1e-6, atol=2e-6 * float(np.max(orc.norm_now)))
+        np.testing.assert_array_equal(te_gpu.cpu().numpy().astype(bool), te_ref)
+    assert not torch.equal(env.u, lin.u)          # the flux really differs from the reference's linear transport
+    if nx == 65:
+        np.testing.assert_array_equal(env.t["history"].cpu().numpy(), orc.hist)
+
+
 def test_history_recording_matches_oracle():
     from oracle import pde_oracle as po
     kw = dict(PARABOLIC_CASES["P2_s1"])
