@@ -1,0 +1,35 @@
+"""Seeded differential fuzz of the 1D step kernels against the oracle (tools/fuzz_1d.py holds the generator; the long run
+is `python tools/fuzz_1d.py 600`).  Bit patterns of rows and observations (so -0.0 != +0.0), flags, time indices, rewards."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fuzz_1d_kernels_against_oracle(seed):
+    import fuzz_1d
+    rng = np.random.default_rng(seed)
+    done = 0
+    for k in range(400):
+        d = fuzz_1d.one_case(rng, k)
+        done += d is not None and not d.endswith(")")
+    assert done >= 100
+
+
+def test_negative_zero_boundary_command_is_kept():
+    """A commanded boundary value of exactly -0.0 survives all sub-steps (the fast loop's frozen slot would turn it into +0.0)."""
+    import torch
+    from pdecontrolgym_amd.batch1d import PDEBatch1D
+    for kind, n in (("transport", 64), ("parabolic", 65)):
+        dx = 1.0 / 64
+        dt = 0.25 * dx * dx if kind == "parabolic" else 0.5 * dx
+        env = PDEBatch1D(kind, 200 * dt, dt, 1, dx, 20 * dt, num_envs=3, device="cuda")
+        env.reset(torch.ones(3, n), torch.zeros(3, n))
+        env.step(torch.tensor([-0.0, 0.0, 0.5]))
+        last = env.u[:, -1].cpu().numpy().view(np.uint32)
+        assert last[0] == 0x80000000 and last[1] == 0 and env.u[2, -1].item() == 0.5
