@@ -33,3 +33,17 @@ def test_negative_zero_boundary_command_is_kept():
         env.step(torch.tensor([-0.0, 0.0, 0.5]))
         last = env.u[:, -1].cpu().numpy().view(np.uint32)
         assert last[0] == 0x80000000 and last[1] == 0 and env.u[2, -1].item() == 0.5
+
+
+@pytest.mark.parametrize("which,count", [("ns", 60), ("traffic", 60), ("tumor", 40)])
+def test_fuzz_other_kernels_against_oracle(which, count):
+    """tools/fuzz_more.py: NS2D float64 bit-exact for random grids / BC combinations / sweep counts (and float32 tiled ==
+    generic), traffic ARZ and brain-tumour (daily steps and the in-kernel growth run) for random parameter sets."""
+    import fuzz_more
+    fn = {"ns": fuzz_more.ns_case, "traffic": fuzz_more.traffic_case, "tumor": fuzz_more.tumor_case}[which]
+    rng = np.random.default_rng(17)
+    done = 0
+    for k in range(count):
+        d = fn(rng, k)
+        done += d is not None and not d.endswith(")")
+    assert done >= count // 2

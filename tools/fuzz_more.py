@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the NS2D (float64 bit-exact; float32 tiled == generic), traffic and brain-tumour kernels against the
+oracle (test infrastructure; run on a GPU box):   python tools/fuzz_more.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pde_oracle as po  # noqa: E402
+
+BCS = ["Neumann", "Dirchilet", "Controllable"]
+
+
+def bits_equal(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    ui = np.uint64 if a.dtype == np.float64 else np.uint32
+    fin = ~(np.isnan(a) & np.isnan(b))
+    return np.array_equal(a.view(ui)[fin], b.view(ui)[fin])
+
+
+def ns_case(rng, idx):
+    from pdecontrolgym_amd.batch2d import NSBatch2D
+    n = int(rng.choice([4, 5, 8, 16, 21, 32, 33, 40, 63, 64, 65, 70, 100, 128])) if rng.random() < 0.7 else int(rng.integers(4, 90))
+    K = int(rng.choice([0, 1, 2, 3, 7, 20, 50, 51]))
+    B = int(rng.choice([1, 2, 3, 5]))
+    adim = int(rng.choice([1, 1, n]))
+    bc = {e: [str(rng.choice(BCS)), str(rng.choice(BCS))] for e in ("upper", "lower", "left", "right")}
+    dx = 1.0 / (n - 1)
+    nu = float(rng.choice([0.1, 0.01, 1.0]))
+    dt = 0.2 * 0.5 * dx * dx / nu * float(rng.choice([1.0, 0.5]))
+    nt = int(rng.integers(3, 7))
+    inter = bool(rng.random() < 0.5)
+    xs = np.linspace(0, 1, n)
+    Xg, Yg = np.meshgrid(xs, xs)
+    style = rng.choice(["smooth", "const", "zero", "rand"])
+    def field():
+        if style == "smooth":
+            return np.stack([np.sin(2 * np.pi * Xg * rng.uniform(0.5, 2)) * np.cos(np.pi * Yg) * rng.uniform(0.5, 2) + rng.uniform(-1, 1) for _ in range(B)])
+        if style == "const":
+            return np.stack([np.full((n, n), rng.uniform(-5, 5)) for _ in range(B)])
+        if style == "zero":
+            return np.zeros((B, n, n))
+        return rng.uniform(-1, 1, (B, n, n))
+    u0, v0, p0 = field(), field(), field()
+    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=bc, U_ref=rng.uniform(-1, 1, (nt, n, n, 2)),
+              action_ref=rng.uniform(1, 3, nt), gamma=float(rng.choice([0.1, 0.0, 2.0])), maximum_pressure_iteration=K, viscosity=nu,
+              density=float(rng.choice([1.0, 2.0])))
+    desc = f"#{idx} ns n={n} K={K} B={B} adim={adim} nt={nt} inter={inter} ic={style} bc={bc}"
+    orc = po.NavierStokesOracle(**kw)
+    env = NSBatch2D(num_envs=B, device="cuda", dtype=torch.float64, interleaved_state=inter, action_dim=adim, **kw)
+    orc.reset(u0, v0, p0)
+    env.reset(u0, v0, p0)
+    for i in range(nt - 1):      # U_ref[t] is read after the increment: the reference cannot step further either
+        a = rng.uniform(2, 4, (B, adim)) * float(rng.choice([1.0, 0.0, -1.0]))
+        o_ref, r_ref, te_ref, _ = orc.step(a)
+        obs, r, te = env.step(a)
+        assert bits_equal(obs.cpu().numpy(), o_ref), desc + f" step {i}: obs"
+        assert bits_equal(env.p.cpu().numpy(), orc.p), desc + f" step {i}: p"
+        assert np.allclose(r.cpu().numpy(), r_ref, rtol=1e-12, atol=1e-300), desc + f" step {i}: reward {r.cpu().numpy()} {r_ref}"
+        assert np.array_equal(te.cpu().numpy().astype(bool), te_ref), desc + f" step {i}: terminate"
+    # float32: tiled kernel == generic kernel for the sizes the tiled path exists for
+    if n in (64, 128):
+        outs = []
+        for force in ("0", "1"):
+            os.environ["PDEGYM_NS_GENERIC"] = force
+            e32 = NSBatch2D(num_envs=B, device="cuda", dtype=torch.float32, interleaved_state=inter, action_dim=adim, **kw)
+            e32.reset(u0, v0, p0)
+            acts = np.random.default_rng(idx).uniform(2, 4, (2, B, adim))
+            res = []
+            for a in acts:
+                obs, r, te = e32.step(a)
+                res.append((obs.cpu().numpy().copy(), e32.p.cpu().numpy().copy()))
+            outs.append(res)
+        os.environ["PDEGYM_NS_GENERIC"] = "0"
+        for (o1, p1), (o2, p2) in zip(*outs):
+            assert bits_equal(o1, o2) and bits_equal(p1, p2), desc + " f32 tile != generic"
+    return desc
+
+
+def traffic_case(rng, idx):
+    from pdecontrolgym_amd.batch_traffic import TrafficBatch
+    sim = str(rng.choice(["inlet", "outlet", "both", "outlet-train"]))
+    cf = int(rng.choice([1, 2, 3, 5]))
+    B = int(rng.choice([1, 2, 7, 33, 64, 65]))
+    dxs = float(rng.choice([10, 20, 12.5, 8]))
+    X = float(rng.choice([500, 400, 250]))
+    dt = float(rng.choice([0.25, 0.1]))
+    limit = bool(rng.random() < 0.7)
+    T = float(rng.choice([240, 5, 2]))
+    M = len(np.arange(0, X + dxs, dxs))
+    if M > 64:
+        return None
+    desc = f"#{idx} traffic {sim} cf={cf} B={B} X={X} dx={dxs} dt={dt} T={T} limit={limit}"
+    orc = po.TrafficOracle(T, dt, X, dxs, sim, 40, 0.16, 60, limit, cf)
+    env = TrafficBatch(T, dt, X, dxs, sim, 40, 0.16, 60, limit, cf, num_envs=B, device="cuda")
+    rs = rng.choice([0.115, 0.12, 0.125, 0.1], B)
+    qclip = rng.choice([0.115, 0.12, 0.125], B)
+    qclip = qclip * (40 * (1 - qclip / 0.16))
+    env.set_action_bounds(qclip)
+    o_ref = orc.reset(rs, qclip)
+    o = env.reset(rs)
+    assert bits_equal(o.cpu().numpy(), o_ref), desc + " reset"
+    nact = 2 if sim == "both" else 1
+    for k in range(int(rng.integers(3, 30))):
+        a = rng.uniform(0.5, 1.5, (B, nact)) * orc.qs[:, None]
+        with np.errstate(all="ignore"):
+            o_ref, r_ref, d_ref, t_ref = orc.step(a)
+        o, r, d, t = env.step(a)
+        assert bits_equal(o.cpu().numpy(), o_ref), desc + f" step {k}: obs"
+        assert bits_equal(env.t["r"].cpu().numpy(), orc.r) and bits_equal(env.t["y"].cpu().numpy(), orc.y), desc + f" step {k}: fields"
+        assert np.allclose(r.cpu().numpy(), r_ref, rtol=1e-12, equal_nan=True), desc + f" step {k}: reward"
+        assert np.array_equal(d.cpu().numpy().astype(bool), d_ref) and np.array_equal(t.cpu().numpy().astype(bool), t_ref), desc + f" step {k}: flags"
+    return desc
+
+
+def tumor_case(rng, idx):
+    from pdecontrolgym_amd.batch_tumor import TumorBatch
+    from pdecontrolgym_amd import _native as N
+    X = int(rng.choice([200, 100, 64, 300]))
+    dx = float(rng.choice([1, 1, 0.5, 2]))
+    T = int(rng.choice([600, 300, 260, 100]))
+    B = int(rng.choice([1, 3, 4, 5, 9]))
+    tot = float(rng.choice([61.2, 30.0, 100.0]))
+    kwp = dict(t1_detection_threshold=float(rng.choice([0.8, 0.6])), t2_detection_threshold=float(rng.choice([0.16, 0.3])),
+               dosage_termination_threshold=float(rng.choice([0.1, 1.0])), D=float(rng.choice([0.2, 0.1, 0.05])), rho=float(rng.choice([0.03, 0.05])),
+               alpha=float(rng.choice([0.04, 0.1])), alpha_beta_ratio=float(rng.choice([10, 3])), k=float(rng.choice([1e5, 1.0, 3e4])),
+               t1_detection_radius=float(rng.choice([15, 10])), t1_death_radius=float(rng.choice([35, 25])))
+    if kwp["D"] * 1 / dx ** 2 > 0.45:
+        return None
+    desc = f"#{idx} tumor X={X} dx={dx} T={T} B={B} tot={tot} {kwp}"
+    orc = po.BrainTumorOracle(T, 1, X, dx, tot, **kwp)
+    eng = TumorBatch(T, 1, X, dx, tot, num_envs=B, **kwp)
+    xs = np.linspace(0, X, orc.nx)
+    init = (0.8 * kwp["k"] * np.exp(-0.25 * xs ** 2))[None] * rng.uniform(0.8, 1.0, (B, 1))
+    tb = np.where(rng.random(B) < 0.3, np.nan, rng.integers(100, 400, B).astype(np.float64))
+    eng.set_benchmark(tb)
+    eng.reset(init)
+    orc.reset(init, tb)
+    mode = rng.choice(["daily", "loops"])
+    hi = rng.uniform(0.02, 0.4, B)
+    if mode == "loops":          # growth in one launch, then daily therapy, then post in one launch
+        eng.advance(N.TUMOR_RUN_GROWTH)
+        for _ in range(T):
+            part = (orc.stage == po.GROWTH) & (orc.time_index < orc.nt - 1)
+            if not part.any():
+                break
+            keep = [np.copy(x) for x in (orc.u, orc.time_index, orc.stage, orc.remaining, orc.growthDays, orc.therapyDays, orc.postDays, orc.simulationDays, orc.cDeathDay)]
+            orc.step(np.zeros(B))
+            new = [orc.u, orc.time_index, orc.stage, orc.remaining, orc.growthDays, orc.therapyDays, orc.postDays, orc.simulationDays, orc.cDeathDay]
+            merged = [np.where(part.reshape((-1,) + (1,) * (k.ndim - 1)), n_, k) for k, n_ in zip(keep, new)]
+            (orc.u, orc.time_index, orc.stage, orc.remaining, orc.growthDays, orc.therapyDays, orc.postDays, orc.simulationDays, orc.cDeathDay) = merged
+        assert bits_equal(eng.t["u"].cpu().numpy(), orc.u), desc + " growth run: rows"
+        assert np.array_equal(eng.t["time_index"].cpu().numpy(), orc.time_index) and np.array_equal(eng.t["stage"].cpu().numpy(), orc.stage), desc + " growth run: state"
+    for n in range(int(rng.integers(5, 60))):
+        a = rng.uniform(0, 1, B) * hi
+        try:
+            o, ro, teo, tro = orc.step(a)
+        except ZeroDivisionError:      # treatment radius 0 (tumour invisible on T2): the reference's reward raises
+            return desc + " (reference raises)"
+        u, r, te, tr = eng.step(a)
+        assert np.allclose(u.cpu().numpy(), o, rtol=1e-12, atol=0), desc + f" day {n}: rows"
+        assert np.allclose(r.cpu().numpy(), ro, rtol=1e-11, atol=0, equal_nan=True), desc + f" day {n}: reward {r.cpu().numpy()} {ro}"
+        assert np.array_equal(te.cpu().numpy().astype(bool), teo) and np.array_equal(tr.cpu().numpy().astype(bool), tro), desc + f" day {n}: flags"
+        assert np.array_equal(eng.t["stage"].cpu().numpy(), orc.stage), desc + f" day {n}: stage"
+        d = eng.t["days"].cpu().numpy()
+        assert np.array_equal(d, np.stack([orc.growthDays, orc.therapyDays, orc.postDays, orc.simulationDays, orc.cDeathDay], axis=1)), desc + f" day {n}: days"
+        # keep both sides on identical rows (the in-kernel exp may differ from libm's in the last bit)
+        orc.u = u.cpu().numpy().copy()
+    return desc
+
+
+if __name__ == "__main__":
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    which = sys.argv[3].split(",") if len(sys.argv) > 3 else ["ns", "traffic", "tumor"]
+    fns = {"ns": ns_case, "traffic": traffic_case, "tumor": tumor_case}
+    rng = np.random.default_rng(seed)
+    t0, k = time.time(), 0
+    counts = {w: 0 for w in which}
+    while time.time() - t0 < seconds:
+        w = which[k % len(which)]
+        d = fns[w](rng, k)
+        counts[w] += d is not None
+        k += 1
+        if k % 30 == 0:
+            print(f"{k} cases ok {counts}  last: {d}"[:300], flush=True)
+    print(f"FUZZ OK: {counts}, seed {seed}")
