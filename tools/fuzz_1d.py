@@ -75,10 +75,12 @@ def one_case(rng, idx):
     beta = (amp * rng.uniform(0, 1) * np.cos(rng.uniform(1, 8.5, (1 if shared else B, 1)) * np.arccos(x))).astype(np.float32)
     rargs = (nt - 1, float(rng.choice([-1e3, -1e-4])), float(rng.choice([3e2, 1e2])))
     hist = bool(rng.random() < 0.25)
+    auto = bool(rng.random() < 0.35)          # fused VecEnv auto-reset from a pool of initial rows
     ocls = {"parabolic": po.ParabolicOracle, "transport": po.TransportOracle, "burgers": po.BurgersOracle}[kind]
     okw = {k: kw[k] for k in ("T", "dt", "X", "dx", "control_sample_rate", "control_type", "sensing_loc", "sensing_type", "normalize",
                               "max_control_value", "limit_pde_state_size", "max_state_value")}
-    desc = f"#{idx} {kind} nx={nx} S={S} nt={nt} B={B} {ctrl} {sloc}/{kw['sensing_type']} norm={normalize} limit={limit}/{max_state} ic={style} hist={hist} shared_beta={shared}"
+    pool = (rng.uniform(0.1, 3, (B, 1)) * np.ones((1, n))).astype(np.float32)
+    desc = f"#{idx} auto={auto} {kind} nx={nx} S={S} nt={nt} B={B} {ctrl} {sloc}/{kw['sensing_type']} norm={normalize} limit={limit}/{max_state} ic={style} hist={hist} shared_beta={shared}"
     try:
         orc = ocls(reward=po.TunedReward1DOracle(*rargs), keep_history=True, **okw)
     except Exception as ex:      # invalid option combination: the product must refuse it too
@@ -92,6 +94,10 @@ def one_case(rng, idx):
     o_ref = orc.reset(init, bfull)
     o_gpu = env.reset(torch.tensor(init), torch.tensor(beta[0] if shared else beta))
     assert np.array_equal(o_gpu.cpu().numpy().reshape(B, -1), np.asarray(o_ref, dtype=np.float32).reshape(B, -1)), desc + " reset obs"
+    if auto:
+        env.enable_auto_reset(torch.tensor(pool), keep_final_obs=True)
+        fresh = ocls(reward=po.TunedReward1DOracle(*rargs), keep_history=True, **okw)
+        fresh_obs = np.asarray(fresh.reset(pool, bfull), dtype=np.float32).reshape(B, -1)
     for i in range(nsteps + 1):
         a = rng.uniform(-1, 1, B).astype(np.float32) * float(rng.choice([1.0, 0.0, 10.0]))
         try:
@@ -100,6 +106,22 @@ def one_case(rng, idx):
         except IndexError:
             return desc + " (reference look-back raises: skipped)"
         o_gpu, r_gpu, te_gpu, tr_gpu = env.step(torch.tensor(a))
+        og = o_gpu.cpu().numpy().reshape(B, -1)
+        orf = np.asarray(o_ref, dtype=np.float32).reshape(B, -1)
+        if auto:
+            done = te_ref | tr_ref
+            if done.any():      # the kernel restarted these instances: terminal observation kept, new episode's first obs returned
+                fo = env.t["final_obs"].cpu().numpy().reshape(B, -1)
+                okf = ~(np.isnan(fo) & np.isnan(orf))
+                assert np.array_equal(fo[done].view(np.uint32)[okf[done]], orf[done].view(np.uint32)[okf[done]]), desc + f" step {i}: final_obs"
+                orc.row[done] = fresh.row[done]
+                orc.time_index[done] = 0
+                orc.bsum[done] = fresh.bsum[done]
+                orc.ring[done, 0] = po._rownorm(fresh.row[done])
+                orc.hist[done] = 0
+                orc.hist[done, 0] = fresh.row[done]
+                orf = orf.copy()
+                orf[done] = fresh_obs[done]
         row_g, row_o = env.u.cpu().numpy(), orc.row
         if not np.array_equal(row_g.view(np.uint32), row_o.view(np.uint32)):
             bad = np.argwhere(row_g.view(np.uint32) != row_o.view(np.uint32))
@@ -107,8 +129,6 @@ def one_case(rng, idx):
             fin = ~(np.isnan(row_g) & np.isnan(row_o))
             if (row_g.view(np.uint32)[fin] != row_o.view(np.uint32)[fin]).any():
                 raise AssertionError(desc + f" step {i}: rows differ at {bad[:4].tolist()} gpu {row_g[tuple(bad[0])]} ref {row_o[tuple(bad[0])]}")
-        og = o_gpu.cpu().numpy().reshape(B, -1)
-        orf = np.asarray(o_ref, dtype=np.float32).reshape(B, -1)
         fin = ~(np.isnan(og) & np.isnan(orf))
         assert np.array_equal(og.view(np.uint32)[fin], orf.view(np.uint32)[fin]), desc + f" step {i}: obs differ"
         assert np.array_equal(env.time_index.cpu().numpy(), orc.time_index), desc + f" step {i}: time index"
