@@ -44,8 +44,10 @@ __device__ __forceinline__ double clip0k(double x, double k) { return fmin(fmax(
 // LDS copies owned by the wave (no workgroup barrier: waves of a block run different numbers of days), the scalars of the
 // stage machine live in registers (all lanes carry the same values), global memory sees the row and the scalars once
 // at the end -- plus one history row per day if the caller asked for the trajectory.
+template <bool SINGLE_DAY>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void tumor_step_kernel(pdegym_params_tumor P, pdegym_bufs_tumor Bf, int mode,
-                                                                           int max_days, int B) {
+                                                                           int max_days_arg, int B) {
+  const int max_days = SINGLE_DAY ? 1 : max_days_arg;
   extern __shared__ double lds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int w = threadIdx.x >> 6;
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tumor_step_kernel(pdegy
       const int c = i == 0 ? 1 : (i == nx - 1 ? nx - 2 : i);           // :241-242 copy the neighbour's new value
       const bool rad = therapy && Bf.xscale[c] <= treat_r;             // outside: BED = 0 -> R = 1 - exp(-0) = 0
       const double v = clip0k(fd_node(P, cur[c - 1], cur[c], cur[c + 1], kill, rad), P.k);
-      nxt[i] = v;
+      if constexpr (SINGLE_DAY) g[i] = v;      // the only day of this launch: straight to global memory
+      else nxt[i] = v;
       if (hrow) hrow[i] = v;
       if (v >= P.thr_t1) t1_idx = i;
       if (v >= P.thr_t2) t2n_idx = i;
@@ -173,9 +176,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tumor_step_kernel(pdegy
     if (term || lethal) break;
     if (mode == PDEGYM_TUMOR_RUN_GROWTH && stage != PDEGYM_TUMOR_GROWTH) break;
   }
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  for (int i = lane; i < nx; i += kWave) g[i] = cur[i];
+  if constexpr (!SINGLE_DAY) {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int i = lane; i < nx; i += kWave) g[i] = cur[i];
+  }
   if (lane != 0) return;
   Bf.time_index[inst] = t;
   Bf.stage[inst] = stage;
@@ -239,7 +244,10 @@ static int tumor_launch(const pdegym_params_tumor* prm, const pdegym_bufs_tumor*
   const int wpb = prm->nx <= 1024 ? 4 : (prm->nx <= 2048 ? 2 : 1);
   const dim3 grid((B + wpb - 1) / wpb), block(kWave * wpb);
   const size_t lds = (size_t)2 * wpb * prm->nx * sizeof(double);
-  hipLaunchKernelGGL(tumor_step_kernel, grid, block, lds, (hipStream_t)stream, *prm, *buf, mode, max_days, B);
+  if (max_days == 1)
+    hipLaunchKernelGGL(tumor_step_kernel<true>, grid, block, lds, (hipStream_t)stream, *prm, *buf, mode, max_days, B);
+  else
+    hipLaunchKernelGGL(tumor_step_kernel<false>, grid, block, lds, (hipStream_t)stream, *prm, *buf, mode, max_days, B);
   return pdegym::check_launch("tumor_step");
 }
 

@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-for wl in parabolic_c2 transport_c3 ns2d_c4 traffic_arz brain_tumor; do
+for wl in parabolic_c2 transport_c3 burgers_c3 ns2d_c4 ns2d_c5 traffic_arz brain_tumor; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -o p -- python3 $R/bench.py --steps 200 --warmup 20 --no-also --no-cpu-baseline --workload $wl > $OUT/stats_$wl.json 2> $OUT/stats_$wl.err
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${wl}_$c -o p -- python3 $R/bench.py --steps 30 --warmup 5 --no-also --no-cpu-baseline --workload $wl > /dev/null 2>&1

@@ -17,7 +17,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-DOM = {"parabolic_c2": "step1d_kernel", "transport_c3": "step1d_kernel", "ns2d_c4": "ns_tile_step", "traffic_arz": "traffic_step_kernel",
+DOM = {"parabolic_c2": "step1d_kernel", "transport_c3": "step1d_kernel", "burgers_c3": "step1d_kernel", "ns2d_c4": "ns_tile_step",
+       "ns2d_c5": "ns_slab_jacobi", "traffic_arz": "traffic_step_kernel",
        "brain_tumor": "tumor_step_kernel"}
 summary = {"tag": tag, "units": "bytes per launch of the dominant kernel", "workloads": {}}
 
