@@ -28,27 +28,31 @@ def ns_case(rng, idx):
     B = int(rng.choice([1, 2, 3, 5]))
     adim = int(rng.choice([1, 1, n]))
     bc = {e: [str(rng.choice(BCS)), str(rng.choice(BCS))] for e in ("upper", "lower", "left", "right")}
+    # non-square grids and cells: nx = round(X/dx + 1) columns, ny = round(Y/dy + 1) rows (base_env_2d.py:27-36)
+    m = n if rng.random() < 0.5 else int(rng.choice([4, 5, 9, 16, 21, 33, 64, 65]))
     dx = 1.0 / (n - 1)
+    dy = (1.0 if rng.random() < 0.6 else 0.5) / (m - 1)
+    Yl = dy * (m - 1)
     nu = float(rng.choice([0.1, 0.01, 1.0]))
-    dt = 0.2 * 0.5 * dx * dx / nu * float(rng.choice([1.0, 0.5]))
+    dt = 0.2 * 0.5 * min(dx, dy) ** 2 / nu * float(rng.choice([1.0, 0.5]))
     nt = int(rng.integers(3, 7))
     inter = bool(rng.random() < 0.5)
-    xs = np.linspace(0, 1, n)
-    Xg, Yg = np.meshgrid(xs, xs)
+    adim = int(rng.choice([1, 1, max(n, m)])) if n == m else 1
+    Xg, Yg = np.meshgrid(np.linspace(0, 1, n), np.linspace(0, Yl, m))
     style = rng.choice(["smooth", "const", "zero", "rand"])
     def field():
         if style == "smooth":
             return np.stack([np.sin(2 * np.pi * Xg * rng.uniform(0.5, 2)) * np.cos(np.pi * Yg) * rng.uniform(0.5, 2) + rng.uniform(-1, 1) for _ in range(B)])
         if style == "const":
-            return np.stack([np.full((n, n), rng.uniform(-5, 5)) for _ in range(B)])
+            return np.stack([np.full((m, n), rng.uniform(-5, 5)) for _ in range(B)])
         if style == "zero":
-            return np.zeros((B, n, n))
-        return rng.uniform(-1, 1, (B, n, n))
+            return np.zeros((B, m, n))
+        return rng.uniform(-1, 1, (B, m, n))
     u0, v0, p0 = field(), field(), field()
-    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=bc, U_ref=rng.uniform(-1, 1, (nt, n, n, 2)),
+    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=Yl, dy=dy, boundary_condition=bc, U_ref=rng.uniform(-1, 1, (nt, m, n, 2)),
               action_ref=rng.uniform(1, 3, nt), gamma=float(rng.choice([0.1, 0.0, 2.0])), maximum_pressure_iteration=K, viscosity=nu,
               density=float(rng.choice([1.0, 2.0])))
-    desc = f"#{idx} ns n={n} K={K} B={B} adim={adim} nt={nt} inter={inter} ic={style} bc={bc}"
+    desc = f"#{idx} ns nx={n} ny={m} K={K} B={B} adim={adim} nt={nt} inter={inter} ic={style} bc={bc}"
     orc = po.NavierStokesOracle(**kw)
     env = NSBatch2D(num_envs=B, device="cuda", dtype=torch.float64, interleaved_state=inter, action_dim=adim, **kw)
     orc.reset(u0, v0, p0)
@@ -62,7 +66,7 @@ def ns_case(rng, idx):
         assert np.allclose(r.cpu().numpy(), r_ref, rtol=1e-12, atol=1e-300), desc + f" step {i}: reward {r.cpu().numpy()} {r_ref}"
         assert np.array_equal(te.cpu().numpy().astype(bool), te_ref), desc + f" step {i}: terminate"
     # float32: tiled kernel == generic kernel for the sizes the tiled path exists for
-    if n in (64, 128):
+    if n == m and n in (64, 128):
         outs = []
         for force in ("0", "1"):
             os.environ["PDEGYM_NS_GENERIC"] = force
