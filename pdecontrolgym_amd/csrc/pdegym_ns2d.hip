@@ -557,11 +557,32 @@ __device__ __forceinline__ void jacobi_sweep_rot(float (&ph)[PR + 1][PC], const 
     // ((W + S) + E) + N   (navier_stokes2D.py:106-108), stage-major over the PC independent cells of the row so that
     // consecutive instructions do not depend on each other; W / E of the edge columns ride in on the DPP adds
     float nv[PC];
+    if constexpr (PC == 4) {
+      // The two DPP adds ride at the END of four-instruction blocks: the three plain adds in front of them are the wait
+      // states the VALU-write -> DPP-read hazard asks for (no s_nop slots; the blocks' early-clobber outputs cannot alias
+      // the shifted operand).  Same operations in the same order as the generic form below.
+      const float x0 = ph[src][0], x1 = ph[src][1], x2 = ph[src][2], x3 = ph[src][3];
+      asm volatile(
+          "v_add_f32 %1, %5, %9\n\t"
+          "v_add_f32 %2, %6, %10\n\t"
+          "v_add_f32 %3, %7, %11\n\t"
+          "v_add_f32_dpp %0, %4, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+          : "=&v"(nv[0]), "=&v"(nv[1]), "=&v"(nv[2]), "=&v"(nv[3])
+          : "v"(x3), "v"(x0), "v"(x1), "v"(x2), "v"(ph[dst][0]), "v"(ph[dst][1]), "v"(ph[dst][2]), "v"(ph[dst][3]));
+      asm volatile(
+          "v_add_f32 %0, %0, %5\n\t"
+          "v_add_f32 %1, %1, %6\n\t"
+          "v_add_f32 %2, %2, %7\n\t"
+          "v_add_f32_dpp %3, %4, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+          : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3])
+          : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+    } else {
 #pragma unroll
-    for (int k = 0; k < PC; ++k)
-      nv[k] = (k == 0) ? add_lane_left(ph[src][PC - 1], ph[dst][k]) : (ph[src][k - 1] + ph[dst][k]);
+      for (int k = 0; k < PC; ++k)
+        nv[k] = (k == 0) ? add_lane_left(ph[src][PC - 1], ph[dst][k]) : (ph[src][k - 1] + ph[dst][k]);
 #pragma unroll
-    for (int k = 0; k < PC; ++k) nv[k] = (k == PC - 1) ? add_lane_right(ph[src][0], nv[k]) : (nv[k] + ph[src][k + 1]);
+      for (int k = 0; k < PC; ++k) nv[k] = (k == PC - 1) ? add_lane_right(ph[src][0], nv[k]) : (nv[k] + ph[src][k + 1]);
+    }
 #pragma unroll
     for (int k = 0; k < PC; ++k) nv[k] = nv[k] + ((a == PR - 1) ? hb[k] : ph[nxt][k]);
 #pragma unroll
