@@ -4,7 +4,7 @@ random grid sizes, sub-step counts, episode lengths (incl. nt <= 128 and episode
 modes, normalisation, truncation thresholds, shared or per-instance beta, zero / tiny / large states, history recording and
 the fused auto-reset.  Rows, observations and flags must agree bit for bit, rewards to rtol 1e-6.
 
-    python tools/fuzz_1d.py [seconds] [seed]
+    python tests/fuzz_1d.py [seconds] [seed]
 """
 import os
 import sys

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Differential fuzz of the NS2D (float64 bit-exact; float32 tiled == generic), traffic and brain-tumour kernels against the
-oracle (test infrastructure; run on a GPU box):   python tools/fuzz_more.py [seconds] [seed]"""
+oracle (test infrastructure; run on a GPU box):   python tests/fuzz_more.py [seconds] [seed]"""
 import os
 import sys
 import time

@@ -1,12 +1,12 @@
-"""Seeded differential fuzz of the 1D step kernels against the oracle (tools/fuzz_1d.py holds the generator; the long run
-is `python tools/fuzz_1d.py 600`).  Bit patterns of rows and observations (so -0.0 != +0.0), flags, time indices, rewards."""
+"""Seeded differential fuzz of the 1D step kernels against the oracle (tests/fuzz_1d.py holds the generator; the long run
+is `python tests/fuzz_1d.py 600`).  Bit patterns of rows and observations (so -0.0 != +0.0), flags, time indices, rewards."""
 import os
 import sys
 
 import numpy as np
 import pytest
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
@@ -37,7 +37,7 @@ def test_negative_zero_boundary_command_is_kept():
 
 @pytest.mark.parametrize("which,count", [("ns", 60), ("traffic", 60), ("tumor", 40)])
 def test_fuzz_other_kernels_against_oracle(which, count):
-    """tools/fuzz_more.py: NS2D float64 bit-exact for random grids / BC combinations / sweep counts (and float32 tiled ==
+    """tests/fuzz_more.py: NS2D float64 bit-exact for random grids / BC combinations / sweep counts (and float32 tiled ==
     generic), traffic ARZ and brain-tumour (daily steps and the in-kernel growth run) for random parameter sets."""
     import fuzz_more
     fn = {"ns": fuzz_more.ns_case, "traffic": fuzz_more.traffic_case, "tumor": fuzz_more.tumor_case}[which]
