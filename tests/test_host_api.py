@@ -306,6 +306,30 @@ def test_vecenv_sb3_semantics_autoreset_and_terminal_observation():
     assert not dones.any() and (env.core.time_index.numpy() == 30).all()
 
 
+def test_gymnasium_vector_face_reshapes_the_sb3_face():
+    import pde_control_gym
+    a, b = _vec(3), pde_control_gym.GymnasiumVectorAdapter(_vec(3))
+    o1 = a.reset()
+    o2, info = b.reset(seed=1)
+    assert info == {} and np.array_equal(o1, o2) and b.num_envs == 3 and b.single_action_space.shape == (1,)
+    rng = np.random.default_rng(2)
+    seen_done = False
+    for k in range(16):
+        act = rng.uniform(-1, 1, (3, 1)).astype(np.float32)
+        o1, r1, d1, i1 = a.step(act)
+        o2, r2, te, tr, i2 = b.step(act)
+        assert np.array_equal(r1, r2) and np.array_equal(d1, te | tr) and not (te & tr).any()
+        if d1.any():
+            seen_done = True
+            assert i2["_final_observation"].tolist() == d1.tolist()
+            for i in np.nonzero(d1)[0]:
+                np.testing.assert_array_equal(i2["final_observation"][i], i1[i]["terminal_observation"])
+                assert te[i] != bool(i1[i]["TimeLimit.truncated"])
+        else:
+            assert i2 == {}
+    assert seen_done
+
+
 def test_vecenv_fused_autoreset_tensor_path():
     import torch
     B = 3
