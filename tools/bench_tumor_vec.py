@@ -41,3 +41,21 @@ torch.cuda.synchronize()
 el = time.perf_counter() - t0
 print(f"B={B}: {steps} VecEnv steps in {el:.3f} s = {B * steps / el:.4g} treatment-steps/s; {int(episodes)} episodes finished "
       f"(each one = ~213 growth + therapy + ~190 post-therapy days simulated in-kernel)")
+
+# ---- the same loop with an MLP policy, captured once into a hipGraph and replayed (DeviceRollout)
+torch.manual_seed(0)
+pol = torch.nn.Sequential(torch.nn.Linear(venv.core.nx, 64), torch.nn.Tanh(), torch.nn.Linear(64, 1), torch.nn.Sigmoid()).double().cuda()
+policy = lambda o: pol(o / 1e5) * 0.06          # noqa: E731
+T = 50
+for use_graph in (False, True):
+    venv.reset_tensor()
+    ro = pde_control_gym.DeviceRollout(venv, policy, n_steps=T, use_graph=use_graph, action_low=0.0, action_high=1.0)
+    ro.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 4
+    for _ in range(reps):
+        ro.run()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(f"DeviceRollout graph={use_graph}: {B * T * reps / el:.4g} treatment-steps/s incl. the MLP policy ({el / (T * reps) * 1e6:.0f} us per VecEnv step)")
