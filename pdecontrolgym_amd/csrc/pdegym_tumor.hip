@@ -130,20 +130,33 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tumor_step_kernel(pdegy
     // ---- finite-difference update, Neumann ends, clip to [0, k]; T1/T2 radii of the new row
     int t1_idx = -1, t2n_idx = -1;
     double* hrow = hist ? hist + (size_t)t * nx : nullptr;
-    for (int i0 = 0; i0 < nx; i0 += kWave) {
-      const int i = i0 + lane;
-      const bool in = i < nx;
-      double v = -1.0;
-      if (in) {
-        const int c = i == 0 ? 1 : (i == nx - 1 ? nx - 2 : i);         // :241-242 copy the neighbour's new value
-        const bool rad = therapy && Bf.xscale[c] <= treat_r;           // outside: BED = 0 -> R = 1 - exp(-0) = 0
-        v = clip0k(fd_node(P, cur[c - 1], cur[c], cur[c + 1], kill, rad), P.k);
-        if constexpr (SINGLE_DAY) g[i] = v;    // the only day of this launch: straight to global memory
-        else nxt[i] = v;
-        if (hrow) hrow[i] = v;
+    // four chunks of 64 nodes per trip, fully unrolled: their LDS reads and f64 division chains are independent, so one
+    // wave overlaps them (a lone wave issues an instruction only every ~6.5 cycles; the day loop is latency-bound)
+    for (int ib = 0; ib < nx; ib += 4 * kWave) {
+      double vv[4];
+      bool inn[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = ib + q * kWave + lane;
+        inn[q] = i < nx;
+        vv[q] = -1.0;
+        if (inn[q]) {
+          const int c = i == 0 ? 1 : (i == nx - 1 ? nx - 2 : i);       // :241-242 copy the neighbour's new value
+          const bool rad = therapy && Bf.xscale[c] <= treat_r;         // outside: BED = 0 -> R = 1 - exp(-0) = 0
+          vv[q] = clip0k(fd_node(P, cur[c - 1], cur[c], cur[c + 1], kill, rad), P.k);
+        }
       }
-      t1_idx = rightmost(__ballot(in && v >= P.thr_t1), i0, t1_idx);
-      t2n_idx = rightmost(__ballot(in && v >= P.thr_t2), i0, t2n_idx);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i0 = ib + q * kWave, i = i0 + lane;
+        if (inn[q]) {
+          if constexpr (SINGLE_DAY) g[i] = vv[q];   // the only day of this launch: straight to global memory
+          else nxt[i] = vv[q];
+          if (hrow) hrow[i] = vv[q];
+        }
+        t1_idx = rightmost(__ballot(inn[q] && vv[q] >= P.thr_t1), i0, t1_idx);
+        t2n_idx = rightmost(__ballot(inn[q] && vv[q] >= P.thr_t2), i0, t2n_idx);
+      }
     }
     t2_idx = t2n_idx;
     {
