@@ -1160,7 +1160,7 @@ __global__ void ns_reset_kernel(NSConst C, NSPtrs<T> P, const T* u0, const T* v0
 template <typename T>
 int fill(const pdegym_params_ns2d* prm, NSConst& C, NSScal<T>& S) {
   if (!prm) return pdegym::fail(-1, "null params");
-  if (prm->nx < 4 || prm->ny < 4) return pdegym::fail(-2, "grid must be at least 4x4");
+  if (prm->nx < 3 || prm->ny < 3) return pdegym::fail(-2, "grid must be at least 3x3");
   if (prm->iters < 0) return pdegym::fail(-2, "iters must be >= 0");
   if (prm->action_dim != 1 && (prm->action_dim != prm->nx || prm->nx != prm->ny))
     return pdegym::fail(-2, "action_dim must be 1 or the edge length of a square grid");

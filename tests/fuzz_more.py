@@ -23,13 +23,13 @@ def bits_equal(a, b):
 
 def ns_case(rng, idx):
     from pdecontrolgym_amd.batch2d import NSBatch2D
-    n = int(rng.choice([4, 5, 8, 16, 21, 32, 33, 40, 63, 64, 65, 70, 100, 128])) if rng.random() < 0.7 else int(rng.integers(4, 90))
+    n = int(rng.choice([3, 4, 5, 8, 16, 21, 32, 33, 40, 63, 64, 65, 70, 100, 128])) if rng.random() < 0.7 else int(rng.integers(3, 90))
     K = int(rng.choice([0, 1, 2, 3, 7, 20, 50, 51]))
     B = int(rng.choice([1, 2, 3, 5]))
     adim = int(rng.choice([1, 1, n]))
     bc = {e: [str(rng.choice(BCS)), str(rng.choice(BCS))] for e in ("upper", "lower", "left", "right")}
     # non-square grids and cells: nx = round(X/dx + 1) columns, ny = round(Y/dy + 1) rows (base_env_2d.py:27-36)
-    m = n if rng.random() < 0.5 else int(rng.choice([4, 5, 9, 16, 21, 33, 64, 65]))
+    m = n if rng.random() < 0.5 else int(rng.choice([3, 4, 5, 9, 16, 21, 33, 64, 65]))
     dx = 1.0 / (n - 1)
     dy = (1.0 if rng.random() < 0.6 else 0.5) / (m - 1)
     Yl = dy * (m - 1)
