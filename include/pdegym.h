@@ -188,7 +188,7 @@ int pdegym_ns2d_reset_masked_f64(const pdegym_params_ns2d* prm, const pdegym_buf
  *   pdegym_traffic_reset_masked  replaces the state part of TrafficPDE1D.reset     traffic_arz_env.py:245-260
  * ------------------------------------------------------------------------------------------------ */
 enum { PDEGYM_TRAFFIC_INLET = 0, PDEGYM_TRAFFIC_OUTLET = 1, PDEGYM_TRAFFIC_BOTH = 2, PDEGYM_TRAFFIC_OUTLET_TRAIN = 3 };
-#define PDEGYM_TRAFFIC_MAX_M 64  /* nodes handled by the wave-per-instance kernel (the reference uses 51) */
+#define PDEGYM_TRAFFIC_MAX_M 1024  /* nodes per freeway (the reference notebook uses 51; up to 64 stay in registers) */
 
 typedef struct pdegym_params_traffic {
   int32_t M;               /* len(np.arange(0, X+dx, dx))                                   traffic_arz_env.py:77-79 */

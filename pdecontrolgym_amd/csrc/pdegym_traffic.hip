@@ -103,23 +103,139 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pde
   }
 }
 
+// ---- rows of more than 64 nodes (finer grids than the reference notebook's M = 51): one wave still owns one freeway,
+// node j lives in lane j % 64; the fields and the per-sub-step intermediates go through a wave-private LDS region so that
+// every node reaches its neighbours (wave-level ordering only: no workgroup barrier).  Same expressions, same order.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_wide_kernel(pdegym_params_traffic P, pdegym_bufs_traffic Bf, int B) {
+  extern __shared__ double tl[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int inst = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + w);
+  if (inst >= B) return;
+  const int M = P.M;
+  double* R = tl + (size_t)w * 7 * M;      // r, y, fr, fy | y_pm, Frp, Fyp
+  double* Y = R + M;
+  double* FR = Y + M;
+  double* FY = FR + M;
+  double* YPM = FY + M;
+  double* FRP = YPM + M;
+  double* FYP = FRP + M;
+  const double vm = P.vm, rm = P.rm, dt = P.dt, dx = P.dx;
+  for (int j = lane; j < M; j += kWave) {
+    R[j] = Bf.r[(size_t)inst * M + j];
+    Y[j] = Bf.y[(size_t)inst * M + j];
+  }
+  const double rs = Bf.rs[inst];
+  const double vs = Veq(vm, rm, rs);
+  const double qs = rs * vs;
+  const double qc = Bf.qs_clip[inst];
+  double a0 = Bf.action[(size_t)inst * 2], a1 = Bf.action[(size_t)inst * 2 + 1];
+  const double lo = qc * 0.8, hi = 1.2 * qc;
+  a0 = fmin(fmax(a0, lo), hi);
+  a1 = fmin(fmax(a1, lo), hi);
+  double q_in, q_out;
+  if (P.sim == PDEGYM_TRAFFIC_BOTH) { q_in = a0; q_out = a1; }
+  else if (P.sim == PDEGYM_TRAFFIC_INLET) { q_in = a0; q_out = qs; }
+  else { q_in = qs; q_out = a0; }
+  double time = Bf.time[inst] + dt;
+  const double c1 = dt / (2 * dx), c2 = 0.25 * dt / P.tau, c3 = dt / dx, c4 = 0.5 * dt / P.tau;
+  wave_lds_sync();
+  if (time < P.T) {
+    for (int s = 0; s < P.control_freq; ++s) {
+      // boundary conditions :174-190 (read the neighbours first, then overwrite the two end nodes)
+      const double r1 = R[1], rm2 = R[M - 2];
+      wave_lds_sync();
+      if (lane == 0) {
+        R[0] = r1;
+        Y[0] = q_in - r1 * Veq(vm, rm, r1);
+        R[M - 1] = rm2;
+        Y[M - 1] = q_out - rm2 * Veq(vm, rm, rm2);
+      }
+      wave_lds_sync();
+      for (int j = lane; j < M; j += kWave) {      // nodal fluxes :201-204
+        const double r = R[j], y = Y[j];
+        FR[j] = F_r(vm, rm, r, y);
+        FY[j] = F_y(vm, rm, r, y);
+      }
+      wave_lds_sync();
+      for (int j = lane; j < M - 1; j += kWave) {  // "plus" midpoint of node j and its fluxes :205-216
+        const double r = R[j], y = Y[j], r_p = R[j + 1], y_p = Y[j + 1];
+        const double r_pm = 0.5 * (r_p + r) - c1 * (FR[j + 1] - FR[j]);
+        const double y_pm = (0.5 * (y_p + y) - c1 * (FY[j + 1] - FY[j])) - c2 * (y_p + y);
+        YPM[j] = y_pm;
+        FRP[j] = F_r(vm, rm, r_pm, y_pm);
+        FYP[j] = F_y(vm, rm, r_pm, y_pm);
+      }
+      wave_lds_sync();
+      for (int j = lane; j < M; j += kWave) {      // inner update :219-223 ("minus" midpoint of j = "plus" of j-1)
+        if (j >= 1 && j <= M - 2) {
+          const double r = R[j], y = Y[j];
+          R[j] = r - c3 * (FRP[j] - FRP[j - 1]);
+          Y[j] = y - (c3 * (FYP[j] - FYP[j - 1]) + c4 * (YPM[j] + YPM[j - 1]));
+        }
+      }
+      wave_lds_sync();
+    }
+  }
+  double sv = 0.0, sr = 0.0;
+  bool over = false, moved = false;
+  double* o = Bf.obs + (size_t)inst * 2 * M;
+  for (int j = lane; j < M; j += kWave) {
+    const double r = R[j], y = Y[j];
+    const double v = y / r + Veq(vm, rm, r);       // :227
+    const double dv = v - vs, dr = r - rs;
+    sv += dv * dv;
+    sr += dr * dr;
+    over = over || v > vm || r > rm;
+    moved = moved || dr != 0.0 || dv != 0.0;
+    Bf.r[(size_t)inst * M + j] = r;
+    Bf.y[(size_t)inst * M + j] = y;
+    if (P.sim == PDEGYM_TRAFFIC_OUTLET_TRAIN) {
+      o[j] = (r - rs) / rs;
+      o[M + j] = (v - vs) / vs;
+    } else {
+      o[j] = r;
+      o[M + j] = v;
+    }
+  }
+  const double nv = sqrt(wave_sum_d(sv)), nr = sqrt(wave_sum_d(sr));
+  const double reward = -(nv / vs + nr / rs);
+  const bool term = time >= P.T / dt;
+  if (term) time = 0.0;
+  bool trunc = false;
+  if (P.limit) trunc = __any(over);
+  trunc = trunc || !__any(moved);
+  const bool done = (P.sim == PDEGYM_TRAFFIC_OUTLET_TRAIN) ? term : (term || reward > -0.00023);
+  if (lane == 0) {
+    Bf.time[inst] = time;
+    Bf.reward[inst] = reward;
+    Bf.done[inst] = done ? 1 : 0;
+    Bf.truncated[inst] = trunc ? 1 : 0;
+  }
+}
+
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_reset_kernel(pdegym_params_traffic P, pdegym_bufs_traffic Bf,
                                                                                const double* profile, const uint8_t* mask, int B) {
   const int lane = threadIdx.x & (kWave - 1);
   const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (inst >= B || (mask && !mask[inst])) return;
   const int M = P.M;
-  if (lane < M) {
+  for (int j = lane; j < M; j += kWave) {
     const double rs = Bf.rs[inst];
     const double vs = Veq(P.vm, P.rm, rs), qs = rs * vs;
     // :256-258   r = rs*(sin(3x/L pi)*0.1 + 1) ; y = qs - vm r + vm/rm r^2 ; v = y/r + Veq(r)
-    const double r = rs * profile[lane];
+    const double r = rs * profile[j];
     const double y = (qs * 1.0 - P.vm * r) + (P.vm / P.rm) * (r * r);
     const double v = y / r + Veq(P.vm, P.rm, r);
-    Bf.r[(size_t)inst * M + lane] = r;
-    Bf.y[(size_t)inst * M + lane] = y;
-    Bf.obs[(size_t)inst * 2 * M + lane] = r;
-    Bf.obs[(size_t)inst * 2 * M + M + lane] = v;
+    Bf.r[(size_t)inst * M + j] = r;
+    Bf.y[(size_t)inst * M + j] = y;
+    Bf.obs[(size_t)inst * 2 * M + j] = r;
+    Bf.obs[(size_t)inst * 2 * M + M + j] = v;
   }
   if (lane == 0) {
     Bf.time[inst] = 0.0;
@@ -130,7 +246,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_reset_kernel(pd
 
 int check(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf) {
   if (!prm || !buf) return pdegym::fail(-1, "null params/bufs");
-  if (prm->M < 4 || prm->M > PDEGYM_TRAFFIC_MAX_M) return pdegym::fail(-2, "M must be in [4, 64] for the wave-per-instance traffic kernel");
+  if (prm->M < 4 || prm->M > PDEGYM_TRAFFIC_MAX_M) return pdegym::fail(-2, "traffic: M must be in [4, 1024]");
   if (prm->control_freq < 1) return pdegym::fail(-2, "control_freq must be >= 1");
   if (prm->sim < 0 || prm->sim > 3) return pdegym::fail(-2, "bad simulation type");
   if (!buf->r || !buf->y || !buf->time || !buf->rs || !buf->qs_clip || !buf->obs || !buf->done || !buf->truncated)
@@ -146,8 +262,15 @@ int pdegym_traffic_step(const pdegym_params_traffic* prm, const pdegym_bufs_traf
   if (int rc = check(prm, buf)) return rc;
   if (!buf->action || !buf->reward) return pdegym::fail(-3, "null device buffer");
   if (B <= 0) return 0;
-  const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-  hipLaunchKernelGGL(traffic_step_kernel, grid, block, 0, (hipStream_t)stream, *prm, *buf, B);
+  if (prm->M <= kWave) {       // the reference's grid (M = 51): one node per lane, fields in registers
+    const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+    hipLaunchKernelGGL(traffic_step_kernel, grid, block, 0, (hipStream_t)stream, *prm, *buf, B);
+  } else {                     // finer grids: wave-private LDS rows, at most 56 KB per workgroup
+    const int wpb = prm->M <= 256 ? 4 : (prm->M <= 512 ? 2 : 1);
+    const dim3 grid((B + wpb - 1) / wpb), block(kWave * wpb);
+    hipLaunchKernelGGL(traffic_step_wide_kernel, grid, block, (size_t)wpb * 7 * prm->M * sizeof(double), (hipStream_t)stream,
+                       *prm, *buf, B);
+  }
   return pdegym::check_launch("traffic_step");
 }
 

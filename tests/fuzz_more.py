@@ -89,13 +89,13 @@ def traffic_case(rng, idx):
     sim = str(rng.choice(["inlet", "outlet", "both", "outlet-train"]))
     cf = int(rng.choice([1, 2, 3, 5]))
     B = int(rng.choice([1, 2, 7, 33, 64, 65]))
-    dxs = float(rng.choice([10, 20, 12.5, 8]))
+    dxs = float(rng.choice([10, 20, 12.5, 8, 5, 4, 2, 1, 0.5]))
     X = float(rng.choice([500, 400, 250]))
-    dt = float(rng.choice([0.25, 0.1]))
+    dt = float(rng.choice([0.25, 0.1])) if dxs >= 8 else float(rng.choice([0.02, 0.01])) * dxs
     limit = bool(rng.random() < 0.7)
     T = float(rng.choice([240, 5, 2]))
     M = len(np.arange(0, X + dxs, dxs))
-    if M > 64:
+    if M > 1024:
         return None
     desc = f"#{idx} traffic {sim} cf={cf} B={B} X={X} dx={dxs} dt={dt} T={T} limit={limit}"
     orc = po.TrafficOracle(T, dt, X, dxs, sim, 40, 0.16, 60, limit, cf)
