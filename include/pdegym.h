@@ -39,7 +39,8 @@ extern "C" {
 #define PDEGYM_ABI_VERSION 7
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
-#define PDEGYM_MAX_N1D 2048      /* nodes per 1D row handled by the wave-per-instance kernels */
+#define PDEGYM_MAX_N1D 2048      /* nodes per 1D row kept in registers by the wave-per-instance kernels */
+#define PDEGYM_MAX_N1D_WIDE 8192 /* longer rows (up to this) ping-pong through wave-private LDS */
 
 /* control_type (hyperbolic.py:66-124): the reference's (mis)spelling "Dirchilet" is kept in the Python layer */
 enum { PDEGYM_CONTROL_DIRICHLET = 0, PDEGYM_CONTROL_NEUMANN = 1 };

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 ABI_VERSION = 7
 RING = 128
 LOOKBACK = 100
-MAX_N1D = 2048
+MAX_N1D = 8192
 
 CONTROL = {"Dirchilet": 0, "Neumann": 1}
 FLUX_LINEAR, FLUX_BURGERS = 0, 1

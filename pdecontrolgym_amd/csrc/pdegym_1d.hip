@@ -524,6 +524,187 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
 #endif
 }
 
+
+// ================================================================================================
+// Rows of more than 2048 nodes: the register-resident layout would not fit, so the row ping-pongs between two LDS copies
+// owned by the wave (node j lives in lane j % 64; wave-level ordering only, no workgroup barrier).  This is the plain
+// select form of the reference arithmetic -- same expressions and order as run_substeps<..., FAST = false> -- with the
+// same bookkeeping (reward ring, look-back, history, sensing, fused auto-reset).  n <= PDEGYM_MAX_N1D_WIDE.
+// ================================================================================================
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <bool PARABOLIC, bool BURGERS>
+__global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, pdegym_bufs1d Bf, int B) {
+  extern __shared__ float wl[];
+  constexpr int J0 = PARABOLIC ? 1 : 0;
+  const int lane = threadIdx.x;
+  const int inst = blockIdx.x;
+  if (inst >= B) return;
+  const int n = P.n;
+  float* cur = wl;
+  float* nxt = wl + n;
+  float* urow = Bf.u + (size_t)inst * n;
+  const float* brow = Bf.beta + (size_t)inst * Bf.beta_stride;
+  float* ring = Bf.ring + (size_t)inst * PDEGYM_RING;
+  float* hist = Bf.history ? Bf.history + (size_t)inst * P.nt * n : nullptr;
+  const bool neumann = P.control_type == PDEGYM_CONTROL_NEUMANN;
+  for (int j = lane; j < n; j += kWave) cur[j] = urow[j];
+  const int t_in = Bf.time_index[inst];
+  const int S = P.substeps > 0 ? P.substeps : 1;
+  int nsub = P.nt - 1 - t_in;
+  nsub = nsub < P.substeps ? nsub : P.substeps;
+  nsub = nsub > 0 ? nsub : 0;
+  const float a = Bf.action[inst];
+  int t = t_in, k = (t_in + PDEGYM_LOOKBACK) % S;
+  double bsum = Bf.bsum[inst];
+  const int t_end = t_in + nsub;
+  const int tb = t_end - PDEGYM_LOOKBACK;
+  const int src_row = tb < 0 ? P.nt + tb : tb;
+  const bool zero_row = (tb < 0 && src_row > t_end) || src_row < 0;
+  const bool from_ring = !zero_row && src_row <= t_in;
+  const float norm_back_pre = from_ring ? ring[src_row & (PDEGYM_RING - 1)] : 0.f;
+  const int back_row = (!zero_row && !from_ring) ? src_row : -1;
+  float back_norm = 0.f;
+  const bool rec_all = P.nt <= PDEGYM_RING;
+  const float dx = P.dx, dt = P.dt, F = P.F;
+  const float cdx = a * dx;
+  float bval = neumann ? normalize_ctrl(cdx + 0.0f, P.max_control, P.normalize) : normalize_ctrl(a, P.max_control, P.normalize);
+  auto row_norm = [&](const float* row) {
+    float ss = 0.f;
+    for (int j = lane; j < n; j += kWave) ss += row[j] * row[j];
+    return sqrtf(wave_sum(ss));
+  };
+  wave_lds_sync();
+  for (int s = 0; s < nsub; ++s) {
+    if (PARABOLIC && neumann) bval = normalize_ctrl(cdx + cur[n - 2], P.max_control, P.normalize);   // parabolic.py:148-150
+    const float p0 = cur[0];
+    for (int j = lane; j < n; j += kWave) {
+      const float p = cur[j];
+      float v;
+      if (j == n - 1) {
+        v = bval;                                                       // controlled boundary node
+      } else if (PARABOLIC && j == 0) {
+        v = 0.0f;                                                       // parabolic.py:146
+      } else if constexpr (PARABOLIC) {
+        const float pm = cur[j - 1], pp = cur[j + 1];
+        const float t1 = 2.0f * p;                                      // parabolic.py:143-144
+        const float t2 = pm - t1;
+        const float t3 = t2 + pp;
+        const float t4 = F * t3;
+        const float t5 = p + t4;
+        const float t7 = (dt * brow[j]) * p;
+        v = t5 + t7;
+      } else {
+        const float pp = cur[j + 1];
+        const float d1 = pp - p;                                        // hyperbolic.py:146-155
+        const float d2 = d1 / dx;
+        const float r = p0 * brow[j];
+        const float d3 = (BURGERS ? p * d2 : d2) + r;
+        const float d4 = dt * d3;
+        v = p + d4;
+      }
+      nxt[j] = v;
+    }
+    {
+      float* sw = cur;
+      cur = nxt;
+      nxt = sw;
+    }
+    ++t;
+    k = (k + 1 == S) ? 0 : k + 1;
+    if (neumann) bsum += (double)fabsf(bval);
+    wave_lds_sync();
+    if (hist) {
+      float* hrow = hist + (size_t)t * n;
+      for (int j = lane; j < n; j += kWave) hrow[j] = cur[j];
+    }
+    if (s + 1 < nsub && (rec_all || k == 0 || t + PDEGYM_LOOKBACK == P.nt - 1)) {   // tuned_reward_1d.py:40 look-back rows
+      const float nr = row_norm(cur);
+      if (lane == 0) ring[t & (PDEGYM_RING - 1)] = nr;
+      if (t == back_row) back_norm = nr;
+    }
+  }
+  if (!neumann) bsum += (double)nsub * (double)fabsf(bval);
+  const float norm_now = row_norm(cur);
+  if (nsub > 0 && (rec_all || k == 0 || t + PDEGYM_LOOKBACK == P.nt - 1)) {
+    if (lane == 0) ring[t & (PDEGYM_RING - 1)] = norm_now;
+  }
+  const bool terminate = t >= P.nt - 1;
+  const bool truncate = P.limit_state && (norm_now >= P.max_state);
+  float nr_alt = norm_now;
+  if (P.reward_kind == PDEGYM_REWARD_NORM_L1) {
+    float s1 = 0.f;
+    for (int j = lane; j < n; j += kWave) s1 += fabsf(cur[j]);
+    nr_alt = wave_sum(s1);
+  } else if (P.reward_kind == PDEGYM_REWARD_NORM_LINF) {
+    float m = 0.f;
+    for (int j = lane; j < n; j += kWave) m = fmaxf(m, fabsf(cur[j]));
+    nr_alt = wave_max(m);
+  }
+  const float norm_back = from_ring ? norm_back_pre : ((back_row >= 0) ? ((back_row == t) ? norm_now : back_norm) : 0.f);
+  float reward = 0.f;
+  if (P.reward_kind == PDEGYM_REWARD_TUNED1D) {
+    if (terminate && norm_now < 20.0f) reward = (P.terminate_reward - ((float)bsum) / 1000.0f) - norm_now;
+    else if (truncate) reward = (float)((double)P.truncate_penalty * (double)(P.reward_nt - t));
+    else reward = norm_back - norm_now;
+  } else if (P.reward_kind >= PDEGYM_REWARD_NORM_L1) {
+    reward = terminate ? P.terminate_reward : (truncate ? (float)((double)P.truncate_penalty * (double)(P.reward_nt - t)) : -nr_alt);
+  }
+  const bool auto_reset = (Bf.reset_init != nullptr) && (terminate || truncate);
+  auto emit_obs = [&](float* obs_base, const float* row) {
+    if (P.sensing == PDEGYM_SENSE_FULL) {
+      float* orow = obs_base + (size_t)inst * n;
+      for (int j = lane; j < n; j += kWave) orow[j] = row[j];
+    } else if (lane == 0) {
+      float o;
+      if (P.sensing == PDEGYM_SENSE_LAST) o = row[n - 1];
+      else if (P.sensing == PDEGYM_SENSE_LAST_DERIV) o = (row[n - 1] - row[n - 2]) / P.dx;
+      else if (P.sensing == PDEGYM_SENSE_FIRST_DERIV) o = (row[1] - row[0]) / P.dx;
+      else o = row[0];
+      obs_base[inst] = o;
+    }
+  };
+  if (lane == 0) {
+    if (P.reward_kind != PDEGYM_REWARD_NONE) Bf.reward[inst] = reward;
+    Bf.norm_now[inst] = norm_now;
+    Bf.norm_back[inst] = norm_back;
+    Bf.terminated[inst] = terminate ? 1 : 0;
+    Bf.truncated[inst] = truncate ? 1 : 0;
+  }
+  if (!auto_reset) {
+    if (nsub > 0)
+      for (int j = lane; j < n; j += kWave) urow[j] = cur[j];
+    emit_obs(Bf.obs, cur);
+    if (lane == 0) {
+      Bf.time_index[inst] = t;
+      Bf.bsum[inst] = bsum;
+    }
+  } else {
+    if (Bf.final_obs) emit_obs(Bf.final_obs, cur);
+    const float* irow = Bf.reset_init + (size_t)inst * n;
+    wave_lds_sync();
+    for (int j = lane; j < n; j += kWave) {
+      const float v = irow[j];
+      nxt[j] = v;
+      urow[j] = v;
+    }
+    if (hist)
+      for (size_t q = lane; q < (size_t)P.nt * n; q += kWave) hist[q] = (q < (size_t)n) ? irow[q] : 0.f;
+    wave_lds_sync();
+    const float n0 = row_norm(nxt);
+    emit_obs(Bf.obs, nxt);
+    if (lane == 0) {
+      Bf.time_index[inst] = 0;
+      Bf.bsum[inst] = (double)fabsf(nxt[n - 1]);
+      ring[0] = n0;
+    }
+  }
+  (void)J0;
+}
+
 // ---- reset (state part of hyperbolic.py:214-227 / parabolic.py:208-221) -----------------------------
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void reset1d_kernel(pdegym_params1d P, pdegym_bufs1d Bf,
                                                                          const float* init, const uint8_t* mask, int B) {
@@ -639,13 +820,17 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
   if (!prm || !buf) return pdegym::fail(-1, "null params/bufs");
   if (B <= 0) return 0;
   const pdegym_params1d& P = *prm;
-  if (P.n < 3 || P.n > PDEGYM_MAX_N1D) return pdegym::fail(-2, "n must be in [3, 2048] for the wave-per-instance 1D kernels");
+  if (P.n < 3 || P.n > PDEGYM_MAX_N1D_WIDE) return pdegym::fail(-2, "n must be in [3, 8192] for the 1D kernels");
   if (P.nt < 2) return pdegym::fail(-2, "nt must be >= 2");
   if (!buf->u || !buf->beta || !buf->action || !buf->time_index || !buf->bsum || !buf->ring || !buf->obs ||
       !buf->norm_now || !buf->norm_back || !buf->terminated || !buf->truncated)
     return pdegym::fail(-3, "null device buffer");
   if (P.reward_kind != PDEGYM_REWARD_NONE && !buf->reward) return pdegym::fail(-3, "null reward buffer");
   hipStream_t st = (hipStream_t)stream;
+  if (P.n > PDEGYM_MAX_N1D) {    // LDS-resident rows (one wave per instance, two row copies)
+    hipLaunchKernelGGL((step1d_wide_kernel<PARABOLIC, BURGERS>), dim3(B), dim3(kWave), 2 * (size_t)P.n * sizeof(float), st, P, *buf, B);
+    return pdegym::check_launch("step1d_wide");
+  }
   const int nslots = P.n - (PARABOLIC ? 1 : 0);  // parabolic node 0 lives in a wave-uniform register
   const int epl = (nslots + kWave - 1) / kWave;
   switch (epl) {

@@ -24,9 +24,7 @@ def one_case(rng, idx):
     flux = "burgers" if kind == "burgers" else "linear"
     base = "parabolic" if kind == "parabolic" else "transport"
     nx = int(rng.choice([3, 4, 5, 31, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300, 511, 512, 513, 700, 1023, 1024, 1025,
-                         1500, 2047, 2048])) if rng.random() < 0.6 else int(rng.integers(3, 2049))
-    if base == "parabolic" and nx > 2047:
-        nx = 2047
+                         1500, 2047, 2048, 2049, 2500, 4096])) if rng.random() < 0.6 else int(rng.integers(3, 2600))
     S = int(rng.choice([1, 2, 3, 7, 10, 33, 100, 101, 128, 250]))
     nsteps = int(rng.integers(1, 7))
     extra = int(rng.integers(0, S))                      # the last step of the episode is cut short by `extra` sub-steps

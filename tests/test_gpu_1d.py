@@ -71,6 +71,9 @@ def _oracle_kwargs(kw):
     ("transport", 31, 12, 5, "Dirchilet"), ("parabolic", 2, 3, 4, "Dirchilet"),
     ("transport", 1500, 9, 3, "Dirchilet"), ("parabolic", 2047, 4, 3, "Dirchilet"), ("transport", 2048, 5, 2, "Neumann"),
     ("parabolic", 1300, 6, 2, "Neumann"),
+    # rows beyond 2048 nodes: the LDS-resident wide kernel
+    ("transport", 2049, 7, 3, "Dirchilet"), ("parabolic", 3000, 5, 2, "Neumann"), ("transport", 4096, 4, 2, "Neumann"),
+    ("parabolic", 8191, 3, 2, "Dirchilet"),
 ])
 def test_hip_matches_oracle_random_batches(kind, nx, S, B, ctrl):
     """Seeded random per-instance IC / beta / actions: every row bit-exact vs the oracle."""
@@ -333,7 +336,7 @@ def test_abi_rejects_bad_arguments():
     from pdecontrolgym_amd import _native as N
     from pdecontrolgym_amd.batch1d import PDEBatch1D
     with pytest.raises(N.NativeError):
-        env = PDEBatch1D("transport", 1, 1e-3, 1, 1.0 / 2100, 0.01, num_envs=2, device="cuda")   # n = 2100 > 2048
+        env = PDEBatch1D("transport", 1, 1e-3, 1, 1.0 / 9000, 0.01, num_envs=2, device="cuda")   # n = 9000 > 8192
         env.step(torch.zeros(2))
 
 
