@@ -1,6 +1,8 @@
 """GPU tests of the drop-in Python API (pde_control_gym.*) on the real HIP backend, including the
 reference's PUBLISHED known answers reproduced in closed loop (backstepping controller episodes; notebook
 stored outputs cited in SURVEY.md section 6 / BASELINE.md)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -137,3 +139,12 @@ def test_device_rollout_graph_equals_eager_on_gpu():
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
     assert outs[0][3][13].all() and not outs[0][3][12].any()      # every instance terminates at step 14 and restarts
+
+
+def test_quickstart_example_runs():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "quickstart.py")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("quickstart ok"), r.stdout[-2000:]
