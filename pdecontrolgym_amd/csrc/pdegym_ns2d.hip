@@ -206,6 +206,76 @@ __device__ __forceinline__ void jacobi_sweeps_lds(T* p, const T* rhs, T* sh, int
   }
 }
 
+// Grids whose two copies do not fit the LDS (up to kLds1Cells cells, e.g. float64 128x128 = 128 KB): ONE LDS copy of p; a
+// sweep computes the new values of a thread's cells into registers from the old copy, then -- after a barrier -- writes
+// them (and the Neumann wall copies) back.  Two barriers per sweep instead of one, still no L2 round trip.  Same arithmetic.
+constexpr int kLds1CPT = 16;
+constexpr int kLds1Cells = 1024 * kLds1CPT;
+constexpr int kLds1MaxBytes = 160 * 1024 - 1024;
+
+template <typename T>
+__device__ __forceinline__ void jacobi_sweeps_lds1(T* p, const T* rhs, T* buf, int ny, int nx, int K, T dxdy) {
+  const int ncell = ny * nx;
+  T rq[kLds1CPT];
+  int flag[kLds1CPT];
+#pragma unroll
+  for (int k = 0; k < kLds1CPT; ++k) {
+    const int c = threadIdx.x + k * blockDim.x;
+    flag[k] = 0;
+    rq[k] = 0;
+    if (c < ncell) {
+      buf[c] = p[c];
+      const int i = c / nx, j = c - i * nx;
+      if (i >= 1 && i <= ny - 2 && j >= 1 && j <= nx - 2) {
+        flag[k] = 1 | ((i == 1) << 1) | ((i == ny - 2) << 2) | ((j == 1) << 3) | ((j == nx - 2) << 4);
+        if constexpr (sizeof(T) == 4) rq[k] = jacobi_rhs_term(dxdy, rhs[c]);
+        else rq[k] = dxdy * rhs[c];
+      }
+    }
+  }
+  __syncthreads();
+  for (int it = 0; it < K; ++it) {
+    T val[kLds1CPT];
+#pragma unroll
+    for (int k = 0; k < kLds1CPT; ++k) {
+      val[k] = 0;
+      if (flag[k]) {
+        const int c = threadIdx.x + k * blockDim.x;
+        const T s4 = ((buf[c - 1] + buf[c - nx]) + buf[c + 1]) + buf[c + nx];
+        if constexpr (sizeof(T) == 4) val[k] = jacobi_update(s4, rq[k]);
+        else val[k] = (T)0.25 * (s4 - rq[k]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kLds1CPT; ++k) {
+      const int f = flag[k];
+      if (f) {
+        const int c = threadIdx.x + k * blockDim.x;
+        const T v = val[k];
+        buf[c] = v;
+        if (f != 1) {
+          const bool top = f & 2, bot = f & 4, lef = f & 8, rig = f & 16;
+          if (top) buf[c - nx] = v;
+          if (bot) buf[c + nx] = v;
+          if (lef) buf[c - 1] = v;
+          if (rig) buf[c + 1] = v;
+          if (top && lef) buf[c - nx - 1] = v;
+          if (top && rig) buf[c - nx + 1] = v;
+          if (bot && lef) buf[c + nx - 1] = v;
+          if (bot && rig) buf[c + nx + 1] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < kLds1CPT; ++k) {
+    const int c = threadIdx.x + k * blockDim.x;
+    if (c < ncell) p[c] = buf[c];
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ void compute_rhs(const T* us, const T* vs, T* rhs, int ny, int nx, const NSScal<T>& S) {
   const int ncell = ny * nx;
@@ -338,7 +408,7 @@ __device__ __forceinline__ void gen_back(const NSConst& C, const NSScal<T>& S, c
   }
 }
 
-template <typename T, bool LDSJ>
+template <typename T, int LDSJ>   // 0: global-memory Jacobi, 1: two LDS copies, 2: one LDS copy
 __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, NSPtrs<T> P, int B) {
   __shared__ T red[16];
   extern __shared__ double ns_dyn_lds[];
@@ -351,8 +421,11 @@ __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, 
   gen_front<T>(C, S, P, b);
   __syncthreads();
   // pressure Poisson (:142, :94-116), result in p
-  if constexpr (LDSJ) {
+  if constexpr (LDSJ == 1) {
     jacobi_sweeps_lds<T>(p, rhs, reinterpret_cast<T*>(ns_dyn_lds), C.ny, C.nx, C.iters, S.dxdy);
+    __syncthreads();
+  } else if constexpr (LDSJ == 2) {
+    jacobi_sweeps_lds1<T>(p, rhs, reinterpret_cast<T*>(ns_dyn_lds), C.ny, C.nx, C.iters, S.dxdy);
     __syncthreads();
   } else {
     jacobi_sweeps<T>(p, pB, rhs, C.ny, C.nx, C.iters, S.dxdy);
@@ -1112,7 +1185,7 @@ __global__ void ns256_finish(NSConst C, NSScal<float> S, NSPtrs<float> P, int B)
   P.terminated[b] = (t >= C.nt - 1) ? 1 : 0;
 }
 
-template <typename T, bool LDSJ>
+template <typename T, int LDSJ>
 __global__ __launch_bounds__(1024) void ns_generic_pressure(NSConst C, NSScal<T> S, const T* ug, const T* vg, const T* p_in,
                                                              T* p_out, T* scratch, int B) {
   extern __shared__ double ns_dyn_lds[];
@@ -1130,7 +1203,8 @@ __global__ __launch_bounds__(1024) void ns_generic_pressure(NSConst C, NSScal<T>
     for (int c = threadIdx.x; c < ncell; c += blockDim.x) po[c] = pi[c];
   }
   __syncthreads();
-  if constexpr (LDSJ) jacobi_sweeps_lds<T>(po, rhs, reinterpret_cast<T*>(ns_dyn_lds), ny, nx, C.iters, S.dxdy);
+  if constexpr (LDSJ == 1) jacobi_sweeps_lds<T>(po, rhs, reinterpret_cast<T*>(ns_dyn_lds), ny, nx, C.iters, S.dxdy);
+  else if constexpr (LDSJ == 2) jacobi_sweeps_lds1<T>(po, rhs, reinterpret_cast<T*>(ns_dyn_lds), ny, nx, C.iters, S.dxdy);
   else jacobi_sweeps<T>(po, pB, rhs, ny, nx, C.iters, S.dxdy);
 }
 
@@ -1217,6 +1291,19 @@ inline bool pdegym_no_lds_jacobi() {
   return e && e[0] == '1';
 }
 
+inline bool allow_big_lds(const void* kernel) {
+  return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds1MaxBytes) == hipSuccess;
+}
+
+// 1: two LDS copies (<= kLdsCells cells); 2: one LDS copy (larger grids that still fit the 160 KB of a CU); 0: global memory
+template <typename T>
+inline int lds_jacobi_mode(int ncell) {
+  if (pdegym_no_lds_jacobi()) return 0;
+  if (ncell <= kLdsCells) return 1;
+  if (ncell <= kLds1Cells && (size_t)ncell * sizeof(T) <= (size_t)kLds1MaxBytes) return 2;
+  return 0;
+}
+
 inline int block_threads(int ncell) {
   if (ncell >= 4096) return 1024;
   if (ncell >= 1024) return 512;
@@ -1288,11 +1375,17 @@ int ns_step(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int B, v
     }
   }
   const int ncell = C.nx * C.ny;
-  if (ncell <= kLdsCells && !pdegym_no_lds_jacobi())
-    hipLaunchKernelGGL((ns_generic_step<T, true>), dim3(B), dim3(lds_block_threads(ncell, B)), 2 * (size_t)ncell * sizeof(T),
+  const int mode = lds_jacobi_mode<T>(ncell);
+  if (mode == 1) {
+    hipLaunchKernelGGL((ns_generic_step<T, 1>), dim3(B), dim3(lds_block_threads(ncell, B)), 2 * (size_t)ncell * sizeof(T),
                        (hipStream_t)stream, C, S, P, B);
-  else
-    hipLaunchKernelGGL((ns_generic_step<T, false>), dim3(B), dim3(block_threads(ncell)), 0, (hipStream_t)stream, C, S, P, B);
+  } else if (mode == 2) {
+    static const bool ok = allow_big_lds(reinterpret_cast<const void*>(&ns_generic_step<T, 2>));
+    if (!ok) return pdegym::fail(-4, "cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL((ns_generic_step<T, 2>), dim3(B), dim3(1024), (size_t)ncell * sizeof(T), (hipStream_t)stream, C, S, P, B);
+  } else {
+    hipLaunchKernelGGL((ns_generic_step<T, 0>), dim3(B), dim3(block_threads(ncell)), 0, (hipStream_t)stream, C, S, P, B);
+  }
   return pdegym::check_launch("ns2d_step");
 }
 
@@ -1306,12 +1399,19 @@ int ns_pressure(const pdegym_params_ns2d* prm, const void* u, const void* v, con
   if (!u || !v || !p_in || !p_out || !scratch) return pdegym::fail(-3, "null device buffer");
   C.nt_ref = 1;
   const int ncell = C.nx * C.ny;
-  if (ncell <= kLdsCells && !pdegym_no_lds_jacobi())
-    hipLaunchKernelGGL((ns_generic_pressure<T, true>), dim3(B), dim3(lds_block_threads(ncell, B)), 2 * (size_t)ncell * sizeof(T),
+  const int mode = lds_jacobi_mode<T>(ncell);
+  if (mode == 1) {
+    hipLaunchKernelGGL((ns_generic_pressure<T, 1>), dim3(B), dim3(lds_block_threads(ncell, B)), 2 * (size_t)ncell * sizeof(T),
                        (hipStream_t)stream, C, S, (const T*)u, (const T*)v, (const T*)p_in, (T*)p_out, (T*)scratch, B);
-  else
-    hipLaunchKernelGGL((ns_generic_pressure<T, false>), dim3(B), dim3(block_threads(ncell)), 0, (hipStream_t)stream, C, S,
+  } else if (mode == 2) {
+    static const bool ok = allow_big_lds(reinterpret_cast<const void*>(&ns_generic_pressure<T, 2>));
+    if (!ok) return pdegym::fail(-4, "cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL((ns_generic_pressure<T, 2>), dim3(B), dim3(1024), (size_t)ncell * sizeof(T), (hipStream_t)stream, C, S,
                        (const T*)u, (const T*)v, (const T*)p_in, (T*)p_out, (T*)scratch, B);
+  } else {
+    hipLaunchKernelGGL((ns_generic_pressure<T, 0>), dim3(B), dim3(block_threads(ncell)), 0, (hipStream_t)stream, C, S,
+                       (const T*)u, (const T*)v, (const T*)p_in, (T*)p_out, (T*)scratch, B);
+  }
   return pdegym::check_launch("ns2d_solve_pressure");
 }
 

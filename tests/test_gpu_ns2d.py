@@ -224,7 +224,10 @@ def test_ns_f32_tiled_kernel_equals_generic_kernel_bitwise(n):
 
 
 @pytest.mark.parametrize("n,dtype,K", [(21, "float64", 200), (21, "float64", 7), (33, "float32", 50), (64, "float64", 31),
-                                       (64, "float32", 50), (5, "float64", 12)])
+                                       (64, "float32", 50), (5, "float64", 12),
+                                       # one LDS copy (grids of 4097..16384 cells): float64 128x128 is 128 KB
+                                       (128, "float64", 31), (100, "float64", 8), (100, "float32", 21), (128, "float32", 12),
+                                       (65, "float64", 9)])
 def test_ns_lds_resident_jacobi_equals_global_memory_jacobi_bitwise(n, dtype, K):
     """Grids of <= 4096 cells keep p in LDS during the sweeps; same arithmetic as the global-memory loop -> identical
     fields, pressure (incl. the public solve_pressure) and rewards.  Odd and even K, both dtypes."""
