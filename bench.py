@@ -331,8 +331,9 @@ class BrainTumor:
                 "substeps_per_env_step": 1, "reward": "BrainTumorReward", "parallelism": "independent instances, no collective"}
 
 
-from bench_ns2d import NavierStokesC4, NavierStokesC5  # noqa: E402
+from bench_ns2d import NavierStokesC4, NavierStokesC4F64, NavierStokesC5  # noqa: E402
 WORKLOADS["ns2d_c4"] = NavierStokesC4
+WORKLOADS["ns2d_c4_f64"] = NavierStokesC4F64
 WORKLOADS["ns2d_c5"] = NavierStokesC5
 WORKLOADS["traffic_arz"] = TrafficARZ
 WORKLOADS["brain_tumor"] = BrainTumor

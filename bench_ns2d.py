@@ -9,7 +9,7 @@ import time
 class NavierStokesC4:
     name = "NavierStokes2D 128x128 K=50 B=512 fp32 (BASELINE configs[3])"
     n, B, K = 128, 512, 50
-    dtype = "f32"
+    dtype = "f32"          # "f64" = the reference's own precision (navier_stokes2D.py:186, base_env_2d.py:50)
     BC = {"upper": ["Controllable", "Dirchilet"], "lower": ["Dirchilet", "Dirchilet"],
           "left": ["Dirchilet", "Dirchilet"], "right": ["Dirchilet", "Dirchilet"]}
 
@@ -25,19 +25,20 @@ class NavierStokesC4:
         self.kw = dict(T=self.nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=self.BC, gamma=0.1,
                        viscosity=0.1, density=1.0, maximum_pressure_iteration=self.K)
         self.device = device
-        U_ref = torch.zeros(self.nt, n, n, 2, dtype=torch.float32, device=device)
-        a_ref = 2.0 * torch.ones(self.nt, dtype=torch.float32, device=device)
-        self.env = NSBatch2D(U_ref=U_ref, action_ref=a_ref, num_envs=self.B, device=device, dtype=torch.float32,
+        td = self.td = torch.float64 if self.dtype == "f64" else torch.float32
+        U_ref = torch.zeros(self.nt, n, n, 2, dtype=td, device=device)
+        a_ref = 2.0 * torch.ones(self.nt, dtype=td, device=device)
+        self.env = NSBatch2D(U_ref=U_ref, action_ref=a_ref, num_envs=self.B, device=device, dtype=td,
                              interleaved_state=os.environ.get("PDEGYM_NS_SEPARATE_UV", "0") != "1", **self.kw)
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.gen = g
         c = torch.rand(self.B, 3, generator=g) * 10 - 5
         one = torch.ones(1, n, n)
-        self.ic = [(c[:, k].reshape(self.B, 1, 1) * one).float().to(device) for k in range(3)]
+        self.ic = [(c[:, k].reshape(self.B, 1, 1) * one).to(td).to(device) for k in range(3)]
 
     def prepare(self, total_steps):
         import torch
-        self.actions = (torch.rand(total_steps, self.B, generator=self.gen) * 2 + 2).float().to(self.device)
+        self.actions = (torch.rand(total_steps, self.B, generator=self.gen) * 2 + 2).to(self.td).to(self.device)
         self.env.reset(*self.ic)
         self.i = 0
 
@@ -65,3 +66,9 @@ class NavierStokesC5(NavierStokesC4):
     """BASELINE configs[4] per-GPU shard: NavierStokes2D 256x256, 50 Jacobi sweeps/step, 512 instances per GPU, fp32."""
     name = "NavierStokes2D 256x256 K=50 B=512/GPU fp32 (BASELINE configs[4] shard)"
     n, B, K = 256, 512, 50
+
+
+class NavierStokesC4F64(NavierStokesC4):
+    """BASELINE configs[3] at the reference's own precision (float64 end to end, bit-exact against NumPy)."""
+    name = "NavierStokes2D 128x128 K=50 B=512 fp64 (BASELINE configs[3] at the reference's precision)"
+    dtype = "f64"

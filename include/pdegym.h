@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PDEGYM_ABI_VERSION 7
+#define PDEGYM_ABI_VERSION 8
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
 #define PDEGYM_MAX_N1D 2048      /* nodes per 1D row kept in registers by the wave-per-instance kernels */
@@ -45,6 +45,16 @@ extern "C" {
 /* control_type (hyperbolic.py:66-124): the reference's (mis)spelling "Dirchilet" is kept in the Python layer */
 enum { PDEGYM_CONTROL_DIRICHLET = 0, PDEGYM_CONTROL_NEUMANN = 1 };
 enum { PDEGYM_FLUX_LINEAR = 0, PDEGYM_FLUX_BURGERS = 1 };   /* transport kernels only */
+/* What the caller of the reference's step() passed as `control` -- it decides, under NumPy's promotion rules, in which
+ * precision control_update()/normalize() are evaluated before the value is stored into the float32 row
+ * (hyperbolic.py:143-145, parabolic.py:148-150, base_env_1d.py:36-39): */
+enum {
+  PDEGYM_ACTION_F32 = 0,   /* float32 array / np.float32 (what SB3 passes): everything in float32; action = float[B]     */
+  PDEGYM_ACTION_F64 = 1,   /* np.float64 scalar or array (and a Python float under NumPy 1.x value-based casting):
+                              control*dx + neighbour and (a+1)*max-max in double, rounded once on store; action = double[B] */
+  PDEGYM_ACTION_WEAK = 2   /* Python float / int under NumPy >= 2 (NEP 50 weak scalar): Dirichlet as F64; Neumann forms
+                              control*dx in double, then joins the float32 neighbour in float32; action = double[B]        */
+};
 /* sensing_update variants (hyperbolic.py:72-116, parabolic.py:72-116) */
 enum {
   PDEGYM_SENSE_FULL = 0,        /* obs = row                              obs_dim = n */
@@ -84,15 +94,22 @@ typedef struct pdegym_params1d {
                                (float)((double)d * rdx), which equals the IEEE float32 division bit for bit */
   int32_t flux;             /* PDEGYM_FLUX_LINEAR = the reference's transport term; PDEGYM_FLUX_BURGERS = extension,
                                NOT in the reference (parity unpinned): n[j] = p[j] + dt*(p[j]*((p[j+1]-p[j])/dx) + (p[0]*beta)[j]) */
+  int32_t beta_f64;         /* non-zero: bufs.beta is double[] -- the reference's arithmetic when reset_recirculation_func returns
+                               float64 (e.g. np.ones(nx), docs/source/guide/quickstart.rst:27-28): u[0]*beta, dt*beta*u and the
+                               sums they enter are evaluated in double and rounded once when the row is stored
+                               (hyperbolic.py:146-155, parabolic.py:143-144)                                              */
+  int32_t action_kind;      /* PDEGYM_ACTION_*                                                                            */
   int32_t reserved_;        /* keeps sizeof a multiple of 8 */
+  double dt64, dx64;        /* the Python doubles themselves (used where they meet a float64 operand)                     */
+  double max_control64;
 } pdegym_params1d;
 
 /* Per-instance device buffers of a 1D batch (B instances). */
 typedef struct pdegym_bufs1d {
   float* u;                 /* [B, n]   live row (in/out)                                                     */
-  const float* beta;        /* [B, n] or [n]   plant parameter beta(x) / lambda(x)                            */
+  const void* beta;         /* [B, n] or [n]   plant parameter beta(x) / lambda(x): float, or double when beta_f64    */
   int64_t beta_stride;      /* elements between instances; 0 = one shared row                                 */
-  const float* action;      /* [B]      control input of this env-step                                        */
+  const void* action;       /* [B]      control input of this env-step: float, or double when action_kind != F32      */
   int32_t* time_index;      /* [B]      in/out                                                                */
   double* bsum;             /* [B]      running sum |u[tau,-1]| over written rows (in/out)  tuned_reward_1d.py:37 */
   float* ring;              /* [B, PDEGYM_RING]  row norms that a later look-back will read (in/out)          */

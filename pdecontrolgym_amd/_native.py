@@ -11,13 +11,14 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 RING = 128
 LOOKBACK = 100
 MAX_N1D = 8192
 
 CONTROL = {"Dirchilet": 0, "Neumann": 1}
 FLUX_LINEAR, FLUX_BURGERS = 0, 1
+ACTION_F32, ACTION_F64, ACTION_WEAK = 0, 1, 2
 SENSE_FULL, SENSE_LAST, SENSE_LAST_DERIV, SENSE_FIRST_DERIV, SENSE_FIRST = range(5)
 REWARD_NONE, REWARD_TUNED1D, REWARD_NORM_L1, REWARD_NORM_L2, REWARD_NORM_LINF = range(5)
 BC = {"Neumann": 0, "Dirchilet": 1, "Controllable": 2}
@@ -38,7 +39,8 @@ class Params1D(C.Structure):
                 ("reward_kind", C.c_int32), ("reward_nt", C.c_int32), ("dt", C.c_float), ("dx", C.c_float),
                 ("F", C.c_float), ("max_control", C.c_float), ("max_state", C.c_float),
                 ("truncate_penalty", C.c_float), ("terminate_reward", C.c_float), ("rdx", C.c_double),
-                ("flux", C.c_int32), ("reserved_", C.c_int32)]
+                ("flux", C.c_int32), ("beta_f64", C.c_int32), ("action_kind", C.c_int32), ("reserved_", C.c_int32),
+                ("dt64", C.c_double), ("dx64", C.c_double), ("max_control64", C.c_double)]
 
 
 class Bufs1D(C.Structure):
@@ -124,8 +126,6 @@ def load():
     lib.pdegym_selftest_quotient.argtypes = [C.c_void_p, C.c_float, C.c_double, C.c_void_p, C.c_int32, C.c_void_p]
     lib.pdegym_selftest_quotient.restype = C.c_int
     for sfx in ("f32", "f64"):
-        if not hasattr(lib, "pdegym_ns2d_step_" + sfx):   # TEMP until pdegym_ns2d.hip lands
-            continue
         f = getattr(lib, "pdegym_ns2d_step_" + sfx)
         f.argtypes = [C.POINTER(ParamsNS2D), C.POINTER(BufsNS2D), C.c_int32, C.c_void_p]
         f.restype = C.c_int

@@ -23,9 +23,9 @@ class HipBackend:
         import torch
         b = N.Bufs1D()
         b.u = N.dptr(T["u"], torch.float32)
-        b.beta = N.dptr(T["beta"], torch.float32)
+        b.beta = N.dptr(T["beta"])                 # float32, or float64 in the reference's mixed-precision mode (P.beta_f64)
         b.beta_stride = 0 if T["beta"].dim() == 1 else T["beta"].stride(0)
-        b.action = N.dptr(T["action"], torch.float32)
+        b.action = N.dptr(T["action"])             # float32, or float64 when P.action_kind != ACTION_F32
         b.time_index = N.dptr(T["time_index"], torch.int32)
         b.bsum = N.dptr(T["bsum"], torch.float64)
         b.ring = N.dptr(T["ring"], torch.float32)
@@ -43,7 +43,12 @@ class HipBackend:
         return b
 
     def step1d(self, kind: str, P: N.Params1D, T: dict, B: int):
+        import torch
         fn = self.lib.pdegym_transport_step if kind == "transport" else self.lib.pdegym_parabolic_step
+        if T["beta"].dtype != (torch.float64 if P.beta_f64 else torch.float32):
+            raise N.NativeError(f"beta is {T['beta'].dtype} but params.beta_f64 = {P.beta_f64}")
+        if T["action"].dtype != (torch.float32 if P.action_kind == N.ACTION_F32 else torch.float64):
+            raise N.NativeError(f"action is {T['action'].dtype} but params.action_kind = {P.action_kind}")
         bufs = self._bufs1d(T)
         N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["u"].device)), f"pdegym_{kind}_step")
 

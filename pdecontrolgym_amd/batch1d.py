@@ -99,6 +99,8 @@ class PDEBatch1D:
         P.F = dt / (dx ** 2)                      # parabolic.py:138, computed in double then cast
         P.rdx = 1.0 / float(C.c_float(dx).value)  # reciprocal of the float32 dx, in double (see pdegym.h)
         P.max_control = max_control_value
+        P.dt64, P.dx64, P.max_control64 = dt, dx, max_control_value   # the Python doubles, for float64 operands
+        P.beta_f64, P.action_kind = 0, N.ACTION_F32
         P.max_state = min(max_state_value, 3.4028234663852886e38)
         P.flux = N.FLUX_BURGERS if flux == "burgers" else N.FLUX_LINEAR
         P.truncate_penalty = self.reward_spec.truncate_penalty
@@ -144,13 +146,20 @@ class PDEBatch1D:
         return self.t["obs"]
 
     # ---- API -----------------------------------------------------------------------------------------
-    def set_beta(self, beta):
-        """beta: [n] (shared) or [B, n] float32 device tensor."""
+    def set_beta(self, beta, dtype=None):
+        """beta: [n] (shared) or [B, n].  Its dtype selects the arithmetic, as in the reference: float32 -> the float32
+        kernels; float64 (what ``np.ones(nx)`` or an un-cast ``np.cos(...)`` gives) or an integer type -> the reference's
+        mixed-precision update, evaluated in double and rounded once per stored row (hyperbolic.py:146-155,
+        parabolic.py:143-144; slower kernel).  ``dtype=torch.float32`` forces the float32 path."""
         import torch
-        beta = torch.as_tensor(beta, dtype=torch.float32, device=self.device).contiguous()
+        beta = torch.as_tensor(beta)
+        if dtype is None:
+            dtype = torch.float32 if beta.dtype in (torch.float32, torch.float16, torch.bfloat16) else torch.float64
+        beta = beta.to(device=self.device, dtype=dtype).contiguous()
         if beta.shape[-1] != self.n:
             raise ValueError(f"beta must have {self.n} nodes, got {tuple(beta.shape)}")
         self.t["beta"] = beta
+        self.params.beta_f64 = 1 if dtype == torch.float64 else 0
 
     def reset(self, init, beta=None, mask=None):
         """(Re)start instances from ``init`` [B, n]; where ``mask`` [B] (uint8/bool) is given only those."""
@@ -184,13 +193,20 @@ class PDEBatch1D:
         self.t["reset_init"] = None
         self.t["final_obs"] = None
 
-    def step(self, action, out_obs=None, out_reward=None, out_terminated=None, out_truncated=None):
-        """Advance every instance by one env-step (S sub-steps). action: [B] float32 tensor.
+    def step(self, action, out_obs=None, out_reward=None, out_terminated=None, out_truncated=None, action_kind=None):
+        """Advance every instance by one env-step (S sub-steps). action: [B] tensor.
         Returns (obs, reward, terminated, truncated) device tensors (uint8 flags).  The ``out_*`` tensors, when given,
-        receive the outputs directly (contiguous, right dtype/shape) -- e.g. slot t of a rollout buffer."""
+        receive the outputs directly (contiguous, right dtype/shape) -- e.g. slot t of a rollout buffer.
+        ``action_kind``: how NumPy would type the reference's ``control`` argument (_native.ACTION_F32 / _F64 / _WEAK, see
+        include/pdegym.h); default: float64 tensors -> ACTION_F64, everything else -> float32."""
         import torch
-        a = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(self.num_envs).contiguous()
+        action = torch.as_tensor(action)
+        if action_kind is None:
+            action_kind = N.ACTION_F64 if action.dtype == torch.float64 else N.ACTION_F32
+        adt = torch.float32 if action_kind == N.ACTION_F32 else torch.float64
+        a = action.to(device=self.device, dtype=adt).reshape(self.num_envs).contiguous()
         self.t["action"] = a
+        self.params.action_kind = action_kind
         if out_obs is not None:
             self.t["obs"] = out_obs.view(self.num_envs, self.obs_dim)
         else:

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
 #endif
   const int n = P.n, ns = n - J0, s0 = lane * EPL;
   float* urow = Bf.u + (size_t)inst * n;
-  const float* brow = Bf.beta + (size_t)inst * Bf.beta_stride;
+  const float* brow = static_cast<const float*>(Bf.beta) + (size_t)inst * Bf.beta_stride;
   float* ring = Bf.ring + (size_t)inst * PDEGYM_RING;
   float* hist = (HIST && Bf.history) ? Bf.history + (size_t)inst * P.nt * n : nullptr;
 
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
   int nsub = P.nt - 1 - t_in;  // hyperbolic.py:140: while i < sample_rate and time_index < nt-1
   nsub = nsub < P.substeps ? nsub : P.substeps;
   nsub = nsub > 0 ? nsub : 0;
-  const float a = Bf.action[inst];
+  const float a = static_cast<const float*>(Bf.action)[inst];
   R.t = t_in;
   R.k = (t_in + PDEGYM_LOOKBACK) % S;
   R.bsum = bsum_in;
@@ -536,7 +536,28 @@ __device__ __forceinline__ void wave_lds_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-template <bool PARABOLIC, bool BURGERS>
+// normalize(control_update(control, neighbour, dx), max_control_value) as NumPy evaluates it for the given kind of `control`
+// (hyperbolic.py:143-145, parabolic.py:148-150, base_env_1d.py:36-39); the result is what lands in the float32 row.
+template <bool M64>
+__device__ __forceinline__ float boundary_value(const pdegym_params1d& P, float a32, double a64, float neighbour, bool neumann) {
+  if (!M64 || P.action_kind == PDEGYM_ACTION_F32) {
+    const float v = neumann ? a32 * P.dx + neighbour : a32;
+    return normalize_ctrl(v, P.max_control, P.normalize);
+  }
+  if (P.action_kind == PDEGYM_ACTION_F64 || !neumann) {
+    double v = neumann ? a64 * P.dx64 + (double)neighbour : a64;
+    if (P.normalize) v = (v + 1.0) * P.max_control64 - P.max_control64;
+    return (float)v;
+  }
+  // NEP 50 weak Python scalar: control*dx is a Python float product, then adopts the float32 of the neighbour
+  const float v = (float)(a64 * P.dx64) + neighbour;
+  return normalize_ctrl(v, P.max_control, P.normalize);
+}
+
+// M64 = the reference's mixed-precision arithmetic for a float64 beta and/or a float64 / Python-float control input
+// (pdegym_params1d.beta_f64 / action_kind): the parity mode of the docs quickstart (beta = np.ones(nx)).  Rows of ANY length
+// take this kernel in that mode; with M64 = false it is the float32 kernel for rows beyond the register-resident limit.
+template <bool PARABOLIC, bool BURGERS, bool M64 = false>
 __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, pdegym_bufs1d Bf, int B) {
   extern __shared__ float wl[];
   constexpr int J0 = PARABOLIC ? 1 : 0;
@@ -547,7 +568,9 @@ __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, p
   float* cur = wl;
   float* nxt = wl + n;
   float* urow = Bf.u + (size_t)inst * n;
-  const float* brow = Bf.beta + (size_t)inst * Bf.beta_stride;
+  const bool beta64 = M64 && P.beta_f64;
+  const float* brow = static_cast<const float*>(Bf.beta) + (beta64 ? 0 : (size_t)inst * Bf.beta_stride);
+  const double* brow64 = static_cast<const double*>(Bf.beta) + (beta64 ? (size_t)inst * Bf.beta_stride : 0);
   float* ring = Bf.ring + (size_t)inst * PDEGYM_RING;
   float* hist = Bf.history ? Bf.history + (size_t)inst * P.nt * n : nullptr;
   const bool neumann = P.control_type == PDEGYM_CONTROL_NEUMANN;
@@ -557,7 +580,9 @@ __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, p
   int nsub = P.nt - 1 - t_in;
   nsub = nsub < P.substeps ? nsub : P.substeps;
   nsub = nsub > 0 ? nsub : 0;
-  const float a = Bf.action[inst];
+  const bool act64 = M64 && P.action_kind != PDEGYM_ACTION_F32;
+  const float a = act64 ? 0.f : static_cast<const float*>(Bf.action)[inst];
+  const double a64 = act64 ? static_cast<const double*>(Bf.action)[inst] : 0.0;
   int t = t_in, k = (t_in + PDEGYM_LOOKBACK) % S;
   double bsum = Bf.bsum[inst];
   const int t_end = t_in + nsub;
@@ -570,8 +595,8 @@ __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, p
   float back_norm = 0.f;
   const bool rec_all = P.nt <= PDEGYM_RING;
   const float dx = P.dx, dt = P.dt, F = P.F;
-  const float cdx = a * dx;
-  float bval = neumann ? normalize_ctrl(cdx + 0.0f, P.max_control, P.normalize) : normalize_ctrl(a, P.max_control, P.normalize);
+  // transport/Neumann reads u[t][-2] of the NEW (still zero) row, hyperbolic.py:144
+  float bval = boundary_value<M64>(P, a, a64, 0.0f, neumann);
   auto row_norm = [&](const float* row) {
     float ss = 0.f;
     for (int j = lane; j < n; j += kWave) ss += row[j] * row[j];
@@ -579,7 +604,7 @@ __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, p
   };
   wave_lds_sync();
   for (int s = 0; s < nsub; ++s) {
-    if (PARABOLIC && neumann) bval = normalize_ctrl(cdx + cur[n - 2], P.max_control, P.normalize);   // parabolic.py:148-150
+    if (PARABOLIC && neumann) bval = boundary_value<M64>(P, a, a64, cur[n - 2], true);   // parabolic.py:148-150
     const float p0 = cur[0];
     for (int j = lane; j < n; j += kWave) {
       const float p = cur[j];
@@ -595,16 +620,28 @@ __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, p
         const float t3 = t2 + pp;
         const float t4 = F * t3;
         const float t5 = p + t4;
-        const float t7 = (dt * brow[j]) * p;
-        v = t5 + t7;
+        if (beta64) {                                                   // float64 beta: dt*beta and its product with u are double
+          const double t7 = (P.dt64 * brow64[j]) * (double)p;
+          v = (float)((double)t5 + t7);
+        } else {
+          const float t7 = (dt * brow[j]) * p;
+          v = t5 + t7;
+        }
       } else {
         const float pp = cur[j + 1];
         const float d1 = pp - p;                                        // hyperbolic.py:146-155
         const float d2 = d1 / dx;
-        const float r = p0 * brow[j];
-        const float d3 = (BURGERS ? p * d2 : d2) + r;
-        const float d4 = dt * d3;
-        v = p + d4;
+        if (beta64) {                                                   // float64 beta: u[0]*beta, the sum, dt*(...) and u + ... are double
+          const double r = (double)p0 * brow64[j];
+          const double d3 = (double)(BURGERS ? p * d2 : d2) + r;
+          const double d4 = P.dt64 * d3;
+          v = (float)((double)p + d4);
+        } else {
+          const float r = p0 * brow[j];
+          const float d3 = (BURGERS ? p * d2 : d2) + r;
+          const float d4 = dt * d3;
+          v = p + d4;
+        }
       }
       nxt[j] = v;
     }
@@ -827,8 +864,13 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
     return pdegym::fail(-3, "null device buffer");
   if (P.reward_kind != PDEGYM_REWARD_NONE && !buf->reward) return pdegym::fail(-3, "null reward buffer");
   hipStream_t st = (hipStream_t)stream;
+  if (P.action_kind < PDEGYM_ACTION_F32 || P.action_kind > PDEGYM_ACTION_WEAK) return pdegym::fail(-2, "bad action_kind");
+  if (P.beta_f64 || P.action_kind != PDEGYM_ACTION_F32) {   // the reference's float64-operand arithmetic (parity mode)
+    hipLaunchKernelGGL((step1d_wide_kernel<PARABOLIC, BURGERS, true>), dim3(B), dim3(kWave), 2 * (size_t)P.n * sizeof(float), st, P, *buf, B);
+    return pdegym::check_launch("step1d_m64");
+  }
   if (P.n > PDEGYM_MAX_N1D) {    // LDS-resident rows (one wave per instance, two row copies)
-    hipLaunchKernelGGL((step1d_wide_kernel<PARABOLIC, BURGERS>), dim3(B), dim3(kWave), 2 * (size_t)P.n * sizeof(float), st, P, *buf, B);
+    hipLaunchKernelGGL((step1d_wide_kernel<PARABOLIC, BURGERS, false>), dim3(B), dim3(kWave), 2 * (size_t)P.n * sizeof(float), st, P, *buf, B);
     return pdegym::check_launch("step1d_wide");
   }
   const int nslots = P.n - (PARABOLIC ? 1 : 0);  // parabolic node 0 lives in a wave-uniform register

@@ -61,7 +61,7 @@ class FakeBackend:
         orc = self._orc1d(P)
         self._load(orc, T, B)
         with np.errstate(all="ignore"):
-            obs, r, te, tr = orc.step(T["action"].numpy())
+            obs, r, te, tr = orc.step(T["action"].numpy(), action_kind=("f32", "f64", "weak")[P.action_kind])
         T["obs"].copy_(torch.from_numpy(np.asarray(obs, dtype=np.float32).reshape(B, -1)))
         if r is not None:
             T["reward"].copy_(torch.from_numpy(r.astype(np.float32)))

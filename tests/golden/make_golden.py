@@ -77,8 +77,21 @@ def cheb_beta(x, gamma, amp):
     return beta
 
 
-def run_1d(src, cls_name, kw, init, beta, actions, reward_args, extra=None):
-    """Drive one reference 1D env with float32 (1,) actions like SB3 does; record everything."""
+def _as_control(a, action_as):
+    """The Python object handed to the reference's step(): what decides NumPy's promotion of control_update/normalize."""
+    if action_as == "f32arr":
+        return np.array([a], dtype=np.float32)       # what SB3 passes
+    if action_as == "npf64":
+        return np.float64(a)                         # e.g. a backstepping controller's dot product
+    if action_as == "pyfloat":
+        return float(a)
+    if action_as == "pyint":
+        return int(a)
+    raise ValueError(action_as)
+
+
+def run_1d(src, cls_name, kw, init, beta, actions, reward_args, extra=None, action_as="f32arr"):
+    """Drive one reference 1D env (by default with float32 (1,) actions like SB3 does); record everything."""
     cls = getattr(src, cls_name)
     kw = dict(kw)
     kw["reward_class"] = src.TunedReward1D(*reward_args)
@@ -89,7 +102,7 @@ def run_1d(src, cls_name, kw, init, beta, actions, reward_args, extra=None):
     obs0, _ = env.reset()
     obs, rew, term, trunc, tidx, rows = [np.array(obs0, dtype=np.float32)], [], [], [], [], []
     for a in actions:
-        o, r, te, tr, _ = env.step(np.array([a], dtype=np.float32))
+        o, r, te, tr, _ = env.step(_as_control(a, action_as))
         obs.append(np.array(o, dtype=np.float32).reshape(-1))
         rew.append(np.float64(r))
         term.append(te)
@@ -99,7 +112,8 @@ def run_1d(src, cls_name, kw, init, beta, actions, reward_args, extra=None):
     obs[0] = obs[0].reshape(-1)
     return dict(obs=np.stack(obs), reward=np.array(rew), terminate=np.array(term), truncate=np.array(trunc),
                 time_index=np.array(tidx), rows=np.stack(rows), init=np.asarray(init), beta=np.asarray(beta),
-                actions=np.asarray(actions, dtype=np.float32), reward_args=np.array(reward_args, dtype=np.float64))
+                actions=np.asarray(actions, dtype=np.float32 if action_as == "f32arr" else np.float64),
+                reward_args=np.array(reward_args, dtype=np.float64), action_as=np.array(action_as))
 
 
 def pack(prefix, d, store):
@@ -277,6 +291,40 @@ def gen_kat(src):
                               rewards=np.array(rews, dtype=np.float64), kernel_row=krow, beta=beta, last_obs=np.array(obs)), store)
         print("KAT parabolic", u0, total, l2)
     np.savez_compressed(os.path.join(OUT, "kat.npz"), **store)
+
+
+def gen_mixed(src):
+    """float64 plant parameter and/or float64 / Python-scalar control inputs: NumPy then evaluates parts of the update in
+    double and rounds once when the row is stored (hyperbolic.py:146-155, parabolic.py:143-150).  Case table: tests/cases.py
+    MIXED_CASES (kwargs) -- here only the data."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from tests.cases import MIXED_CASES
+    store = {}
+    rng = np.random.default_rng(8642)
+    for name, (kind, kw, action_as, beta_kind, nsteps) in MIXED_CASES.items():
+        nx = int(round(kw["X"] / kw["dx"]))
+        n = nx + (1 if kind == "parabolic" else 0)
+        x = np.linspace(0, 1, n)
+        if beta_kind == "ones64":            # docs/source/guide/quickstart.rst:27-28
+            beta = np.ones(n)
+        elif beta_kind == "cos64":           # an un-cast NumPy expression is float64
+            beta = (50 if kind == "parabolic" else 5) * np.cos(rng.uniform(7, 8.5) * np.arccos(x))
+        elif beta_kind == "int":
+            beta = np.arange(n) % 3
+        else:                                # "cos32": the examples' float32 beta (only the control input is float64)
+            beta = cheb_beta(x, 7.35 if kind == "transport" else 8.0, 5 if kind == "transport" else 50)
+        init = np.ones(n) * rng.uniform(1, 10) if name.startswith("Q_quick") else \
+            (rng.uniform(1, 10) * (1 + 0.3 * np.sin(2 * np.pi * x * rng.uniform(0.5, 3))))
+        if action_as == "pyint":
+            acts = np.zeros(nsteps)          # quickstart.rst:68: env.step(0)
+        else:
+            acts = rng.uniform(-1, 1, nsteps)
+        nt1 = int(round(kw["T"] / kw["dt"]))
+        cls = "ReactionDiffusionPDE1D" if kind == "parabolic" else "TransportPDE1D"
+        with np.errstate(all="ignore"):
+            pack(name, run_1d(src, cls, kw, init, beta, acts, (nt1, -1e-4, 1e2) if name.startswith("Q_quick") else (nt1, -1e3, 3e2),
+                              action_as=action_as), store)
+    np.savez_compressed(os.path.join(OUT, "mixed.npz"), **store)
 
 
 NS_BC = {"upper": ["Controllable", "Dirchilet"], "lower": ["Dirchilet", "Dirchilet"],
@@ -485,10 +533,10 @@ def gen_tumor(src):
 
 if __name__ == "__main__":
     src = import_reference()
-    which = sys.argv[1:] or ["transport", "parabolic", "kat", "ns", "traffic", "tumor"]
+    which = sys.argv[1:] or ["transport", "parabolic", "kat", "mixed", "ns", "traffic", "tumor"]
     store_meta = dict(numpy=np.__version__)
     for w in which:
-        {"transport": gen_transport, "parabolic": gen_parabolic, "kat": gen_kat, "ns": gen_ns, "traffic": gen_traffic, "tumor": gen_tumor}[w](src)
+        {"transport": gen_transport, "parabolic": gen_parabolic, "kat": gen_kat, "mixed": gen_mixed, "ns": gen_ns, "traffic": gen_traffic, "tumor": gen_tumor}[w](src)
         print("wrote", w)
     with open(os.path.join(OUT, "VERSIONS.txt"), "w") as f:
         f.write(f"numpy {np.__version__}\nreference snapshot 2026-01-09 (lukebhan/PDEControlGym)\n")

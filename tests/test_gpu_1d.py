@@ -8,7 +8,7 @@ Bars (stated tolerances):
 import numpy as np
 import pytest
 
-from tests.cases import PARABOLIC_CASES, TRANSPORT_CASES
+from tests.cases import ACTION_KIND, MIXED_CASES, PARABOLIC_CASES, TRANSPORT_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -55,6 +55,36 @@ def test_transport_hip_matches_reference_golden(golden_transport, case):
 @pytest.mark.parametrize("case", sorted(PARABOLIC_CASES))
 def test_parabolic_hip_matches_reference_golden(golden_parabolic, case):
     _run_golden("parabolic", PARABOLIC_CASES[case], golden_parabolic[case])
+
+
+@pytest.mark.parametrize("case", sorted(MIXED_CASES))
+def test_mixed_precision_hip_matches_reference_golden(golden_mixed, case):
+    """float64 beta and/or float64 / Python-scalar control (the reference's mixed-precision arithmetic, incl. the docs
+    quickstart 'Q_quick'): rows and observations BIT-EXACT on the HIP path, engine level (dtype of the beta tensor and the
+    action kind select the kernel mode)."""
+    from pdecontrolgym_amd import _native as N
+    kind, kw, action_as, _, _ = MIXED_CASES[case]
+    g = golden_mixed[case]
+    B = 3
+    env = _mk(kind, kw, g.reward_args, B)
+    init = torch.tensor(np.tile(g.init.astype(np.float32)[None], (B, 1)))
+    beta = torch.tensor(np.tile(g.beta[None], (B, 1)))          # dtype preserved: float64 / int64 / float32
+    obs = env.reset(init, beta)
+    assert env.params.beta_f64 == (0 if g.beta.dtype == np.float32 else 1)
+    np.testing.assert_array_equal(obs.cpu().numpy()[B - 1].reshape(-1), g.obs[0])
+    ak = {"f32": N.ACTION_F32, "f64": N.ACTION_F64, "weak": N.ACTION_WEAK}[ACTION_KIND[action_as]]
+    for i, a in enumerate(g.actions):
+        obs, r, te, tr = env.step(torch.full((B,), float(a), dtype=torch.float32 if ak == N.ACTION_F32 else torch.float64), action_kind=ak)
+        obs, r, te, tr = obs.cpu().numpy(), r.cpu().numpy(), te.cpu().numpy(), tr.cpu().numpy()
+        rows = env.u.cpu().numpy()
+        for b in (0, B - 1):
+            np.testing.assert_array_equal(rows[b], g.rows[i], err_msg=f"row step {i} inst {b}")
+            np.testing.assert_array_equal(obs[b].reshape(-1), g.obs[i + 1], err_msg=f"obs step {i}")
+            assert int(env.time_index[b]) == int(g.time_index[i])
+            assert bool(te[b]) == bool(g.terminate[i]) and bool(tr[b]) == bool(g.truncate[i]), f"flags step {i}"
+            if np.isfinite(g.reward[i]):
+                nrm = float(np.linalg.norm(g.rows[i]))
+                np.testing.assert_allclose(r[b], g.reward[i], rtol=1e-6, atol=2e-6 * max(1.0, nrm), err_msg=f"reward step {i}")
 
 
 def _oracle_kwargs(kw):

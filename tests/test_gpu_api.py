@@ -17,7 +17,7 @@ torch = pytest.importorskip("torch")
 def test_loaded_backend_is_the_hip_library():
     from pdecontrolgym_amd.backend import default_backend
     b = default_backend()
-    assert b.name == "hip-gfx950" and b.lib.pdegym_abi_version() == 7
+    assert b.name == "hip-gfx950" and b.lib.pdegym_abi_version() == 8
 
 
 @pytest.mark.parametrize("name", sorted(KAT_PUBLISHED))
@@ -52,6 +52,51 @@ def test_published_known_answers_closed_loop_on_gpu(golden_kat, name):
     np.testing.assert_allclose(total, pub_total, rtol=1e-5)
     np.testing.assert_allclose(l2, pub_l2, rtol=1e-5)
     np.testing.assert_array_equal(obs, g.last_obs)          # final state bit-identical to the reference's
+
+
+def test_docs_quickstart_is_bit_reproduced_on_gpu(golden_mixed):
+    """docs/source/guide/quickstart.rst:9-70 as written (float64 ``np.ones(nx)`` beta, ``normalize: None``, ``env.step(0)``
+    with a Python int) through the drop-in API: every observation equals the reference's, bit for bit."""
+    import pde_control_gym
+    from pde_control_gym.src import TunedReward1D
+    g = golden_mixed["Q_quick"]
+    T, dt, dx, X = 5, 1e-4, 1e-2, 1
+    params = {"T": T, "dt": dt, "X": X, "dx": dx, "reward_class": TunedReward1D(int(round(T / dt)), -1e-4, 1e2), "normalize": None,
+              "sensing_loc": "full", "control_type": "Dirchilet", "sensing_type": None, "sensing_noise_func": lambda state: state,
+              "limit_pde_state_size": True, "max_state_value": 1e10, "max_control_value": 20,
+              "reset_init_condition_func": lambda nx: g.init, "reset_recirculation_func": lambda nx: np.ones(nx),
+              "control_sample_rate": 0.1}
+    env = pde_control_gym.make("PDEControlGym-TransportPDE1D", **params)
+    obs, _ = env.reset()
+    np.testing.assert_array_equal(obs, g.obs[0])
+    terminate = truncate = False
+    total, k = 0.0, 0
+    while not truncate and not terminate:
+        obs, rewards, terminate, truncate, info = env.step(0)
+        total += rewards
+        k += 1
+        np.testing.assert_array_equal(obs, g.obs[k], err_msg=f"step {k}")
+        assert terminate == bool(g.terminate[k - 1]) and truncate == bool(g.truncate[k - 1])
+    np.testing.assert_allclose(total, float(np.sum(g.reward[:k])), rtol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["Q_p_b64_neu_py", "Q_t_b32_neu_np64_norm", "Q_p_b32_neu_py_norm", "Q_t_b64_py_norm"])
+def test_dropin_env_follows_the_type_of_the_control_argument(golden_mixed, case):
+    """The single-environment classes classify ``control`` like NumPy does (Python float = weak scalar, np.float64, float32
+    array) and keep the dtype of the plant parameter: bit-exact against the reference for each combination."""
+    import pde_control_gym
+    from pde_control_gym.src import TunedReward1D
+    from tests.cases import MIXED_CASES
+    kind, kw, action_as, _, _ = MIXED_CASES[case]
+    g = golden_mixed[case]
+    p = dict(kw, reward_class=TunedReward1D(int(g.reward_args[0]), g.reward_args[1], g.reward_args[2]),
+             sensing_noise_func=lambda s: s, reset_init_condition_func=lambda nx: g.init, reset_recirculation_func=lambda nx: g.beta)
+    env = pde_control_gym.make("PDEControlGym-ReactionDiffusionPDE1D" if kind == "parabolic" else "PDEControlGym-TransportPDE1D", **p)
+    obs, _ = env.reset()
+    conv = {"pyfloat": float, "npf64": np.float64, "f32arr": lambda a: np.array([a], dtype=np.float32), "pyint": int}[action_as]
+    for i, a in enumerate(g.actions):
+        obs, r, te, tr, _ = env.step(conv(a))
+        np.testing.assert_array_equal(np.asarray(obs).reshape(-1), g.obs[i + 1], err_msg=f"step {i}")
 
 
 def test_vecenv_gpu_autoreset_matches_single_envs():

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import pde_oracle as po
-from tests.cases import NS_BC, PARABOLIC_CASES, TRANSPORT_CASES, ns_bc_from_array
+from tests.cases import ACTION_KIND, MIXED_CASES, NS_BC, PARABOLIC_CASES, TRANSPORT_CASES, ns_bc_from_array
 
 
 def _oracle_kwargs(kw):
@@ -17,14 +17,15 @@ def _oracle_kwargs(kw):
                                "max_state_value")}
 
 
-def _run_1d(cls, kw, g, keep_history):
+def _run_1d(cls, kw, g, keep_history, action_kind="f32", force_f32=False):
     rw = po.TunedReward1DOracle(int(g.reward_args[0]), g.reward_args[1], g.reward_args[2])
     env = cls(reward=rw, keep_history=keep_history, **_oracle_kwargs(kw))
-    obs0 = env.reset(g.init[None, :], g.beta[None, :])
+    beta = g.beta.astype(np.float32) if force_f32 else g.beta
+    obs0 = env.reset(g.init[None, :], beta[None, :])
     np.testing.assert_array_equal(np.asarray(obs0, dtype=np.float32).reshape(-1), g.obs[0])
     for i, a in enumerate(g.actions):
         with np.errstate(all="ignore"):
-            obs, r, te, tr = env.step(np.array([a], dtype=np.float32))
+            obs, r, te, tr = env.step(np.array([a], dtype=g.actions.dtype), action_kind=action_kind)
         np.testing.assert_array_equal(env.row[0], g.rows[i], err_msg=f"row step {i}")
         np.testing.assert_array_equal(np.asarray(obs, dtype=np.float32).reshape(-1), g.obs[i + 1], err_msg=f"obs step {i}")
         assert int(env.time_index[0]) == int(g.time_index[i])
@@ -48,6 +49,29 @@ def test_parabolic_oracle_matches_reference(golden_parabolic, case, keep_history
     if case == "P1" and keep_history:
         pytest.skip("80 MB history; the streaming variant covers P1")
     _run_1d(po.ParabolicOracle, PARABOLIC_CASES[case], golden_parabolic[case], keep_history)
+
+
+@pytest.mark.parametrize("case", sorted(MIXED_CASES))
+def test_mixed_precision_oracle_matches_reference(golden_mixed, case):
+    """float64 beta and/or float64 / Python-scalar control inputs (the docs quickstart is 'Q_quick'): bit-exact."""
+    kind, kw, action_as, _, _ = MIXED_CASES[case]
+    g = golden_mixed[case]
+    assert str(g.action_as) == action_as
+    cls = po.ParabolicOracle if kind == "parabolic" else po.TransportOracle
+    _run_1d(cls, kw, g, False, action_kind=ACTION_KIND[action_as])
+
+
+def test_mixed_precision_goldens_differ_from_float32_arithmetic(golden_mixed):
+    """The fixtures are meaningful: casting beta and the control input to float32 first (what round 1 did) does NOT
+    reproduce them -- except where NumPy's rules make both routes identical (Dirichlet without normalize, float32 beta)."""
+    differ = 0
+    for case, (kind, kw, action_as, _, _) in MIXED_CASES.items():
+        cls = po.ParabolicOracle if kind == "parabolic" else po.TransportOracle
+        try:
+            _run_1d(cls, kw, golden_mixed[case], False, action_kind="f32", force_f32=True)
+        except AssertionError:
+            differ += 1
+    assert differ >= len(MIXED_CASES) - 2, differ
 
 
 def test_reward_edge_cases_present(golden_transport):

@@ -18,8 +18,10 @@ src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 DOM = {"parabolic_c2": "step1d_kernel", "transport_c3": "step1d_kernel", "burgers_c3": "step1d_kernel", "ns2d_c4": "ns_tile_step",
-       "ns2d_c5": "ns_slab_jacobi", "traffic_arz": "traffic_step_kernel",
+       "ns2d_c5": "ns_slab_jacobi", "ns2d_c4_f64": "ns_", "traffic_arz": "traffic_step_kernel",
        "brain_tumor": "tumor_step_kernel"}
+if os.path.exists(os.path.join(root, "tools", "dominant_kernels.json")):
+    DOM.update(json.load(open(os.path.join(root, "tools", "dominant_kernels.json"))))
 summary = {"tag": tag, "units": "bytes per launch of the dominant kernel", "workloads": {}}
 
 
@@ -38,7 +40,7 @@ for wl, ksub in DOM.items():
         shutil.copy(st, os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv"))
         for r in csv.DictReader(open(st)):
             if ksub in r["Name"]:
-                entry["kernel"] = r["Name"].split("(")[0][-60:]
+                entry["kernel"] = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-80:]
                 entry["calls"] = int(r["Calls"])
                 entry["avg_ns"] = float(r["AverageNs"])
                 entry["min_ns"] = float(r["MinNs"])
@@ -64,11 +66,30 @@ for wl, ksub in DOM.items():
         tr["hbm_bytes"] = tr["hbm_read_bytes"] + tr["hbm_write_bytes"]
     entry["traffic"] = tr
     summary["workloads"][wl] = entry
-for name, ksub in (("pmc_sq_parabolic_c2", "step1d_kernel"), ("pmc_sq_ns2d_c4", "ns_tile_step")):
-    f = os.path.join(src, name, "p_counter_collection.csv")
-    if os.path.exists(f):
-        avg, n = counter_avg(f, ksub)
-        summary.setdefault("sq_counters", {})[name] = {"per_launch_avg": avg, "launches": max(n.values()) if n else 0}
+# SQ counters of EVERY kernel of every workload (per-launch averages), so that each roofline fraction can be recomputed from
+# tracked files: valu_issue_frac = SQ_INSTS_VALU * 2 cycles / (1024 SIMDs * duration * clock)
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0][-80:]
+
+
+def counters_by_kernel(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        name = short(r["Kernel_Name"])
+        agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: dict({c: sum(v) / len(v) for c, v in d.items()}, launches=max(len(v) for v in d.values())) for k, d in agg.items()}
+
+
+for wl in DOM:
+    merged = {}
+    for grp in ("sq1", "sq2"):
+        f = os.path.join(src, f"pmc_{grp}_{wl}", "p_counter_collection.csv")
+        if os.path.exists(f):
+            for k, d in counters_by_kernel(f).items():
+                merged.setdefault(k, {}).update(d)
+    if merged:
+        summary.setdefault("sq_counters", {})[wl] = merged
 with open(os.path.join(dst, f"{tag}_summary.json"), "w") as fh:
     json.dump(summary, fh, indent=1)
 with open(os.path.join(dst, "traffic_latest.json"), "w") as fh:
