@@ -72,38 +72,50 @@ def one_case(rng, idx):
     shared = bool(rng.random() < 0.3)
     beta = (amp * rng.uniform(0, 1) * np.cos(rng.uniform(1, 8.5, (1 if shared else B, 1)) * np.arccos(x))).astype(np.float32)
     rargs = (nt - 1, float(rng.choice([-1e3, -1e-4])), float(rng.choice([3e2, 1e2])))
+    # reward evaluated in the kernel epilogue: TunedReward1D, or NormReward "temporal" with the 1 / 2 / inf norm
+    rkind = str(rng.choice(["tuned", "tuned", "tuned", "n1", "n2", "ninf"]))
+    rcode = {"tuned": N.REWARD_TUNED1D, "n1": N.REWARD_NORM_L1, "n2": N.REWARD_NORM_L2, "ninf": N.REWARD_NORM_LINF}[rkind]
+    mk_reward = (lambda: po.TunedReward1DOracle(*rargs)) if rkind == "tuned" else \
+        (lambda: po.NormRewardOracle(rargs[0], {"n1": "1", "n2": "2", "ninf": "inf"}[rkind], rargs[1], rargs[2]))
+    # the reference's mixed-precision modes: float64 plant parameter, float64 / Python-scalar control input
+    beta64 = bool(rng.random() < 0.2)
+    akind = str(rng.choice(["f32", "f32", "f32", "f64", "weak"]))
+    acode = {"f32": N.ACTION_F32, "f64": N.ACTION_F64, "weak": N.ACTION_WEAK}[akind]
+    if beta64:
+        beta = amp * rng.uniform(0, 1) * np.cos(rng.uniform(1, 8.5, (1 if shared else B, 1)) * np.arccos(x))
     hist = bool(rng.random() < 0.25)
     auto = bool(rng.random() < 0.35)          # fused VecEnv auto-reset from a pool of initial rows
     ocls = {"parabolic": po.ParabolicOracle, "transport": po.TransportOracle, "burgers": po.BurgersOracle}[kind]
     okw = {k: kw[k] for k in ("T", "dt", "X", "dx", "control_sample_rate", "control_type", "sensing_loc", "sensing_type", "normalize",
                               "max_control_value", "limit_pde_state_size", "max_state_value")}
     pool = (rng.uniform(0.1, 3, (B, 1)) * np.ones((1, n))).astype(np.float32)
-    desc = f"#{idx} auto={auto} {kind} nx={nx} S={S} nt={nt} B={B} {ctrl} {sloc}/{kw['sensing_type']} norm={normalize} limit={limit}/{max_state} ic={style} hist={hist} shared_beta={shared}"
+    desc = f"#{idx} reward={rkind} beta64={beta64} act={akind} auto={auto} {kind} nx={nx} S={S} nt={nt} B={B} {ctrl} {sloc}/{kw['sensing_type']} norm={normalize} limit={limit}/{max_state} ic={style} hist={hist} shared_beta={shared}"
     try:
-        orc = ocls(reward=po.TunedReward1DOracle(*rargs), keep_history=True, **okw)
+        orc = ocls(reward=mk_reward(), keep_history=True, **okw)
     except Exception as ex:      # invalid option combination: the product must refuse it too
         try:
-            PDEBatch1D(base, reward=RewardSpec(N.REWARD_TUNED1D, *rargs), num_envs=B, device="cuda", flux=flux, **kw)
+            PDEBatch1D(base, reward=RewardSpec(rcode, *rargs), num_envs=B, device="cuda", flux=flux, **kw)
         except Exception:
             return desc + " (both refuse)"
         raise AssertionError(desc + f": oracle refuses ({ex}) but the engine accepts")
-    env = PDEBatch1D(base, reward=RewardSpec(N.REWARD_TUNED1D, *rargs), num_envs=B, device="cuda", record_history=hist, flux=flux, **kw)
+    env = PDEBatch1D(base, reward=RewardSpec(rcode, *rargs), num_envs=B, device="cuda", record_history=hist, flux=flux, **kw)
     bfull = np.tile(beta, (B, 1)) if shared else beta
     o_ref = orc.reset(init, bfull)
     o_gpu = env.reset(torch.tensor(init), torch.tensor(beta[0] if shared else beta))
     assert np.array_equal(o_gpu.cpu().numpy().reshape(B, -1), np.asarray(o_ref, dtype=np.float32).reshape(B, -1)), desc + " reset obs"
     if auto:
         env.enable_auto_reset(torch.tensor(pool), keep_final_obs=True)
-        fresh = ocls(reward=po.TunedReward1DOracle(*rargs), keep_history=True, **okw)
+        fresh = ocls(reward=mk_reward(), keep_history=True, **okw)
         fresh_obs = np.asarray(fresh.reset(pool, bfull), dtype=np.float32).reshape(B, -1)
     for i in range(nsteps + 1):
-        a = rng.uniform(-1, 1, B).astype(np.float32) * float(rng.choice([1.0, 0.0, 10.0]))
+        a = rng.uniform(-1, 1, B) * float(rng.choice([1.0, 0.0, 10.0]))
+        a = a.astype(np.float32) if akind == "f32" else a
         try:
             with np.errstate(all="ignore"):
-                o_ref, r_ref, te_ref, tr_ref = orc.step(a)
+                o_ref, r_ref, te_ref, tr_ref = orc.step(a, action_kind=akind)
         except IndexError:
             return desc + " (reference look-back raises: skipped)"
-        o_gpu, r_gpu, te_gpu, tr_gpu = env.step(torch.tensor(a))
+        o_gpu, r_gpu, te_gpu, tr_gpu = env.step(torch.tensor(a), action_kind=acode)
         og = o_gpu.cpu().numpy().reshape(B, -1)
         orf = np.asarray(o_ref, dtype=np.float32).reshape(B, -1)
         if auto:

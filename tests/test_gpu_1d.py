@@ -223,6 +223,55 @@ def test_burgers_extension_matches_own_restatement(nx, S, B, ctrl):
         np.testing.assert_array_equal(env.t["history"].cpu().numpy(), orc.hist)
 
 
+@pytest.mark.parametrize("norm", ["1", "2", "inf"])
+@pytest.mark.parametrize("kind,nx,beta64", [("parabolic", 256, False), ("transport", 100, False), ("transport", 2100, False),
+                                            ("parabolic", 2500, False), ("parabolic", 200, True), ("transport", 64, True)])
+def test_norm_reward_epilogues_match_oracle(kind, nx, beta64, norm):
+    """PDEGYM_REWARD_NORM_L1 / L2 / LINF ("temporal" NormReward, parity unpinned: the reference class raises) through the
+    register-resident kernel (n <= 2048), the wide LDS kernel (n > 2048) and the mixed-precision kernel (float64 beta) against
+    NormRewardOracle: -||u_t|| per step, the truncation penalty and the terminal reward.  rtol 1e-6 (reduction order)."""
+    from oracle import pde_oracle as po
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
+    rng = np.random.default_rng(nx + int(beta64))
+    S, nsteps, B = 10, 5, 6
+    dx = 1.0 / nx
+    dt = 0.25 * dx * dx if kind == "parabolic" else 0.5 * dx
+    kw = dict(T=nsteps * S * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type="Dirchilet", sensing_loc="full",
+              sensing_type=None, normalize=False, max_control_value=20, limit_pde_state_size=True, max_state_value=1e10)
+    n = nx + (1 if kind == "parabolic" else 0)
+    x = np.linspace(0, 1, n)
+    beta = (5 * np.cos(rng.uniform(7, 8, (B, 1)) * np.arccos(x)))
+    beta = beta if beta64 else beta.astype(np.float32)
+    init = (rng.uniform(2, 10, (B, 1)) * (1 + 0.3 * np.sin(2 * np.pi * x * rng.uniform(0.5, 3, (B, 1))))).astype(np.float32)
+    init[3] = -init[3]
+    # instance 0 stays above max_state_value, the others well below -> the truncation branch is taken by instance 0 only
+    rargs = (int(round(kw["T"] / dt)), -2.5, 77.0)
+    code = {"1": N.REWARD_NORM_L1, "2": N.REWARD_NORM_L2, "inf": N.REWARD_NORM_LINF}[norm]
+    l2_0 = float(np.linalg.norm(init[0]))
+    kw["max_state_value"] = 0.5 * l2_0
+    init[1:] *= np.float32(0.2 * l2_0 / np.max(np.linalg.norm(init[1:], axis=1)))
+    orc = (po.ParabolicOracle if kind == "parabolic" else po.TransportOracle)(
+        reward=po.NormRewardOracle(rargs[0], norm, rargs[1], rargs[2]), keep_history=False, **_oracle_kwargs(kw))
+    env = PDEBatch1D(kind, reward=RewardSpec(code, *rargs), num_envs=B, device="cuda", **kw)
+    orc.reset(init, beta)
+    env.reset(torch.tensor(init), torch.tensor(beta))
+    saw_trunc = saw_term = False
+    for i in range(nsteps):
+        a = rng.uniform(-1, 1, B).astype(np.float32)
+        with np.errstate(all="ignore"):
+            o_ref, r_ref, te_ref, tr_ref = orc.step(a)
+        o, r, te, tr = env.step(torch.tensor(a))
+        np.testing.assert_array_equal(env.u.cpu().numpy(), orc.row, err_msg=f"step {i}")
+        np.testing.assert_array_equal(te.cpu().numpy().astype(bool), te_ref)
+        np.testing.assert_array_equal(tr.cpu().numpy().astype(bool), tr_ref)
+        np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-6, err_msg=f"step {i}")
+        saw_trunc |= bool((tr_ref & ~te_ref).any())
+        saw_term |= bool(te_ref.any())
+        assert (r_ref[~te_ref & ~tr_ref] < 0).all()
+    assert saw_trunc and saw_term
+
+
 def test_history_recording_matches_oracle():
     from oracle import pde_oracle as po
     kw = dict(PARABOLIC_CASES["P2_s1"])
@@ -280,7 +329,8 @@ def test_masked_reset_and_shared_beta():
 def test_baseline_size_properties_c2():
     """BASELINE config 2 (nx=256, B=4096, S=100): properties that need no oracle at full size:
     (1) batch invariance -- duplicated instances give identical rows; (2) u(0,t) == 0 and the boundary
-    node equals the action; (3) linearity of the (linear) plant in the state for zero action."""
+    node equals the action; (3) linearity of the (linear) plant in the state for zero action; plus 64 sampled instances
+    bit-identical to the oracle (rows) / rtol 1e-6 (rewards)."""
     from pdecontrolgym_amd import _native as N
     B, n = 4096, 257
     dx = 1.0 / 256
@@ -288,6 +338,7 @@ def test_baseline_size_properties_c2():
     kw = dict(T=1000 * 100 * dt, dt=dt, X=1, dx=dx, control_sample_rate=100 * dt, control_type="Dirchilet",
               sensing_loc="full", sensing_type=None, normalize=False, max_control_value=20,
               limit_pde_state_size=True, max_state_value=1e10)
+    from oracle import pde_oracle as po
     env = _mk("parabolic", kw, (100000, -1e3, 3e2), B)
     g = torch.Generator(device="cpu").manual_seed(7)
     x = torch.linspace(0, 1, n)
@@ -297,10 +348,17 @@ def test_baseline_size_properties_c2():
     init = (torch.rand(B // 2, 1, generator=g) * 9 + 1) * torch.ones(1, n)
     init = torch.cat([init, init]).float()
     env.reset(init, beta)
+    # 64 instances spread over the batch also run on the oracle: rows bit-identical, rewards rtol 1e-6, at the FULL batch size
+    sel = torch.arange(0, B, B // 64)
+    orc = po.ParabolicOracle(reward=po.TunedReward1DOracle(100000, -1e3, 3e2), keep_history=False, **_oracle_kwargs(kw))
+    orc.reset(init[sel].numpy(), beta[sel].numpy())
     for _ in range(3):
         a = torch.rand(B // 2, generator=g) * 2 - 1
         a = torch.cat([a, a])
-        env.step(a)
+        _, r, _, _ = env.step(a)
+        _, r_ref, _, _ = orc.step(a[sel].numpy())
+        np.testing.assert_array_equal(env.u.cpu()[sel].numpy(), orc.row)
+        np.testing.assert_allclose(r.cpu()[sel].numpy(), r_ref, rtol=1e-6, atol=2e-6 * float(np.max(orc.norm_now)))
     u = env.u.cpu()
     assert torch.equal(u[: B // 2], u[B // 2:])
     assert torch.all(u[:, 0] == 0) and torch.equal(u[:, -1], a)

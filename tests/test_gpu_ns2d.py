@@ -153,6 +153,67 @@ def test_ns_f32_single_step_vs_f64_oracle(n, B, K, bc):
         u0, v0, p0 = o_ref[..., 0], o_ref[..., 1], orc.p
 
 
+def test_ns_f32_horizon_vs_f64_oracle_c4():
+    """STATED float32 HORIZON: BASELINE config 4 (128x128, K=50, lid-driven boundary set of NS2Dppo.py:21-26),
+    smooth and constant initial fields, random lid actions U(2,4): over a 100-step episode the float32 throughput kernels stay
+    within 1e-5 * max|U| of the float64 oracle in the velocity field (measured 2e-6, tools/ns_f32_horizon.py) and within
+    5e-5 * max|p| in the pressure (measured 1e-6 .. 7e-6); rewards rtol 1e-5.  The flow is dissipative (nu = 0.1), the Jacobi
+    solve is a contraction: rounding errors do not accumulate, the bound is flat in the number of steps."""
+    from oracle import pde_oracle as po
+    n, B, K, steps = 128, 2, 50, 100
+    rng = np.random.default_rng(5)
+    dx = 1.0 / (n - 1)
+    dt = 0.2 * 0.5 * dx * dx / 0.1
+    nt = steps + 2
+    xs = np.linspace(0, 1, n)
+    Xg, Yg = np.meshgrid(xs, xs)
+    u0 = np.stack([np.sin(2 * np.pi * Xg) * np.cos(np.pi * Yg) * 1.5 + 0.3, -3.7 * np.ones((n, n))]).astype(np.float32)
+    v0 = np.stack([np.cos(np.pi * Xg) * np.sin(2 * np.pi * Yg) * 0.8 - 0.5, 2.2 * np.ones((n, n))]).astype(np.float32)
+    p0 = np.zeros((B, n, n), dtype=np.float32)
+    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=NS_BC, U_ref=np.zeros((nt, n, n, 2)),
+              action_ref=2.0 * np.ones(nt), gamma=0.1, maximum_pressure_iteration=K)
+    orc = po.NavierStokesOracle(**kw)
+    env = _mk(kw, B, torch.float32)
+    orc.reset(u0.astype(np.float64), v0.astype(np.float64), p0.astype(np.float64))
+    env.reset(u0, v0, p0)
+    worst_u = worst_p = 0.0
+    for t in range(steps):
+        a = rng.uniform(2, 4, B).astype(np.float32)
+        o_ref, r_ref, _, _ = orc.step(a.astype(np.float64))
+        obs, r, te = env.step(a)
+        if t % 10 == 9 or t < 3:
+            o = obs.cpu().numpy().astype(np.float64)
+            worst_u = max(worst_u, float(np.abs(o - o_ref).max() / np.abs(o_ref).max()))
+            worst_p = max(worst_p, float(np.abs(env.p.cpu().numpy() - orc.p).max() / np.abs(orc.p).max()))
+            np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-5)
+    assert worst_u < 1e-5 and worst_p < 5e-5, (worst_u, worst_p)
+
+
+@pytest.mark.parametrize("n,steps", [(64, 300), (128, 400), (256, 60)])
+def test_ns_f32_long_horizon_vs_f64_kernels(n, steps):
+    """Same bound over longer episodes and the other register-tiled grid sizes, against the float64 HIP kernels (which the
+    tests above pin bit-exactly to the oracle): max|U32 - U64| <= 1e-5 * max|U64| at every checkpoint."""
+    B, K = 4, 50
+    rng = np.random.default_rng(n)
+    dx = 1.0 / (n - 1)
+    dt = 0.2 * 0.5 * dx * dx / 0.1
+    nt = steps + 2
+    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=NS_BC, U_ref=np.zeros((nt, n, n, 2)),
+              action_ref=2.0 * np.ones(nt), gamma=0.1, maximum_pressure_iteration=K)
+    e64, e32 = _mk(kw, B, torch.float64), _mk(kw, B, torch.float32)
+    c = rng.uniform(-5, 5, (3, B, 1, 1)).astype(np.float32)
+    ic = [np.broadcast_to(c[k], (B, n, n)).copy() for k in range(3)]
+    e64.reset(*[x.astype(np.float64) for x in ic])
+    e32.reset(*ic)
+    for t in range(steps):
+        a = rng.uniform(2, 4, B).astype(np.float32)
+        o64, _, _ = e64.step(a.astype(np.float64))
+        o32, _, _ = e32.step(a)
+        if t % 20 == 19:
+            err = float((o32.double() - o64).abs().max() / o64.abs().max())
+            assert err < 1e-5, (t, err)
+
+
 def test_solve_pressure_public_api_f64():
     """env.solve_pressure on arbitrary fields (examples/NavierStokes/NS2Doptimization.py:97)."""
     from oracle import pde_oracle as po
