@@ -261,7 +261,7 @@ class TrafficARZ:
     def prepare(self, total_steps):
         import torch
         a = (torch.rand(total_steps, self.B, 1, generator=self.gen, dtype=torch.float64) * 0.4 + 0.8) * self.qs.reshape(1, -1, 1)
-        self.actions = torch.cat([a, torch.zeros_like(a)], dim=2).to(self.device).contiguous()
+        self.actions = a.to(self.device).contiguous()          # [T, B, 1]: one outlet command per freeway, used in place
         self.env.reset(self.rs)
         self.i = 0
 

@@ -125,6 +125,14 @@ typedef struct pdegym_bufs1d {
                                time_index := 0) and obs[b] is the first observation of the new episode            */
   float* final_obs;         /* optional [B, obs_dim]: last observation of the finished episode (written only for
                                instances that were auto-reset in this call; SB3's "terminal_observation")          */
+  /* The reference redraws BOTH the initial condition and beta at every reset (hyperbolic.py:207-209).  With a pool of
+   * reset_pool_rows >= B rows, the k-th restart of instance b takes pool row (b + k*B) mod reset_pool_rows, so consecutive
+   * episodes of one instance start from different rows without any host work; reset_pool_rows == 0 means B (row b always). */
+  const void* reset_beta;   /* optional [reset_pool_rows, n] (same element type as beta): on an auto-reset beta[b] := the pool row
+                               (needs beta_stride != 0, i.e. per-instance beta, and a writable beta buffer)        */
+  int32_t* reset_count;     /* optional [B] in/out: restarts of each instance so far (k above); NULL = always row b  */
+  int32_t reset_pool_rows;  /* rows of reset_init / reset_beta (0 = B)                                            */
+  int32_t reserved_;
 } pdegym_bufs1d;
 
 int pdegym_abi_version(void);
@@ -220,7 +228,7 @@ typedef struct pdegym_params_traffic {
 typedef struct pdegym_bufs_traffic {
   double* r;               /* [B, M] density (in/out)                                                       */
   double* y;               /* [B, M] relative flow y = r (v - Veq(r)) (in/out)                              */
-  const double* action;    /* [B, 2] inlet / outlet flux command; column 1 is used by 'both' only           */
+  const double* action;    /* [B, action_stride] inlet / outlet flux command; column 1 is used by 'both' only */
   double* time;            /* [B] simulated seconds ("time_index" of the reference) in/out                  */
   const double* rs;        /* [B] steady-state density of each instance (vs, qs follow the equilibrium law) */
   const double* qs_clip;   /* [B] qs the action bounds [0.8 qs, 1.2 qs] were built from (:97-100)           */
@@ -228,6 +236,9 @@ typedef struct pdegym_bufs_traffic {
   double* reward;          /* [B] out                                                                       */
   uint8_t* done;           /* [B] out: terminate() or reward > -0.00023 (:230)                              */
   uint8_t* truncated;      /* [B] out                                                                       */
+  int32_t action_stride;   /* elements between the commands of consecutive instances: 2 (or 0 = 2), or 1 for the
+                              single-command simulation types (the caller's [B] / [B,1] tensor is used as it is)      */
+  int32_t reserved_;
 } pdegym_bufs_traffic;
 
 int pdegym_traffic_step(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf, int32_t B, void* stream);

@@ -37,6 +37,17 @@ class DeviceRollout:
     def _body(self):
         import torch
         core = self.venv.core
+        own = {k: core.t[k] for k in ("reward", "terminated", "truncated")} if self._direct else {}
+        try:
+            self._steps(core, torch)
+        finally:
+            # the step kernel was pointed at slot t of the rollout buffers; hand the engine its own output tensors back so
+            # that a later plain env.step() cannot overwrite rewards[T-1] / terminated[T-1] / truncated[T-1]
+            # (graph-safe: only Python references change)
+            for k, v in own.items():
+                core.t[k] = v
+
+    def _steps(self, core, torch):
         for t in range(self.T):
             with torch.no_grad():
                 a = self.policy(self.obs[t]).reshape(core.num_envs).clamp(self.lo, self.hi)
@@ -64,7 +75,9 @@ class DeviceRollout:
             torch.cuda.synchronize()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            keys = ("u", "time_index", "bsum", "ring") if self._direct else [k for k, v in core.t.items() if torch.is_tensor(v)]
+            # everything a step mutates in place (the fused auto-reset advances reset_count and may redraw beta rows)
+            keys = [k for k in ("u", "time_index", "bsum", "ring", "reset_count", "beta") if torch.is_tensor(core.t.get(k))] \
+                if self._direct else [k for k, v in core.t.items() if torch.is_tensor(v)]
             snapshot = {k: core.t[k].clone() for k in keys}
             extra = {k: getattr(self.venv, k).clone() for k in ("_consecutive", "treatment_calls", "soft_constraint_violations")
                      if torch.is_tensor(getattr(self.venv, k, None))}

@@ -199,91 +199,95 @@ class BrainTumor1D(PDEEnv1D):
 
 
 class TherapyWrapper(Wrapper):
-    """Hides the Growth and Post-Therapy stages: ``reset`` runs the growth stage, ``step`` applies one treatment day
-    (plus forced two-day breaks after five consecutive treatment days if ``weekends``), and once therapy is over one
-    ``step`` simulates until death or the time limit (reference brain_tumor_env.py:385-505)."""
+    """Shows an agent only the treatment days of a ``BrainTumor1D`` episode (behaviour of the reference's wrapper,
+    brain_tumor_env.py:385-505; the implementation is this repository's).
+
+    An episode is three stretches of simulated days.  The two untreated ones -- growth up to detection, and post-therapy
+    up to death or the time limit -- never need the agent, so the wrapper *coasts* through them: ``reset`` coasts through
+    growth, the first ``step`` after the dose budget is spent coasts to the end of the episode, and ``benchmark`` coasts
+    through a whole untreated episode to obtain the survival baseline.  A coast is ONE kernel launch
+    (``BrainTumor1D.run_days``: the day loop, the stage machine and the history stay on the GPU); day-by-day ``step(0)``
+    calls are used only when per-day printing is wanted or ``fused_loops=False``.
+
+    ``weekends``: after ``WORK_DAYS`` consecutive treated days (``control > 0``) the patient rests ``REST_DAYS`` untreated
+    days whose results the agent never sees.
+    """
+
+    WORK_DAYS, REST_DAYS = 5, 2
 
     def __init__(self, env: BrainTumor1D, weekends=False, verbose=True, fused_loops=True):
         super().__init__(env)
-        self.verbose, self.weekends = verbose, weekends
-        self.fused_loops = fused_loops
-        self.treatment_calls = 0
-        self.soft_constraint_violations = 0
-        self.consecutive_treatment_days = 0
+        self.verbose, self.weekends, self.fused_loops = verbose, weekends, fused_loops
+        self.treatment_calls = 0                  # agent-visible steps so far
+        self.soft_constraint_violations = 0       # ... of which drew a toxicity penalty
+        self.consecutive_treatment_days = 0       # current run of treated days (weekend rule)
 
-    def _fused(self, base):
-        """The untreated stretches run inside one launch unless somebody wants the per-day prints."""
-        return self.fused_loops and not self.verbose and not getattr(base, "verbose", False) and hasattr(base, "run_days")
-
-    def reset(self, seed: Optional[int] = None, options: Optional[dict] = None):
+    # ---- coasting ---------------------------------------------------------------------------------------------------
+    def _say(self, msg):
         if self.verbose:
-            print("Wrapper: Reset environment")
+            print(f"[therapy wrapper] {msg}")
+
+    def _in_kernel(self):
+        base = self.env.unwrapped
+        return self.fused_loops and not (self.verbose or getattr(base, "verbose", False)) and hasattr(base, "run_days")
+
+    def _coast(self, stretch):
+        """Untreated days until the stretch is over.  ``stretch``: "growth" (while the stage is Growth), "post" / "to_end"
+        (until terminated or truncated).  Returns the last simulated day's 5-tuple, or None if no day was simulated."""
+        base = self.env.unwrapped
+        last = base.run_days(stretch) if self._in_kernel() else None
+        over = (lambda: base.stage != "Growth") if stretch == "growth" else (lambda: False)
+        while not over() and not (last is not None and (last[2] or last[3])):
+            last = self.env.step(0)
+            if last is None:        # stepping a finished episode: the reference fails unpacking the None its step() returns
+                raise TypeError("cannot unpack non-iterable NoneType object (the episode is over: call reset())")
+        return last
+
+    # ---- gym interface ----------------------------------------------------------------------------------------------
+    def reset(self, seed: Optional[int] = None, options: Optional[dict] = None):
+        """Reset the patient and coast through the growth stage; the returned observation is the day of detection."""
         self.consecutive_treatment_days = 0
         obs, info = self.env.reset()
-        if self.verbose:
-            print("Wrapper: Start Growth Stage")
-        base = self.env.unwrapped
-        if self._fused(base) and base.stage == "Growth":
-            obs, _, terminated, truncated, info = base.run_days("growth")       # the loop below in one kernel launch
-        while self.env.unwrapped.stage == "Growth":
-            obs, _, terminated, truncated, info = self.env.step(0)
-            if terminated or truncated:
-                break
-        if self.verbose:
-            print("Wrapper: End Growth Stage\n")
+        self._say("reset; coasting through the growth stage")
+        day = self._coast("growth")
+        if day is not None:
+            obs, info = day[0], day[4]
+        self._say(f"tumour detected after {self.env.unwrapped.growthDays} days")
         return obs, info
 
     def step(self, control: float):
-        if self.env.unwrapped.stage == "Post-Therapy":
-            if self.verbose:
-                print("Wrapper: Post-Therapy step()")
-            terminated, truncated = False, False
-            base = self.env.unwrapped
-            if self._fused(base):
-                obs, reward, terminated, truncated, info = base.run_days("post")
-            while not (terminated or truncated):
-                obs, reward, terminated, truncated, info = self.env.step(0)
-            if self.verbose:
-                print(f"[Episode Reward] {reward}\n")
-                print(f"Soft constraint violation rate: {(self.soft_constraint_violations / self.treatment_calls) * 100}%")
-            return obs, reward, terminated, truncated, info
-        if self.verbose:
-            print("Wrapper: Therapy step()")
-        obs, reward, terminated, truncated, info = self.env.step(control)
+        """One treatment day with dose fraction ``control`` -- or, once therapy is over, the rest of the episode."""
+        base = self.env.unwrapped
+        if base.stage == "Post-Therapy":
+            day = self._coast("post")
+            rate = 100.0 * self.soft_constraint_violations / max(self.treatment_calls, 1)
+            self._say(f"episode over, reward {day[1]}; {rate:.1f}% of the treatment days were toxic")
+            return day
+        day = self.env.step(control)
+        reward, ended = day[1], bool(day[2] or day[3])
         self.treatment_calls += 1
-        if reward < 0.0:
-            self.soft_constraint_violations += 1
+        self.soft_constraint_violations += int(reward < 0.0)
         if self.weekends:
-            if control > 0:
-                self.consecutive_treatment_days += 1
-            else:
+            self.consecutive_treatment_days = self.consecutive_treatment_days + 1 if control > 0 else 0
+            if self.consecutive_treatment_days >= self.WORK_DAYS:
                 self.consecutive_treatment_days = 0
-        if self.weekends and self.consecutive_treatment_days >= 5:
-            self.consecutive_treatment_days = 0
-            if self.verbose:
-                print("Wrapper: Force weekend")
-            for _ in range(2):
-                _ = self.env.step(0)
-                if terminated or truncated:      # flags of the treatment step, as in the reference (:476-479)
-                    return obs, reward, terminated, truncated, info
-        if self.verbose:
-            print(f"[Therapy Reward] {reward}\n")
-        return obs, reward, terminated, truncated, info
+                # an episode that ended on the treatment day still receives ONE (ineffective) rest call in the reference
+                # (:476-479 test the treatment day's flags after the first rest call); kept so that call counts agree
+                rest = 1 if ended else self.REST_DAYS
+                self._say(f"weekend: {rest} rest day(s)")
+                for _ in range(rest):
+                    self.env.step(0)
+        self._say(f"treatment day reward {reward}")
+        return day
 
     def benchmark(self):
-        """Open-loop episode without treatment; stores the survival days as ``t_benchmark`` and resets."""
-        obs, info = self.env.reset()
-        if self.verbose:
-            print("Wrapper: Benchmark (episode run with no action and no reward):")
-        terminated = truncated = False
+        """Survival (in simulated days) of the untreated patient; stored on the environment as ``t_benchmark`` -- the
+        baseline of the episode reward -- and returned.  Call once before training or evaluation."""
         base = self.env.unwrapped
-        if self._fused(base):
-            obs, _, terminated, truncated, info = base.run_days("to_end")
-        while not (terminated or truncated):
-            obs, _, terminated, truncated, info = self.env.step(0)
-        t_benchmark = self.env.unwrapped.simulationDays
-        self.env.unwrapped.t_benchmark = t_benchmark
-        if self.verbose:
-            print(f"Set t_benchmark = {t_benchmark}\n\n\n")
-        obs, info = self.env.reset()
-        return t_benchmark
+        self.env.reset()
+        self._say("benchmark: one untreated episode")
+        self._coast("to_end")
+        base.t_benchmark = base.simulationDays
+        self._say(f"t_benchmark = {base.t_benchmark} days")
+        self.env.reset()
+        return base.t_benchmark

@@ -14,30 +14,41 @@ from pde_control_gym.src.rewards.base_reward import BaseReward
 
 
 class BrainTumorReward(BaseReward):
-    LAMBDA_TOXIC = 50
+    """Dispatches on what the caller knows: no baseline yet -> 0; episode over -> survival gain; otherwise (a treatment
+    day) -> toxicity penalty of the dose just applied.  Same values as the reference's single ``reward`` body."""
+
+    LAMBDA_TOXIC = 50            # weight of the toxicity penalty
+    SAFE_DOSE_COEFF, SAFE_DOSE_EXPONENT = 116, -0.685
+
+    @classmethod
+    def dmaxsafe(cls, treatment_radius):
+        """Largest dose (Gy) considered safe for a treated region of this radius (mm)."""
+        return cls.SAFE_DOSE_COEFF * (treatment_radius ** cls.SAFE_DOSE_EXPONENT)
 
     @staticmethod
-    def dmaxsafe(treatment_radius):
-        return 116 * (treatment_radius ** -0.685)
+    def survival_gain(time_index, t_benchmark):
+        return time_index - t_benchmark
+
+    @classmethod
+    def toxicity(cls, treatment_radius, applied_dosage, total_dosage):
+        """Fraction in [0, 1] of the way from the safe dose to the whole prescription, cube-rooted."""
+        safe = cls.dmaxsafe(treatment_radius)
+        excess = (applied_dosage - safe) / (total_dosage - safe)
+        return min(max(excess, 0.0), 1.0) ** (1 / 3)
 
     def reward(self, uVec: np.ndarray = None, time_index: int = None, terminate: Optional[bool] = None,
                truncate: Optional[bool] = None, action: Optional[float] = None, verbose=True, **kwargs):
+        """Keywords: ``t_benchmark`` always; ``treatment_radius``, ``applied_dosage``, ``total_dosage`` on treatment days."""
         t_benchmark = kwargs["t_benchmark"]
         if t_benchmark is None:
-            if verbose:
-                print("Warning: t_benchmark is not yet set -> returned reward of 0\n")
-            return 0
-        if terminate or truncate:
-            if verbose:
-                print(f"Reward Class: time_index - t_benchmark = {time_index} - {t_benchmark}")
-            return time_index - t_benchmark
-        treatment_radius, applied_dosage = kwargs["treatment_radius"], kwargs["applied_dosage"]
-        total_dosage = kwargs["total_dosage"]
-        maxsafe = self.dmaxsafe(treatment_radius)
-        ratio = (applied_dosage - maxsafe) / (total_dosage - maxsafe)
-        r_toxic = (min(max(ratio, 0.0), 1.0)) ** (1 / 3)
+            value, why = 0, "no t_benchmark yet (run TherapyWrapper.benchmark() first)"
+        elif terminate or truncate:
+            value, why = self.survival_gain(time_index, t_benchmark), f"survival gain {time_index} - {t_benchmark}"
+        else:
+            tox = self.toxicity(kwargs["treatment_radius"], kwargs["applied_dosage"], kwargs["total_dosage"])
+            value = - self.LAMBDA_TOXIC * tox
+            why = (f"toxicity {tox:.4f} (radius {kwargs['treatment_radius']}, dose {kwargs['applied_dosage']}, "
+                   f"safe {self.dmaxsafe(kwargs['treatment_radius'])})")
         if verbose:
-            print(f"Reward Class: - l_t*r_toxic = {- self.LAMBDA_TOXIC * r_toxic}")
-            print(f"\tParams: treatment_radius={treatment_radius} applied_dosage={applied_dosage} "
-                  f"dmaxsafe(treatment_radius)={maxsafe}")
-        return - self.LAMBDA_TOXIC * r_toxic
+            print(f"[brain tumour reward] {value}: {why}")
+        return value

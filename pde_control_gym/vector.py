@@ -61,6 +61,7 @@ class PDEVecEnv:
         from pdecontrolgym_amd.batch1d import PDEBatch1D
         from pde_control_gym.src.environments1d.base_env_1d import reward_spec_for
         self.sensing_noise_func = kw.get("sensing_noise_func", None)
+        self._beta_dtype = kw.get("beta_dtype", None)
         self.reset_init_condition_func = kw.get("reset_init_condition_func")
         self.reset_recirculation_func = kw.get("reset_recirculation_func")
         spec = reward_spec_for(self.reward_class)
@@ -136,11 +137,16 @@ class PDEVecEnv:
             init, beta = self.batched_reset_func(idx, self.nx)
             return init, beta
         init = np.zeros((len(idx), n), dtype=np.float32)
-        beta = np.zeros((len(idx), n), dtype=np.float32)
+        beta = None
         try:
             for k in range(len(idx)):
                 init[k] = self.reset_init_condition_func(self.nx)
-                beta[k] = self.reset_recirculation_func(self.nx)
+                b = np.asarray(self.reset_recirculation_func(self.nx))
+                if beta is None:      # the dtype the callback returns selects the arithmetic, as in the reference (float64 ->
+                    # mixed-precision kernel); pass ``beta_dtype="float32"`` to make_vec to force the float32 kernels
+                    dt = np.float32 if (b.dtype in (np.float32, np.float16) or self._beta_dtype == "float32") else np.float64
+                    beta = np.zeros((len(idx), n), dtype=dt)
+                beta[k] = b
         except:  # noqa: E722 - reference hyperbolic.py:207-213
             raise Exception(_RESET_ERR)
         return init, beta
@@ -175,21 +181,45 @@ class PDEVecEnv:
         init, beta = self._sample_1d(idx)
         return self.core.reset(init, beta)
 
-    def enable_fused_auto_reset(self, init_pool=None):
-        """1D only: finished instances restart from ``init_pool[b]`` inside the step kernel (no host sync).
-        The pool defaults to one fresh draw of the reset callbacks; refresh it with ``refresh_pool()``."""
+    def enable_fused_auto_reset(self, init_pool=None, beta_pool=None, pool_episodes: int = 4):
+        """1D only: finished instances restart inside the step kernel (no host sync).  The reference calls BOTH reset
+        callbacks at every reset (hyperbolic.py:207-209); here they are drawn ahead of time into pools of
+        ``pool_episodes * num_envs`` rows (initial condition AND beta), and the k-th restart of instance b takes row
+        (b + k*num_envs) mod rows.  Call ``refresh_pool()`` (any time between steps) to draw fresh rows; pass explicit
+        ``init_pool`` / ``beta_pool`` tensors [P >= num_envs, n] to control them (``beta_pool=False`` keeps beta fixed)."""
         if self.kind == "ns2d":
-            raise NotImplementedError("fused auto-reset is implemented for the 1D environments")
+            return self._enable_fused_auto_reset_ns(init_pool)
+        if self.kind == "traffic":
+            raise NotImplementedError("fused auto-reset is implemented for the transport / reaction-diffusion / NS environments")
         if init_pool is None:
-            init_pool, _ = self._sample_1d(np.arange(self.num_envs))
-        self.core.enable_auto_reset(init_pool)
+            init_pool, drawn_beta = self._sample_1d(np.arange(self.num_envs * max(1, int(pool_episodes))))
+            if beta_pool is None:
+                beta_pool = drawn_beta
+        if beta_pool is False:
+            beta_pool = None
+        self.core.enable_auto_reset(init_pool, beta_pool=beta_pool)
         self._fused_reset = True
 
-    def refresh_pool(self, init_pool=None):
+    def refresh_pool(self, init_pool=None, beta_pool=None):
+        """Draw (or install) fresh pool rows in place; the restart counters keep running."""
         import torch
+        if self.kind == "ns2d":
+            return self._refresh_pool_ns(init_pool)
+        rows = self.core.t["reset_init"].shape[0]
         if init_pool is None:
-            init_pool, _ = self._sample_1d(np.arange(self.num_envs))
+            init_pool, drawn_beta = self._sample_1d(np.arange(rows))
+            if beta_pool is None:
+                beta_pool = drawn_beta
         self.core.t["reset_init"].copy_(torch.as_tensor(init_pool, dtype=torch.float32, device=self.device))
+        if beta_pool is not None and self.core.t.get("reset_beta") is not None:
+            rb = self.core.t["reset_beta"]
+            rb.copy_(torch.as_tensor(beta_pool).to(device=self.device, dtype=rb.dtype))
+
+    def _enable_fused_auto_reset_ns(self, init_pool):
+        raise NotImplementedError("fused auto-reset for NavierStokes2D: see NSBatch2D.enable_auto_reset")
+
+    def _refresh_pool_ns(self, init_pool):
+        raise NotImplementedError
 
     def step_tensor(self, actions):
         """actions: device tensor [B] (1D) / [B, action_dim] (NS).  Returns device tensors
@@ -248,8 +278,8 @@ class PDEVecEnv:
                 else:
                     init, beta = self._sample_1d(idx)
                     if self.core.t["beta"].dim() == 2:
-                        self.core.t["beta"][torch.as_tensor(idx, device=self.device)] = torch.as_tensor(
-                            beta, dtype=torch.float32, device=self.device)
+                        self.core.t["beta"][torch.as_tensor(idx, device=self.device)] = torch.as_tensor(beta).to(
+                            device=self.device, dtype=self.core.t["beta"].dtype)
                     new = self.core.reset(self._scatter(init, idx, (self.core.n,)), mask=mask)
                 if self.kind != "traffic":
                     obs[idx] = self._obs_np(new)[idx]

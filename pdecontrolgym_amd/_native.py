@@ -48,7 +48,8 @@ class Bufs1D(C.Structure):
                 ("time_index", C.c_void_p), ("bsum", C.c_void_p), ("ring", C.c_void_p), ("obs", C.c_void_p),
                 ("reward", C.c_void_p), ("norm_now", C.c_void_p), ("norm_back", C.c_void_p),
                 ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("history", C.c_void_p),
-                ("reset_init", C.c_void_p), ("final_obs", C.c_void_p)]
+                ("reset_init", C.c_void_p), ("final_obs", C.c_void_p), ("reset_beta", C.c_void_p),
+                ("reset_count", C.c_void_p), ("reset_pool_rows", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class ParamsNS2D(C.Structure):
@@ -76,7 +77,7 @@ class ParamsTraffic(C.Structure):
 class BufsTraffic(C.Structure):
     _fields_ = [("r", C.c_void_p), ("y", C.c_void_p), ("action", C.c_void_p), ("time", C.c_void_p), ("rs", C.c_void_p),
                 ("qs_clip", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
-                ("truncated", C.c_void_p)]
+                ("truncated", C.c_void_p), ("action_stride", C.c_int32), ("reserved_", C.c_int32)]
 
 
 TUMOR_GROWTH, TUMOR_THERAPY, TUMOR_POST = range(3)

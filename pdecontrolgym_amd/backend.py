@@ -11,6 +11,30 @@ import ctypes as C
 from . import _native as N
 
 
+def _on_device_of(key):
+    """Decorator: run the C-ABI call with the device of tensor-dict entry ``key`` (or of the tensor argument at that position)
+    current.  The kernels launch on the thread's current HIP device and the stream handle passed is that device's current
+    stream, so an engine built on cuda:1 while cuda:0 is current must switch first."""
+    def deco(fn):
+        def wrapped(self, *args, **kw):
+            import torch
+            dev = None
+            for a in args:
+                if isinstance(a, dict) and key in a:
+                    dev = a[key].device
+                    break
+                if torch.is_tensor(a):
+                    dev = a.device
+                    break
+            if dev is None or dev.type != "cuda":
+                return fn(self, *args, **kw)
+            with torch.cuda.device(dev):
+                return fn(self, *args, **kw)
+        wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+        return wrapped
+    return deco
+
+
 class HipBackend:
     name = "hip-gfx950"
 
@@ -40,8 +64,15 @@ class HipBackend:
         ri, fo = T.get("reset_init"), T.get("final_obs")
         b.reset_init = N.dptr(ri, torch.float32) if ri is not None else None
         b.final_obs = N.dptr(fo, torch.float32) if fo is not None else None
+        rb, rc = T.get("reset_beta"), T.get("reset_count")
+        b.reset_beta = N.dptr(rb, T["beta"].dtype) if rb is not None else None
+        b.reset_count = N.dptr(rc, torch.int32) if rc is not None else None
+        b.reset_pool_rows = int(ri.shape[0]) if ri is not None else 0
+        if rb is not None and (T["beta"].dim() == 1 or rb.shape != ri.shape):
+            raise N.NativeError("reset_beta needs a per-instance beta [B, n] and the shape of reset_init")
         return b
 
+    @_on_device_of("u")
     def step1d(self, kind: str, P: N.Params1D, T: dict, B: int):
         import torch
         fn = self.lib.pdegym_transport_step if kind == "transport" else self.lib.pdegym_parabolic_step
@@ -52,6 +83,7 @@ class HipBackend:
         bufs = self._bufs1d(T)
         N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["u"].device)), f"pdegym_{kind}_step")
 
+    @_on_device_of("u")
     def reset1d(self, P: N.Params1D, T: dict, init, mask, B: int):
         import torch
         bufs = self._bufs1d(T)
@@ -59,6 +91,7 @@ class HipBackend:
         N.check(self.lib.pdegym_reset1d_masked(C.byref(P), C.byref(bufs), N.dptr(init, torch.float32), m, B,
                                                N.current_stream_ptr(T["u"].device)), "pdegym_reset1d_masked")
 
+    @_on_device_of("u")
     def rownorm2(self, rows, out):
         import torch
         B, n = rows.shape
@@ -84,12 +117,14 @@ class HipBackend:
         import torch
         return "f32" if dtype == torch.float32 else "f64"
 
+    @_on_device_of("p")
     def ns2d_step(self, P: N.ParamsNS2D, T: dict, B: int):
         dtype = T["p"].dtype
         bufs = self._bufs_ns(T, dtype)
         fn = getattr(self.lib, "pdegym_ns2d_step_" + self._sfx(dtype))
         N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["p"].device)), "pdegym_ns2d_step")
 
+    @_on_device_of("p")
     def ns2d_reset(self, P: N.ParamsNS2D, T: dict, u0, v0, p0, mask, B: int):
         import torch
         dtype = T["p"].dtype
@@ -99,6 +134,7 @@ class HipBackend:
         N.check(fn(C.byref(P), C.byref(bufs), N.dptr(u0, dtype), N.dptr(v0, dtype), N.dptr(p0, dtype), m, B,
                    N.current_stream_ptr(T["p"].device)), "pdegym_ns2d_reset_masked")
 
+    @_on_device_of("p")
     def ns2d_solve_pressure(self, P: N.ParamsNS2D, u, v, p_in, p_out, scratch, B: int):
         dtype = u.dtype
         fn = getattr(self.lib, "pdegym_ns2d_solve_pressure_" + self._sfx(dtype))
@@ -115,13 +151,16 @@ class HipBackend:
             setattr(b, k, N.dptr(T[k], torch.float64))
         b.done = N.dptr(T["done"], torch.uint8)
         b.truncated = N.dptr(T["truncated"], torch.uint8)
+        b.action_stride = int(T["action"].shape[1]) if T["action"].dim() == 2 else 1
         return b
 
+    @_on_device_of("r")
     def traffic_step(self, P: N.ParamsTraffic, T: dict, B: int):
         bufs = self._bufs_traffic(T)
         N.check(self.lib.pdegym_traffic_step(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["r"].device)),
                 "pdegym_traffic_step")
 
+    @_on_device_of("r")
     def traffic_reset(self, P: N.ParamsTraffic, T: dict, profile, mask, B: int):
         import torch
         bufs = self._bufs_traffic(T)
@@ -146,16 +185,19 @@ class HipBackend:
         b.t1_log = N.dptr(T.get("t1_log"), torch.float64) if T.get("t1_log") is not None else None
         return b
 
+    @_on_device_of("u")
     def tumor_advance(self, P: N.ParamsTumor, T: dict, mode: int, max_days: int, B: int):
         bufs = self._bufs_tumor(T)
         N.check(self.lib.pdegym_tumor_advance(C.byref(P), C.byref(bufs), mode, max_days, B, N.current_stream_ptr(T["u"].device)),
                 "pdegym_tumor_advance")
 
+    @_on_device_of("u")
     def tumor_step(self, P: N.ParamsTumor, T: dict, B: int):
         bufs = self._bufs_tumor(T)
         N.check(self.lib.pdegym_tumor_step(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["u"].device)),
                 "pdegym_tumor_step")
 
+    @_on_device_of("u")
     def tumor_reset(self, P: N.ParamsTumor, T: dict, init, mask, B: int):
         import torch
         bufs = self._bufs_tumor(T)

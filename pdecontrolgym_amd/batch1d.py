@@ -125,6 +125,8 @@ class PDEBatch1D:
             "history": torch.zeros(B, self.nt, n, dtype=f32, device=dev) if record_history else None,
             "reset_init": None,
             "final_obs": None,
+            "reset_beta": None,
+            "reset_count": None,
         }
         # observations are double-buffered: the tensor returned by step k stays valid during step k+1
         self._obs = [torch.zeros(B, self.obs_dim, dtype=f32, device=dev) for _ in range(2)]
@@ -177,21 +179,35 @@ class PDEBatch1D:
         self.backend.reset1d(self.params, self.t, init, mask, self.num_envs)
         return self.t["obs"]
 
-    def enable_auto_reset(self, init_pool, keep_final_obs: bool = True):
-        """Fused VecEnv auto-reset: an instance that ends a step terminated|truncated restarts from
-        ``init_pool[b]`` inside the same kernel launch (no host round trip).  The pool is a caller-owned
-        [B, n] tensor that may be refreshed between steps (e.g. re-sampled on device)."""
+    def enable_auto_reset(self, init_pool, keep_final_obs: bool = True, beta_pool=None):
+        """Fused VecEnv auto-reset: an instance that ends a step terminated|truncated restarts inside the same kernel launch
+        (no host round trip).  ``init_pool`` is a caller-owned [P, n] tensor with P >= B rows; the k-th restart of instance b
+        takes row (b + k*B) mod P, so with P > B consecutive episodes of one instance start from different rows.  With
+        ``beta_pool`` [P, n] (same dtype as the current beta) the plant parameter is redrawn from the same row -- the
+        reference calls BOTH reset callbacks at every reset (hyperbolic.py:207-209).  Pools may be refreshed between steps
+        (e.g. re-sampled on device)."""
         import torch
         pool = torch.as_tensor(init_pool, dtype=torch.float32, device=self.device).contiguous()
-        if pool.shape != (self.num_envs, self.n):
-            raise ValueError(f"init_pool must be [{self.num_envs}, {self.n}], got {tuple(pool.shape)}")
+        if pool.dim() != 2 or pool.shape[1] != self.n or pool.shape[0] < self.num_envs:
+            raise ValueError(f"init_pool must be [P >= {self.num_envs}, {self.n}], got {tuple(pool.shape)}")
         self.t["reset_init"] = pool
+        self.t["reset_count"] = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        self.t["reset_beta"] = None
+        if beta_pool is not None:
+            if self.t["beta"].dim() == 1:        # a shared row cannot be redrawn per instance: give every instance its own
+                self.t["beta"] = self.t["beta"].unsqueeze(0).repeat(self.num_envs, 1).contiguous()
+            bp = torch.as_tensor(beta_pool).to(device=self.device, dtype=self.t["beta"].dtype).contiguous()
+            if bp.shape != pool.shape:
+                raise ValueError(f"beta_pool must have the shape of init_pool {tuple(pool.shape)}, got {tuple(bp.shape)}")
+            self.t["reset_beta"] = bp
         self.t["final_obs"] = (torch.zeros(self.num_envs, self.obs_dim, dtype=torch.float32, device=self.device)
                                if keep_final_obs else None)
 
     def disable_auto_reset(self):
         self.t["reset_init"] = None
         self.t["final_obs"] = None
+        self.t["reset_beta"] = None
+        self.t["reset_count"] = None
 
     def step(self, action, out_obs=None, out_reward=None, out_terminated=None, out_truncated=None, action_kind=None):
         """Advance every instance by one env-step (S sub-steps). action: [B] tensor.

@@ -78,9 +78,9 @@ class TrafficBatch:
         """action [B] / [B,1] (inlet, outlet) or [B,2] ('both'). Returns (obs [B,2M], reward, done, truncated)."""
         import torch
         a = torch.as_tensor(action, dtype=torch.float64, device=self.device).reshape(self.num_envs, -1)
-        buf = torch.zeros(self.num_envs, 2, dtype=torch.float64, device=self.device)
-        buf[:, : a.shape[1]] = a
-        self.t["action"] = buf
+        if a.shape[1] > 2 or (self.action_dim == 2 and a.shape[1] != 2):
+            raise ValueError(f"action must be [B] / [B, 1] / [B, 2] ('both' needs two columns), got {tuple(a.shape)}")
+        self.t["action"] = a.contiguous()       # used in place: the kernel takes the column count as the stride
         self._next_obs()
         self.backend.traffic_step(self.params, self.t, self.num_envs)
         return self.t["obs"], self.t["reward"], self.t["done"], self.t["truncated"]

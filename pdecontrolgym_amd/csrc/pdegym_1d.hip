@@ -87,6 +87,13 @@ __device__ __forceinline__ float slots_sumsq(const float (&x)[EPL], int s0, int 
 // (a+1)*m-m, base_env_1d.py:36-39
 __device__ __forceinline__ float normalize_ctrl(float a, float m, int on) { return on ? (a + 1.0f) * m - m : a; }
 
+// Row of the reset pools that the next restart of instance `inst` takes (see pdegym_bufs1d.reset_pool_rows).
+__device__ __forceinline__ int pool_row(const pdegym_bufs1d& Bf, int inst, int B) {
+  const int rows = Bf.reset_pool_rows > 0 ? Bf.reset_pool_rows : B;
+  const long long k = Bf.reset_count ? (long long)Bf.reset_count[inst] : 0;
+  return (int)(((long long)inst + k * (long long)B) % rows);
+}
+
 // Per-wave state of one instance while it is stepped.
 template <int EPL>
 struct Row {
@@ -382,6 +389,23 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
     // The fast loop freezes the controlled boundary slot with zero coefficients: x + 0*t keeps every x except -0.0
     // (-0.0 + +0.0 = +0.0), so a commanded boundary value of exactly -0.0 takes the exact loop (wave-uniform test).
     bool exact = __float_as_uint(normalize_ctrl(a, P.max_control, P.normalize)) == 0x80000000u;
+    if constexpr (PARABOLIC) {
+      // The fast stencil forms um - 2u as ONE fma, which stays finite where the reference's 2*u overflows (|u| >= 2^127)
+      // and could then decay back to a finite row that the non-finite test below never sees.  Rule it out up front: for
+      // 0 <= F <= 1/2 the diffusion part is a convex combination (max-norm contraction), so one sub-step grows max|u| by at
+      // most g = 1 + max|dt*beta| (+ rounding); otherwise by 1 + 4|F| + max|dt*beta|.  If max|u| * g^nsub can reach 2^126 the
+      // exact loop runs instead (wave-uniform; costs two wave reductions per launch).
+      float mx = fmaxf(fabsf(R.bl), fabsf(normalize_ctrl(a, P.max_control, P.normalize))), cm = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        mx = fmaxf(mx, fabsf(R.x[e]));
+        cm = fmaxf(cm, fabsf(P.dt * beta[e]));
+      }
+      mx = wave_max(mx);
+      cm = wave_max(cm);
+      const float g = ((P.F >= 0.0f && P.F <= 0.5f) ? 1.0f : 1.0f + 4.0f * fabsf(P.F)) + cm + 9.5367431640625e-7f;
+      exact = exact || !(__log2f(mx) + (float)nsub * __log2f(g) < 126.0f);   // NaN / inf anywhere -> exact
+    }
     norm_now = 0.f;
     if (!exact) {
       run_substeps<EPL, PARABOLIC, false, true, false, BURGERS>(R, beta, P, nsub, a, ring, nullptr, lane);
@@ -491,7 +515,14 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
   } else {
     // fused VecEnv auto-reset: keep the terminal observation, restart from the pool row (hyperbolic.py:214-227)
     if (Bf.final_obs) emit_obs(Bf.final_obs);
-    const float* irow = Bf.reset_init + (size_t)inst * n;
+    const int prow = pool_row(Bf, inst, B);
+    const float* irow = Bf.reset_init + (size_t)prow * n;
+    if (Bf.reset_beta && Bf.beta_stride != 0) {      // the reference redraws beta at every reset (hyperbolic.py:208)
+      float* bdst = const_cast<float*>(brow);
+      const float* bsrc = static_cast<const float*>(Bf.reset_beta) + (size_t)prow * n;
+      for (int j = lane; j < n; j += kWave) bdst[j] = bsrc[j];
+    }
+    if (Bf.reset_count && lane == 0) Bf.reset_count[inst] += 1;
     R.bl = PARABOLIC ? irow[0] : 0.f;
     if (PARABOLIC && lane == 0) urow[0] = R.bl;
 #pragma unroll
@@ -721,7 +752,20 @@ __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, p
     }
   } else {
     if (Bf.final_obs) emit_obs(Bf.final_obs, cur);
-    const float* irow = Bf.reset_init + (size_t)inst * n;
+    const int prow = pool_row(Bf, inst, B);
+    const float* irow = Bf.reset_init + (size_t)prow * n;
+    if (Bf.reset_beta && Bf.beta_stride != 0) {      // the reference redraws beta at every reset (hyperbolic.py:208)
+      if (beta64) {
+        double* bdst = const_cast<double*>(brow64);
+        const double* bsrc = static_cast<const double*>(Bf.reset_beta) + (size_t)prow * n;
+        for (int j = lane; j < n; j += kWave) bdst[j] = bsrc[j];
+      } else {
+        float* bdst = const_cast<float*>(brow);
+        const float* bsrc = static_cast<const float*>(Bf.reset_beta) + (size_t)prow * n;
+        for (int j = lane; j < n; j += kWave) bdst[j] = bsrc[j];
+      }
+    }
+    if (Bf.reset_count && lane == 0) Bf.reset_count[inst] += 1;
     wave_lds_sync();
     for (int j = lane; j < n; j += kWave) {
       const float v = irow[j];
@@ -808,14 +852,15 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void rownorm2_kernel(const f
 // Requesting an (unused) dynamic LDS slice of 160 KiB / ceil(blocks/CUs) caps the resident blocks per CU at the
 // balanced value, which spreads the grid evenly over all 256 CUs.
 inline int balance_lds_bytes(int nblocks) {
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
-    }
-    return n;
-  }();
+  static int cu_count[pdegym::kMaxDevices] = {};          // per device: a process may drive several GPUs
+  const int dev = pdegym::current_device();
+  if (cu_count[dev] == 0) {
+    int n = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+    cu_count[dev] = n;
+  }
+  const int cus = cu_count[dev];
   const char* off = getenv("PDEGYM_NO_BALANCE");
   if (off && off[0] == '1') return 0;
   const int per_cu = (nblocks + cus - 1) / cus;

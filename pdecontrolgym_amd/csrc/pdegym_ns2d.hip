@@ -1291,9 +1291,6 @@ inline bool pdegym_no_lds_jacobi() {
   return e && e[0] == '1';
 }
 
-inline bool allow_big_lds(const void* kernel) {
-  return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds1MaxBytes) == hipSuccess;
-}
 
 // 1: two LDS copies (<= kLdsCells cells); 2: one LDS copy (larger grids that still fit the 160 KB of a CU); 0: global memory
 template <typename T>
@@ -1380,8 +1377,9 @@ int ns_step(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int B, v
     hipLaunchKernelGGL((ns_generic_step<T, 1>), dim3(B), dim3(lds_block_threads(ncell, B)), 2 * (size_t)ncell * sizeof(T),
                        (hipStream_t)stream, C, S, P, B);
   } else if (mode == 2) {
-    static const bool ok = allow_big_lds(reinterpret_cast<const void*>(&ns_generic_step<T, 2>));
-    if (!ok) return pdegym::fail(-4, "cannot raise the dynamic LDS limit");
+    static signed char attr_done[pdegym::kMaxDevices] = {};
+    if (!pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&ns_generic_step<T, 2>), kLds1MaxBytes, attr_done))
+      return pdegym::fail(-4, "cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL((ns_generic_step<T, 2>), dim3(B), dim3(1024), (size_t)ncell * sizeof(T), (hipStream_t)stream, C, S, P, B);
   } else {
     hipLaunchKernelGGL((ns_generic_step<T, 0>), dim3(B), dim3(block_threads(ncell)), 0, (hipStream_t)stream, C, S, P, B);
@@ -1404,8 +1402,9 @@ int ns_pressure(const pdegym_params_ns2d* prm, const void* u, const void* v, con
     hipLaunchKernelGGL((ns_generic_pressure<T, 1>), dim3(B), dim3(lds_block_threads(ncell, B)), 2 * (size_t)ncell * sizeof(T),
                        (hipStream_t)stream, C, S, (const T*)u, (const T*)v, (const T*)p_in, (T*)p_out, (T*)scratch, B);
   } else if (mode == 2) {
-    static const bool ok = allow_big_lds(reinterpret_cast<const void*>(&ns_generic_pressure<T, 2>));
-    if (!ok) return pdegym::fail(-4, "cannot raise the dynamic LDS limit");
+    static signed char attr_done[pdegym::kMaxDevices] = {};
+    if (!pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&ns_generic_pressure<T, 2>), kLds1MaxBytes, attr_done))
+      return pdegym::fail(-4, "cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL((ns_generic_pressure<T, 2>), dim3(B), dim3(1024), (size_t)ncell * sizeof(T), (hipStream_t)stream, C, S,
                        (const T*)u, (const T*)v, (const T*)p_in, (T*)p_out, (T*)scratch, B);
   } else {

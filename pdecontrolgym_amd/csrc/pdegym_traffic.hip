@@ -40,7 +40,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pde
   const double qs = rs * vs;
   const double qc = Bf.qs_clip[inst];
   // action clip (:151-156) -- np.clip(a, low, high) = min(max(a, low), high)
-  double a0 = Bf.action[(size_t)inst * 2], a1 = Bf.action[(size_t)inst * 2 + 1];
+  const int astr = Bf.action_stride > 0 ? Bf.action_stride : 2;      // 1: one command per freeway (no second column to read)
+  double a0 = Bf.action[(size_t)inst * astr], a1 = astr > 1 ? Bf.action[(size_t)inst * astr + 1] : 0.0;
   const double lo = qc * 0.8, hi = 1.2 * qc;
   a0 = fmin(fmax(a0, lo), hi);
   a1 = fmin(fmax(a1, lo), hi);
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_wide_kerne
   const double vs = Veq(vm, rm, rs);
   const double qs = rs * vs;
   const double qc = Bf.qs_clip[inst];
-  double a0 = Bf.action[(size_t)inst * 2], a1 = Bf.action[(size_t)inst * 2 + 1];
+  const int astr = Bf.action_stride > 0 ? Bf.action_stride : 2;      // 1: one command per freeway (no second column to read)
+  double a0 = Bf.action[(size_t)inst * astr], a1 = astr > 1 ? Bf.action[(size_t)inst * astr + 1] : 0.0;
   const double lo = qc * 0.8, hi = 1.2 * qc;
   a0 = fmin(fmax(a0, lo), hi);
   a1 = fmin(fmax(a1, lo), hi);

@@ -75,7 +75,15 @@ class FakeBackend:
             if done.any():
                 if T.get("final_obs") is not None:
                     T["final_obs"][torch.from_numpy(done)] = T["obs"][torch.from_numpy(done)]
-                self.reset1d(P, T, T["reset_init"], torch.from_numpy(done.astype(np.uint8)), B, _keep_flags=True)
+                # pool row of the k-th restart of instance b: (b + k*B) mod P  (include/pdegym.h)
+                cnt = T["reset_count"].numpy().astype(np.int64) if T.get("reset_count") is not None else np.zeros(B, dtype=np.int64)
+                rows = torch.from_numpy((np.arange(B) + cnt * B) % T["reset_init"].shape[0])
+                dm = torch.from_numpy(done)
+                if T.get("reset_beta") is not None:
+                    T["beta"][dm] = T["reset_beta"][rows][dm]
+                if T.get("reset_count") is not None:
+                    T["reset_count"][dm] += 1
+                self.reset1d(P, T, T["reset_init"][rows].contiguous(), torch.from_numpy(done.astype(np.uint8)), B, _keep_flags=True)
 
     def reset1d(self, P, T, init, mask, B, _keep_flags=False):
         orc = self._orc1d(P)

@@ -88,8 +88,12 @@ def one_case(rng, idx):
     ocls = {"parabolic": po.ParabolicOracle, "transport": po.TransportOracle, "burgers": po.BurgersOracle}[kind]
     okw = {k: kw[k] for k in ("T", "dt", "X", "dx", "control_sample_rate", "control_type", "sensing_loc", "sensing_type", "normalize",
                               "max_control_value", "limit_pde_state_size", "max_state_value")}
-    pool = (rng.uniform(0.1, 3, (B, 1)) * np.ones((1, n))).astype(np.float32)
-    desc = f"#{idx} reward={rkind} beta64={beta64} act={akind} auto={auto} {kind} nx={nx} S={S} nt={nt} B={B} {ctrl} {sloc}/{kw['sensing_type']} norm={normalize} limit={limit}/{max_state} ic={style} hist={hist} shared_beta={shared}"
+    P = B * int(rng.choice([1, 1, 2, 3]))           # pool rows: the k-th restart of instance b takes row (b + k*B) mod P
+    pool = (rng.uniform(0.1, 3, (P, 1)) * np.ones((1, n))).astype(np.float32)
+    use_bpool = auto and (not shared) and bool(rng.random() < 0.5)
+    bpool = (amp * rng.uniform(0, 1) * np.cos(rng.uniform(1, 8.5, (P, 1)) * np.arccos(x)))
+    bpool = bpool if beta64 else bpool.astype(np.float32)
+    desc = f"#{idx} P={P} bpool={use_bpool} reward={rkind} beta64={beta64} act={akind} auto={auto} {kind} nx={nx} S={S} nt={nt} B={B} {ctrl} {sloc}/{kw['sensing_type']} norm={normalize} limit={limit}/{max_state} ic={style} hist={hist} shared_beta={shared}"
     try:
         orc = ocls(reward=mk_reward(), keep_history=True, **okw)
     except Exception as ex:      # invalid option combination: the product must refuse it too
@@ -104,9 +108,8 @@ def one_case(rng, idx):
     o_gpu = env.reset(torch.tensor(init), torch.tensor(beta[0] if shared else beta))
     assert np.array_equal(o_gpu.cpu().numpy().reshape(B, -1), np.asarray(o_ref, dtype=np.float32).reshape(B, -1)), desc + " reset obs"
     if auto:
-        env.enable_auto_reset(torch.tensor(pool), keep_final_obs=True)
-        fresh = ocls(reward=mk_reward(), keep_history=True, **okw)
-        fresh_obs = np.asarray(fresh.reset(pool, bfull), dtype=np.float32).reshape(B, -1)
+        env.enable_auto_reset(torch.tensor(pool), keep_final_obs=True, beta_pool=torch.tensor(bpool) if use_bpool else None)
+        cnt = np.zeros(B, dtype=np.int64)
     for i in range(nsteps + 1):
         a = rng.uniform(-1, 1, B) * float(rng.choice([1.0, 0.0, 10.0]))
         a = a.astype(np.float32) if akind == "f32" else a
@@ -124,6 +127,13 @@ def one_case(rng, idx):
                 fo = env.t["final_obs"].cpu().numpy().reshape(B, -1)
                 okf = ~(np.isnan(fo) & np.isnan(orf))
                 assert np.array_equal(fo[done].view(np.uint32)[okf[done]], orf[done].view(np.uint32)[okf[done]]), desc + f" step {i}: final_obs"
+                rows = (np.arange(B) + cnt * B) % P
+                cnt[done] += 1
+                if use_bpool:
+                    orc.beta = orc.beta.copy()
+                    orc.beta[done] = bpool[rows[done]]
+                fresh = ocls(reward=mk_reward(), keep_history=True, **okw)
+                fresh_obs = np.asarray(fresh.reset(pool[rows], orc.beta), dtype=np.float32).reshape(B, -1)
                 orc.row[done] = fresh.row[done]
                 orc.time_index[done] = 0
                 orc.bsum[done] = fresh.bsum[done]

@@ -462,6 +462,104 @@ def test_fused_auto_reset():
         np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-6, atol=1e-4)
 
 
+def test_fused_auto_reset_redraws_beta_and_rotates_pool_rows():
+    """The reference calls both reset callbacks at every reset (hyperbolic.py:207-209): with pools of P = 3B rows the k-th
+    restart of instance b takes initial condition AND beta from row (b + k*B) mod P, inside the launch; every episode
+    equals a fresh oracle started from that row."""
+    from oracle import pde_oracle as po
+    kw = dict(TRANSPORT_CASES["R_tiny"])                # nt=91, S=15 -> an episode is 6 steps
+    B, n, P = 4, 100, 12
+    rng = np.random.default_rng(8)
+    x = np.linspace(0, 1, n)
+    pool = rng.uniform(1, 3, (P, n)).astype(np.float32)
+    bpool = (5 * np.cos(rng.uniform(7, 8, (P, 1)) * np.arccos(x))).astype(np.float32)
+    init = rng.uniform(1, 3, (B, n)).astype(np.float32)
+    beta0 = (5 * np.cos(7.35 * np.arccos(x))).astype(np.float32)
+    env = _mk("transport", kw, (90, -1e3, 3e2), B)
+    env.reset(torch.tensor(init), torch.tensor(beta0))            # shared beta row: enable_auto_reset un-shares it
+    env.enable_auto_reset(torch.tensor(pool), beta_pool=torch.tensor(bpool))
+    orcs = []
+    for b in range(B):
+        o = po.TransportOracle(reward=po.TunedReward1DOracle(90, -1e3, 3e2), keep_history=False, **_oracle_kwargs(kw))
+        o.reset(init[b:b + 1], beta0[None])
+        orcs.append(o)
+    restarts = np.zeros(B, dtype=int)
+    for i in range(20):
+        a = rng.uniform(-1, 1, B).astype(np.float32)
+        obs, r, te, tr = env.step(torch.tensor(a))
+        obs, r = obs.cpu().numpy(), r.cpu().numpy()
+        for b in range(B):
+            o_ref, r_ref, te_ref, tr_ref = orcs[b].step(a[b:b + 1])
+            np.testing.assert_allclose(r[b], r_ref[0], rtol=1e-6, atol=1e-4)
+            if te_ref[0] or tr_ref[0]:
+                row = (b + restarts[b] * B) % P
+                restarts[b] += 1
+                np.testing.assert_array_equal(env.t["final_obs"].cpu().numpy()[b], o_ref[0])
+                orcs[b] = po.TransportOracle(reward=po.TunedReward1DOracle(90, -1e3, 3e2), keep_history=False, **_oracle_kwargs(kw))
+                o_ref = orcs[b].reset(pool[row:row + 1], bpool[row:row + 1])
+                np.testing.assert_array_equal(env.t["beta"].cpu().numpy()[b], bpool[row])
+            np.testing.assert_array_equal(obs[b], np.asarray(o_ref)[0], err_msg=f"step {i} inst {b}")
+    assert restarts.min() >= 3 and (env.t["reset_count"].cpu().numpy() == restarts).all()
+
+
+def test_parabolic_transient_overflow_takes_the_exact_loop():
+    """|u| >= 2^127: the reference's 2*u overflows to inf (and the row turns NaN for good) while a fused um - 2u would stay
+    finite and could decay back below FLT_MAX unnoticed.  The fast loop must not be used there: bit patterns equal the oracle."""
+    from oracle import pde_oracle as po
+    nx, S, B = 64, 8, 4
+    dx = 1.0 / nx
+    dt = 0.25 * dx * dx
+    kw = dict(T=4 * S * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type="Dirchilet", sensing_loc="full",
+              sensing_type=None, normalize=False, max_control_value=20, limit_pde_state_size=False, max_state_value=1e10)
+    n = nx + 1
+    init = np.zeros((B, n), dtype=np.float32)
+    init[0, 30] = 2.0e38                      # a lone spike above 2^127: the reference overflows in 2*u, the spike itself would halve
+    init[1, 10:50] = 1.0e38                   # plateau below 2^127: stays finite in both
+    init[2, 20] = -3.0e38
+    init[3] = 1.0
+    beta = np.zeros((B, n), dtype=np.float32)
+    orc = po.ParabolicOracle(reward=po.TunedReward1DOracle(4 * S, -1e3, 3e2), keep_history=False, **_oracle_kwargs(kw))
+    env = _mk("parabolic", kw, (4 * S, -1e3, 3e2), B)
+    orc.reset(init, beta)
+    env.reset(torch.tensor(init), torch.tensor(beta))
+    for i in range(3):
+        a = np.zeros(B, dtype=np.float32)
+        with np.errstate(all="ignore"):
+            orc.step(a)
+        env.step(torch.tensor(a))
+        g, o = env.u.cpu().numpy(), orc.row
+        both_nan = np.isnan(g) & np.isnan(o)
+        np.testing.assert_array_equal(g.view(np.uint32)[~both_nan], o.view(np.uint32)[~both_nan], err_msg=f"step {i}")
+        np.testing.assert_array_equal(np.isnan(g), np.isnan(o))
+    assert np.isnan(orc.row[0]).any() and np.isfinite(orc.row[1]).all() and np.isfinite(orc.row[3]).all()
+
+
+def test_engine_on_a_non_current_device():
+    """An engine built on cuda:1 while cuda:0 is the current device launches on ITS device (the C ABI launches on
+    the thread's current device).  Needs two GPUs; skipped on a single-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from oracle import pde_oracle as po
+    kw = dict(PARABOLIC_CASES["P2_s100"])
+    B, n = 8, 257
+    rng = np.random.default_rng(2)
+    init = rng.uniform(1, 3, (B, n)).astype(np.float32)
+    beta = rng.uniform(-10, 10, (B, n)).astype(np.float32)
+    torch.cuda.set_device(0)
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
+    env = PDEBatch1D("parabolic", reward=RewardSpec(N.REWARD_TUNED1D, 1000, -1e3, 3e2), num_envs=B, device="cuda:1", **kw)
+    orc = po.ParabolicOracle(reward=po.TunedReward1DOracle(1000, -1e3, 3e2), keep_history=False, **_oracle_kwargs(kw))
+    orc.reset(init, beta)
+    env.reset(torch.tensor(init), torch.tensor(beta))
+    for _ in range(3):
+        a = rng.uniform(-1, 1, B).astype(np.float32)
+        orc.step(a)
+        env.step(torch.tensor(a))
+    assert torch.cuda.current_device() == 0 and env.u.device.index == 1
+    np.testing.assert_array_equal(env.u.cpu().numpy(), orc.row)
+
+
 @pytest.mark.parametrize("dx", [1e-2, 1.0 / 512, 1.0 / 3, 0.1, 5e-3, 1.0 / 100, 0.999999, 1.9999999, 3.0e-5, 7.0])
 def test_transport_quotient_equals_ieee_division(dx):
     """(float)((double)d * (1/(double)dx)) == d / dx for every float32 d: 64 M random bit patterns (all exponents,
