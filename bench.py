@@ -339,28 +339,52 @@ WORKLOADS["traffic_arz"] = TrafficARZ
 WORKLOADS["brain_tumor"] = BrainTumor
 
 
-def measured_traffic(workload_key):
-    """HBM bytes per launch from the last committed PMC collection (tools/profile_round.sh -> profiles/traffic_latest.json);
-    bench.py itself never runs under the profiler."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+CLOCK_GHZ = 2.4          # MI355X peak shader clock (MI355X_MICROARCH.md); sustained clocks under VALU load are nearer 2.0
+N_SIMD = 256 * 4         # 256 CUs x 4 SIMDs
+VALU_PEAK_GINST = N_SIMD * CLOCK_GHZ / 2.0     # one wave64 VALU instruction per SIMD every 2 cycles -> 1228.8 G wave-inst/s
+REPEATS = 5              # median of 5 repeats of the K timed steps
+
+
+def profiled_counters(workload_key):
+    """Per-env-step-batch counters of the last committed rocprofv3 collection (tools/profile_round.sh ->
+    tools/summarize_profiles.py -> profiles/counters_latest.json): HBM bytes (FETCH_SIZE*2 + WRITE_SIZE, separate PMC passes)
+    and SQ_INSTS_VALU summed over the kernels of one step.  bench.py itself never runs under the profiler; the counters
+    belong to the default batch / sub-step count of the workload."""
+    path = os.path.join(ROOT, "profiles", "counters_latest.json")
     try:
         with open(path) as fh:
             d = json.load(fh)
-        return d["bytes_per_launch"].get(workload_key), d.get("source")
+        return d["workloads"].get(workload_key), d.get("source")
     except Exception:
         return None, None
 
 
-def run_workload(wl, steps, warmup, world, graph=False):
-    """Returns (seconds for `steps` steps [max over ranks], average launch duration in ms from HIP events bracketing
-    the timed region on the launch stream, median duration of isolated launches timed one by one afterwards).
-    graph=True: the `steps` launches are captured once into a hipGraph and replayed (no Python between launches)."""
+def _timed(fn, world):
+    """barrier + synchronize on both sides; HIP events on the launch stream bracket the same region."""
     import torch
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    _barrier(world)
+    t0 = time.perf_counter()
+    ev0.record()
+    fn()
+    ev1.record()
+    _barrier(world)
+    return time.perf_counter() - t0, ev0.elapsed_time(ev1)
+
+
+def run_workload(wl, steps, warmup, world, graph=False, repeats=REPEATS):
+    """W untimed warm-up steps, then `repeats` timed regions of EXACTLY `steps` steps each (barrier + synchronize on both
+    sides of every region).  Returns a dict: the median region (seconds, max over ranks), this rank's own median, every
+    region's time, the per-step duration from HIP events over the median region, and the median duration of isolated
+    single launches timed one by one afterwards.  graph=True: the `steps` launches are captured once into a hipGraph and
+    each region is one replay (no Python between launches)."""
+    import torch
+    from pdecontrolgym_amd.sharding import max_over_ranks
     extra = min(steps, 50)
-    wl.prepare(warmup + (2 * steps if graph else steps) + extra)
+    wl.prepare(warmup + ((repeats + 2) * steps) + extra)
     for _ in range(warmup):
         wl.step()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    regions = []
     if graph:
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
@@ -374,26 +398,19 @@ def run_workload(wl, steps, warmup, world, graph=False):
                     wl.step()
         torch.cuda.current_stream().wait_stream(side)
         g.replay()                          # untimed first replay (graph upload)
-        _barrier(world)
-        t0 = time.perf_counter()
-        ev0.record()
-        g.replay()
-        ev1.record()
-        _barrier(world)
-        el = time.perf_counter() - t0
+        for _ in range(repeats):
+            regions.append(_timed(g.replay, world))
     else:
-        _barrier(world)
-        t0 = time.perf_counter()
-        ev0.record()
-        for _ in range(steps):
-            wl.step()
-        ev1.record()
-        _barrier(world)
-        el = time.perf_counter() - t0
-    region_ms = ev0.elapsed_time(ev1) / steps      # HIP events on the launch stream, over the timed region
-    from pdecontrolgym_amd.sharding import max_over_ranks
-    el = max_over_ranks(el, device="cuda")      # the only communication of a multi-GPU run (no data-path collective)
-    # per-launch kernel duration with HIP events on the launch stream (outside the timed region)
+        def loop():
+            for _ in range(steps):
+                wl.step()
+        for _ in range(repeats):
+            regions.append(_timed(loop, world))
+    # the only communication of a multi-GPU run (no data-path collective): MAX over ranks of every region's time
+    maxes = [max_over_ranks(r[0], device="cuda") for r in regions]
+    med = sorted(range(repeats), key=lambda k: maxes[k])[repeats // 2]
+    el, (el_local, ev_ms) = maxes[med], regions[med]
+    # per-launch duration with HIP events on the launch stream (outside the timed regions)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(extra)]
     for a, b in evs:
         a.record()
@@ -401,7 +418,43 @@ def run_workload(wl, steps, warmup, world, graph=False):
         b.record()
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b) for a, b in evs)
-    return el, region_ms, ms[len(ms) // 2]
+    return {"seconds": el, "seconds_this_rank": el_local, "step_ms_events": ev_ms / steps, "isolated_step_ms_median": ms[len(ms) // 2],
+            "all_regions_s": maxes}
+
+
+def roofline_block(wl, key, step_ms, default_config):
+    """The resource that binds the step and how close the step is to it.  Two candidates, both reported:
+      * VALU issue: SQ_INSTS_VALU of one step (profiled) x 2 cycles / (1024 SIMDs x step time x 2.4 GHz);
+      * HBM: PMC bytes of one step (profiled) / step time against the 8 TB/s specification.
+    `bound` names the larger fraction.  The SURVEY section 8d streaming-model figure (algorithmic bytes / time) is kept as
+    `effective_*`: the fused kernels keep state on chip across sub-steps / sweeps, so it may exceed the HBM peak and is NOT
+    a utilisation."""
+    t = step_ms * 1e-3
+    alg = wl.algorithmic_bytes_per_step()
+    ctr, src = profiled_counters(key) if default_config else (None, None)
+    valu = hbm = None
+    if ctr and ctr.get("valu_insts_per_step"):
+        a = ctr["valu_insts_per_step"] / t / 1e9
+        valu = {"wave_insts_per_step": ctr["valu_insts_per_step"], "achieved": a, "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s",
+                "frac": a / VALU_PEAK_GINST}
+    if ctr and ctr.get("hbm_bytes_per_step"):
+        a = ctr["hbm_bytes_per_step"] / t / 1e9
+        hbm = {"bytes_per_step": ctr["hbm_bytes_per_step"], "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS}
+    cands = [(v["frac"], n, v) for n, v in (("valu_issue", valu), ("hbm", hbm)) if v]
+    out = {}
+    if cands:
+        _, name, best = max(cands)
+        out = {"bound": name, "achieved": best["achieved"], "peak": best["peak"], "unit": best["unit"], "frac": best["frac"]}
+    else:       # no profile for this configuration: only the effective figure is available
+        eff = alg / t / 1e9
+        out = {"bound": "hbm", "achieved": eff, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
+               "note": "no committed counters for this batch / sub-step count: achieved is the EFFECTIVE streaming-model bandwidth"}
+    out["traffic"] = hbm["bytes_per_step"] if hbm else None
+    out.update({"valu_issue": valu, "hbm": hbm, "step_ms": step_ms, "counters_source": src,
+                "kernels_per_step": (ctr or {}).get("kernels"),
+                "effective_streaming_GBps": alg / t / 1e9, "effective_streaming_frac_of_hbm_peak": alg / t / 1e9 / HBM_PEAK_GBPS,
+                "algorithmic_bytes_per_step": alg, "compulsory_bytes_per_step": wl.compulsory_bytes_per_step()})
+    return out
 
 
 def main():
@@ -415,6 +468,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads in the default run")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--repeats", type=int, default=REPEATS, help="timed regions of K steps each; the median is reported")
     ap.add_argument("--eager", action="store_true",
                     help="one Python call per launch instead of replaying the K timed launches from one captured hipGraph")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
@@ -441,7 +495,7 @@ def main():
     wl = WORKLOADS[args.workload](device, 1234 + rank, **kw)
     use_graph = not args.eager
     try:
-        el, kernel_ms, kernel_ms_med = run_workload(wl, args.steps, args.warmup, world, graph=use_graph)
+        res = run_workload(wl, args.steps, args.warmup, world, graph=use_graph, repeats=args.repeats)
     except Exception as ex:                 # capture unsupported in this environment -> time the eager loop instead
         if not use_graph:
             raise
@@ -449,27 +503,33 @@ def main():
         use_graph = False
         torch.cuda.synchronize()
         wl = WORKLOADS[args.workload](device, 1234 + rank, **kw)
-        el, kernel_ms, kernel_ms_med = run_workload(wl, args.steps, args.warmup, world, graph=False)
+        res = run_workload(wl, args.steps, args.warmup, world, graph=False, repeats=args.repeats)
+    el = res["seconds"]
     value = wl.units_per_step() * args.steps * world / el
-    alg = wl.algorithmic_bytes_per_step()
-    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    default_config = not args.batch and not args.substeps
     out = {
         "metric": "env-steps/sec (whole node)", "value": value, "unit": "env-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
-        "config": dict(wl.config(), launch="hipGraph replay of the K timed launches" if use_graph else "eager (one Python call per launch)"),
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel_ms_avg": kernel_ms, "kernel_ms_isolated_median": kernel_ms_med,
-                     "algorithmic_bytes_per_launch": alg, "compulsory_bytes_per_launch": wl.compulsory_bytes_per_step(),
-                     "note": "achieved = streaming-model algorithmic bytes / kernel time; the fused kernel keeps state "
-                             "on-chip across sub-steps, so this is an EFFECTIVE bandwidth and may exceed the HBM peak "
-                             "(real HBM traffic ~ compulsory bytes; see DESIGN.md)"},
+        "config": dict(wl.config(), launch="hipGraph replay of the K timed launches" if use_graph else "eager (one Python call per launch)",
+                       timing=f"median of {args.repeats} regions of exactly K steps, each bracketed by barrier + synchronize; max over ranks"),
+        "timed_regions_s": res["all_regions_s"],
+        "roofline": roofline_block(wl, args.workload, res["step_ms_events"], default_config),
     }
-    tb, tsrc = measured_traffic(args.workload)
-    if tb and not args.batch and not args.substeps:
-        out["roofline"]["traffic"] = tb
-        out["roofline"]["traffic_source"] = tsrc
+    out["roofline"]["isolated_step_ms_median"] = res["isolated_step_ms_median"]
+    if world > 1:
+        # per-rank figures so that a scaling record can be cross-checked: every rank steps its own full per-GPU batch
+        # (weak scaling), so each per-rank value should equal the N=1 line of the same box
+        import torch.distributed as dist
+        mine = torch.tensor([wl.units_per_step() * args.steps / res["seconds_this_rank"]], dtype=torch.float64,
+                            device="cpu" if dist.get_backend() == "gloo" else device)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        per_rank = [float(v.item()) for v in allv]
+        out["per_rank_env_steps_per_s"] = per_rank
+        out["n1_equivalent"] = {"value": sum(per_rank) / world, "note": "mean per-rank rate = what one GPU of this node does alone; "
+                                "value / (n_gpus * this) is the scaling efficiency the driver computes from its own N=1 run"}
+        out["process_group"] = dist.get_backend()
     if cpu_rep is not None:
         out["cpu_baseline"] = cpu_rep
     if rank == 0 and world == 1 and not args.no_also and args.workload == "parabolic_c2" and not args.batch:
@@ -479,11 +539,12 @@ def main():
                 continue
             try:
                 w2 = cls(device, 99)
-                e2, k2, k2m = run_workload(w2, max(20, args.steps // 4), max(5, args.warmup // 2), 1, graph=use_graph)
                 n2 = max(20, args.steps // 4)
-                a2 = w2.algorithmic_bytes_per_step() / (k2 * 1e-3) / 1e9
-                also[name] = {"value": w2.units_per_step() * n2 / e2, "unit": "env-steps/s", "ms_per_step": e2 / n2 * 1e3,
-                              "kernel_ms_avg": k2, "roofline_frac": a2 / HBM_PEAK_GBPS, "config": w2.config()}
+                r2 = run_workload(w2, n2, max(5, args.warmup // 2), 1, graph=use_graph, repeats=3)
+                rf = roofline_block(w2, name, r2["step_ms_events"], True)
+                also[name] = {"value": w2.units_per_step() * n2 / r2["seconds"], "unit": "env-steps/s", "ms_per_step": r2["seconds"] / n2 * 1e3,
+                              "dtype": w2.dtype, "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "step_ms")},
+                              "config": w2.config()}
                 del w2
             except Exception as ex:  # keep the headline line alive
                 also[name] = {"error": repr(ex)}

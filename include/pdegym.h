@@ -185,6 +185,9 @@ typedef struct pdegym_bufs_ns2d {
   void* obs;                /* [B, ny, nx, 2] out (u,v interleaved; base_env_2d.py:50)                         */
   void* reward;             /* [B] out                                                                        */
   uint8_t* terminated;      /* [B] out; truncated is always False in the reference (navier_stokes2D.py:155)    */
+  void* p_out;              /* optional [B, ny, nx]: where the solved pressure of this step goes (must not alias p).  NULL = in place
+                               (p is overwritten).  With it the caller ping-pongs two pressure tensors: the 256x256 pipeline
+                               then needs no copy of its last pass back into p                                             */
   const void* state_in;     /* optional [B, ny, nx, 2]: the observation written by the PREVIOUS call.  When non-NULL the
                                velocity state is read from it and written only to obs (the reference's obs is the state,
                                navier_stokes2D.py:147-154), which saves one write of u and v per step; must not alias obs */

@@ -62,7 +62,7 @@ class BufsNS2D(C.Structure):
     _fields_ = [("u", C.c_void_p), ("v", C.c_void_p), ("p", C.c_void_p), ("scratch", C.c_void_p),
                 ("action", C.c_void_p), ("time_index", C.c_void_p), ("U_ref", C.c_void_p),
                 ("action_ref", C.c_void_p), ("nt_ref", C.c_int32), ("obs", C.c_void_p), ("reward", C.c_void_p),
-                ("terminated", C.c_void_p), ("state_in", C.c_void_p)]
+                ("terminated", C.c_void_p), ("p_out", C.c_void_p), ("state_in", C.c_void_p)]
 
 
 TRAFFIC_SIM = {"inlet": 0, "outlet": 1, "both": 2, "outlet-train": 3}

@@ -105,7 +105,7 @@ class HipBackend:
         b = N.BufsNS2D()
         for k in ("p", "scratch", "action", "U_ref", "action_ref", "obs", "reward"):
             setattr(b, k, N.dptr(T[k], dtype))
-        for k in ("u", "v", "state_in"):
+        for k in ("u", "v", "state_in", "p_out"):
             setattr(b, k, N.dptr(T[k], dtype) if T.get(k) is not None else None)
         b.time_index = N.dptr(T["time_index"], torch.int32)
         b.terminated = N.dptr(T["terminated"], torch.uint8)

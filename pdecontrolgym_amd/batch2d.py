@@ -79,6 +79,7 @@ class NSBatch2D:
             "v": None if self.interleaved_state else torch.zeros(B, ny, nx, dtype=dt_, device=dev),
             "state_in": None,
             "p": torch.zeros(B, ny, nx, dtype=dt_, device=dev),
+            "p_out": None,
             "scratch": torch.zeros(B, 4, ny, nx, dtype=dt_, device=dev),
             "action": torch.zeros(B, self.action_dim, dtype=dt_, device=dev),
             "time_index": torch.zeros(B, dtype=torch.int32, device=dev),
@@ -91,6 +92,11 @@ class NSBatch2D:
         self._obs = [torch.zeros(B, ny, nx, 2, dtype=dt_, device=dev) for _ in range(2)]
         self._flip = 0
         self.t["obs"] = self._obs[0]
+        # the 256x256 pipeline finishes its pressure solve in a second buffer: ping-pong two pressure tensors instead of
+        # copying the result home every step (include/pdegym.h: p_out)
+        self._p_pingpong = self.interleaved_state and dt_ == torch.float32 and nx == 256 and ny == 256
+        if self._p_pingpong:
+            self.t["p_out"] = torch.zeros(B, ny, nx, dtype=dt_, device=dev)
 
     @property
     def u(self):
@@ -132,6 +138,8 @@ class NSBatch2D:
         self.t["action"] = a
         self._next_obs()
         self.backend.ns2d_step(self.params, self.t, self.num_envs)
+        if self._p_pingpong:        # the solved pressure is in p_out: it becomes p (the warm start of the next step)
+            self.t["p"], self.t["p_out"] = self.t["p_out"], self.t["p"]
         return self.t["obs"], self.t["reward"], self.t["terminated"]
 
     def solve_pressure(self, u, v, p_prev):

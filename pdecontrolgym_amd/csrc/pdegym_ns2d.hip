@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "pdegym.h"
 #include "pdegym_common.h"
@@ -59,6 +60,7 @@ struct NSPtrs {
   T* reward;
   uint8_t* terminated;
   const T* state_in;  // optional [B, ny, nx, 2]: (u, v) of the previous call's observation; then u, v may be NULL
+  T* p_out;           // optional [B, ny, nx]: the solved pressure goes here instead of back into p
 };
 
 // Value of boundary cell (i,j) after apply_boundary's four ordered passes (navier_stokes2D.py:76-90), as a
@@ -348,7 +350,7 @@ __device__ __forceinline__ void gen_back(const NSConst& C, const NSScal<T>& S, c
   const int nx = C.nx, ny = C.ny, ncell = nx * ny;
   T* u = (P.u && !P.state_in) ? P.u + (size_t)b * ncell : nullptr;
   T* v = (P.v && !P.state_in) ? P.v + (size_t)b * ncell : nullptr;
-  T* pdst = P.p + (size_t)b * ncell;
+  T* pdst = (P.p_out ? P.p_out : P.p) + (size_t)b * ncell;
   T* us = P.scratch + (size_t)b * 4 * ncell;
   T* vs = us + ncell;
   const T* act = P.action + (size_t)b * C.action_dim;
@@ -631,24 +633,36 @@ __device__ __forceinline__ void jacobi_sweep_rot(float (&ph)[PR + 1][PC], const 
     // consecutive instructions do not depend on each other; W / E of the edge columns ride in on the DPP adds
     float nv[PC];
     if constexpr (PC == 4) {
-      // The two DPP adds ride at the END of four-instruction blocks: the three plain adds in front of them are the wait
-      // states the VALU-write -> DPP-read hazard asks for (no s_nop slots; the blocks' early-clobber outputs cannot alias
-      // the shifted operand).  Same operations in the same order as the generic form below.
-      const float x0 = ph[src][0], x1 = ph[src][1], x2 = ph[src][2], x3 = ph[src][3];
+      // The whole row update is ONE 16-instruction block that works in place on the registers of old row a-1 (the South
+      // neighbours, dead afterwards): ((W + S) + E) + N, then fma(0.25, s4, -rq) -- stage-major over the four independent
+      // cells, the two DPP adds at the end of their four-instruction groups (the three plain adds in front of them are the
+      // wait states of the VALU-write -> DPP-read hazard; no s_nop slots).  One block = no temporaries and nothing for the
+      // scheduler to hoist: the compiler used to start all PR rows at once and spill.  Same operations, same order as the
+      // generic form below.
+      float (&sv)[PC] = ph[dst];
+      const float (&xv)[PC] = ph[src];
+      const float (&nn)[PC] = (a == PR - 1) ? hb : ph[nxt];
       asm volatile(
-          "v_add_f32 %1, %5, %9\n\t"
-          "v_add_f32 %2, %6, %10\n\t"
-          "v_add_f32 %3, %7, %11\n\t"
-          "v_add_f32_dpp %0, %4, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-          : "=&v"(nv[0]), "=&v"(nv[1]), "=&v"(nv[2]), "=&v"(nv[3])
-          : "v"(x3), "v"(x0), "v"(x1), "v"(x2), "v"(ph[dst][0]), "v"(ph[dst][1]), "v"(ph[dst][2]), "v"(ph[dst][3]));
-      asm volatile(
+          "v_add_f32 %1, %4, %1\n\t"
+          "v_add_f32 %2, %5, %2\n\t"
+          "v_add_f32 %3, %6, %3\n\t"
+          "v_add_f32_dpp %0, %7, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
           "v_add_f32 %0, %0, %5\n\t"
           "v_add_f32 %1, %1, %6\n\t"
           "v_add_f32 %2, %2, %7\n\t"
-          "v_add_f32_dpp %3, %4, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-          : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3])
-          : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+          "v_add_f32_dpp %3, %4, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_add_f32 %0, %0, %8\n\t"
+          "v_add_f32 %1, %1, %9\n\t"
+          "v_add_f32 %2, %2, %10\n\t"
+          "v_add_f32 %3, %3, %11\n\t"
+          "v_fma_f32 %0, %0, %16, -%12\n\t"
+          "v_fma_f32 %1, %1, %16, -%13\n\t"
+          "v_fma_f32 %2, %2, %16, -%14\n\t"
+          "v_fma_f32 %3, %3, %16, -%15"
+          : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3])
+          : "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]), "v"(nn[0]), "v"(nn[1]), "v"(nn[2]), "v"(nn[3]),
+            "v"(rq[a][0]), "v"(rq[a][1]), "v"(rq[a][2]), "v"(rq[a][3]), "s"(0.25f));
+      continue;
     } else {
 #pragma unroll
       for (int k = 0; k < PC; ++k)
@@ -863,7 +877,7 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
     unrotate<PR, PC, 0>(ph, pf, rot);
   }
   PDEGYM_STAMP(3, pf[0][0]);
-  store_patch<PR, PC>(pf, p, n, r0, c0);
+  store_patch<PR, PC>(pf, P.p_out ? P.p_out + (size_t)b * ncell : p, n, r0, c0);
 
   // ---- corrector (:143-146), observation, reward ----
   float acc = 0.f;
@@ -1122,7 +1136,8 @@ __global__ __launch_bounds__(1024) void ns256_back(NSConst C, NSScal<float> S, N
   row4(pfin, i + 1, pd);
   row4(us, i, un);
   row4(vs, i, vn);
-  if (final_in_scratch) *reinterpret_cast<float4*>(P.p + (size_t)b * ncell + i * n + c0) = make_float4(pc[0], pc[1], pc[2], pc[3]);
+  if (final_in_scratch || P.p_out)
+    *reinterpret_cast<float4*>((P.p_out ? P.p_out : P.p) + (size_t)b * ncell + i * n + c0) = make_float4(pc[0], pc[1], pc[2], pc[3]);
   const float pl = lane_left(pc[3]), pr = lane_right(pc[0]);
   // ---- corrector (:143-145) ----
 #pragma unroll
@@ -1183,6 +1198,444 @@ __global__ void ns256_finish(NSConst C, NSScal<float> S, NSPtrs<float> P, int B)
   P.reward[b] = ((-0.5f * ss) / (float)n) / (float)n - S.gamma_half * asq;
   P.time_index[b] = t;
   P.terminated[b] = (t >= C.nt - 1) ? 1 : 0;
+}
+
+// ================================================================================================
+// 256x256 float32, interleaved state (the observation of the previous call IS the velocity state): second-generation
+// pipeline (round 2).  Three launches move 12 fields' worth of HBM traffic per env-step instead of 18.5 (+ register spills):
+//   ns256_rq_front   state -> 0.25 dx dy rhs (one field)                                  [u*, v* are never written]
+//   ns_slab_jacobi_rq<15, 12>   ALL K <= 52 sweeps in ONE pass: two slabs per instance of 128 own + 52 halo rows,
+//                               12 waves (3 per SIMD: the best barrier-per-sweep shape, tools/ubench_barrier.hip),
+//                               p and rq in registers (15 x 4 patch per lane), loads/stores of whole 1 KB rows
+//   ns256_back_pred  state + solved p -> observation (the predictor is re-evaluated per row: the corrector only needs
+//                               u*, v* of interior cells, which apply_boundary never touches)
+// Same expression trees as ns_generic_step<float>: bit-identical results (tested).
+// ================================================================================================
+// predictor of grid row i (navier_stokes2D.py:130-138) from the state rows i-1, i, i+1; edge cells keep the state value
+__device__ __forceinline__ void predictor_row_256(const NSScal<float>& S, int i, int lane, const float (&uc)[4], const float (&vc)[4],
+                                                  const float (&uu)[4], const float (&vu)[4], const float (&ud)[4], const float (&vd)[4],
+                                                  float (&un)[4], float (&vn)[4]) {
+  constexpr int n = 256;
+  const float ul = lane_left(uc[3]), ur = lane_right(uc[0]), vl = lane_left(vc[3]), vr = lane_right(vc[0]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float uw = (k == 0) ? ul : uc[k - 1], ue = (k == 3) ? ur : uc[k + 1];
+    const float vw = (k == 0) ? vl : vc[k - 1], ve = (k == 3) ? vr : vc[k + 1];
+    const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx), dudy = div_c(ud[k] - uu[k], S.two_dy, S.inv_two_dy);
+    const float dvdx = div_c(ve - vw, S.two_dx, S.inv_two_dx), dvdy = div_c(vd[k] - vu[k], S.two_dy, S.inv_two_dy);
+    const float lapu = div_c((((uw + uu[k]) - 4.0f * uc[k]) + ue) + ud[k], S.dxdy, S.inv_dxdy);
+    const float lapv = div_c((((vw + vu[k]) - 4.0f * vc[k]) + ve) + vd[k], S.dxdy, S.inv_dxdy);
+    const float a = uc[k] + S.dt * (((-uc[k]) * dudx - vc[k] * dudy) + S.nu * lapu);
+    const float d = vc[k] + S.dt * (((-uc[k]) * dvdx - vc[k] * dvdy) + S.nu * lapv);
+    const bool edge = (i == 0) || (i == n - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
+    un[k] = edge ? uc[k] : a;
+    vn[k] = edge ? vc[k] : d;
+  }
+}
+
+__device__ __forceinline__ void load_state_row_256(const float* state, int row, int c0, float (&fu)[4], float (&fv)[4]) {
+  constexpr int n = 256;
+  const int r = row < 0 ? 0 : (row > n - 1 ? n - 1 : row);
+  const float4* q = reinterpret_cast<const float4*>(state + (r * n + c0) * 2);
+  const float4 a = q[0], d = q[1];
+  fu[0] = a.x; fv[0] = a.y; fu[1] = a.z; fv[1] = a.w; fu[2] = d.x; fv[2] = d.y; fu[3] = d.z; fv[3] = d.w;
+}
+
+// One wave per grid row; a workgroup of 16 waves covers rows b0-1 .. b0+14 and emits rq for the 14 rows b0 .. b0+13 (the
+// two outer rows only supply v* to their neighbours: 16/14 redundant predictor work instead of a u*, v* round trip).
+constexpr int kRqBand = 14;
+__global__ __launch_bounds__(1024) void ns256_rq_front(NSConst C, NSScal<float> S, NSPtrs<float> P, int B) {
+  constexpr int n = 256, ncell = n * n, nband = (n + kRqBand - 1) / kRqBand;
+  __shared__ __attribute__((aligned(16))) float lds_u[16 * n], lds_v[16 * n], lds_v2[16 * n];
+  const int b = blockIdx.x / nband, band = blockIdx.x - b * nband;
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c0 = 4 * lane;
+  const int i = band * kRqBand - 1 + w;                          // grid row of this wave
+  const bool live = i >= 0 && i < n;                             // wave-uniform
+  const float* state = P.state_in + (size_t)b * ncell * 2;
+  const float* act = P.action + (size_t)b * C.action_dim;
+  float un[4] = {0.f, 0.f, 0.f, 0.f}, vn[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    float uc[4], vc[4], uu[4], vu[4], ud[4], vd[4];
+    load_state_row_256(state, i, c0, uc, vc);
+    load_state_row_256(state, i - 1, c0, uu, vu);
+    load_state_row_256(state, i + 1, c0, ud, vd);
+    predictor_row_256(S, i, lane, uc, vc, uu, vu, ud, vd, un, vn);
+  }
+  *reinterpret_cast<float4*>(lds_u + w * n + c0) = make_float4(un[0], un[1], un[2], un[3]);
+  *reinterpret_cast<float4*>(lds_v + w * n + c0) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+  __syncthreads();
+  // apply_boundary(u*, v*) (:140): the wall rows read the row next to them, which is a neighbouring wave of this workgroup
+  // (row 0 sits at w >= 1 with row 1 at w+1; row 255 at w <= 14 with row 254 at w-1)
+  if (live) bc_rows_256<16>(un, vn, i, lane, w, lds_u, lds_v, C.bc, act, C.action_dim);
+  *reinterpret_cast<float4*>(lds_v2 + w * n + c0) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+  __syncthreads();
+  if (!live || w == 0 || w == 15) return;
+  // 0.25 dx dy rhs, rhs = rho/dt (d/dx u* + d/dy v*) (:101-103); zero on the domain edge (never read by a sweep)
+  const float ul = lane_left(un[3]), ur = lane_right(un[0]);
+  const float4 va = *reinterpret_cast<const float4*>(lds_v2 + (w - 1) * n + c0);
+  const float4 vb = *reinterpret_cast<const float4*>(lds_v2 + (w + 1) * n + c0);
+  const float vup[4] = {va.x, va.y, va.z, va.w}, vdn[4] = {vb.x, vb.y, vb.z, vb.w};
+  float rq[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float uw = (k == 0) ? ul : un[k - 1], ue = (k == 3) ? ur : un[k + 1];
+    const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx);
+    const float dvdy = div_c(vdn[k] - vup[k], S.two_dy, S.inv_two_dy);
+    const float r = S.rho_over_dt * (dudx + dvdy);
+    const bool edge = (i == 0) || (i == n - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
+    rq[k] = edge ? 0.0f : jacobi_rhs_term(S.dxdy, r);
+  }
+  float* rqd = P.scratch + (size_t)b * 4 * ncell + 2 * (size_t)ncell;
+  *reinterpret_cast<float4*>(rqd + i * n + c0) = make_float4(rq[0], rq[1], rq[2], rq[3]);
+}
+
+template <int PR, int PC, int R, int RC>
+__device__ __forceinline__ void store_rotated_rows(const float (&ph)[PR + 1][PC], int rot, float* pd, int g0, int c0, int own_lo, int own_hi) {
+  if (rot == R) {
+#pragma unroll
+    for (int a = 0; a < PR; ++a) {
+      const int g = g0 + a;
+      if (g >= own_lo && g < own_hi) {        // wave-uniform
+        constexpr int n = 256;
+        const float (&row)[PC] = ph[prow<PR>(a, R)];
+        *reinterpret_cast<float4*>(pd + a * n + c0) = make_float4(row[0], row[1], row[2], row[3]);
+      }
+    }
+  } else if constexpr (R + 1 < RC) {
+    store_rotated_rows<PR, PC, R + 1, RC>(ph, rot, pd, g0, c0, own_lo, own_hi);
+  }
+}
+
+// ---- boustrophedon sweeps: a rotation with period two ---------------------------------------------------------------
+// ph has PR+1 physical rows.  State 0: logical patch row a sits in physical row a, physical row PR is free.  An UP sweep
+// (rows 0 -> PR-1) writes new row a into the registers of old row a-1 (the top halo is loaded into the free row), leaving
+// logical row a in physical row a-1 (row 0 in PR) and physical row PR-1 free (state 1).  A DOWN sweep (rows PR-1 -> 0) writes
+// new row a into the registers of old row a+1 (the bottom halo is loaded into the free row) and restores state 0.  Two sweep
+// bodies instead of PR+1, no register copies, and the halo row a sweep needs FIRST is the row its neighbour produced first
+// in the previous sweep.  Arithmetic and its order are those of jacobi_sweep_rot / ns_generic_step<float>.
+template <int PR>
+__device__ constexpr int bphys(int a, int state) {          // physical row of logical row a (a = -1: top halo in an UP sweep)
+  return state == 0 ? a : (a == 0 ? PR : a - 1);
+}
+
+// ((W + S) + E) + N -> fma(0.25, ., -rq), in place on the registers of the South row (UP) ...
+__device__ __forceinline__ void jacobi_row_into_south(float (&sv)[4], const float (&xv)[4], const float (&nn)[4], const float (&rq)[4]) {
+  asm volatile(
+      "v_add_f32 %1, %4, %1\n\t"
+      "v_add_f32 %2, %5, %2\n\t"
+      "v_add_f32 %3, %6, %3\n\t"
+      "v_add_f32_dpp %0, %7, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %0, %0, %5\n\t"
+      "v_add_f32 %1, %1, %6\n\t"
+      "v_add_f32 %2, %2, %7\n\t"
+      "v_add_f32_dpp %3, %4, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %0, %0, %8\n\t"
+      "v_add_f32 %1, %1, %9\n\t"
+      "v_add_f32 %2, %2, %10\n\t"
+      "v_add_f32 %3, %3, %11\n\t"
+      "v_fma_f32 %0, %0, %16, -%12\n\t"
+      "v_fma_f32 %1, %1, %16, -%13\n\t"
+      "v_fma_f32 %2, %2, %16, -%14\n\t"
+      "v_fma_f32 %3, %3, %16, -%15"
+      : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3])
+      : "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]), "v"(nn[0]), "v"(nn[1]), "v"(nn[2]), "v"(nn[3]), "v"(rq[0]), "v"(rq[1]),
+        "v"(rq[2]), "v"(rq[3]), "s"(0.25f));
+}
+// ... and on the registers of the North row (DOWN): the partial sums (W + S) + E need four temporaries
+__device__ __forceinline__ void jacobi_row_into_north(float (&nv)[4], const float (&xv)[4], const float (&ss)[4], const float (&rq)[4]) {
+  float t0, t1, t2, t3;
+  asm volatile(
+      "v_add_f32 %5, %8, %13\n\t"
+      "v_add_f32 %6, %9, %14\n\t"
+      "v_add_f32 %7, %10, %15\n\t"
+      "v_add_f32_dpp %4, %11, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %4, %4, %9\n\t"
+      "v_add_f32 %5, %5, %10\n\t"
+      "v_add_f32 %6, %6, %11\n\t"
+      "v_add_f32_dpp %7, %8, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %0, %4, %0\n\t"
+      "v_add_f32 %1, %5, %1\n\t"
+      "v_add_f32 %2, %6, %2\n\t"
+      "v_add_f32 %3, %7, %3\n\t"
+      "v_fma_f32 %0, %0, %20, -%16\n\t"
+      "v_fma_f32 %1, %1, %20, -%17\n\t"
+      "v_fma_f32 %2, %2, %20, -%18\n\t"
+      "v_fma_f32 %3, %3, %20, -%19"
+      : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]), "v"(ss[0]), "v"(ss[1]), "v"(ss[2]), "v"(ss[3]), "v"(rq[0]), "v"(rq[1]),
+        "v"(rq[2]), "v"(rq[3]), "s"(0.25f));
+}
+
+// Two rows per block (8 independent dependency chains instead of 4: a wave issues only about every 8 cycles along ONE
+// chain of 4, so three or four waves per SIMD cannot fill it with single-row blocks -- tools/ubench_dpp.hip).
+// UP, rows a (A) and a+1 (B):  da = old row a-1 (South of A, becomes new row a), db = old row a (centre of A, South of B,
+// becomes new row a+1), xb = old row a+1 (North of A, centre of B), nb = old row a+2 / bottom halo (North of B).
+// A accumulates in place; B keeps its partial sums in four temporaries until A has read db for the last time (A8).
+__device__ __forceinline__ void jacobi_pair_up(float (&da)[4], float (&db)[4], const float (&xb)[4], const float (&nb)[4],
+                                               const float (&rqa)[4], const float (&rqb)[4]) {
+  float t0, t1, t2, t3;
+  asm volatile(
+      "v_add_f32 %1, %4, %1\n\t"                  // A: W + S
+      "v_add_f32 %9, %12, %5\n\t"                 // B
+      "v_add_f32 %2, %5, %2\n\t"
+      "v_add_f32 %10, %13, %6\n\t"
+      "v_add_f32 %3, %6, %3\n\t"
+      "v_add_f32 %11, %14, %7\n\t"
+      "v_add_f32_dpp %0, %7, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %8, %15, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %0, %0, %5\n\t"                  // + E
+      "v_add_f32 %8, %8, %13\n\t"
+      "v_add_f32 %1, %1, %6\n\t"
+      "v_add_f32 %9, %9, %14\n\t"
+      "v_add_f32 %2, %2, %7\n\t"
+      "v_add_f32 %10, %10, %15\n\t"
+      "v_add_f32_dpp %3, %4, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %11, %12, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %0, %0, %12\n\t"                 // + N
+      "v_add_f32 %8, %8, %16\n\t"
+      "v_add_f32 %1, %1, %13\n\t"
+      "v_add_f32 %9, %9, %17\n\t"
+      "v_add_f32 %2, %2, %14\n\t"
+      "v_add_f32 %10, %10, %18\n\t"
+      "v_add_f32 %3, %3, %15\n\t"
+      "v_add_f32 %11, %11, %19\n\t"
+      "v_fma_f32 %0, %0, %28, -%20\n\t"           // 0.25 * s4 - rq ; B lands in db (A no longer reads it)
+      "v_fma_f32 %4, %8, %28, -%24\n\t"
+      "v_fma_f32 %1, %1, %28, -%21\n\t"
+      "v_fma_f32 %5, %9, %28, -%25\n\t"
+      "v_fma_f32 %2, %2, %28, -%22\n\t"
+      "v_fma_f32 %6, %10, %28, -%26\n\t"
+      "v_fma_f32 %3, %3, %28, -%23\n\t"
+      "v_fma_f32 %7, %11, %28, -%27"
+      : "+v"(da[0]), "+v"(da[1]), "+v"(da[2]), "+v"(da[3]), "+v"(db[0]), "+v"(db[1]), "+v"(db[2]), "+v"(db[3]), "=&v"(t0), "=&v"(t1),
+        "=&v"(t2), "=&v"(t3)
+      : "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]), "v"(nb[0]), "v"(nb[1]), "v"(nb[2]), "v"(nb[3]), "v"(rqa[0]), "v"(rqa[1]),
+        "v"(rqa[2]), "v"(rqa[3]), "v"(rqb[0]), "v"(rqb[1]), "v"(rqb[2]), "v"(rqb[3]), "s"(0.25f));
+}
+
+// DOWN, rows a (A) and a-1 (B):  da = old row a+1 / bottom halo (North of A, becomes new row a), db = old row a (centre of A,
+// North of B, becomes new row a-1), xb = old row a-1 (South of A, centre of B), sb = old row a-2 / top halo (South of B).
+// North is the LAST addend of ((W + S) + E) + N, so both rows form (W + S) + E in temporaries first.
+__device__ __forceinline__ void jacobi_pair_down(float (&da)[4], float (&db)[4], const float (&xb)[4], const float (&sb)[4],
+                                                 const float (&rqa)[4], const float (&rqb)[4]) {
+  float a0, a1, a2, a3, b0, b1, b2, b3;
+  asm volatile(
+      "v_add_f32 %9, %4, %17\n\t"                 // A: W + S   (W = db[k-1], S = xb[k])
+      "v_add_f32 %13, %16, %21\n\t"               // B:          (W = xb[k-1], S = sb[k])
+      "v_add_f32 %10, %5, %18\n\t"
+      "v_add_f32 %14, %17, %22\n\t"
+      "v_add_f32 %11, %6, %19\n\t"
+      "v_add_f32 %15, %18, %23\n\t"
+      "v_add_f32_dpp %8, %7, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %12, %19, %20 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %8, %8, %5\n\t"                  // + E
+      "v_add_f32 %12, %12, %17\n\t"
+      "v_add_f32 %9, %9, %6\n\t"
+      "v_add_f32 %13, %13, %18\n\t"
+      "v_add_f32 %10, %10, %7\n\t"
+      "v_add_f32 %14, %14, %19\n\t"
+      "v_add_f32_dpp %11, %4, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %15, %16, %15 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %0, %8, %0\n\t"                  // + N, in place on the North rows (A has read db for the last time)
+      "v_add_f32 %4, %12, %4\n\t"
+      "v_add_f32 %1, %9, %1\n\t"
+      "v_add_f32 %5, %13, %5\n\t"
+      "v_add_f32 %2, %10, %2\n\t"
+      "v_add_f32 %6, %14, %6\n\t"
+      "v_add_f32 %3, %11, %3\n\t"
+      "v_add_f32 %7, %15, %7"
+      : "+v"(da[0]), "+v"(da[1]), "+v"(da[2]), "+v"(da[3]), "+v"(db[0]), "+v"(db[1]), "+v"(db[2]), "+v"(db[3]), "=&v"(a0), "=&v"(a1),
+        "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+      : "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]), "v"(sb[0]), "v"(sb[1]), "v"(sb[2]), "v"(sb[3]));
+  asm volatile(
+      "v_fma_f32 %0, %0, %16, -%8\n\t"
+      "v_fma_f32 %4, %4, %16, -%12\n\t"
+      "v_fma_f32 %1, %1, %16, -%9\n\t"
+      "v_fma_f32 %5, %5, %16, -%13\n\t"
+      "v_fma_f32 %2, %2, %16, -%10\n\t"
+      "v_fma_f32 %6, %6, %16, -%14\n\t"
+      "v_fma_f32 %3, %3, %16, -%11\n\t"
+      "v_fma_f32 %7, %7, %16, -%15"
+      : "+v"(da[0]), "+v"(da[1]), "+v"(da[2]), "+v"(da[3]), "+v"(db[0]), "+v"(db[1]), "+v"(db[2]), "+v"(db[3])
+      : "v"(rqa[0]), "v"(rqa[1]), "v"(rqa[2]), "v"(rqa[3]), "v"(rqb[0]), "v"(rqb[1]), "v"(rqb[2]), "v"(rqb[3]), "s"(0.25f));
+}
+
+// Neumann walls (:110-113) on the new rows, which sit in state `st`
+template <int PR, int ST>
+__device__ __forceinline__ void jacobi_walls_state(float (&ph)[PR + 1][4], const EdgeFlags& E) {
+  constexpr int n0 = bphys<PR>(0, ST), n1 = bphys<PR>(1, ST), nl = bphys<PR>(PR - 1, ST), nm = bphys<PR>(PR - 2, ST);
+  if (E.top) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ph[n0][k] = ph[n1][k];
+  }
+  if (E.bot) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ph[nl][k] = ph[nm][k];
+  }
+  if (E.lef) {
+#pragma unroll
+    for (int a = 0; a < PR; ++a) ph[bphys<PR>(a, ST)][0] = ph[bphys<PR>(a, ST)][1];
+  }
+  if (E.rig) {
+#pragma unroll
+    for (int a = 0; a < PR; ++a) ph[bphys<PR>(a, ST)][3] = ph[bphys<PR>(a, ST)][2];
+  }
+}
+
+// One sweep starting from state ST (0: UP, 1: DOWN).  Halo rows cross thread rows through the double-buffered LDS area of
+// halo_tb (one barrier); the halo used LAST lands in four temporaries.
+template <int PR, int ST, int NT, int RS>
+__device__ __forceinline__ void jacobi_sweep_bous(float (&ph)[PR + 1][4], const float (&rq)[PR][4], const EdgeFlags& E, float* lds,
+                                                  int& xc, int tid, int ty) {
+  float hlast[4];
+  if constexpr (ST == 0) {
+    halo_tb<4, NT, RS>(ph[bphys<PR>(0, 0)], ph[bphys<PR>(PR - 1, 0)], ph[PR], hlast, lds, xc, tid, ty);   // top halo -> free row PR
+#pragma unroll
+    for (int a = 0; a + 1 < PR; a += 2) {       // rows (a, a+1)
+      float (&da)[4] = ph[a == 0 ? PR : a - 1];
+      if (a + 2 == PR) jacobi_pair_up(da, ph[a], ph[a + 1], hlast, rq[a], rq[a + 1]);
+      else jacobi_pair_up(da, ph[a], ph[a + 1], ph[a + 2], rq[a], rq[a + 1]);
+    }
+    if constexpr (PR % 2 == 1) jacobi_row_into_south(ph[PR - 2], ph[PR - 1], hlast, rq[PR - 1]);
+    jacobi_walls_state<PR, 1>(ph, E);
+  } else {
+    // state 1: logical row a in physical row a-1 (row 0 in PR); physical row PR-1 is free -> bottom halo
+    halo_tb<4, NT, RS>(ph[bphys<PR>(0, 1)], ph[bphys<PR>(PR - 1, 1)], hlast, ph[PR - 1], lds, xc, tid, ty);
+#pragma unroll
+    for (int a = PR - 1; a >= 1; a -= 2) {      // rows (a, a-1): new row a -> physical row a, new row a-1 -> physical row a-1
+      // physical rows: old logical a+1 (or bottom halo) = a, old a = a-1, old a-1 = bphys(a-1), old a-2 = bphys(a-2) / top halo
+      if (a == 1) jacobi_pair_down(ph[a], ph[a - 1], ph[bphys<PR>(0, 1)], hlast, rq[a], rq[a - 1]);
+      else jacobi_pair_down(ph[a], ph[a - 1], ph[bphys<PR>(a - 1, 1)], ph[bphys<PR>(a - 2, 1)], rq[a], rq[a - 1]);
+    }
+    if constexpr (PR % 2 == 1) jacobi_row_into_north(ph[0], ph[bphys<PR>(0, 1)], hlast, rq[0]);
+    jacobi_walls_state<PR, 0>(ph, E);
+  }
+}
+
+// NTR thread rows (= waves) of PR patch rows each: NTR * PR = 128 own rows + H halo rows of the other slab.
+template <int PR, int NTR>
+__global__ __launch_bounds__(64 * NTR, NTR / 4) void ns_slab_jacobi_rq(const float* p_src, size_t src_stride, float* p_dst,
+                                                                      size_t dst_stride, const float* rq_base, size_t rq_stride,
+                                                                      int nsweeps, int B) {
+  constexpr int n = 256, PC = 4, NT = 64 * NTR, RS = 64, OWN = 128, ROWS = NTR * PR;
+  static_assert(ROWS > OWN && ROWS <= n, "a slab is its own half plus halo rows of the other half");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* lds = reinterpret_cast<float*>(smem_raw);
+  const int b = blockIdx.x >> 1, slab = blockIdx.x & 1;
+  if (b >= B) return;
+  const int tid = threadIdx.x, tx = tid & 63;
+  const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: row offsets become scalar address arithmetic
+  const int c0 = tx * PC;
+  const int g0 = (slab == 0 ? 0 : n - ROWS) + ty * PR;           // global row of this thread's first patch row
+  const EdgeFlags E{slab == 0 && ty == 0, slab == 1 && ty == NTR - 1, tx == 0, tx == 63};
+  const float* ps = p_src + (size_t)b * src_stride + (size_t)g0 * n;
+  const float* rqs = rq_base + (size_t)b * rq_stride + (size_t)g0 * n;
+  float ph[PR + 1][PC], rq[PR][PC];
+#pragma unroll
+  for (int a = 0; a < PR; ++a) {
+    const float4 w = *reinterpret_cast<const float4*>(ps + a * n + c0);
+    const float4 q = *reinterpret_cast<const float4*>(rqs + a * n + c0);
+    ph[a][0] = w.x; ph[a][1] = w.y; ph[a][2] = w.z; ph[a][3] = w.w;
+    rq[a][0] = q.x; rq[a][1] = q.y; rq[a][2] = q.z; rq[a][3] = q.w;
+  }
+#pragma unroll
+  for (int k = 0; k < PC; ++k) ph[PR][k] = 0.f;
+  int xc = 0, it = 0;
+  for (; it + 2 <= nsweeps; it += 2) {
+    jacobi_sweep_bous<PR, 0, NT, RS>(ph, rq, E, lds, xc, tid, ty);
+    jacobi_sweep_bous<PR, 1, NT, RS>(ph, rq, E, lds, xc, tid, ty);
+  }
+  float* pd = p_dst + (size_t)b * dst_stride + (size_t)g0 * n;
+  const int own_lo = slab == 0 ? 0 : n - OWN, own_hi = slab == 0 ? OWN : n;
+  if (it < nsweeps) {      // odd sweep count: one more UP sweep, the rows are stored from state 1
+    jacobi_sweep_bous<PR, 0, NT, RS>(ph, rq, E, lds, xc, tid, ty);
+#pragma unroll
+    for (int a = 0; a < PR; ++a) {
+      const int g = g0 + a;
+      if (g >= own_lo && g < own_hi) {        // wave-uniform
+        const float (&row)[PC] = ph[bphys<PR>(a, 1)];
+        *reinterpret_cast<float4*>(pd + a * n + c0) = make_float4(row[0], row[1], row[2], row[3]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < PR; ++a) {
+      const int g = g0 + a;
+      if (g >= own_lo && g < own_hi) {
+        const float (&row)[PC] = ph[a];
+        *reinterpret_cast<float4*>(pd + a * n + c0) = make_float4(row[0], row[1], row[2], row[3]);
+      }
+    }
+  }
+}
+
+// corrector + apply_boundary + observation + reward partials, u*, v* re-evaluated from the state (interleaved mode only: the
+// state is the previous observation, a different buffer from the one written here)
+__global__ __launch_bounds__(1024) void ns256_back_pred(NSConst C, NSScal<float> S, NSPtrs<float> P, const float* pfin_base,
+                                                        size_t pfin_stride, float* p_copy_to, int B) {
+  constexpr int n = 256, ncell = n * n;
+  __shared__ __attribute__((aligned(16))) float lds_u[16 * n], lds_v[16 * n];
+  __shared__ float red[16];
+  const int b = blockIdx.x >> 4, rb = blockIdx.x & 15;
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = rb * 16 + w, c0 = 4 * lane;
+  float* sc = P.scratch + (size_t)b * 4 * ncell;
+  const float* pfin = pfin_base + (size_t)b * pfin_stride;
+  const float* state = P.state_in + (size_t)b * ncell * 2;
+  const float* act = P.action + (size_t)b * C.action_dim;
+  auto row4 = [&](const float* base, int row, float (&f)[4]) {
+    const int r = row < 0 ? 0 : (row > n - 1 ? n - 1 : row);
+    const float4 a = *reinterpret_cast<const float4*>(base + r * n + c0);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
+  };
+  float pc[4], pu[4], pd[4], un[4], vn[4];
+  row4(pfin, i, pc);
+  row4(pfin, i - 1, pu);
+  row4(pfin, i + 1, pd);
+  {
+    float uc[4], vc[4], uu[4], vu[4], ud[4], vd[4];
+    load_state_row_256(state, i, c0, uc, vc);
+    load_state_row_256(state, i - 1, c0, uu, vu);
+    load_state_row_256(state, i + 1, c0, ud, vd);
+    predictor_row_256(S, i, lane, uc, vc, uu, vu, ud, vd, un, vn);     // u*, v* of this row (edge cells: the state)
+  }
+  if (p_copy_to) *reinterpret_cast<float4*>(p_copy_to + (size_t)b * ncell + i * n + c0) = make_float4(pc[0], pc[1], pc[2], pc[3]);
+  const float pl = lane_left(pc[3]), pr = lane_right(pc[0]);
+  // ---- corrector (:143-145) ----
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float pw = (k == 0) ? pl : pc[k - 1], pe = (k == 3) ? pr : pc[k + 1];
+    const float dpdx = div_c(pe - pw, S.two_dx, S.inv_two_dx);
+    const float dpdy = div_c(pd[k] - pu[k], S.two_dy, S.inv_two_dy);
+    const bool edge = (i == 0) || (i == n - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
+    un[k] = edge ? un[k] : un[k] - S.dt_over_rho * dpdx;
+    vn[k] = edge ? vn[k] : vn[k] - S.dt_over_rho * dpdy;
+  }
+  // ---- apply_boundary(u, v) (:146): boundary cells are functions of the interior cells next to them only ----
+  *reinterpret_cast<float4*>(lds_u + w * n + c0) = make_float4(un[0], un[1], un[2], un[3]);
+  *reinterpret_cast<float4*>(lds_v + w * n + c0) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+  __syncthreads();
+  bc_rows_256<16>(un, vn, i, lane, w, lds_u, lds_v, C.bc, act, C.action_dim);
+  // ---- observation (:147-154) and the reward's squared distance to the reference frame (ns_reward.py:28) ----
+  const int t = P.time_index[b] + 1;
+  const int tr = t < C.nt_ref ? t : C.nt_ref - 1;
+  const float4* rr = reinterpret_cast<const float4*>(P.U_ref + (size_t)tr * ncell * 2 + (i * n + c0) * 2);
+  float4* oo = reinterpret_cast<float4*>(P.obs + (size_t)b * ncell * 2 + (i * n + c0) * 2);
+  float acc = 0.f;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float4 r4 = rr[q];
+    const float a0 = un[2 * q], b0 = vn[2 * q], a1 = un[2 * q + 1], b1 = vn[2 * q + 1];
+    oo[q] = make_float4(a0, b0, a1, b1);
+    const float d0 = a0 - r4.x, d1 = b0 - r4.y, d2 = a1 - r4.z, d3 = b1 - r4.w;
+    acc += d0 * d0;
+    acc += d1 * d1;
+    acc += d2 * d2;
+    acc += d3 * d3;
+  }
+  const float ss = block_sum<float>(acc, red);
+  if (threadIdx.x == 0) sc[2 * ncell + rb] = ss;   // partial sum of this 16-row band (rq is dead by now)
 }
 
 template <typename T, int LDSJ>
@@ -1286,6 +1739,12 @@ inline int lds_block_threads(int ncell, int B) {
   return 1024;
 }
 
+// PDEGYM_NS256_OLD=1: the round-1 256x256 pipeline (u*, v* round trip, two 32-sweep passes) for A/B runs
+inline bool pdegym_ns256_old_pipeline() {
+  const char* e = getenv("PDEGYM_NS256_OLD");
+  return e && e[0] == '1';
+}
+
 inline bool pdegym_no_lds_jacobi() {
   const char* e = getenv("PDEGYM_NS_NO_LDS_JACOBI");
   return e && e[0] == '1';
@@ -1324,7 +1783,8 @@ int ns_step(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int B, v
   C.nt_ref = buf->nt_ref;
   NSPtrs<T> P{(T*)buf->u, (T*)buf->v, (T*)buf->p, (T*)buf->scratch, (const T*)buf->action, buf->time_index,
               (const T*)buf->U_ref, (const T*)buf->action_ref, (T*)buf->obs, (T*)buf->reward, buf->terminated,
-              (const T*)buf->state_in};
+              (const T*)buf->state_in, (T*)buf->p_out};
+  if (buf->p_out && buf->p_out == buf->p) return pdegym::fail(-3, "p_out must not alias p");
   if constexpr (sizeof(T) == 4) {
     // register-tiled float32 path for the square grids it is instantiated for (BASELINE config 4 is 128x128)
     if (!pdegym_force_generic() && C.nx == C.ny && (C.nx == 128 || C.nx == 64)) {
@@ -1346,17 +1806,46 @@ int ns_step(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int B, v
   if constexpr (sizeof(T) == 4) {
     // 256x256 float32 (BASELINE config 5): front kernel -> slab Jacobi passes -> back kernel
     if (!pdegym_force_generic() && C.nx == 256 && C.ny == 256) {
-      constexpr int kH = 32, kPR = 10;
       const size_t ncell = (size_t)C.nx * C.ny;
       hipStream_t st = (hipStream_t)stream;
       const bool inter = buf->state_in != nullptr;
+      float* bufs[2] = {P.p, P.scratch + 3 * ncell};
+      const size_t strides[2] = {ncell, 4 * ncell};
+      int cur = 0;
+      if (inter && !pdegym_ns256_old_pipeline()) {
+        // second-generation pipeline: rq from the state, all sweeps of a pass in registers (up to 52 per pass), the back
+        // kernel re-evaluates the predictor
+        constexpr int nband = (256 + kRqBand - 1) / kRqBand;
+        constexpr int kPR = 15, kNTR = 12, kH = kNTR * kPR - 128;         // 12 waves x 15 rows = 128 own + 52 halo rows
+        hipLaunchKernelGGL(ns256_rq_front, dim3(nband * B), dim3(1024), 0, st, C, S, P, B);
+        const int npass = C.iters > 0 ? (C.iters + kH - 1) / kH : 0;
+        // pass i reads src and writes dst; the last pass lands in p_out when the caller ping-pongs pressure tensors, otherwise
+        // passes alternate p <-> scratch quarter 3 and the back kernel copies the result home if it ended in the scratch
+        const float* src = P.p;
+        size_t src_stride = ncell;
+        int left = C.iters;
+        for (int i = 0; i < npass; ++i, left -= kH) {
+          const int nsw = left < kH ? left : kH;
+          float* dst;
+          size_t dst_stride;
+          const bool to_scratch = P.p_out ? ((npass - 1 - i) & 1) : !(i & 1);
+          if (to_scratch) { dst = P.scratch + 3 * ncell; dst_stride = 4 * ncell; }
+          else { dst = P.p_out ? P.p_out : P.p; dst_stride = ncell; }
+          hipLaunchKernelGGL((ns_slab_jacobi_rq<kPR, kNTR>), dim3(2 * B), dim3(64 * kNTR), 2 * 2 * (64 * kNTR) * 16, st, src, src_stride, dst,
+                             dst_stride, P.scratch + 2 * ncell, 4 * ncell, nsw, B);
+          src = dst;
+          src_stride = dst_stride;
+        }
+        float* home = P.p_out ? P.p_out : P.p;
+        hipLaunchKernelGGL(ns256_back_pred, dim3(16 * B), dim3(1024), 0, st, C, S, P, src, src_stride, src == home ? (float*)nullptr : home, B);
+        hipLaunchKernelGGL(ns256_finish, dim3((B + 255) / 256), dim3(256), 0, st, C, S, P, B);
+        return pdegym::check_launch("ns2d_slab_step");
+      }
+      constexpr int kH = 32, kPR = 10;
       if (inter)
         hipLaunchKernelGGL(ns256_front<true>, dim3(16 * B), dim3(1024), 0, st, C, S, P, B);
       else
         hipLaunchKernelGGL(ns256_front<false>, dim3(16 * B), dim3(1024), 0, st, C, S, P, B);
-      float* bufs[2] = {P.p, P.scratch + 3 * ncell};
-      const size_t strides[2] = {ncell, 4 * ncell};
-      int cur = 0;
       for (int left = C.iters; left > 0; left -= kH) {
         const int nsw = left < kH ? left : kH;
         hipLaunchKernelGGL((ns_slab_jacobi<kPR, kH>), dim3(2 * B), dim3(1024), 2 * 2 * 1024 * 16, st, S, bufs[cur], strides[cur],
@@ -1424,7 +1913,7 @@ int ns_reset(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, const v
   if (B <= 0) return 0;
   C.nt_ref = 1;
   NSPtrs<T> P{(T*)buf->u, (T*)buf->v, (T*)buf->p, (T*)buf->scratch, (const T*)buf->action, buf->time_index,
-              (const T*)buf->U_ref, (const T*)buf->action_ref, (T*)buf->obs, (T*)buf->reward, buf->terminated, nullptr};
+              (const T*)buf->U_ref, (const T*)buf->action_ref, (T*)buf->obs, (T*)buf->reward, buf->terminated, nullptr, nullptr};
   const int ncell = C.nx * C.ny;
   const int gx = (ncell + 255) / 256 > 64 ? 64 : (ncell + 255) / 256;
   hipLaunchKernelGGL(ns_reset_kernel<T>, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, C, P, (const T*)u0, (const T*)v0,

@@ -126,7 +126,7 @@ class FakeBackend:
             orc.reset(T["u"].numpy(), T["v"].numpy(), T["p"].numpy())
         orc.time_index = T["time_index"].numpy().astype(np.int64)
         obs, r, te, _ = orc.step(T["action"].numpy())
-        for k, a in (("u", orc.u), ("v", orc.v), ("p", orc.p), ("obs", obs), ("reward", r)):
+        for k, a in (("u", orc.u), ("v", orc.v), ("p_out" if T.get("p_out") is not None else "p", orc.p), ("obs", obs), ("reward", r)):
             if T.get(k) is not None:
                 T[k].copy_(torch.from_numpy(np.ascontiguousarray(a)).to(T[k].dtype))
         T["time_index"].copy_(torch.from_numpy(orc.time_index.astype(np.int32)))

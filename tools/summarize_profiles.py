@@ -90,6 +90,67 @@ for wl in DOM:
                 merged.setdefault(k, {}).update(d)
     if merged:
         summary.setdefault("sq_counters", {})[wl] = merged
+# ---- per-STEP totals for bench.py's roofline block (profiles/counters_latest.json) -------------------------------------
+def totals_by_kernel(path):
+    tot = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[k][r["Counter_Name"]] += 1
+    return tot, cnt
+
+
+def is_step_kernel(name):
+    return not ("at::native" in name or "reset" in name or "Functor" in name or "elementwise" in name)
+
+
+latest = {"source": f"profiles/{tag}_summary.json: rocprofv3 --pmc, separate passes for FETCH_SIZE, WRITE_SIZE and the SQ group; "
+                    "HBM bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (MI355X_MICROARCH.md: gfx950 tallies 128-byte reads at 64 bytes); "
+                    "per-step = total over all launches of the step's kernels / number of steps",
+          "workloads": {}}
+for wl in DOM:
+    per = {}
+    kernels = {}
+    for label, sub, counter, scale in (("valu_insts_per_step", f"pmc_sq1_{wl}", "SQ_INSTS_VALU", 1.0),
+                                       ("_fetch", f"pmc_{wl}_FETCH_SIZE", "FETCH_SIZE", 2048.0),
+                                       ("_write", f"pmc_{wl}_WRITE_SIZE", "WRITE_SIZE", 1024.0)):
+        f = os.path.join(src, sub, "p_counter_collection.csv")
+        if not os.path.exists(f):
+            continue
+        tot, cnt = totals_by_kernel(f)
+        step_k = {k: v for k, v in tot.items() if is_step_kernel(k) and cnt[k].get(counter, 0) >= 10}
+        if not step_k:
+            continue
+        n_steps = min(cnt[k][counter] for k in step_k)
+        per[label] = sum(v.get(counter, 0.0) for v in step_k.values()) * scale / n_steps
+        for k, v in step_k.items():
+            e = kernels.setdefault(k, {})
+            e["launches_per_step"] = cnt[k][counter] / n_steps
+            e[counter + "_per_step"] = v.get(counter, 0.0) * (scale if counter != "SQ_INSTS_VALU" else 1.0) / n_steps
+    if "_fetch" in per and "_write" in per:
+        per["hbm_bytes_per_step"] = per.pop("_fetch") + per.pop("_write")
+    per = {k: v for k, v in per.items() if not k.startswith("_")}
+    st = os.path.join(src, f"stats_{wl}", "p_kernel_stats.csv")
+    if os.path.exists(st):
+        for r in csv.DictReader(open(st)):
+            k = short(r["Name"])
+            if k in kernels:
+                kernels[k]["avg_ns"] = float(r["AverageNs"])
+    if per:
+        per["kernels"] = kernels
+        latest["workloads"][wl] = per
+if latest["workloads"]:
+    prev_path = os.path.join(dst, "counters_latest.json")
+    if os.path.exists(prev_path):       # keep workloads that this round did not re-profile
+        try:
+            prev = json.load(open(prev_path))
+            for k, v in prev.get("workloads", {}).items():
+                latest["workloads"].setdefault(k, dict(v, stale_from=prev.get("source", "")[:40]))
+        except Exception:
+            pass
+    with open(prev_path, "w") as fh:
+        json.dump(latest, fh, indent=1)
 with open(os.path.join(dst, f"{tag}_summary.json"), "w") as fh:
     json.dump(summary, fh, indent=1)
 with open(os.path.join(dst, "traffic_latest.json"), "w") as fh:
