@@ -739,6 +739,212 @@ __device__ __forceinline__ void unrotate(const float (&ph)[PR + 1][PC], float (&
   }
 }
 
+// ---- boustrophedon sweeps: a rotation with period two ---------------------------------------------------------------
+// ph has PR+1 physical rows.  State 0: logical patch row a sits in physical row a, physical row PR is free.  An UP sweep
+// (rows 0 -> PR-1) writes new row a into the registers of old row a-1 (the top halo is loaded into the free row), leaving
+// logical row a in physical row a-1 (row 0 in PR) and physical row PR-1 free (state 1).  A DOWN sweep (rows PR-1 -> 0) writes
+// new row a into the registers of old row a+1 (the bottom halo is loaded into the free row) and restores state 0.  Two sweep
+// bodies instead of PR+1, no register copies, and the halo row a sweep needs FIRST is the row its neighbour produced first
+// in the previous sweep.  Arithmetic and its order are those of jacobi_sweep_rot / ns_generic_step<float>.
+template <int PR>
+__device__ constexpr int bphys(int a, int state) {          // physical row of logical row a (a = -1: top halo in an UP sweep)
+  return state == 0 ? a : (a == 0 ? PR : a - 1);
+}
+
+// ((W + S) + E) + N -> fma(0.25, ., -rq), in place on the registers of the South row (UP) ...
+__device__ __forceinline__ void jacobi_row_into_south(float (&sv)[4], const float (&xv)[4], const float (&nn)[4], const float (&rq)[4]) {
+  asm volatile(
+      "v_add_f32 %1, %4, %1\n\t"
+      "v_add_f32 %2, %5, %2\n\t"
+      "v_add_f32 %3, %6, %3\n\t"
+      "v_add_f32_dpp %0, %7, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %0, %0, %5\n\t"
+      "v_add_f32 %1, %1, %6\n\t"
+      "v_add_f32 %2, %2, %7\n\t"
+      "v_add_f32_dpp %3, %4, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %0, %0, %8\n\t"
+      "v_add_f32 %1, %1, %9\n\t"
+      "v_add_f32 %2, %2, %10\n\t"
+      "v_add_f32 %3, %3, %11\n\t"
+      "v_fma_f32 %0, %0, %16, -%12\n\t"
+      "v_fma_f32 %1, %1, %16, -%13\n\t"
+      "v_fma_f32 %2, %2, %16, -%14\n\t"
+      "v_fma_f32 %3, %3, %16, -%15"
+      : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3])
+      : "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]), "v"(nn[0]), "v"(nn[1]), "v"(nn[2]), "v"(nn[3]), "v"(rq[0]), "v"(rq[1]),
+        "v"(rq[2]), "v"(rq[3]), "s"(0.25f));
+}
+// ... and on the registers of the North row (DOWN): the partial sums (W + S) + E need four temporaries
+__device__ __forceinline__ void jacobi_row_into_north(float (&nv)[4], const float (&xv)[4], const float (&ss)[4], const float (&rq)[4]) {
+  float t0, t1, t2, t3;
+  asm volatile(
+      "v_add_f32 %5, %8, %13\n\t"
+      "v_add_f32 %6, %9, %14\n\t"
+      "v_add_f32 %7, %10, %15\n\t"
+      "v_add_f32_dpp %4, %11, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %4, %4, %9\n\t"
+      "v_add_f32 %5, %5, %10\n\t"
+      "v_add_f32 %6, %6, %11\n\t"
+      "v_add_f32_dpp %7, %8, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %0, %4, %0\n\t"
+      "v_add_f32 %1, %5, %1\n\t"
+      "v_add_f32 %2, %6, %2\n\t"
+      "v_add_f32 %3, %7, %3\n\t"
+      "v_fma_f32 %0, %0, %20, -%16\n\t"
+      "v_fma_f32 %1, %1, %20, -%17\n\t"
+      "v_fma_f32 %2, %2, %20, -%18\n\t"
+      "v_fma_f32 %3, %3, %20, -%19"
+      : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]), "v"(ss[0]), "v"(ss[1]), "v"(ss[2]), "v"(ss[3]), "v"(rq[0]), "v"(rq[1]),
+        "v"(rq[2]), "v"(rq[3]), "s"(0.25f));
+}
+
+// Two rows per block (8 independent dependency chains instead of 4: a wave issues only about every 8 cycles along ONE
+// chain of 4, so three or four waves per SIMD cannot fill it with single-row blocks -- tools/ubench_dpp.hip).
+// UP, rows a (A) and a+1 (B):  da = old row a-1 (South of A, becomes new row a), db = old row a (centre of A, South of B,
+// becomes new row a+1), xb = old row a+1 (North of A, centre of B), nb = old row a+2 / bottom halo (North of B).
+// A accumulates in place; B keeps its partial sums in four temporaries until A has read db for the last time (A8).
+__device__ __forceinline__ void jacobi_pair_up(float (&da)[4], float (&db)[4], const float (&xb)[4], const float (&nb)[4],
+                                               const float (&rqa)[4], const float (&rqb)[4]) {
+  float t0, t1, t2, t3;
+  asm volatile(
+      "v_add_f32 %1, %4, %1\n\t"                  // A: W + S
+      "v_add_f32 %9, %12, %5\n\t"                 // B
+      "v_add_f32 %2, %5, %2\n\t"
+      "v_add_f32 %10, %13, %6\n\t"
+      "v_add_f32 %3, %6, %3\n\t"
+      "v_add_f32 %11, %14, %7\n\t"
+      "v_add_f32_dpp %0, %7, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %8, %15, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %0, %0, %5\n\t"                  // + E
+      "v_add_f32 %8, %8, %13\n\t"
+      "v_add_f32 %1, %1, %6\n\t"
+      "v_add_f32 %9, %9, %14\n\t"
+      "v_add_f32 %2, %2, %7\n\t"
+      "v_add_f32 %10, %10, %15\n\t"
+      "v_add_f32_dpp %3, %4, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %11, %12, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %0, %0, %12\n\t"                 // + N
+      "v_add_f32 %8, %8, %16\n\t"
+      "v_add_f32 %1, %1, %13\n\t"
+      "v_add_f32 %9, %9, %17\n\t"
+      "v_add_f32 %2, %2, %14\n\t"
+      "v_add_f32 %10, %10, %18\n\t"
+      "v_add_f32 %3, %3, %15\n\t"
+      "v_add_f32 %11, %11, %19\n\t"
+      "v_fma_f32 %0, %0, %28, -%20\n\t"           // 0.25 * s4 - rq ; B lands in db (A no longer reads it)
+      "v_fma_f32 %4, %8, %28, -%24\n\t"
+      "v_fma_f32 %1, %1, %28, -%21\n\t"
+      "v_fma_f32 %5, %9, %28, -%25\n\t"
+      "v_fma_f32 %2, %2, %28, -%22\n\t"
+      "v_fma_f32 %6, %10, %28, -%26\n\t"
+      "v_fma_f32 %3, %3, %28, -%23\n\t"
+      "v_fma_f32 %7, %11, %28, -%27"
+      : "+v"(da[0]), "+v"(da[1]), "+v"(da[2]), "+v"(da[3]), "+v"(db[0]), "+v"(db[1]), "+v"(db[2]), "+v"(db[3]), "=&v"(t0), "=&v"(t1),
+        "=&v"(t2), "=&v"(t3)
+      : "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]), "v"(nb[0]), "v"(nb[1]), "v"(nb[2]), "v"(nb[3]), "v"(rqa[0]), "v"(rqa[1]),
+        "v"(rqa[2]), "v"(rqa[3]), "v"(rqb[0]), "v"(rqb[1]), "v"(rqb[2]), "v"(rqb[3]), "s"(0.25f));
+}
+
+// DOWN, rows a (A) and a-1 (B):  da = old row a+1 / bottom halo (North of A, becomes new row a), db = old row a (centre of A,
+// North of B, becomes new row a-1), xb = old row a-1 (South of A, centre of B), sb = old row a-2 / top halo (South of B).
+// North is the LAST addend of ((W + S) + E) + N, so both rows form (W + S) + E in temporaries first.
+__device__ __forceinline__ void jacobi_pair_down(float (&da)[4], float (&db)[4], const float (&xb)[4], const float (&sb)[4],
+                                                 const float (&rqa)[4], const float (&rqb)[4]) {
+  float a0, a1, a2, a3, b0, b1, b2, b3;
+  asm volatile(
+      "v_add_f32 %9, %4, %17\n\t"                 // A: W + S   (W = db[k-1], S = xb[k])
+      "v_add_f32 %13, %16, %21\n\t"               // B:          (W = xb[k-1], S = sb[k])
+      "v_add_f32 %10, %5, %18\n\t"
+      "v_add_f32 %14, %17, %22\n\t"
+      "v_add_f32 %11, %6, %19\n\t"
+      "v_add_f32 %15, %18, %23\n\t"
+      "v_add_f32_dpp %8, %7, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %12, %19, %20 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %8, %8, %5\n\t"                  // + E
+      "v_add_f32 %12, %12, %17\n\t"
+      "v_add_f32 %9, %9, %6\n\t"
+      "v_add_f32 %13, %13, %18\n\t"
+      "v_add_f32 %10, %10, %7\n\t"
+      "v_add_f32 %14, %14, %19\n\t"
+      "v_add_f32_dpp %11, %4, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %15, %16, %15 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32 %0, %8, %0\n\t"                  // + N, in place on the North rows (A has read db for the last time)
+      "v_add_f32 %4, %12, %4\n\t"
+      "v_add_f32 %1, %9, %1\n\t"
+      "v_add_f32 %5, %13, %5\n\t"
+      "v_add_f32 %2, %10, %2\n\t"
+      "v_add_f32 %6, %14, %6\n\t"
+      "v_add_f32 %3, %11, %3\n\t"
+      "v_add_f32 %7, %15, %7"
+      : "+v"(da[0]), "+v"(da[1]), "+v"(da[2]), "+v"(da[3]), "+v"(db[0]), "+v"(db[1]), "+v"(db[2]), "+v"(db[3]), "=&v"(a0), "=&v"(a1),
+        "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+      : "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]), "v"(sb[0]), "v"(sb[1]), "v"(sb[2]), "v"(sb[3]));
+  asm volatile(
+      "v_fma_f32 %0, %0, %16, -%8\n\t"
+      "v_fma_f32 %4, %4, %16, -%12\n\t"
+      "v_fma_f32 %1, %1, %16, -%9\n\t"
+      "v_fma_f32 %5, %5, %16, -%13\n\t"
+      "v_fma_f32 %2, %2, %16, -%10\n\t"
+      "v_fma_f32 %6, %6, %16, -%14\n\t"
+      "v_fma_f32 %3, %3, %16, -%11\n\t"
+      "v_fma_f32 %7, %7, %16, -%15"
+      : "+v"(da[0]), "+v"(da[1]), "+v"(da[2]), "+v"(da[3]), "+v"(db[0]), "+v"(db[1]), "+v"(db[2]), "+v"(db[3])
+      : "v"(rqa[0]), "v"(rqa[1]), "v"(rqa[2]), "v"(rqa[3]), "v"(rqb[0]), "v"(rqb[1]), "v"(rqb[2]), "v"(rqb[3]), "s"(0.25f));
+}
+
+// Neumann walls (:110-113) on the new rows, which sit in state `st`
+template <int PR, int ST>
+__device__ __forceinline__ void jacobi_walls_state(float (&ph)[PR + 1][4], const EdgeFlags& E) {
+  constexpr int n0 = bphys<PR>(0, ST), n1 = bphys<PR>(1, ST), nl = bphys<PR>(PR - 1, ST), nm = bphys<PR>(PR - 2, ST);
+  if (E.top) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ph[n0][k] = ph[n1][k];
+  }
+  if (E.bot) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ph[nl][k] = ph[nm][k];
+  }
+  if (E.lef) {
+#pragma unroll
+    for (int a = 0; a < PR; ++a) ph[bphys<PR>(a, ST)][0] = ph[bphys<PR>(a, ST)][1];
+  }
+  if (E.rig) {
+#pragma unroll
+    for (int a = 0; a < PR; ++a) ph[bphys<PR>(a, ST)][3] = ph[bphys<PR>(a, ST)][2];
+  }
+}
+
+// One sweep starting from state ST (0: UP, 1: DOWN).  Halo rows cross thread rows through the double-buffered LDS area of
+// halo_tb (one barrier); the halo used LAST lands in four temporaries.
+template <int PR, int ST, int NT, int RS>
+__device__ __forceinline__ void jacobi_sweep_bous(float (&ph)[PR + 1][4], const float (&rq)[PR][4], const EdgeFlags& E, float* lds,
+                                                  int& xc, int tid, int ty) {
+  float hlast[4];
+  if constexpr (ST == 0) {
+    halo_tb<4, NT, RS>(ph[bphys<PR>(0, 0)], ph[bphys<PR>(PR - 1, 0)], ph[PR], hlast, lds, xc, tid, ty);   // top halo -> free row PR
+#pragma unroll
+    for (int a = 0; a + 1 < PR; a += 2) {       // rows (a, a+1)
+      float (&da)[4] = ph[a == 0 ? PR : a - 1];
+      if (a + 2 == PR) jacobi_pair_up(da, ph[a], ph[a + 1], hlast, rq[a], rq[a + 1]);
+      else jacobi_pair_up(da, ph[a], ph[a + 1], ph[a + 2], rq[a], rq[a + 1]);
+    }
+    if constexpr (PR % 2 == 1) jacobi_row_into_south(ph[PR - 2], ph[PR - 1], hlast, rq[PR - 1]);
+    jacobi_walls_state<PR, 1>(ph, E);
+  } else {
+    // state 1: logical row a in physical row a-1 (row 0 in PR); physical row PR-1 is free -> bottom halo
+    halo_tb<4, NT, RS>(ph[bphys<PR>(0, 1)], ph[bphys<PR>(PR - 1, 1)], hlast, ph[PR - 1], lds, xc, tid, ty);
+#pragma unroll
+    for (int a = PR - 1; a >= 1; a -= 2) {      // rows (a, a-1): new row a -> physical row a, new row a-1 -> physical row a-1
+      // physical rows: old logical a+1 (or bottom halo) = a, old a = a-1, old a-1 = bphys(a-1), old a-2 = bphys(a-2) / top halo
+      if (a == 1) jacobi_pair_down(ph[a], ph[a - 1], ph[bphys<PR>(0, 1)], hlast, rq[a], rq[a - 1]);
+      else jacobi_pair_down(ph[a], ph[a - 1], ph[bphys<PR>(a - 1, 1)], ph[bphys<PR>(a - 2, 1)], rq[a], rq[a - 1]);
+    }
+    if constexpr (PR % 2 == 1) jacobi_row_into_north(ph[0], ph[bphys<PR>(0, 1)], hlast, rq[0]);
+    jacobi_walls_state<PR, 0>(ph, E);
+  }
+}
+
 template <int PR, int PC, bool INTERLEAVED>
 __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> S, NSPtrs<float> P, int B) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -866,15 +1072,36 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
 #pragma unroll
       for (int k = 0; k < PC; ++k) ph[PR][k] = 0.f;
     }
-    int it = 0, rot = 0;
-    while (true) {
-      const int r = SweepChain<PR, PC, 0>::run(ph, rq, E, lds, xc, tid, ty, it, C.iters);
-      if (r >= 0) {
-        rot = r;
-        break;
+    if constexpr (PC == 4) {
+      // period-two rotation (UP / DOWN sweeps, two-row in-place blocks): see jacobi_sweep_bous
+      int it = 0;
+      for (; it + 2 <= C.iters; it += 2) {
+        jacobi_sweep_bous<PR, 0, 512, 32>(ph, rq, E, lds, xc, tid, ty);
+        jacobi_sweep_bous<PR, 1, 512, 32>(ph, rq, E, lds, xc, tid, ty);
       }
+      if (it < C.iters) {
+        jacobi_sweep_bous<PR, 0, 512, 32>(ph, rq, E, lds, xc, tid, ty);
+#pragma unroll
+        for (int a = 0; a < PR; ++a)
+#pragma unroll
+          for (int k = 0; k < PC; ++k) pf[a][k] = ph[bphys<PR>(a, 1)][k];
+      } else {
+#pragma unroll
+        for (int a = 0; a < PR; ++a)
+#pragma unroll
+          for (int k = 0; k < PC; ++k) pf[a][k] = ph[a][k];
+      }
+    } else {
+      int it = 0, rot = 0;
+      while (true) {
+        const int r = SweepChain<PR, PC, 0>::run(ph, rq, E, lds, xc, tid, ty, it, C.iters);
+        if (r >= 0) {
+          rot = r;
+          break;
+        }
+      }
+      unrotate<PR, PC, 0>(ph, pf, rot);
     }
-    unrotate<PR, PC, 0>(ph, pf, rot);
   }
   PDEGYM_STAMP(3, pf[0][0]);
   store_patch<PR, PC>(pf, P.p_out ? P.p_out + (size_t)b * ncell : p, n, r0, c0);
@@ -1307,209 +1534,311 @@ __device__ __forceinline__ void store_rotated_rows(const float (&ph)[PR + 1][PC]
   }
 }
 
-// ---- boustrophedon sweeps: a rotation with period two ---------------------------------------------------------------
-// ph has PR+1 physical rows.  State 0: logical patch row a sits in physical row a, physical row PR is free.  An UP sweep
-// (rows 0 -> PR-1) writes new row a into the registers of old row a-1 (the top halo is loaded into the free row), leaving
-// logical row a in physical row a-1 (row 0 in PR) and physical row PR-1 free (state 1).  A DOWN sweep (rows PR-1 -> 0) writes
-// new row a into the registers of old row a+1 (the bottom halo is loaded into the free row) and restores state 0.  Two sweep
-// bodies instead of PR+1, no register copies, and the halo row a sweep needs FIRST is the row its neighbour produced first
-// in the previous sweep.  Arithmetic and its order are those of jacobi_sweep_rot / ns_generic_step<float>.
+// ================================================================================================
+// float64 register-tiled step for 128x128 (the reference's own precision, BASELINE config 4 at float64): 1024 threads per
+// instance, one WAVE per thread row: lane tx of wave ty owns the 8 x 2 patch at rows 8 ty .. 8 ty + 7, columns 2 tx, 2 tx + 1.
+//   * left/right neighbours are the neighbouring lanes (two v_mov_b32_dpp per double);
+//   * top/bottom halo rows (2 doubles = 16 bytes per lane) cross waves through a double-buffered LDS area, one barrier per
+//     exchange;
+//   * p and dx dy rhs stay in registers for all K sweeps; the rows rotate with period two (UP / DOWN sweeps, see
+//     jacobi_sweep_bous) so a sweep has no register copies;
+//   * every expression is the one of ns_generic_step<double> -- IEEE division included -- so the result is bit-identical to
+//     NumPy (tests: goldens N3, oracle at 128x128, equality with the generic kernel).
+// ================================================================================================
+__device__ __forceinline__ double dpp_shr_f64(double v) {       // lane i <- lane i-1 (lane 0: 0, a domain-edge lane)
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x138, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double dpp_shl_f64(double v) {       // lane i <- lane i+1
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x130, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// top/bottom halo rows of a 2-wide double patch through LDS (waves are thread rows: RS = 64)
+__device__ __forceinline__ void halo_tb_f64(const double (&top)[2], const double (&bot)[2], double (&ht)[2], double (&hb)[2], double* lds,
+                                            int& xc, int tid, int ty) {
+  constexpr int NT = 1024, RS = 64;
+  double2* base = reinterpret_cast<double2*>(lds) + (xc & 1) * (2 * NT);
+  ++xc;
+  double2* eT = base;
+  double2* eB = base + NT;
+  eT[tid] = make_double2(top[0], top[1]);
+  eB[tid] = make_double2(bot[0], bot[1]);
+  __syncthreads();
+  const int up = (ty > 0) ? tid - RS : tid, dn = (ty < NT / RS - 1) ? tid + RS : tid;
+  const double2 a = eB[up], b = eT[dn];
+  ht[0] = a.x; ht[1] = a.y;
+  hb[0] = b.x; hb[1] = b.y;
+}
+
 template <int PR>
-__device__ constexpr int bphys(int a, int state) {          // physical row of logical row a (a = -1: top halo in an UP sweep)
-  return state == 0 ? a : (a == 0 ? PR : a - 1);
-}
-
-// ((W + S) + E) + N -> fma(0.25, ., -rq), in place on the registers of the South row (UP) ...
-__device__ __forceinline__ void jacobi_row_into_south(float (&sv)[4], const float (&xv)[4], const float (&nn)[4], const float (&rq)[4]) {
-  asm volatile(
-      "v_add_f32 %1, %4, %1\n\t"
-      "v_add_f32 %2, %5, %2\n\t"
-      "v_add_f32 %3, %6, %3\n\t"
-      "v_add_f32_dpp %0, %7, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32 %0, %0, %5\n\t"
-      "v_add_f32 %1, %1, %6\n\t"
-      "v_add_f32 %2, %2, %7\n\t"
-      "v_add_f32_dpp %3, %4, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32 %0, %0, %8\n\t"
-      "v_add_f32 %1, %1, %9\n\t"
-      "v_add_f32 %2, %2, %10\n\t"
-      "v_add_f32 %3, %3, %11\n\t"
-      "v_fma_f32 %0, %0, %16, -%12\n\t"
-      "v_fma_f32 %1, %1, %16, -%13\n\t"
-      "v_fma_f32 %2, %2, %16, -%14\n\t"
-      "v_fma_f32 %3, %3, %16, -%15"
-      : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3])
-      : "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]), "v"(nn[0]), "v"(nn[1]), "v"(nn[2]), "v"(nn[3]), "v"(rq[0]), "v"(rq[1]),
-        "v"(rq[2]), "v"(rq[3]), "s"(0.25f));
-}
-// ... and on the registers of the North row (DOWN): the partial sums (W + S) + E need four temporaries
-__device__ __forceinline__ void jacobi_row_into_north(float (&nv)[4], const float (&xv)[4], const float (&ss)[4], const float (&rq)[4]) {
-  float t0, t1, t2, t3;
-  asm volatile(
-      "v_add_f32 %5, %8, %13\n\t"
-      "v_add_f32 %6, %9, %14\n\t"
-      "v_add_f32 %7, %10, %15\n\t"
-      "v_add_f32_dpp %4, %11, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32 %4, %4, %9\n\t"
-      "v_add_f32 %5, %5, %10\n\t"
-      "v_add_f32 %6, %6, %11\n\t"
-      "v_add_f32_dpp %7, %8, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32 %0, %4, %0\n\t"
-      "v_add_f32 %1, %5, %1\n\t"
-      "v_add_f32 %2, %6, %2\n\t"
-      "v_add_f32 %3, %7, %3\n\t"
-      "v_fma_f32 %0, %0, %20, -%16\n\t"
-      "v_fma_f32 %1, %1, %20, -%17\n\t"
-      "v_fma_f32 %2, %2, %20, -%18\n\t"
-      "v_fma_f32 %3, %3, %20, -%19"
-      : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-      : "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]), "v"(ss[0]), "v"(ss[1]), "v"(ss[2]), "v"(ss[3]), "v"(rq[0]), "v"(rq[1]),
-        "v"(rq[2]), "v"(rq[3]), "s"(0.25f));
-}
-
-// Two rows per block (8 independent dependency chains instead of 4: a wave issues only about every 8 cycles along ONE
-// chain of 4, so three or four waves per SIMD cannot fill it with single-row blocks -- tools/ubench_dpp.hip).
-// UP, rows a (A) and a+1 (B):  da = old row a-1 (South of A, becomes new row a), db = old row a (centre of A, South of B,
-// becomes new row a+1), xb = old row a+1 (North of A, centre of B), nb = old row a+2 / bottom halo (North of B).
-// A accumulates in place; B keeps its partial sums in four temporaries until A has read db for the last time (A8).
-__device__ __forceinline__ void jacobi_pair_up(float (&da)[4], float (&db)[4], const float (&xb)[4], const float (&nb)[4],
-                                               const float (&rqa)[4], const float (&rqb)[4]) {
-  float t0, t1, t2, t3;
-  asm volatile(
-      "v_add_f32 %1, %4, %1\n\t"                  // A: W + S
-      "v_add_f32 %9, %12, %5\n\t"                 // B
-      "v_add_f32 %2, %5, %2\n\t"
-      "v_add_f32 %10, %13, %6\n\t"
-      "v_add_f32 %3, %6, %3\n\t"
-      "v_add_f32 %11, %14, %7\n\t"
-      "v_add_f32_dpp %0, %7, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %8, %15, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32 %0, %0, %5\n\t"                  // + E
-      "v_add_f32 %8, %8, %13\n\t"
-      "v_add_f32 %1, %1, %6\n\t"
-      "v_add_f32 %9, %9, %14\n\t"
-      "v_add_f32 %2, %2, %7\n\t"
-      "v_add_f32 %10, %10, %15\n\t"
-      "v_add_f32_dpp %3, %4, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %11, %12, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32 %0, %0, %12\n\t"                 // + N
-      "v_add_f32 %8, %8, %16\n\t"
-      "v_add_f32 %1, %1, %13\n\t"
-      "v_add_f32 %9, %9, %17\n\t"
-      "v_add_f32 %2, %2, %14\n\t"
-      "v_add_f32 %10, %10, %18\n\t"
-      "v_add_f32 %3, %3, %15\n\t"
-      "v_add_f32 %11, %11, %19\n\t"
-      "v_fma_f32 %0, %0, %28, -%20\n\t"           // 0.25 * s4 - rq ; B lands in db (A no longer reads it)
-      "v_fma_f32 %4, %8, %28, -%24\n\t"
-      "v_fma_f32 %1, %1, %28, -%21\n\t"
-      "v_fma_f32 %5, %9, %28, -%25\n\t"
-      "v_fma_f32 %2, %2, %28, -%22\n\t"
-      "v_fma_f32 %6, %10, %28, -%26\n\t"
-      "v_fma_f32 %3, %3, %28, -%23\n\t"
-      "v_fma_f32 %7, %11, %28, -%27"
-      : "+v"(da[0]), "+v"(da[1]), "+v"(da[2]), "+v"(da[3]), "+v"(db[0]), "+v"(db[1]), "+v"(db[2]), "+v"(db[3]), "=&v"(t0), "=&v"(t1),
-        "=&v"(t2), "=&v"(t3)
-      : "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]), "v"(nb[0]), "v"(nb[1]), "v"(nb[2]), "v"(nb[3]), "v"(rqa[0]), "v"(rqa[1]),
-        "v"(rqa[2]), "v"(rqa[3]), "v"(rqb[0]), "v"(rqb[1]), "v"(rqb[2]), "v"(rqb[3]), "s"(0.25f));
-}
-
-// DOWN, rows a (A) and a-1 (B):  da = old row a+1 / bottom halo (North of A, becomes new row a), db = old row a (centre of A,
-// North of B, becomes new row a-1), xb = old row a-1 (South of A, centre of B), sb = old row a-2 / top halo (South of B).
-// North is the LAST addend of ((W + S) + E) + N, so both rows form (W + S) + E in temporaries first.
-__device__ __forceinline__ void jacobi_pair_down(float (&da)[4], float (&db)[4], const float (&xb)[4], const float (&sb)[4],
-                                                 const float (&rqa)[4], const float (&rqb)[4]) {
-  float a0, a1, a2, a3, b0, b1, b2, b3;
-  asm volatile(
-      "v_add_f32 %9, %4, %17\n\t"                 // A: W + S   (W = db[k-1], S = xb[k])
-      "v_add_f32 %13, %16, %21\n\t"               // B:          (W = xb[k-1], S = sb[k])
-      "v_add_f32 %10, %5, %18\n\t"
-      "v_add_f32 %14, %17, %22\n\t"
-      "v_add_f32 %11, %6, %19\n\t"
-      "v_add_f32 %15, %18, %23\n\t"
-      "v_add_f32_dpp %8, %7, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %12, %19, %20 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32 %8, %8, %5\n\t"                  // + E
-      "v_add_f32 %12, %12, %17\n\t"
-      "v_add_f32 %9, %9, %6\n\t"
-      "v_add_f32 %13, %13, %18\n\t"
-      "v_add_f32 %10, %10, %7\n\t"
-      "v_add_f32 %14, %14, %19\n\t"
-      "v_add_f32_dpp %11, %4, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32_dpp %15, %16, %15 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_add_f32 %0, %8, %0\n\t"                  // + N, in place on the North rows (A has read db for the last time)
-      "v_add_f32 %4, %12, %4\n\t"
-      "v_add_f32 %1, %9, %1\n\t"
-      "v_add_f32 %5, %13, %5\n\t"
-      "v_add_f32 %2, %10, %2\n\t"
-      "v_add_f32 %6, %14, %6\n\t"
-      "v_add_f32 %3, %11, %3\n\t"
-      "v_add_f32 %7, %15, %7"
-      : "+v"(da[0]), "+v"(da[1]), "+v"(da[2]), "+v"(da[3]), "+v"(db[0]), "+v"(db[1]), "+v"(db[2]), "+v"(db[3]), "=&v"(a0), "=&v"(a1),
-        "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
-      : "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]), "v"(sb[0]), "v"(sb[1]), "v"(sb[2]), "v"(sb[3]));
-  asm volatile(
-      "v_fma_f32 %0, %0, %16, -%8\n\t"
-      "v_fma_f32 %4, %4, %16, -%12\n\t"
-      "v_fma_f32 %1, %1, %16, -%9\n\t"
-      "v_fma_f32 %5, %5, %16, -%13\n\t"
-      "v_fma_f32 %2, %2, %16, -%10\n\t"
-      "v_fma_f32 %6, %6, %16, -%14\n\t"
-      "v_fma_f32 %3, %3, %16, -%11\n\t"
-      "v_fma_f32 %7, %7, %16, -%15"
-      : "+v"(da[0]), "+v"(da[1]), "+v"(da[2]), "+v"(da[3]), "+v"(db[0]), "+v"(db[1]), "+v"(db[2]), "+v"(db[3])
-      : "v"(rqa[0]), "v"(rqa[1]), "v"(rqa[2]), "v"(rqa[3]), "v"(rqb[0]), "v"(rqb[1]), "v"(rqb[2]), "v"(rqb[3]), "s"(0.25f));
-}
-
-// Neumann walls (:110-113) on the new rows, which sit in state `st`
-template <int PR, int ST>
-__device__ __forceinline__ void jacobi_walls_state(float (&ph)[PR + 1][4], const EdgeFlags& E) {
-  constexpr int n0 = bphys<PR>(0, ST), n1 = bphys<PR>(1, ST), nl = bphys<PR>(PR - 1, ST), nm = bphys<PR>(PR - 2, ST);
+__device__ __forceinline__ void apply_bc_patch_f64(double (&f)[PR][2], const EdgeFlags& E, const int (&bc)[4][2], int comp,
+                                                   const double* act, int action_dim, int r0, int c0) {
+  auto aval = [&](int idx) -> double { return action_dim == 1 ? act[0] : act[idx]; };
   if (E.top) {
+    const int c = bc[PDEGYM_EDGE_LOWER][comp];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ph[n0][k] = ph[n1][k];
+    for (int b = 0; b < 2; ++b) f[0][b] = (c == PDEGYM_BC_NEUMANN) ? f[1][b] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0 : aval(c0 + b));
   }
   if (E.bot) {
+    const int c = bc[PDEGYM_EDGE_UPPER][comp];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ph[nl][k] = ph[nm][k];
+    for (int b = 0; b < 2; ++b) f[PR - 1][b] = (c == PDEGYM_BC_NEUMANN) ? f[PR - 2][b] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0 : aval(c0 + b));
   }
+  if (E.lef) {
+    const int c = bc[PDEGYM_EDGE_LEFT][comp];
+#pragma unroll
+    for (int a = 0; a < PR; ++a) f[a][0] = (c == PDEGYM_BC_NEUMANN) ? f[a][1] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0 : aval(r0 + a));
+  }
+  if (E.rig) {
+    const int c = bc[PDEGYM_EDGE_RIGHT][comp];
+#pragma unroll
+    for (int a = 0; a < PR; ++a) f[a][1] = (c == PDEGYM_BC_NEUMANN) ? f[a][0] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0 : aval(r0 + a));
+  }
+}
+
+// Neumann pressure walls on the new rows in state ST (see bphys)
+template <int PR, int ST>
+__device__ __forceinline__ void jacobi_walls_f64(double (&ph)[PR + 1][2], const EdgeFlags& E) {
+  constexpr int n0 = bphys<PR>(0, ST), n1 = bphys<PR>(1, ST), nl = bphys<PR>(PR - 1, ST), nm = bphys<PR>(PR - 2, ST);
+  if (E.top) { ph[n0][0] = ph[n1][0]; ph[n0][1] = ph[n1][1]; }
+  if (E.bot) { ph[nl][0] = ph[nm][0]; ph[nl][1] = ph[nm][1]; }
   if (E.lef) {
 #pragma unroll
     for (int a = 0; a < PR; ++a) ph[bphys<PR>(a, ST)][0] = ph[bphys<PR>(a, ST)][1];
   }
   if (E.rig) {
 #pragma unroll
-    for (int a = 0; a < PR; ++a) ph[bphys<PR>(a, ST)][3] = ph[bphys<PR>(a, ST)][2];
+    for (int a = 0; a < PR; ++a) ph[bphys<PR>(a, ST)][1] = ph[bphys<PR>(a, ST)][0];
   }
 }
 
-// One sweep starting from state ST (0: UP, 1: DOWN).  Halo rows cross thread rows through the double-buffered LDS area of
-// halo_tb (one barrier); the halo used LAST lands in four temporaries.
-template <int PR, int ST, int NT, int RS>
-__device__ __forceinline__ void jacobi_sweep_bous(float (&ph)[PR + 1][4], const float (&rq)[PR][4], const EdgeFlags& E, float* lds,
-                                                  int& xc, int tid, int ty) {
-  float hlast[4];
+// one float64 Jacobi sweep from state ST (0: UP, rows 0 -> PR-1, 1: DOWN); 1/4 (((W + S) + E) + N - dx dy rhs) (:106-108)
+template <int PR, int ST>
+__device__ __forceinline__ void jacobi_sweep_f64(double (&ph)[PR + 1][2], const double (&rq)[PR][2], const EdgeFlags& E, double* lds,
+                                                 int& xc, int tid, int ty) {
+  double hlast[2];
+  auto update = [&](double (&dst)[2], const double (&x)[2], const double (&sv)[2], const double (&nv)[2], const double (&q)[2]) {
+    const double xl = dpp_shr_f64(x[1]), xr = dpp_shl_f64(x[0]);
+    const double s0 = ((xl + sv[0]) + x[1]) + nv[0];
+    const double s1 = ((x[0] + sv[1]) + xr) + nv[1];
+    dst[0] = 0.25 * (s0 - q[0]);
+    dst[1] = 0.25 * (s1 - q[1]);
+  };
   if constexpr (ST == 0) {
-    halo_tb<4, NT, RS>(ph[bphys<PR>(0, 0)], ph[bphys<PR>(PR - 1, 0)], ph[PR], hlast, lds, xc, tid, ty);   // top halo -> free row PR
+    halo_tb_f64(ph[0], ph[PR - 1], ph[PR], hlast, lds, xc, tid, ty);            // top halo -> free row PR
 #pragma unroll
-    for (int a = 0; a + 1 < PR; a += 2) {       // rows (a, a+1)
-      float (&da)[4] = ph[a == 0 ? PR : a - 1];
-      if (a + 2 == PR) jacobi_pair_up(da, ph[a], ph[a + 1], hlast, rq[a], rq[a + 1]);
-      else jacobi_pair_up(da, ph[a], ph[a + 1], ph[a + 2], rq[a], rq[a + 1]);
+    for (int a = 0; a < PR; ++a) {
+      // new row a overwrites old row a-1 (its South neighbour, dead afterwards); dst may alias sv: all reads come first
+      double out[2];
+      if (a == PR - 1) update(out, ph[a], ph[a == 0 ? PR : a - 1], hlast, rq[a]);
+      else update(out, ph[a], ph[a == 0 ? PR : a - 1], ph[a + 1], rq[a]);
+      ph[a == 0 ? PR : a - 1][0] = out[0];
+      ph[a == 0 ? PR : a - 1][1] = out[1];
     }
-    if constexpr (PR % 2 == 1) jacobi_row_into_south(ph[PR - 2], ph[PR - 1], hlast, rq[PR - 1]);
-    jacobi_walls_state<PR, 1>(ph, E);
+    jacobi_walls_f64<PR, 1>(ph, E);
   } else {
-    // state 1: logical row a in physical row a-1 (row 0 in PR); physical row PR-1 is free -> bottom halo
-    halo_tb<4, NT, RS>(ph[bphys<PR>(0, 1)], ph[bphys<PR>(PR - 1, 1)], hlast, ph[PR - 1], lds, xc, tid, ty);
+    halo_tb_f64(ph[bphys<PR>(0, 1)], ph[bphys<PR>(PR - 1, 1)], hlast, ph[PR - 1], lds, xc, tid, ty);   // bottom halo -> free row PR-1
 #pragma unroll
-    for (int a = PR - 1; a >= 1; a -= 2) {      // rows (a, a-1): new row a -> physical row a, new row a-1 -> physical row a-1
-      // physical rows: old logical a+1 (or bottom halo) = a, old a = a-1, old a-1 = bphys(a-1), old a-2 = bphys(a-2) / top halo
-      if (a == 1) jacobi_pair_down(ph[a], ph[a - 1], ph[bphys<PR>(0, 1)], hlast, rq[a], rq[a - 1]);
-      else jacobi_pair_down(ph[a], ph[a - 1], ph[bphys<PR>(a - 1, 1)], ph[bphys<PR>(a - 2, 1)], rq[a], rq[a - 1]);
+    for (int a = PR - 1; a >= 0; --a) {
+      double out[2];
+      if (a == 0) update(out, ph[bphys<PR>(0, 1)], hlast, ph[a], rq[a]);
+      else update(out, ph[bphys<PR>(a, 1)], ph[bphys<PR>(a - 1, 1)], ph[a], rq[a]);
+      ph[a][0] = out[0];
+      ph[a][1] = out[1];
     }
-    if constexpr (PR % 2 == 1) jacobi_row_into_north(ph[0], ph[bphys<PR>(0, 1)], hlast, rq[0]);
-    jacobi_walls_state<PR, 0>(ph, E);
+    jacobi_walls_f64<PR, 0>(ph, E);
+  }
+}
+
+template <bool INTERLEAVED>
+__global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<double> S, NSPtrs<double> P, int B) {
+  constexpr int n = 128, ncell = n * n, PR = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* lds = reinterpret_cast<double*>(smem_raw);
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int tid = threadIdx.x, tx = tid & 63;
+  const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r0 = ty * PR, c0 = tx * 2;
+  const EdgeFlags E{ty == 0, ty == 15, tx == 0, tx == 63};
+  double* u = INTERLEAVED ? nullptr : P.u + (size_t)b * ncell;
+  double* v = INTERLEAVED ? nullptr : P.v + (size_t)b * ncell;
+  const double* p = P.p + (size_t)b * ncell;
+  double* pout = (P.p_out ? P.p_out : P.p) + (size_t)b * ncell;
+  double* us = P.scratch + (size_t)b * 4 * ncell;
+  double* vs = us + ncell;
+  const double* act = P.action + (size_t)b * C.action_dim;
+  const double* sin = INTERLEAVED ? P.state_in + (size_t)b * ncell * 2 : nullptr;
+  int xc = 0;
+  auto edge_cell = [&](int a, int k) { return (a == 0 && E.top) || (a == PR - 1 && E.bot) || (k == 0 && E.lef) || (k == 1 && E.rig); };
+
+  double rq[PR][2];     // dx dy rhs, kept for all sweeps
+  {
+    double uf[PR][2], vf[PR][2];
+#pragma unroll
+    for (int a = 0; a < PR; ++a) {
+      if constexpr (INTERLEAVED) {
+        const double2* row = reinterpret_cast<const double2*>(sin + ((size_t)(r0 + a) * n + c0) * 2);
+        const double2 w0 = row[0], w1 = row[1];
+        uf[a][0] = w0.x; vf[a][0] = w0.y; uf[a][1] = w1.x; vf[a][1] = w1.y;
+      } else {
+        const double2 wu = *reinterpret_cast<const double2*>(u + (r0 + a) * n + c0);
+        const double2 wv = *reinterpret_cast<const double2*>(v + (r0 + a) * n + c0);
+        uf[a][0] = wu.x; uf[a][1] = wu.y; vf[a][0] = wv.x; vf[a][1] = wv.y;
+      }
+    }
+    // ---- predictor (navier_stokes2D.py:130-138): rows in order, the old row above is carried along ----
+    {
+      double ut[2], ub[2], vt[2], vb[2];
+      halo_tb_f64(uf[0], uf[PR - 1], ut, ub, lds, xc, tid, ty);
+      halo_tb_f64(vf[0], vf[PR - 1], vt, vb, lds, xc, tid, ty);
+      double pu[2] = {ut[0], ut[1]}, pv[2] = {vt[0], vt[1]};
+#pragma unroll
+      for (int a = 0; a < PR; ++a) {
+        const double cu[2] = {uf[a][0], uf[a][1]}, cv[2] = {vf[a][0], vf[a][1]};
+        const double ul = dpp_shr_f64(cu[1]), ur = dpp_shl_f64(cu[0]), vl = dpp_shr_f64(cv[1]), vr = dpp_shl_f64(cv[0]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const double uc = cu[k], vc = cv[k];
+          const double uw = (k == 0) ? ul : cu[0], ue = (k == 1) ? ur : cu[1];
+          const double vw = (k == 0) ? vl : cv[0], ve = (k == 1) ? vr : cv[1];
+          const double usn = pu[k], vsn = pv[k];
+          const double unn = (a == PR - 1) ? ub[k] : uf[a + 1][k];
+          const double vnn = (a == PR - 1) ? vb[k] : vf[a + 1][k];
+          const double dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx), dudy = div_c(unn - usn, S.two_dy, S.inv_two_dy);
+          const double dvdx = div_c(ve - vw, S.two_dx, S.inv_two_dx), dvdy = div_c(vnn - vsn, S.two_dy, S.inv_two_dy);
+          const double lapu = div_c((((uw + usn) - 4.0 * uc) + ue) + unn, S.dxdy, S.inv_dxdy);
+          const double lapv = div_c((((vw + vsn) - 4.0 * vc) + ve) + vnn, S.dxdy, S.inv_dxdy);
+          const double un = uc + S.dt * (((-uc) * dudx - vc * dudy) + S.nu * lapu);
+          const double vn = vc + S.dt * (((-uc) * dvdx - vc * dvdy) + S.nu * lapv);
+          const bool edge = edge_cell(a, k);
+          uf[a][k] = edge ? uc : un;
+          vf[a][k] = edge ? vc : vn;
+        }
+        pu[0] = cu[0]; pu[1] = cu[1]; pv[0] = cv[0]; pv[1] = cv[1];
+      }
+    }
+    // ---- apply_boundary(u*, v*) (:140) ----
+    apply_bc_patch_f64<PR>(uf, E, C.bc, 0, act, C.action_dim, r0, c0);
+    apply_bc_patch_f64<PR>(vf, E, C.bc, 1, act, C.action_dim, r0, c0);
+#pragma unroll
+    for (int a = 0; a < PR; ++a) {
+      *reinterpret_cast<double2*>(us + (r0 + a) * n + c0) = make_double2(uf[a][0], uf[a][1]);
+      *reinterpret_cast<double2*>(vs + (r0 + a) * n + c0) = make_double2(vf[a][0], vf[a][1]);
+    }
+    // ---- rhs (:101-103) times dx dy (:108) ----
+    {
+      double vt[2], vb[2];
+      halo_tb_f64(vf[0], vf[PR - 1], vt, vb, lds, xc, tid, ty);
+#pragma unroll
+      for (int a = 0; a < PR; ++a) {
+        const double ul = dpp_shr_f64(uf[a][1]), ur = dpp_shl_f64(uf[a][0]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const double uw = (k == 0) ? ul : uf[a][0], ue = (k == 1) ? ur : uf[a][1];
+          const double vsn = (a == 0) ? vt[k] : vf[a - 1][k], vnn = (a == PR - 1) ? vb[k] : vf[a + 1][k];
+          const double dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx);
+          const double dvdy = div_c(vnn - vsn, S.two_dy, S.inv_two_dy);
+          const double r = S.rho_over_dt * (dudx + dvdy);
+          rq[a][k] = edge_cell(a, k) ? 0.0 : S.dxdy * r;
+        }
+      }
+    }
+  }
+
+  // ---- K Jacobi sweeps (:104-114) ----
+  double pf[PR][2];
+  {
+    double ph[PR + 1][2];
+#pragma unroll
+    for (int a = 0; a < PR; ++a) {
+      const double2 w = *reinterpret_cast<const double2*>(p + (r0 + a) * n + c0);
+      ph[a][0] = w.x; ph[a][1] = w.y;
+    }
+    ph[PR][0] = ph[PR][1] = 0.0;
+    int it = 0;
+    for (; it + 2 <= C.iters; it += 2) {
+      jacobi_sweep_f64<PR, 0>(ph, rq, E, lds, xc, tid, ty);
+      jacobi_sweep_f64<PR, 1>(ph, rq, E, lds, xc, tid, ty);
+    }
+    if (it < C.iters) {
+      jacobi_sweep_f64<PR, 0>(ph, rq, E, lds, xc, tid, ty);
+#pragma unroll
+      for (int a = 0; a < PR; ++a) { pf[a][0] = ph[bphys<PR>(a, 1)][0]; pf[a][1] = ph[bphys<PR>(a, 1)][1]; }
+    } else {
+#pragma unroll
+      for (int a = 0; a < PR; ++a) { pf[a][0] = ph[a][0]; pf[a][1] = ph[a][1]; }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < PR; ++a) *reinterpret_cast<double2*>(pout + (r0 + a) * n + c0) = make_double2(pf[a][0], pf[a][1]);
+
+  // ---- corrector (:143-146), observation, reward ----
+  double acc = 0.0;
+  const int t = P.time_index[b] + 1;
+  const int tr = t < C.nt_ref ? t : C.nt_ref - 1;
+  {
+    double pt[2], pb[2];
+    halo_tb_f64(pf[0], pf[PR - 1], pt, pb, lds, xc, tid, ty);
+    double uf[PR][2], vf[PR][2];
+#pragma unroll
+    for (int a = 0; a < PR; ++a) {
+      const double2 wu = *reinterpret_cast<const double2*>(us + (r0 + a) * n + c0);   // written by this same thread above
+      const double2 wv = *reinterpret_cast<const double2*>(vs + (r0 + a) * n + c0);
+      uf[a][0] = wu.x; uf[a][1] = wu.y; vf[a][0] = wv.x; vf[a][1] = wv.y;
+    }
+#pragma unroll
+    for (int a = 0; a < PR; ++a) {
+      const double pl = dpp_shr_f64(pf[a][1]), pr = dpp_shl_f64(pf[a][0]);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const double pw = (k == 0) ? pl : pf[a][0], pe = (k == 1) ? pr : pf[a][1];
+        const double ps = (a == 0) ? pt[k] : pf[a - 1][k], pn = (a == PR - 1) ? pb[k] : pf[a + 1][k];
+        const double dpdx = div_c(pe - pw, S.two_dx, S.inv_two_dx);
+        const double dpdy = div_c(pn - ps, S.two_dy, S.inv_two_dy);
+        const bool edge = edge_cell(a, k);
+        uf[a][k] = edge ? uf[a][k] : uf[a][k] - S.dt_over_rho * dpdx;
+        vf[a][k] = edge ? vf[a][k] : vf[a][k] - S.dt_over_rho * dpdy;
+      }
+    }
+    apply_bc_patch_f64<PR>(uf, E, C.bc, 0, act, C.action_dim, r0, c0);
+    apply_bc_patch_f64<PR>(vf, E, C.bc, 1, act, C.action_dim, r0, c0);
+    const double* uref = P.U_ref + (size_t)tr * ncell * 2;
+    double* obs = P.obs + (size_t)b * ncell * 2;
+#pragma unroll
+    for (int a = 0; a < PR; ++a) {
+      if constexpr (!INTERLEAVED) {
+        *reinterpret_cast<double2*>(u + (r0 + a) * n + c0) = make_double2(uf[a][0], uf[a][1]);
+        *reinterpret_cast<double2*>(v + (r0 + a) * n + c0) = make_double2(vf[a][0], vf[a][1]);
+      }
+      const size_t o = ((size_t)(r0 + a) * n + c0) * 2;
+      const double2 w0 = *reinterpret_cast<const double2*>(uref + o), w1 = *reinterpret_cast<const double2*>(uref + o + 2);
+      *reinterpret_cast<double2*>(obs + o) = make_double2(uf[a][0], vf[a][0]);
+      *reinterpret_cast<double2*>(obs + o + 2) = make_double2(uf[a][1], vf[a][1]);
+      // accumulation order of gen_back: cells in index order, du^2 then dv^2 (the reduction order across lanes differs: rtol 1e-12)
+      const double d0 = uf[a][0] - w0.x, d1 = vf[a][0] - w0.y, d2 = uf[a][1] - w1.x, d3 = vf[a][1] - w1.y;
+      acc += d0 * d0;
+      acc += d1 * d1;
+      acc += d2 * d2;
+      acc += d3 * d3;
+    }
+  }
+  const double ss = block_sum<double>(acc, lds);
+  if (tid == 0) {
+    double asq = 0.0;
+    const double aref = P.action_ref[tr];
+    for (int k = 0; k < C.action_dim; ++k) {
+      const double d = act[k] - aref;
+      asq += d * d;
+    }
+    P.reward[b] = ((-0.5 * ss) / (double)n) / (double)n - S.gamma_half * asq;
+    P.time_index[b] = t;
+    P.terminated[b] = (t >= C.nt - 1) ? 1 : 0;
   }
 }
 
@@ -1801,6 +2130,23 @@ int ns_step(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int B, v
       else
         hipLaunchKernelGGL((ns_tile_step<4, 2, false>), dim3(B), dim3(512), lds64, (hipStream_t)stream, C, S, P, B);
       return pdegym::check_launch("ns2d_tile_step");
+    }
+  }
+  if constexpr (sizeof(T) == 8) {
+    // register-tiled float64 path for 128x128 (BASELINE config 4 at the reference's own precision)
+    if (!pdegym_force_generic() && C.nx == 128 && C.ny == 128) {
+      constexpr int lds_bytes = 2 * 2 * 1024 * 16;
+      static signed char attr_a[pdegym::kMaxDevices] = {}, attr_b[pdegym::kMaxDevices] = {};
+      if (buf->state_in) {
+        if (!pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&ns_tile_step_f64<true>), lds_bytes, attr_a))
+          return pdegym::fail(-4, "cannot raise the dynamic LDS limit");
+        hipLaunchKernelGGL(ns_tile_step_f64<true>, dim3(B), dim3(1024), lds_bytes, (hipStream_t)stream, C, S, P, B);
+      } else {
+        if (!pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&ns_tile_step_f64<false>), lds_bytes, attr_b))
+          return pdegym::fail(-4, "cannot raise the dynamic LDS limit");
+        hipLaunchKernelGGL(ns_tile_step_f64<false>, dim3(B), dim3(1024), lds_bytes, (hipStream_t)stream, C, S, P, B);
+      }
+      return pdegym::check_launch("ns2d_tile_step_f64");
     }
   }
   if constexpr (sizeof(T) == 4) {

@@ -284,6 +284,43 @@ def test_ns_f32_tiled_kernel_equals_generic_kernel_bitwise(n):
         np.testing.assert_allclose(r1, r2, rtol=1e-5)
 
 
+@pytest.mark.parametrize("K,interleaved,adim", [(50, True, 1), (7, True, 128), (1, False, 1), (0, True, 1), (33, False, 128)])
+def test_ns_f64_tiled_kernel_equals_generic_kernel_and_oracle_bitwise(K, interleaved, adim):
+    """The float64 register-tiled 128x128 kernel (the reference's precision on the fast path): fields, pressure and
+    observations bit-identical to the generic float64 kernel AND to the NumPy oracle; even / odd / zero sweep counts, the
+    interleaved (observation = state) and the separate-u,v state layouts, scalar and per-node boundary actions."""
+    import os
+    from oracle import pde_oracle as po
+    from pdecontrolgym_amd.batch2d import NSBatch2D
+    B = 3
+    kw, u0, v0, p0, acts = _random_case(128, B, K, 4000 + K, BC_MIX, adim)
+    kw = dict(kw, action_dim=adim)
+    outs = []
+    for force in ("0", "1"):
+        os.environ["PDEGYM_NS_GENERIC"] = force
+        try:
+            env = NSBatch2D(num_envs=B, device="cuda", dtype=torch.float64, interleaved_state=interleaved, **kw)
+            env.reset(u0, v0, p0)
+            res = []
+            for a in acts:
+                obs, r, te = env.step(a)
+                res.append((obs.cpu().numpy().copy(), env.p.cpu().numpy().copy(), r.cpu().numpy().copy(), env.u.cpu().numpy().copy()))
+            outs.append(res)
+        finally:
+            os.environ["PDEGYM_NS_GENERIC"] = "0"
+    orc = po.NavierStokesOracle(**{k: v for k, v in kw.items() if k != "action_dim"})
+    orc.reset(u0, v0, p0)
+    for a, (o1, p1, r1, u1), (o2, p2, r2, u2) in zip(acts, *outs):
+        o_ref, r_ref, _, _ = orc.step(a)
+        np.testing.assert_array_equal(o1, o2)
+        np.testing.assert_array_equal(p1, p2)
+        np.testing.assert_array_equal(u1, u2)
+        np.testing.assert_array_equal(o1, o_ref)
+        np.testing.assert_array_equal(p1, orc.p)
+        np.testing.assert_allclose(r1, r_ref, rtol=1e-12)
+        np.testing.assert_allclose(r1, r2, rtol=1e-12)
+
+
 @pytest.mark.parametrize("n,dtype,K", [(21, "float64", 200), (21, "float64", 7), (33, "float32", 50), (64, "float64", 31),
                                        (64, "float32", 50), (5, "float64", 12),
                                        # one LDS copy (grids of 4097..16384 cells): float64 128x128 is 128 KB
