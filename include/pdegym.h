@@ -191,6 +191,17 @@ typedef struct pdegym_bufs_ns2d {
   const void* state_in;     /* optional [B, ny, nx, 2]: the observation written by the PREVIOUS call.  When non-NULL the
                                velocity state is read from it and written only to obs (the reference's obs is the state,
                                navier_stokes2D.py:147-154), which saves one write of u and v per step; must not alias obs */
+  /* Fused VecEnv auto-reset: when reset_u0 is non-NULL, an instance whose step ends terminated
+   * (time_index >= nt-1, navier_stokes2D.py:159-168) restarts inside the same call, without a host round trip: its observation
+   * is first copied to final_obs (if given), then (u, v, p) := pool row, time_index := 0, obs := (u0, v0).  The k-th restart of
+   * instance b takes pool row (b + k*B) mod reset_pool_rows (k from reset_count, see pdegym_bufs1d). */
+  const void* reset_u0;     /* optional [reset_pool_rows, ny, nx]                                                            */
+  const void* reset_v0;     /* [reset_pool_rows, ny, nx]  (required with reset_u0)                                            */
+  const void* reset_p0;     /* [reset_pool_rows, ny, nx]  (required with reset_u0)                                            */
+  void* final_obs;          /* optional [B, ny, nx, 2]: last observation of the finished episode ("terminal_observation")    */
+  int32_t* reset_count;     /* optional [B] in/out                                                                           */
+  int32_t reset_pool_rows;  /* rows of the pools (0 = B)                                                                     */
+  int32_t reserved_;
 } pdegym_bufs_ns2d;
 
 int pdegym_ns2d_step_f32(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int32_t B, void* stream);

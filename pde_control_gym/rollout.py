@@ -16,18 +16,20 @@ class DeviceRollout:
     def __init__(self, venv, policy, n_steps: int, use_graph: bool = True, action_low: float = -1.0, action_high: float = 1.0):
         import torch
         kind = getattr(venv, "kind", "tumor")
-        if kind == "ns2d":
-            raise NotImplementedError("DeviceRollout drives the 1D environments (transport, reaction-diffusion, Burgers, traffic, tumour)")
         self.venv, self.policy, self.T = venv, policy, int(n_steps)
         self.lo, self.hi = float(action_low), float(action_high)
         core = venv.core
-        # the transport / reaction-diffusion engine writes straight into the rollout buffers; the other engines (traffic,
-        # brain tumour: several launches and device-side masks per step) go through step_tensor and one copy per output
-        self._direct = hasattr(core, "obs_dim")
+        # the transport / reaction-diffusion and Navier-Stokes engines write straight into the rollout buffers; the other
+        # engines (traffic, brain tumour: several launches and device-side masks per step) go through step_tensor and one
+        # copy per output
+        self._ns = kind == "ns2d"
+        self._direct = hasattr(core, "obs_dim") or self._ns
         cur = core.t["obs"] if "obs" in core.t else core.t["u"]      # the tumour engine's observation IS its live row
-        B, D, dev, dt = core.num_envs, cur.shape[-1], core.device, cur.dtype
-        self.obs = torch.zeros(self.T + 1, B, D, dtype=dt, device=dev)
-        self.actions = torch.zeros(self.T, B, dtype=dt, device=dev)
+        B, dev, dt = core.num_envs, core.device, cur.dtype
+        oshape = tuple(cur.shape[1:])                                # (D,) for the 1D engines, (ny, nx, 2) for Navier-Stokes
+        self.obs = torch.zeros((self.T + 1, B) + oshape, dtype=dt, device=dev)
+        adim = core.action_dim if self._ns else 1
+        self.actions = torch.zeros((self.T, B) + ((adim,) if self._ns else ()), dtype=dt, device=dev)
         self.rewards = torch.zeros(self.T, B, dtype=dt, device=dev)
         self.terminated = torch.zeros(self.T, B, dtype=torch.uint8, device=dev)
         self.truncated = torch.zeros(self.T, B, dtype=torch.uint8, device=dev)
@@ -37,10 +39,18 @@ class DeviceRollout:
     def _body(self):
         import torch
         core = self.venv.core
-        own = {k: core.t[k] for k in ("reward", "terminated", "truncated")} if self._direct else {}
+        own = {k: core.t[k] for k in ("reward", "terminated", "truncated", "obs") if k in core.t} if self._direct else {}
+        pingpong = self._ns and getattr(core, "_p_pingpong", False)
+        if pingpong:        # keep the pressure in ONE tensor while the steps are baked into a graph (the C side copies it home)
+            core._p_pingpong, saved_p_out = False, core.t["p_out"]
+            core.t["p_out"] = None
         try:
             self._steps(core, torch)
+            if self._ns:    # the observation IS the Navier-Stokes state: leave it in the engine's own buffer, not in slot T
+                own["obs"].copy_(self.obs[self.T])
         finally:
+            if pingpong:
+                core._p_pingpong, core.t["p_out"] = True, saved_p_out
             # the step kernel was pointed at slot t of the rollout buffers; hand the engine its own output tensors back so
             # that a later plain env.step() cannot overwrite rewards[T-1] / terminated[T-1] / truncated[T-1]
             # (graph-safe: only Python references change)
@@ -48,11 +58,16 @@ class DeviceRollout:
                 core.t[k] = v
 
     def _steps(self, core, torch):
+        if self._ns:        # slot 0 of the rollout buffer is the input state of the first step (not the engine's own buffer,
+            core.t["obs"] = self.obs[0]        # which a graph warm-up run leaves in its end state)
         for t in range(self.T):
             with torch.no_grad():
-                a = self.policy(self.obs[t]).reshape(core.num_envs).clamp(self.lo, self.hi)
+                a = self.policy(self.obs[t]).reshape(self.actions[t].shape).clamp(self.lo, self.hi)
             self.actions[t].copy_(a)
-            if self._direct:
+            if self._ns:
+                # Navier-Stokes: the observation IS the state, so slot t of the rollout buffer is also the next step's input
+                core.step(self.actions[t], out_obs=self.obs[t + 1], out_reward=self.rewards[t], out_terminated=self.terminated[t])
+            elif self._direct:
                 # the step kernel writes observation / reward / flags straight into slot t of the rollout buffers
                 core.step(self.actions[t], out_obs=self.obs[t + 1], out_reward=self.rewards[t],
                           out_terminated=self.terminated[t], out_truncated=self.truncated[t])
@@ -76,8 +91,12 @@ class DeviceRollout:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             # everything a step mutates in place (the fused auto-reset advances reset_count and may redraw beta rows)
-            keys = [k for k in ("u", "time_index", "bsum", "ring", "reset_count", "beta") if torch.is_tensor(core.t.get(k))] \
-                if self._direct else [k for k, v in core.t.items() if torch.is_tensor(v)]
+            if self._ns:
+                keys = [k for k in ("u", "v", "p", "p_out", "time_index", "reset_count") if torch.is_tensor(core.t.get(k))]
+            elif self._direct:
+                keys = [k for k in ("u", "time_index", "bsum", "ring", "reset_count", "beta") if torch.is_tensor(core.t.get(k))]
+            else:
+                keys = [k for k, v in core.t.items() if torch.is_tensor(v)]
             snapshot = {k: core.t[k].clone() for k in keys}
             extra = {k: getattr(self.venv, k).clone() for k in ("_consecutive", "treatment_calls", "soft_constraint_violations")
                      if torch.is_tensor(getattr(self.venv, k, None))}

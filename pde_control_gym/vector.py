@@ -65,10 +65,10 @@ class PDEVecEnv:
         self.reset_init_condition_func = kw.get("reset_init_condition_func")
         self.reset_recirculation_func = kw.get("reset_recirculation_func")
         spec = reward_spec_for(self.reward_class)
-        if spec is None:
-            raise NotImplementedError(
-                "PDEVecEnv evaluates rewards inside the step kernel: use TunedReward1D or NormReward(horizon='temporal'); "
-                "custom BaseReward subclasses are supported by the single-environment classes")
+        # Any other BaseReward subclass (docs/source/utils/customrewards.rst) takes the slow compatibility path: the engine
+        # records the trajectories on the device and after every step the user's reward() is called once per instance on the
+        # host with a lazy view of that instance's history (uVec[t], uVec[:, -1] ... fetch rows on demand).
+        self._host_reward = spec is None
         default_rate = 0.1 if self.kind == "transport" else 1e-4
         self.core = PDEBatch1D(self.kind, kw["T"], kw["dt"], kw["X"], kw["dx"], kw.get("control_sample_rate", default_rate),
                                control_type=kw.get("control_type", "Dirchilet"), sensing_loc=kw.get("sensing_loc", "full"),
@@ -76,7 +76,7 @@ class PDEVecEnv:
                                max_control_value=kw.get("max_control_value", 20),
                                limit_pde_state_size=kw.get("limit_pde_state_size", False),
                                max_state_value=kw.get("max_state_value", 1e10), reward=spec, num_envs=self.num_envs,
-                               device=self.device, backend=backend, flux=self._flux)
+                               device=self.device, backend=backend, flux=self._flux, record_history=self._host_reward)
         self.nx, self.nt = self.core.nx, self.core.nt
         msv = kw.get("max_state_value", 1e10)
         d = self.core.obs_dim
@@ -188,9 +188,11 @@ class PDEVecEnv:
         (b + k*num_envs) mod rows.  Call ``refresh_pool()`` (any time between steps) to draw fresh rows; pass explicit
         ``init_pool`` / ``beta_pool`` tensors [P >= num_envs, n] to control them (``beta_pool=False`` keeps beta fixed)."""
         if self.kind == "ns2d":
-            return self._enable_fused_auto_reset_ns(init_pool)
+            return self._enable_fused_auto_reset_ns(init_pool, min(int(pool_episodes), 2) if init_pool is None else 1)
         if self.kind == "traffic":
             raise NotImplementedError("fused auto-reset is implemented for the transport / reaction-diffusion / NS environments")
+        if getattr(self, "_host_reward", False):
+            raise NotImplementedError("a host reward callback needs the finished trajectory: use the plain auto-reset of step()")
         if init_pool is None:
             init_pool, drawn_beta = self._sample_1d(np.arange(self.num_envs * max(1, int(pool_episodes))))
             if beta_pool is None:
@@ -215,11 +217,20 @@ class PDEVecEnv:
             rb = self.core.t["reset_beta"]
             rb.copy_(torch.as_tensor(beta_pool).to(device=self.device, dtype=rb.dtype))
 
-    def _enable_fused_auto_reset_ns(self, init_pool):
-        raise NotImplementedError("fused auto-reset for NavierStokes2D: see NSBatch2D.enable_auto_reset")
+    def _enable_fused_auto_reset_ns(self, init_pool, pool_episodes: int = 2):
+        """NavierStokes2D: pools of initial (u, v, p) fields, drawn from ``reset_init_condition_func`` unless given as a
+        3-tuple of [P >= num_envs, ny, nx] arrays."""
+        if init_pool is None:
+            init_pool = self._sample_ns(np.arange(self.num_envs * max(1, int(pool_episodes))))
+        self.core.enable_auto_reset(*init_pool)
+        self._fused_reset = True
 
     def _refresh_pool_ns(self, init_pool):
-        raise NotImplementedError
+        import torch
+        if init_pool is None:
+            init_pool = self._sample_ns(np.arange(self.core.t["reset_u0"].shape[0]))
+        for k, a in zip(("reset_u0", "reset_v0", "reset_p0"), init_pool):
+            self.core.t[k].copy_(torch.as_tensor(a, dtype=self.core.dtype, device=self.device))
 
     def step_tensor(self, actions):
         """actions: device tensor [B] (1D) / [B, action_dim] (NS).  Returns device tensors
@@ -228,7 +239,23 @@ class PDEVecEnv:
         if self.kind == "ns2d":
             obs, r, te = self.core.step(actions)
             return obs, r, te, torch.zeros_like(te)
-        return self.core.step(actions)      # 1D envs and traffic: (obs, reward, terminated|done, truncated)
+        out = self.core.step(actions)       # 1D envs and traffic: (obs, reward, terminated|done, truncated)
+        if getattr(self, "_host_reward", False):
+            return (out[0], self._host_rewards(out[2], out[3]), out[2], out[3])
+        return out
+
+    def _host_rewards(self, te_t, tr_t):
+        """Slow path for user reward classes: one reward() call per instance on a lazy view of its device-resident history."""
+        import torch
+        from pde_control_gym.src.environments1d.base_env_1d import HistoryView
+        te, tr = te_t.cpu().numpy().astype(bool), tr_t.cpu().numpy().astype(bool)
+        ti = self.core.time_index.cpu().numpy()
+        hist = self.core.t["history"]
+        vals = np.zeros(self.num_envs, dtype=np.float32)
+        for b in range(self.num_envs):
+            view = HistoryView(hist[b])
+            vals[b] = self.reward_class.reward(view, int(ti[b]), bool(te[b]), bool(tr[b]), view[int(ti[b])][-1])
+        return torch.as_tensor(vals, device=self.device)
 
     # ---- SB3 VecEnv face -----------------------------------------------------------------------------
     def _noise(self, obs):

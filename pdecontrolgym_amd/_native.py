@@ -62,7 +62,9 @@ class BufsNS2D(C.Structure):
     _fields_ = [("u", C.c_void_p), ("v", C.c_void_p), ("p", C.c_void_p), ("scratch", C.c_void_p),
                 ("action", C.c_void_p), ("time_index", C.c_void_p), ("U_ref", C.c_void_p),
                 ("action_ref", C.c_void_p), ("nt_ref", C.c_int32), ("obs", C.c_void_p), ("reward", C.c_void_p),
-                ("terminated", C.c_void_p), ("p_out", C.c_void_p), ("state_in", C.c_void_p)]
+                ("terminated", C.c_void_p), ("p_out", C.c_void_p), ("state_in", C.c_void_p), ("reset_u0", C.c_void_p),
+                ("reset_v0", C.c_void_p), ("reset_p0", C.c_void_p), ("final_obs", C.c_void_p), ("reset_count", C.c_void_p),
+                ("reset_pool_rows", C.c_int32), ("reserved_", C.c_int32)]
 
 
 TRAFFIC_SIM = {"inlet": 0, "outlet": 1, "both": 2, "outlet-train": 3}

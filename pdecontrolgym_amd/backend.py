@@ -105,8 +105,10 @@ class HipBackend:
         b = N.BufsNS2D()
         for k in ("p", "scratch", "action", "U_ref", "action_ref", "obs", "reward"):
             setattr(b, k, N.dptr(T[k], dtype))
-        for k in ("u", "v", "state_in", "p_out"):
+        for k in ("u", "v", "state_in", "p_out", "reset_u0", "reset_v0", "reset_p0", "final_obs"):
             setattr(b, k, N.dptr(T[k], dtype) if T.get(k) is not None else None)
+        b.reset_count = N.dptr(T["reset_count"], torch.int32) if T.get("reset_count") is not None else None
+        b.reset_pool_rows = int(T["reset_u0"].shape[0]) if T.get("reset_u0") is not None else 0
         b.time_index = N.dptr(T["time_index"], torch.int32)
         b.terminated = N.dptr(T["terminated"], torch.uint8)
         b.nt_ref = int(min(T["U_ref"].shape[0], T["action_ref"].shape[0]))

@@ -80,6 +80,7 @@ class NSBatch2D:
             "state_in": None,
             "p": torch.zeros(B, ny, nx, dtype=dt_, device=dev),
             "p_out": None,
+            "reset_u0": None, "reset_v0": None, "reset_p0": None, "final_obs": None, "reset_count": None,
             "scratch": torch.zeros(B, 4, ny, nx, dtype=dt_, device=dev),
             "action": torch.zeros(B, self.action_dim, dtype=dt_, device=dev),
             "time_index": torch.zeros(B, dtype=torch.int32, device=dev),
@@ -115,11 +116,36 @@ class NSBatch2D:
     def time_index(self):
         return self.t["time_index"]
 
-    def _next_obs(self):
+    def _next_obs(self, out_obs=None):
+        prev = self.t["obs"]
         if self.interleaved_state:
-            self.t["state_in"] = self.t["obs"]      # the observation just produced is the next call's input state
+            self.t["state_in"] = prev               # the observation just produced is the next call's input state
+        if out_obs is not None:                     # the caller's buffer (e.g. slot t+1 of a rollout) receives the observation
+            self.t["obs"] = out_obs.view(self.num_envs, self.ny, self.nx, 2)
+            return
         self._flip ^= 1
+        if self._obs[self._flip] is prev:           # never write the observation over the state it is computed from
+            self._flip ^= 1
         self.t["obs"] = self._obs[self._flip]
+
+    def enable_auto_reset(self, u0_pool, v0_pool, p0_pool, keep_final_obs: bool = True):
+        """Fused VecEnv auto-reset: an instance whose step ends terminated restarts inside the same C-ABI call (no host
+        round trip) from row (b + k*B) mod P of the pools ([P >= B, ny, nx] each; k = restarts of instance b so far).  The
+        observation returned for it is the first one of the new episode; the last one of the old episode is kept in
+        ``t["final_obs"]`` (SB3's ``terminal_observation``)."""
+        import torch
+        pools = [torch.as_tensor(a, dtype=self.dtype, device=self.device).contiguous() for a in (u0_pool, v0_pool, p0_pool)]
+        for a in pools:
+            if a.dim() != 3 or a.shape[0] < self.num_envs or tuple(a.shape[1:]) != (self.ny, self.nx) or a.shape != pools[0].shape:
+                raise ValueError(f"pools must be [P >= {self.num_envs}, {self.ny}, {self.nx}], got {tuple(a.shape)}")
+        self.t["reset_u0"], self.t["reset_v0"], self.t["reset_p0"] = pools
+        self.t["reset_count"] = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        self.t["final_obs"] = (torch.zeros(self.num_envs, self.ny, self.nx, 2, dtype=self.dtype, device=self.device)
+                               if keep_final_obs else None)
+
+    def disable_auto_reset(self):
+        for k in ("reset_u0", "reset_v0", "reset_p0", "final_obs", "reset_count"):
+            self.t[k] = None
 
     def reset(self, u0, v0, p0, mask=None):
         import torch
@@ -131,12 +157,17 @@ class NSBatch2D:
         self.backend.ns2d_reset(self.params, self.t, u0, v0, p0, mask, self.num_envs)
         return self.t["obs"]
 
-    def step(self, action):
-        """action: [B] or [B, action_dim]. Returns (obs [B,ny,nx,2], reward [B], terminated [B] uint8)."""
+    def step(self, action, out_obs=None, out_reward=None, out_terminated=None):
+        """action: [B] or [B, action_dim]. Returns (obs [B,ny,nx,2], reward [B], terminated [B] uint8).  The ``out_*``
+        tensors, when given, receive the outputs directly (e.g. slot t of a rollout buffer)."""
         import torch
         a = torch.as_tensor(action, dtype=self.dtype, device=self.device).reshape(self.num_envs, self.action_dim).contiguous()
         self.t["action"] = a
-        self._next_obs()
+        self._next_obs(out_obs)
+        if out_reward is not None:
+            self.t["reward"] = out_reward
+        if out_terminated is not None:
+            self.t["terminated"] = out_terminated
         self.backend.ns2d_step(self.params, self.t, self.num_envs)
         if self._p_pingpong:        # the solved pressure is in p_out: it becomes p (the warm start of the next step)
             self.t["p"], self.t["p_out"] = self.t["p_out"], self.t["p"]

@@ -2013,6 +2013,52 @@ __global__ void ns_reset_kernel(NSConst C, NSPtrs<T> P, const T* u0, const T* v0
   }
 }
 
+// Fused auto-reset, run right after the step kernels of the same call (same stream, no host round trip): instances whose
+// step ended terminated keep their last observation in final_obs and restart from a pool row.
+template <typename T>
+struct NSAutoReset {
+  const T* u0;
+  const T* v0;
+  const T* p0;
+  T* final_obs;
+  int* reset_count;
+  int pool_rows;
+};
+
+template <typename T>
+__global__ void ns_auto_reset_kernel(NSConst C, NSPtrs<T> P, NSAutoReset<T> R, int B) {
+  const int b = blockIdx.y;
+  if (b >= B || !P.terminated[b]) return;
+  const int ncell = C.nx * C.ny;
+  const int rows = R.pool_rows > 0 ? R.pool_rows : B;
+  const long long k = R.reset_count ? (long long)R.reset_count[b] : 0;
+  const size_t src = (size_t)(((long long)b + k * (long long)B) % rows) * ncell, off = (size_t)b * ncell;
+  T* pnew = P.p_out ? P.p_out : P.p;      // where this call left the pressure (the caller swaps p and p_out afterwards)
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += gridDim.x * blockDim.x) {
+    if (R.final_obs) {
+      R.final_obs[2 * (off + c)] = P.obs[2 * (off + c)];
+      R.final_obs[2 * (off + c) + 1] = P.obs[2 * (off + c) + 1];
+    }
+    const T a = R.u0[src + c], bb = R.v0[src + c];
+    if (P.u && !P.state_in) {
+      P.u[off + c] = a;
+      P.v[off + c] = bb;
+    }
+    pnew[off + c] = R.p0[src + c];
+    P.obs[2 * (off + c)] = a;
+    P.obs[2 * (off + c) + 1] = bb;
+  }
+}
+
+// time_index / reset_count are updated by a second tiny launch so that every block of the copy kernel sees the old values
+template <typename T>
+__global__ void ns_auto_reset_finish(NSPtrs<T> P, NSAutoReset<T> R, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B || !P.terminated[b]) return;
+  P.time_index[b] = 0;
+  if (R.reset_count) R.reset_count[b] += 1;
+}
+
 template <typename T>
 int fill(const pdegym_params_ns2d* prm, NSConst& C, NSScal<T>& S) {
   if (!prm) return pdegym::fail(-1, "null params");
@@ -2096,7 +2142,30 @@ inline int block_threads(int ncell) {
 }
 
 template <typename T>
+int ns_step_launch(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int B, void* stream);
+
+template <typename T>
 int ns_step(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int B, void* stream) {
+  if (int rc = ns_step_launch<T>(prm, buf, B, stream)) return rc;
+  if (B <= 0 || !buf->reset_u0) return 0;
+  if (!buf->reset_v0 || !buf->reset_p0) return pdegym::fail(-3, "reset_u0 needs reset_v0 and reset_p0");
+  NSConst C;
+  NSScal<T> S;
+  if (int rc = fill<T>(prm, C, S)) return rc;
+  NSPtrs<T> P{(T*)buf->u, (T*)buf->v, (T*)buf->p, (T*)buf->scratch, (const T*)buf->action, buf->time_index,
+              (const T*)buf->U_ref, (const T*)buf->action_ref, (T*)buf->obs, (T*)buf->reward, buf->terminated,
+              (const T*)buf->state_in, (T*)buf->p_out};
+  NSAutoReset<T> R{(const T*)buf->reset_u0, (const T*)buf->reset_v0, (const T*)buf->reset_p0, (T*)buf->final_obs, buf->reset_count,
+                   buf->reset_pool_rows};
+  const int ncell = C.nx * C.ny;
+  const int gx = (ncell + 255) / 256 > 64 ? 64 : (ncell + 255) / 256;
+  hipLaunchKernelGGL(ns_auto_reset_kernel<T>, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, C, P, R, B);
+  hipLaunchKernelGGL(ns_auto_reset_finish<T>, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, R, B);
+  return pdegym::check_launch("ns2d_auto_reset");
+}
+
+template <typename T>
+int ns_step_launch(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int B, void* stream) {
   NSConst C;
   NSScal<T> S;
   if (int rc = fill<T>(prm, C, S)) return rc;

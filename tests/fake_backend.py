@@ -131,6 +131,21 @@ class FakeBackend:
                 T[k].copy_(torch.from_numpy(np.ascontiguousarray(a)).to(T[k].dtype))
         T["time_index"].copy_(torch.from_numpy(orc.time_index.astype(np.int32)))
         T["terminated"].copy_(torch.from_numpy(te.astype(np.uint8)))
+        if T.get("reset_u0") is not None and te.any():          # fused auto-reset: pool row (b + k*B) mod P
+            dm = torch.from_numpy(te.astype(bool))
+            cnt = T["reset_count"].numpy().astype(np.int64) if T.get("reset_count") is not None else np.zeros(B, dtype=np.int64)
+            rows = torch.from_numpy((np.arange(B) + cnt * B) % T["reset_u0"].shape[0])
+            if T.get("final_obs") is not None:
+                T["final_obs"][dm] = T["obs"][dm]
+            pk = "p_out" if T.get("p_out") is not None else "p"
+            T[pk][dm] = T["reset_p0"][rows][dm]
+            if T.get("u") is not None:
+                T["u"][dm] = T["reset_u0"][rows][dm]
+                T["v"][dm] = T["reset_v0"][rows][dm]
+            T["obs"][dm] = torch.stack([T["reset_u0"][rows][dm], T["reset_v0"][rows][dm]], dim=-1)
+            T["time_index"][dm] = 0
+            if T.get("reset_count") is not None:
+                T["reset_count"][dm] += 1
 
     def ns2d_reset(self, P, T, u0, v0, p0, mask, B):
         m = torch.ones(B, dtype=torch.bool) if mask is None else mask.bool()

@@ -170,11 +170,20 @@ def test_sensing_modes_and_scalar_observations(golden_transport):
         assert obs == g.obs[i + 1][0]
 
 
-def test_export_1d_trajectory(golden_transport, tmp_path):
+# the export / custom-reward / NS public-API tests run on the CPU double here and on the real HIP backend under -m gpu
+BACKENDS = [pytest.param("double", id="cpu-double"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+def _bk(kind):
+    return dict(device="cpu", backend=FakeBackend()) if kind == "double" else dict(device="cuda")
+
+
+@pytest.mark.parametrize("bk", BACKENDS)
+def test_export_1d_trajectory(golden_transport, tmp_path, bk):
     import pde_control_gym
     from pde_control_gym import export
     g = golden_transport["H1"]
-    env = pde_control_gym.make("PDEControlGym-TransportPDE1D", device="cpu", backend=FakeBackend(), record_history=True,
+    env = pde_control_gym.make("PDEControlGym-TransportPDE1D", record_history=True, **_bk(bk),
                                **_transport_params()).unwrapped
     env.reset()
     acts, rews = [], []
@@ -186,14 +195,15 @@ def test_export_1d_trajectory(golden_transport, tmp_path):
     z = np.load(tmp_path / "traj.npz")
     assert z["u"].shape == (env.nt, 100) and int(z["time_index"]) == env.time_index and len(z["rewards"]) == 3
     np.testing.assert_array_equal(z["u"][env.time_index], g.rows[2])
-    env2 = pde_control_gym.make("PDEControlGym-TransportPDE1D", device="cpu", backend=FakeBackend(), record_history=False,
+    env2 = pde_control_gym.make("PDEControlGym-TransportPDE1D", record_history=False, **_bk(bk),
                                 **_transport_params()).unwrapped
     env2.reset()
     with pytest.raises(ValueError, match="record_history"):
         export.save_trajectory_1d(tmp_path / "no.npz", env2)
 
 
-def test_custom_reward_class_gets_a_trajectory_view(golden_transport):
+@pytest.mark.parametrize("bk", BACKENDS)
+def test_custom_reward_class_gets_a_trajectory_view(golden_transport, bk):
     """A user BaseReward subclass (docs/source/utils/customrewards.rst) is called with (uVec, t, term, trunc, action)."""
     from pde_control_gym.src import BaseReward, TransportPDE1D
     g = golden_transport["H1"]
@@ -204,12 +214,46 @@ def test_custom_reward_class_gets_a_trajectory_view(golden_transport):
             calls.append((time_index, terminate, truncate, float(action)))
             return float(-np.linalg.norm(uVec[time_index]) + uVec[0][0] + np.abs(uVec[:, -1]).sum() * 0)
 
-    env = TransportPDE1D(device="cpu", backend=FakeBackend(), **_transport_params(reward_class=MyReward()))
+    env = TransportPDE1D(**_bk(bk), **_transport_params(reward_class=MyReward()))
     env.reset()
     for i, a in enumerate(g.actions[:3]):
-        obs, r, te, tr, _ = env.step(float(a))
+        obs, r, te, tr, _ = env.step(np.float32(a))
         np.testing.assert_allclose(r, -np.linalg.norm(g.rows[i]) + 5.0, rtol=1e-6)
     assert calls[0][0] == 1000 and calls[0][3] == pytest.approx(float(g.actions[0]))
+
+
+@pytest.mark.parametrize("bk", BACKENDS)
+def test_vecenv_accepts_custom_reward_classes(golden_transport, bk):
+    """docs/source/utils/customrewards.rst on the batched face: a user BaseReward subclass is evaluated per instance on a
+    lazy view of the device-resident trajectory (slow compatibility path); values equal those of single environments."""
+    import pde_control_gym
+    from pde_control_gym.src import BaseReward, TransportPDE1D
+    g = golden_transport["H1"]
+
+    class MyReward(BaseReward):
+        def reward(self, uVec=None, time_index=None, terminate=None, truncate=None, action=None):
+            return float(-np.linalg.norm(uVec[time_index]) + 0.5 * np.linalg.norm(uVec[time_index - 100]) + 0.1 * float(action) + 7 * terminate)
+
+    B = 3
+    ics = [np.ones(100, dtype=np.float32) * (2.0 + k) for k in range(B)]
+    it = iter(ics)
+    p = _transport_params(reward_class=MyReward(), reset_init_condition_func=lambda nx: next(it))
+    venv = pde_control_gym.make_vec("PDEControlGym-TransportPDE1D", num_envs=B, **_bk(bk), **p)
+    venv.reset()
+    singles = []
+    for b in range(B):
+        e = TransportPDE1D(**_bk(bk), **_transport_params(reward_class=MyReward(), reset_init_condition_func=lambda nx, b=b: ics[b]))
+        e.reset()
+        singles.append(e)
+    for i in range(3):
+        a = np.array([[0.3], [-0.7], [0.1]], dtype=np.float32) * (i + 1)
+        obs, rew, dones, infos = venv.step(a)
+        for b in range(B):
+            o1, r1, te, tr, _ = singles[b].step(a[b])
+            np.testing.assert_array_equal(obs[b], o1)
+            np.testing.assert_allclose(rew[b], r1, rtol=1e-6)
+    with pytest.raises(NotImplementedError):
+        venv.enable_fused_auto_reset()
 
 
 def test_parabolic_single_env_public_api(golden_parabolic):
@@ -228,7 +272,8 @@ def test_parabolic_single_env_public_api(golden_parabolic):
         assert te == bool(g.terminate[i])
 
 
-def test_ns_single_env_public_api_reproduces_target_frames(golden_ns):
+@pytest.mark.parametrize("bk", BACKENDS)
+def test_ns_single_env_public_api_reproduces_target_frames(golden_ns, bk):
     """NS2Dppo.py:36-50 parameter dict; env.U / env.u / env.solve_pressure as used by NS2Doptimization.py."""
     from pde_control_gym.src import NavierStokes2D, NSReward
     g = golden_ns["N1"]
@@ -238,7 +283,7 @@ def test_ns_single_env_public_api_reproduces_target_frames(golden_ns):
     p = {"T": 0.2, "dt": 1e-3, "X": 1, "dx": 0.05, "Y": 1, "dy": 0.05, "action_dim": 1, "reward_class": NSReward(0.1),
          "normalize": False, "reset_init_condition_func": lambda X: (g.u0.copy(), g.v0.copy(), np.zeros_like(X)),
          "boundary_condition": NS_BC, "U_ref": Uref, "action_ref": 2.0 * np.ones(1000), "maximum_pressure_iteration": 2000}
-    env = NavierStokes2D(device="cpu", backend=FakeBackend(), **p)
+    env = NavierStokes2D(**_bk(bk), **p)
     assert (env.nt, env.nx, env.ny) == (200, 21, 21) and env.X.shape == (21, 21)
     assert env.observation_space.shape == (21, 21, 2) and env.action_space.shape == (1,)
     obs, info = env.reset(seed=400)
