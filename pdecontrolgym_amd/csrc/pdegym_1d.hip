@@ -94,6 +94,24 @@ __device__ __forceinline__ int pool_row(const pdegym_bufs1d& Bf, int inst, int B
   return (int)(((long long)inst + k * (long long)B) % rows);
 }
 
+// normalize(control_update(control, neighbour, dx), max_control_value) as NumPy evaluates it for the given kind of `control`
+// (hyperbolic.py:143-145, parabolic.py:148-150, base_env_1d.py:36-39); the result is what lands in the float32 row.
+template <bool M64>
+__device__ __forceinline__ float boundary_value(const pdegym_params1d& P, float a32, double a64, float neighbour, bool neumann) {
+  if (!M64 || P.action_kind == PDEGYM_ACTION_F32) {
+    const float v = neumann ? a32 * P.dx + neighbour : a32;
+    return normalize_ctrl(v, P.max_control, P.normalize);
+  }
+  if (P.action_kind == PDEGYM_ACTION_F64 || !neumann) {
+    double v = neumann ? a64 * P.dx64 + (double)neighbour : a64;
+    if (P.normalize) v = (v + 1.0) * P.max_control64 - P.max_control64;
+    return (float)v;
+  }
+  // NEP 50 weak Python scalar: control*dx is a Python float product, then adopts the float32 of the neighbour
+  const float v = (float)(a64 * P.dx64) + neighbour;
+  return normalize_ctrl(v, P.max_control, P.normalize);
+}
+
 // Per-wave state of one instance while it is stepped.
 template <int EPL>
 struct Row {
@@ -109,10 +127,13 @@ struct Row {
 // S sub-steps of one instance.  FAST: boundary/padding slots are frozen by zero coefficients (no selects);
 // otherwise explicit selects (exact for non-finite states, and required when the boundary value changes every
 // sub-step, i.e. parabolic Neumann control).
-template <int EPL, bool PARABOLIC, bool NEUMANN, bool FAST, bool HIST, bool BURGERS = false>
+// M64: float64 beta and/or float64 / Python-float control (pdegym_params1d.beta_f64 / action_kind): the select form with the
+// reference's mixed-precision expressions (see step1d_wide_kernel for the same arithmetic on LDS-resident rows).
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool FAST, bool HIST, bool BURGERS = false, bool M64 = false>
 __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EPL], const pdegym_params1d& P, int nsub,
-                                             float a, float* ring, float* hist, int lane) {
+                                             float a, float* ring, float* hist, int lane, const double* b64 = nullptr, double a64 = 0.0) {
   static_assert(!(FAST && (NEUMANN || HIST)), "fast mode is the Dirichlet, history-free path");
+  static_assert(!(FAST && M64), "the mixed-precision mode uses the select form");
   constexpr int J0 = PARABOLIC ? 1 : 0;
   const int n = P.n, ns = n - J0, s0 = lane * EPL;
   const float dx = P.dx, dt = P.dt, F = P.F;
@@ -124,7 +145,14 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
   const float rdxf = 1.0f / dx;   // exact when dx is a power of two (the only case it is used in)
   const bool pow2_dx = !PARABOLIC && dx > 0.0f && (__float_as_uint(dx) & 0x7fffffu) == 0u && rdxf * dx == 1.0f &&
                        rdxf < 3.0e38f;
-  float bval = NEUMANN ? normalize_ctrl(cdx + 0.0f, P.max_control, P.normalize) : normalize_ctrl(a, P.max_control, P.normalize);
+  float bval = M64 ? boundary_value<true>(P, a, a64, 0.0f, NEUMANN)
+                   : (NEUMANN ? normalize_ctrl(cdx + 0.0f, P.max_control, P.normalize) : normalize_ctrl(a, P.max_control, P.normalize));
+  const bool beta64 = M64 && P.beta_f64;
+  double c64[M64 ? EPL : 1];        // parabolic: dt*beta in double (parabolic.py:144 forms dt*beta first); transport: beta
+  if constexpr (M64) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) c64[e] = beta64 ? (PARABOLIC ? P.dt64 * b64[e] : b64[e]) : 0.0;
+  }
 
   // per-slot coefficients: parabolic c = dt*beta (parabolic.py:144 forms dt*beta first), transport c = beta
   float c[EPL], fe[EPL];
@@ -153,7 +181,8 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
     if constexpr (!PARABOLIC) p0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, R.x[0])));
     if constexpr (PARABOLIC && NEUMANN) {
       // parabolic.py:148-150: previous row's neighbour u[t-1][-2]
-      bval = normalize_ctrl(cdx + slot_get<EPL>(R.x, ns - 2), P.max_control, P.normalize);
+      if constexpr (M64) bval = boundary_value<true>(P, a, a64, slot_get<EPL>(R.x, ns - 2), true);
+      else bval = normalize_ctrl(cdx + slot_get<EPL>(R.x, ns - 2), P.max_control, P.normalize);
     }
     float y[EPL];
     if constexpr (FAST && PARABOLIC) {
@@ -232,8 +261,12 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
         const float t3 = t2 + pp;
         const float t4 = fe[e] * t3;
         const float t5 = p + t4;
-        const float t7 = c[e] * p;
-        v = t5 + t7;
+        if (M64 && beta64) {          // float64 beta: (dt*beta)*u and the final sum are double, rounded once
+          v = (float)((double)t5 + c64[M64 ? e : 0] * (double)p);
+        } else {
+          const float t7 = c[e] * p;
+          v = t5 + t7;
+        }
       } else {
         // hyperbolic.py:146-155   u + dt*((up - u)/dx + u[0]*beta)
         const float d1 = pp - p;
@@ -245,10 +278,16 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
         } else {
           d2 = d1 / dx;
         }
-        const float r = p0 * c[e];
-        const float d3 = (BURGERS ? p * d2 : d2) + r;
-        const float d4 = fe[e] * d3;
-        v = p + d4;
+        if (M64 && beta64) {          // float64 beta: u[0]*beta, the sum, dt*(...) and u + ... are double, rounded once
+          const double r = (double)p0 * c64[M64 ? e : 0];
+          const double d3 = (double)(BURGERS ? p * d2 : d2) + r;
+          v = (float)((double)p + P.dt64 * d3);
+        } else {
+          const float r = p0 * c[e];
+          const float d3 = (BURGERS ? p * d2 : d2) + r;
+          const float d4 = fe[e] * d3;
+          v = p + d4;
+        }
         (void)pm;
       }
       if constexpr (!FAST) {
@@ -340,10 +379,10 @@ __device__ __forceinline__ void load_row(Row<EPL>& R, float (&beta)[EPL], const 
   R.bl = PARABOLIC ? urow[0] : 0.f;
 }
 
-template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false>
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false, bool M64 = false>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_params1d P, pdegym_bufs1d Bf, int B) {
   constexpr int J0 = PARABOLIC ? 1 : 0;
-  constexpr bool kFast = !NEUMANN && !HIST;
+  constexpr bool kFast = !NEUMANN && !HIST && !M64;
   const int lane = threadIdx.x & (kWave - 1);
   const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (inst >= B) return;  // wave-uniform
@@ -352,20 +391,30 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
 #endif
   const int n = P.n, ns = n - J0, s0 = lane * EPL;
   float* urow = Bf.u + (size_t)inst * n;
-  const float* brow = static_cast<const float*>(Bf.beta) + (size_t)inst * Bf.beta_stride;
+  const bool beta64 = M64 && P.beta_f64;
+  // float32 beta row; in the mixed-precision mode with a float64 beta it is read as double below (beta then stays zero)
+  const float* brow = beta64 ? urow : static_cast<const float*>(Bf.beta) + (size_t)inst * Bf.beta_stride;
   float* ring = Bf.ring + (size_t)inst * PDEGYM_RING;
   float* hist = (HIST && Bf.history) ? Bf.history + (size_t)inst * P.nt * n : nullptr;
 
   Row<EPL> R;
   float beta[EPL];
   load_row<EPL, PARABOLIC>(R, beta, urow, brow, n, lane);
+  double b64[M64 ? EPL : 1];
+  if constexpr (M64) {
+    const double* brow64 = static_cast<const double*>(Bf.beta) + (size_t)inst * Bf.beta_stride;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) b64[e] = (beta64 && s0 + e < ns) ? brow64[J0 + s0 + e] : 0.0;
+  }
   const int t_in = __builtin_amdgcn_readfirstlane(Bf.time_index[inst]);
   const double bsum_in = Bf.bsum[inst];
   const int S = P.substeps > 0 ? P.substeps : 1;
   int nsub = P.nt - 1 - t_in;  // hyperbolic.py:140: while i < sample_rate and time_index < nt-1
   nsub = nsub < P.substeps ? nsub : P.substeps;
   nsub = nsub > 0 ? nsub : 0;
-  const float a = static_cast<const float*>(Bf.action)[inst];
+  const bool act64 = M64 && P.action_kind != PDEGYM_ACTION_F32;
+  const float a = act64 ? 0.f : static_cast<const float*>(Bf.action)[inst];
+  const double a64 = act64 ? static_cast<const double*>(Bf.action)[inst] : 0.0;
   R.t = t_in;
   R.k = (t_in + PDEGYM_LOOKBACK) % S;
   R.bsum = bsum_in;
@@ -425,7 +474,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
       norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
     }
   } else {
-    run_substeps<EPL, PARABOLIC, NEUMANN, false, HIST, BURGERS>(R, beta, P, nsub, a, ring, hist, lane);
+    run_substeps<EPL, PARABOLIC, NEUMANN, false, HIST, BURGERS, M64>(R, beta, P, nsub, a, ring, hist, lane, b64, a64);
     norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
   }
   const int t = R.t;
@@ -518,9 +567,15 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
     const int prow = pool_row(Bf, inst, B);
     const float* irow = Bf.reset_init + (size_t)prow * n;
     if (Bf.reset_beta && Bf.beta_stride != 0) {      // the reference redraws beta at every reset (hyperbolic.py:208)
-      float* bdst = const_cast<float*>(brow);
-      const float* bsrc = static_cast<const float*>(Bf.reset_beta) + (size_t)prow * n;
-      for (int j = lane; j < n; j += kWave) bdst[j] = bsrc[j];
+      if (beta64) {
+        double* bdst = const_cast<double*>(static_cast<const double*>(Bf.beta)) + (size_t)inst * Bf.beta_stride;
+        const double* bsrc = static_cast<const double*>(Bf.reset_beta) + (size_t)prow * n;
+        for (int j = lane; j < n; j += kWave) bdst[j] = bsrc[j];
+      } else {
+        float* bdst = const_cast<float*>(brow);
+        const float* bsrc = static_cast<const float*>(Bf.reset_beta) + (size_t)prow * n;
+        for (int j = lane; j < n; j += kWave) bdst[j] = bsrc[j];
+      }
     }
     if (Bf.reset_count && lane == 0) Bf.reset_count[inst] += 1;
     R.bl = PARABOLIC ? irow[0] : 0.f;
@@ -565,24 +620,6 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
-// normalize(control_update(control, neighbour, dx), max_control_value) as NumPy evaluates it for the given kind of `control`
-// (hyperbolic.py:143-145, parabolic.py:148-150, base_env_1d.py:36-39); the result is what lands in the float32 row.
-template <bool M64>
-__device__ __forceinline__ float boundary_value(const pdegym_params1d& P, float a32, double a64, float neighbour, bool neumann) {
-  if (!M64 || P.action_kind == PDEGYM_ACTION_F32) {
-    const float v = neumann ? a32 * P.dx + neighbour : a32;
-    return normalize_ctrl(v, P.max_control, P.normalize);
-  }
-  if (P.action_kind == PDEGYM_ACTION_F64 || !neumann) {
-    double v = neumann ? a64 * P.dx64 + (double)neighbour : a64;
-    if (P.normalize) v = (v + 1.0) * P.max_control64 - P.max_control64;
-    return (float)v;
-  }
-  // NEP 50 weak Python scalar: control*dx is a Python float product, then adopts the float32 of the neighbour
-  const float v = (float)(a64 * P.dx64) + neighbour;
-  return normalize_ctrl(v, P.max_control, P.normalize);
 }
 
 // M64 = the reference's mixed-precision arithmetic for a float64 beta and/or a float64 / Python-float control input
@@ -911,8 +948,27 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
   hipStream_t st = (hipStream_t)stream;
   if (P.action_kind < PDEGYM_ACTION_F32 || P.action_kind > PDEGYM_ACTION_WEAK) return pdegym::fail(-2, "bad action_kind");
   if (P.beta_f64 || P.action_kind != PDEGYM_ACTION_F32) {   // the reference's float64-operand arithmetic (parity mode)
+    const int slots = P.n - (PARABOLIC ? 1 : 0), epl64 = (slots + kWave - 1) / kWave;
+    if (!BURGERS && epl64 <= 8) {      // rows of up to 512 nodes stay in registers in this mode too
+      const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+      const bool neu = P.control_type == PDEGYM_CONTROL_NEUMANN, hist = buf->history != nullptr;
+      auto go = [&](auto epl_tag) {
+        constexpr int E = decltype(epl_tag)::value;
+        if (neu && hist) hipLaunchKernelGGL((step1d_kernel<E, PARABOLIC, true, true, false, true>), grid, block, 0, st, P, *buf, B);
+        else if (neu) hipLaunchKernelGGL((step1d_kernel<E, PARABOLIC, true, false, false, true>), grid, block, 0, st, P, *buf, B);
+        else if (hist) hipLaunchKernelGGL((step1d_kernel<E, PARABOLIC, false, true, false, true>), grid, block, 0, st, P, *buf, B);
+        else hipLaunchKernelGGL((step1d_kernel<E, PARABOLIC, false, false, false, true>), grid, block, 0, st, P, *buf, B);
+      };
+      switch (epl64) {
+        case 1: go(std::integral_constant<int, 1>{}); break;
+        case 2: go(std::integral_constant<int, 2>{}); break;
+        case 3: case 4: go(std::integral_constant<int, 4>{}); break;
+        default: go(std::integral_constant<int, 8>{}); break;
+      }
+      return pdegym::check_launch("step1d_m64");
+    }
     hipLaunchKernelGGL((step1d_wide_kernel<PARABOLIC, BURGERS, true>), dim3(B), dim3(kWave), 2 * (size_t)P.n * sizeof(float), st, P, *buf, B);
-    return pdegym::check_launch("step1d_m64");
+    return pdegym::check_launch("step1d_m64_wide");
   }
   if (P.n > PDEGYM_MAX_N1D) {    // LDS-resident rows (one wave per instance, two row copies)
     hipLaunchKernelGGL((step1d_wide_kernel<PARABOLIC, BURGERS, false>), dim3(B), dim3(kWave), 2 * (size_t)P.n * sizeof(float), st, P, *buf, B);
