@@ -72,3 +72,9 @@ class NavierStokesC4F64(NavierStokesC4):
     """BASELINE configs[3] at the reference's own precision (float64 end to end, bit-exact against NumPy)."""
     name = "NavierStokes2D 128x128 K=50 B=512 fp64 (BASELINE configs[3] at the reference's precision)"
     dtype = "f64"
+
+
+class NavierStokesC4B4096(NavierStokesC4):
+    """BASELINE.json's metric string names "NS2D 128x128, batch 4096": configs[3] at eight times its batch on one GPU."""
+    name = "NavierStokes2D 128x128 K=50 B=4096 fp32 (BASELINE metric string)"
+    B = 4096
