@@ -884,29 +884,6 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void rownorm2_kernel(const f
   if (lane == 0) out[inst] = sqrtf(ss);
 }
 
-// The dispatcher fills a CU up to its occupancy limit before moving on, so a grid of 4 blocks per CU can land as
-// 8 blocks on some CUs and none on others (measured: wave end times spread 2x, kernel 30 us vs 20 us of work).
-// Requesting an (unused) dynamic LDS slice of 160 KiB / ceil(blocks/CUs) caps the resident blocks per CU at the
-// balanced value, which spreads the grid evenly over all 256 CUs.
-inline int balance_lds_bytes(int nblocks) {
-  static int cu_count[pdegym::kMaxDevices] = {};          // per device: a process may drive several GPUs
-  const int dev = pdegym::current_device();
-  if (cu_count[dev] == 0) {
-    int n = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
-    cu_count[dev] = n;
-  }
-  const int cus = cu_count[dev];
-  const char* off = getenv("PDEGYM_NO_BALANCE");
-  if (off && off[0] == '1') return 0;
-  const int per_cu = (nblocks + cus - 1) / cus;
-  if (per_cu >= 8) return 0;
-  int bytes = (160 * 1024) / per_cu;
-  bytes &= ~1023;
-  return bytes > 64 * 1024 ? 64 * 1024 : bytes;   // > 64 KiB needs a function attribute; 2 blocks/CU is close enough
-}
-
 __global__ void selftest_quotient_kernel(const float* a, float dx, double rdx, unsigned int* mismatches, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float x = a[i];
@@ -922,7 +899,8 @@ template <int EPL, bool PARABOLIC, bool BURGERS = false>
 int launch_epl(const pdegym_params1d& P, const pdegym_bufs1d& Bf, int B, hipStream_t st) {
   const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
   const bool neu = P.control_type == PDEGYM_CONTROL_NEUMANN, hist = Bf.history != nullptr;
-  const int lds = balance_lds_bytes((int)grid.x);
+  // (a dummy dynamic-LDS request that capped resident workgroups per CU was A/B-tested and removed: profiles/r02_ab_lds_balance.txt)
+  constexpr int lds = 0;
   if (neu && hist)
     hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, true, true, BURGERS>), grid, block, lds, st, P, Bf, B);
   else if (neu)
