@@ -1517,23 +1517,6 @@ __global__ __launch_bounds__(1024) void ns256_rq_front(NSConst C, NSScal<float> 
   *reinterpret_cast<float4*>(rqd + i * n + c0) = make_float4(rq[0], rq[1], rq[2], rq[3]);
 }
 
-template <int PR, int PC, int R, int RC>
-__device__ __forceinline__ void store_rotated_rows(const float (&ph)[PR + 1][PC], int rot, float* pd, int g0, int c0, int own_lo, int own_hi) {
-  if (rot == R) {
-#pragma unroll
-    for (int a = 0; a < PR; ++a) {
-      const int g = g0 + a;
-      if (g >= own_lo && g < own_hi) {        // wave-uniform
-        constexpr int n = 256;
-        const float (&row)[PC] = ph[prow<PR>(a, R)];
-        *reinterpret_cast<float4*>(pd + a * n + c0) = make_float4(row[0], row[1], row[2], row[3]);
-      }
-    }
-  } else if constexpr (R + 1 < RC) {
-    store_rotated_rows<PR, PC, R + 1, RC>(ph, rot, pd, g0, c0, own_lo, own_hi);
-  }
-}
-
 // ================================================================================================
 // float64 register-tiled step for 128x128 (the reference's own precision, BASELINE config 4 at float64): 1024 threads per
 // instance, one WAVE per thread row: lane tx of wave ty owns the 8 x 2 patch at rows 8 ty .. 8 ty + 7, columns 2 tx, 2 tx + 1.
