@@ -51,6 +51,8 @@ def classify_control(control):
     PDEGYM_ACTION_*).  float32 arrays / scalars (SB3) -> float32 arithmetic; np.float64 and integer arrays -> double;
     a Python float / int is a weak scalar under NumPy >= 2 (NEP 50) and a float64 under NumPy 1.x."""
     from pdecontrolgym_amd import _native as N
+    if hasattr(control, "detach"):              # a torch tensor (any device): its dtype plays the role of the NumPy dtype
+        control = control.detach().cpu().numpy()
     if isinstance(control, (np.ndarray, np.generic)):
         a = np.asarray(control)
         kind = N.ACTION_F32 if a.dtype in (np.float32, np.float16) else N.ACTION_F64
