@@ -428,6 +428,35 @@ def test_abi_rejects_bad_arguments():
         env.step(torch.zeros(2))
 
 
+def test_abi_rejects_bad_round2_arguments():
+    """The ABI fields added in round 2 are validated on the C side: unknown action kind, dtype / flag mismatches caught by the
+    binding, a pressure ping-pong buffer that aliases p, auto-reset pools given only in part."""
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D
+    from pdecontrolgym_amd.batch2d import NSBatch2D
+    from tests.cases import NS_BC
+    env = PDEBatch1D("transport", 1, 1e-3, 1, 1e-2, 0.01, num_envs=2, device="cuda")
+    env.reset(torch.ones(2, 100), torch.ones(2, 100))
+    with pytest.raises(N.NativeError, match="action_kind"):
+        env.step(torch.zeros(2, dtype=torch.float64), action_kind=7)
+    env.params.beta_f64 = 1                       # flag says float64 but the tensor is float32
+    with pytest.raises(N.NativeError, match="beta"):
+        env.step(torch.zeros(2))
+    env.params.beta_f64 = 0
+    n = 16
+    dx = 1.0 / (n - 1)
+    dt = 0.2 * 0.5 * dx * dx / 0.1
+    ns = NSBatch2D(4 * dt, dt, 1, dx, 1, dx, NS_BC, np.zeros((4, n, n, 2)), 2.0 * np.ones(4), num_envs=2, device="cuda", dtype=torch.float64)
+    ns.reset(np.zeros((2, n, n)), np.zeros((2, n, n)), np.zeros((2, n, n)))
+    ns.t["p_out"] = ns.t["p"]
+    with pytest.raises(N.NativeError, match="alias"):
+        ns.step(torch.ones(2, 1, dtype=torch.float64))
+    ns.t["p_out"] = None
+    ns.t["reset_u0"] = torch.zeros(2, n, n, dtype=torch.float64, device="cuda")
+    with pytest.raises(N.NativeError, match="reset_v0"):
+        ns.step(torch.ones(2, 1, dtype=torch.float64))
+
+
 def test_fused_auto_reset():
     """Instances that finish restart from the pool inside the launch; others are untouched."""
     from oracle import pde_oracle as po
