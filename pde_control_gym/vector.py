@@ -135,6 +135,8 @@ class PDEVecEnv:
         n = self.core.n
         if self.batched_reset_func is not None:
             init, beta = self.batched_reset_func(idx, self.nx)
+            if self._beta_dtype == "float32":
+                beta = np.asarray(beta, dtype=np.float32)
             return init, beta
         init = np.zeros((len(idx), n), dtype=np.float32)
         beta = None
