@@ -539,11 +539,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_also and args.workload == "parabolic_c2" and not args.batch:
         also = {}
         for name, cls in WORKLOADS.items():
-            if name == args.workload or name == "ns2d_c5":      # C5 is the 8-GPU config: run it explicitly with --workload
+            if name == args.workload:
                 continue
             try:
                 w2 = cls(device, 99)
-                n2 = max(40, args.steps // 2) if name != "ns2d_c4_b4096" else 20
+                n2 = max(40, args.steps // 2) if name not in ("ns2d_c4_b4096", "ns2d_c5") else 20
                 r2 = run_workload(w2, n2, max(5, args.warmup // 2), 1, graph=use_graph, repeats=3)
                 rf = roofline_block(w2, name, r2["step_ms_events"], True)
                 also[name] = {"value": w2.units_per_step() * n2 / r2["seconds"], "unit": "env-steps/s", "ms_per_step": r2["seconds"] / n2 * 1e3,
