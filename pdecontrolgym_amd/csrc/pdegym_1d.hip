@@ -388,8 +388,12 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
   if (inst >= B) return;  // wave-uniform
 #ifdef PDEGYM_TIMING
   const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
 #endif
   const int n = P.n, ns = n - J0, s0 = lane * EPL;
+#ifdef PDEGYM_TIMING
+  const unsigned long long tmk = __builtin_amdgcn_s_memtime() + (unsigned long long)(n == 0x7fffffff);  // kernarg arrived
+#endif
   float* urow = Bf.u + (size_t)inst * n;
   const bool beta64 = M64 && P.beta_f64;
   // float32 beta row; in the mixed-precision mode with a float64 beta it is read as double below (beta then stays zero)
@@ -606,6 +610,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
     dbg[2] = (unsigned int)(tm1 - tm0); dbg[3] = (unsigned int)(tm2 - tm1); dbg[4] = (unsigned int)(tm3 - tm2);
     dbg[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
     dbg[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+    const unsigned long long tr3 = __builtin_amdgcn_s_memrealtime();          // 100 MHz constant clock
+    dbg[7] = (unsigned int)tr0; dbg[8] = (unsigned int)(tr3 - tr0);
+    dbg[9] = (unsigned int)(tmk - tm0);
   }
 #endif
 }
