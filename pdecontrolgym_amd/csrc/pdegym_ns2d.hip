@@ -604,6 +604,40 @@ __device__ __forceinline__ void apply_bc_patch(float (&f)[PR][PC], const EdgeFla
   }
 }
 
+// apply_boundary restricted to HR consecutive patch rows held in f (first_half: they start at patch row 0, last_half: they
+// end at patch row PR-1).  Same four ordered passes as apply_bc_patch: the lower / upper pass of the block's edge row
+// reads the neighbouring row of the same block (HR >= 2), the left / right passes are row-local, so running the passes
+// block by block gives the values of the whole-patch version.
+template <int HR, int PC, typename T>
+__device__ __forceinline__ void apply_bc_rows(T (&f)[HR][PC], const EdgeFlags& E, const int (&bc)[4][2], int comp,
+                                              const T* act, int action_dim, int row0, int c0, bool first_half,
+                                              bool last_half) {
+  static_assert(HR >= 2, "the edge row's neighbour must be in the block");
+  auto aval = [&](int idx) -> T { return action_dim == 1 ? act[0] : act[idx]; };
+  if (first_half && E.top) {
+    const int c = bc[PDEGYM_EDGE_LOWER][comp];
+#pragma unroll
+    for (int b = 0; b < PC; ++b) f[0][b] = (c == PDEGYM_BC_NEUMANN) ? f[1][b] : ((c == PDEGYM_BC_DIRICHLET) ? T(0) : aval(c0 + b));
+  }
+  if (last_half && E.bot) {
+    const int c = bc[PDEGYM_EDGE_UPPER][comp];
+#pragma unroll
+    for (int b = 0; b < PC; ++b)
+      f[HR - 1][b] = (c == PDEGYM_BC_NEUMANN) ? f[HR - 2][b] : ((c == PDEGYM_BC_DIRICHLET) ? T(0) : aval(c0 + b));
+  }
+  if (E.lef) {
+    const int c = bc[PDEGYM_EDGE_LEFT][comp];
+#pragma unroll
+    for (int a = 0; a < HR; ++a) f[a][0] = (c == PDEGYM_BC_NEUMANN) ? f[a][1] : ((c == PDEGYM_BC_DIRICHLET) ? T(0) : aval(row0 + a));
+  }
+  if (E.rig) {
+    const int c = bc[PDEGYM_EDGE_RIGHT][comp];
+#pragma unroll
+    for (int a = 0; a < HR; ++a)
+      f[a][PC - 1] = (c == PDEGYM_BC_NEUMANN) ? f[a][PC - 2] : ((c == PDEGYM_BC_DIRICHLET) ? T(0) : aval(row0 + a));
+  }
+}
+
 template <int PR, int PC>
 __device__ __forceinline__ bool on_domain_edge(const EdgeFlags& E, int a, int b) {
   return (a == 0 && E.top) || (a == PR - 1 && E.bot) || (b == 0 && E.lef) || (b == PC - 1 && E.rig);
@@ -945,6 +979,9 @@ __device__ __forceinline__ void jacobi_sweep_bous(float (&ph)[PR + 1][4], const 
   }
 }
 
+#ifndef PDEGYM_NS_BACK_ROWS
+#define PDEGYM_NS_BACK_ROWS 2
+#endif
 template <int PR, int PC, bool INTERLEAVED>
 __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> S, NSPtrs<float> P, int B) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1111,47 +1148,67 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
   const int t = P.time_index[b] + 1;
   const int tr = t < C.nt_ref ? t : C.nt_ref - 1;
   {
-    Halo<PR, PC> H;
-    halo_exchange<PR, PC>(pf, H, lds, xc, tid, ty);
-    float uf[PR][PC], vf[PR][PC];
-    load_patch<PR, PC>(uf, us, n, r0, c0);   // written by this same thread above
-    load_patch<PR, PC>(vf, vs, n, r0, c0);
-#pragma unroll
-    for (int a = 0; a < PR; ++a)
-#pragma unroll
-      for (int k = 0; k < PC; ++k) {
-        const float pw = (k == 0) ? H.l[a] : pf[a][k - 1], pe = (k == PC - 1) ? H.r[a] : pf[a][k + 1];
-        const float ps = (a == 0) ? H.t[k] : pf[a - 1][k], pn = (a == PR - 1) ? H.b[k] : pf[a + 1][k];
-        const float dpdx = div_c(pe - pw, S.two_dx, S.inv_two_dx);
-        const float dpdy = div_c(pn - ps, S.two_dy, S.inv_two_dy);
-        const bool edge = on_domain_edge<PR, PC>(E, a, k);
-        uf[a][k] = edge ? uf[a][k] : uf[a][k] - S.dt_over_rho * dpdx;
-        vf[a][k] = edge ? vf[a][k] : vf[a][k] - S.dt_over_rho * dpdy;
-      }
-    apply_bc_patch<PR, PC>(uf, E, C.bc, 0, act, C.action_dim, r0, c0);
-    apply_bc_patch<PR, PC>(vf, E, C.bc, 1, act, C.action_dim, r0, c0);
-    if constexpr (!INTERLEAVED) {
-      store_patch<PR, PC>(uf, u, n, r0, c0);
-      store_patch<PR, PC>(vf, v, n, r0, c0);
-    }
+    // Blocks of HR rows: u*, v* and the reference rows of a block are fetched, corrected, bounded, written and reduced
+    // before the next block's loads are issued -- the whole-patch form (64 + 32 more live registers next to pf) spilled the
+    // freshly loaded rows to scratch memory and read them back (80 bytes per lane of extra HBM traffic each way).
+    constexpr int HR = PDEGYM_NS_BACK_ROWS, NBLK = PR / HR;
+    static_assert(PR % HR == 0, "row blocks must tile the patch");
+    float pt[PC], pb[PC];
+    halo_tb<PC>(pf[0], pf[PR - 1], pt, pb, lds, xc, tid, ty);
     const float* uref = P.U_ref + (size_t)tr * ncell * 2;
     float* obs = P.obs + (size_t)b * ncell * 2;
 #pragma unroll
-    for (int a = 0; a < PR; ++a) {
-      const int o = ((r0 + a) * n + c0) * 2;
-      const float4* rrow = reinterpret_cast<const float4*>(uref + o);
-      float4* orow = reinterpret_cast<float4*>(obs + o);
+    for (int h = 0; h < NBLK; ++h) {
+      const int a0 = h * HR;
+      float uf[HR][PC], vf[HR][PC];
+      using V = typename VecOf<PC>::type;
 #pragma unroll
-      for (int q = 0; q < PC / 2; ++q) {
-        const float4 w = rrow[q];
-        const float a0 = uf[a][2 * q], b0 = vf[a][2 * q], a1 = uf[a][2 * q + 1], b1 = vf[a][2 * q + 1];
-        orow[q] = make_float4(a0, b0, a1, b1);
-        const float d0 = a0 - w.x, d1 = b0 - w.y, d2 = a1 - w.z, d3 = b1 - w.w;
-        acc += d0 * d0;
-        acc += d1 * d1;
-        acc += d2 * d2;
-        acc += d3 * d3;
+      for (int la = 0; la < HR; ++la) {     // written by this same thread above
+        unpack_row<PC>(*reinterpret_cast<const V*>(us + ((r0 + a0 + la) * n + c0)), uf[la]);
+        unpack_row<PC>(*reinterpret_cast<const V*>(vs + ((r0 + a0 + la) * n + c0)), vf[la]);
       }
+#pragma unroll
+      for (int la = 0; la < HR; ++la) {
+        const int a = a0 + la;
+        const float pl = lane_left(pf[a][PC - 1]), pr = lane_right(pf[a][0]);
+#pragma unroll
+        for (int k = 0; k < PC; ++k) {
+          const float pw = (k == 0) ? pl : pf[a][k - 1], pe = (k == PC - 1) ? pr : pf[a][k + 1];
+          const float ps = (a == 0) ? pt[k] : pf[a - 1][k], pn = (a == PR - 1) ? pb[k] : pf[a + 1][k];
+          const float dpdx = div_c(pe - pw, S.two_dx, S.inv_two_dx);
+          const float dpdy = div_c(pn - ps, S.two_dy, S.inv_two_dy);
+          const bool edge = on_domain_edge<PR, PC>(E, a, k);
+          uf[la][k] = edge ? uf[la][k] : uf[la][k] - S.dt_over_rho * dpdx;
+          vf[la][k] = edge ? vf[la][k] : vf[la][k] - S.dt_over_rho * dpdy;
+        }
+      }
+      apply_bc_rows<HR, PC>(uf, E, C.bc, 0, act, C.action_dim, r0 + a0, c0, h == 0, h == NBLK - 1);
+      apply_bc_rows<HR, PC>(vf, E, C.bc, 1, act, C.action_dim, r0 + a0, c0, h == 0, h == NBLK - 1);
+#pragma unroll
+      for (int la = 0; la < HR; ++la) {
+        if constexpr (!INTERLEAVED) {
+          *reinterpret_cast<V*>(u + ((r0 + a0 + la) * n + c0)) = pack_row<PC>(uf[la]);
+          *reinterpret_cast<V*>(v + ((r0 + a0 + la) * n + c0)) = pack_row<PC>(vf[la]);
+        }
+        const int o = ((r0 + a0 + la) * n + c0) * 2;
+        const float4* rrow = reinterpret_cast<const float4*>(uref + o);
+        float4* orow = reinterpret_cast<float4*>(obs + o);
+#pragma unroll
+        for (int q = 0; q < PC / 2; ++q) {
+          const float4 w = rrow[q];
+          const float a0v = uf[la][2 * q], b0 = vf[la][2 * q], a1 = uf[la][2 * q + 1], b1 = vf[la][2 * q + 1];
+          orow[q] = make_float4(a0v, b0, a1, b1);
+          const float d0 = a0v - w.x, d1 = b0 - w.y, d2 = a1 - w.z, d3 = b1 - w.w;
+          acc += d0 * d0;
+          acc += d1 * d1;
+          acc += d2 * d2;
+          acc += d3 * d3;
+        }
+      }
+      // pin the block's share of the reward sum here: left alone, the compiler sinks the whole sum of squares below the
+      // last block and keeps (spills) every reference row until then
+      asm volatile("" : "+v"(acc));
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   PDEGYM_STAMP(4, acc);
@@ -1663,26 +1720,37 @@ __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<do
   double rq[PR][2];     // dx dy rhs, kept for all sweeps
   {
     double uf[PR][2], vf[PR][2];
-#pragma unroll
-    for (int a = 0; a < PR; ++a) {
+    auto load_row = [&](int grow, double (&ru)[2], double (&rv)[2]) {
       if constexpr (INTERLEAVED) {
-        const double2* row = reinterpret_cast<const double2*>(sin + ((size_t)(r0 + a) * n + c0) * 2);
+        const double2* row = reinterpret_cast<const double2*>(sin + ((size_t)grow * n + c0) * 2);
         const double2 w0 = row[0], w1 = row[1];
-        uf[a][0] = w0.x; vf[a][0] = w0.y; uf[a][1] = w1.x; vf[a][1] = w1.y;
+        ru[0] = w0.x; rv[0] = w0.y; ru[1] = w1.x; rv[1] = w1.y;
       } else {
-        const double2 wu = *reinterpret_cast<const double2*>(u + (r0 + a) * n + c0);
-        const double2 wv = *reinterpret_cast<const double2*>(v + (r0 + a) * n + c0);
-        uf[a][0] = wu.x; uf[a][1] = wu.y; vf[a][0] = wv.x; vf[a][1] = wv.y;
+        const double2 wu = *reinterpret_cast<const double2*>(u + grow * n + c0);
+        const double2 wv = *reinterpret_cast<const double2*>(v + grow * n + c0);
+        ru[0] = wu.x; ru[1] = wu.y; rv[0] = wv.x; rv[1] = wv.y;
       }
-    }
+    };
     // ---- predictor (navier_stokes2D.py:130-138): rows in order, the old row above is carried along ----
+    // The patch is loaded and predicted in two blocks of PR/2 rows (the second block's loads are issued after the first
+    // block's arithmetic): with all eight rows in flight next to the stencil temporaries the compiler spilled half the
+    // patch to scratch memory (~190 bytes per lane written and read back through HBM).  The old rows just above / below
+    // the patch come straight from the state in global memory (the neighbouring thread's own rows: L2 hits) instead of
+    // an LDS exchange.  Domain-edge threads read a valid row whose values are never used.
     {
-      double ut[2], ub[2], vt[2], vb[2];
-      halo_tb_f64(uf[0], uf[PR - 1], ut, ub, lds, xc, tid, ty);
-      halo_tb_f64(vf[0], vf[PR - 1], vt, vb, lds, xc, tid, ty);
-      double pu[2] = {ut[0], ut[1]}, pv[2] = {vt[0], vt[1]};
+      constexpr int HB = PR / 2;
+      double pu[2], pv[2], ub[2], vb[2];
+      load_row(E.top ? r0 : r0 - 1, pu, pv);
+#pragma unroll
+      for (int a = 0; a <= HB; ++a) load_row(r0 + a, uf[a], vf[a]);
 #pragma unroll
       for (int a = 0; a < PR; ++a) {
+        if (a == HB) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int a2 = HB + 1; a2 < PR; ++a2) load_row(r0 + a2, uf[a2], vf[a2]);
+          load_row(E.bot ? r0 + PR - 1 : r0 + PR, ub, vb);
+        }
         const double cu[2] = {uf[a][0], uf[a][1]}, cv[2] = {vf[a][0], vf[a][1]};
         const double ul = dpp_shr_f64(cu[1]), ur = dpp_shl_f64(cu[0]), vl = dpp_shr_f64(cv[1]), vr = dpp_shl_f64(cv[0]);
 #pragma unroll
@@ -1704,6 +1772,9 @@ __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<do
           vf[a][k] = edge ? vc : vn;
         }
         pu[0] = cu[0]; pu[1] = cu[1]; pv[0] = cv[0]; pv[1] = cv[1];
+#ifdef PDEGYM_F64_ROW_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     }
     // ---- apply_boundary(u*, v*) (:140) ----
@@ -1766,49 +1837,60 @@ __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<do
   const int t = P.time_index[b] + 1;
   const int tr = t < C.nt_ref ? t : C.nt_ref - 1;
   {
+    // blocks of two rows, each finished (corrector, boundary, stores, its share of the reward sum) before the next one's
+    // loads are issued: see ns_tile_step -- the whole-patch form spilled 268 bytes per lane
+    constexpr int HR = 2, NBLK = PR / HR;
     double pt[2], pb[2];
     halo_tb_f64(pf[0], pf[PR - 1], pt, pb, lds, xc, tid, ty);
-    double uf[PR][2], vf[PR][2];
-#pragma unroll
-    for (int a = 0; a < PR; ++a) {
-      const double2 wu = *reinterpret_cast<const double2*>(us + (r0 + a) * n + c0);   // written by this same thread above
-      const double2 wv = *reinterpret_cast<const double2*>(vs + (r0 + a) * n + c0);
-      uf[a][0] = wu.x; uf[a][1] = wu.y; vf[a][0] = wv.x; vf[a][1] = wv.y;
-    }
-#pragma unroll
-    for (int a = 0; a < PR; ++a) {
-      const double pl = dpp_shr_f64(pf[a][1]), pr = dpp_shl_f64(pf[a][0]);
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const double pw = (k == 0) ? pl : pf[a][0], pe = (k == 1) ? pr : pf[a][1];
-        const double ps = (a == 0) ? pt[k] : pf[a - 1][k], pn = (a == PR - 1) ? pb[k] : pf[a + 1][k];
-        const double dpdx = div_c(pe - pw, S.two_dx, S.inv_two_dx);
-        const double dpdy = div_c(pn - ps, S.two_dy, S.inv_two_dy);
-        const bool edge = edge_cell(a, k);
-        uf[a][k] = edge ? uf[a][k] : uf[a][k] - S.dt_over_rho * dpdx;
-        vf[a][k] = edge ? vf[a][k] : vf[a][k] - S.dt_over_rho * dpdy;
-      }
-    }
-    apply_bc_patch_f64<PR>(uf, E, C.bc, 0, act, C.action_dim, r0, c0);
-    apply_bc_patch_f64<PR>(vf, E, C.bc, 1, act, C.action_dim, r0, c0);
     const double* uref = P.U_ref + (size_t)tr * ncell * 2;
     double* obs = P.obs + (size_t)b * ncell * 2;
 #pragma unroll
-    for (int a = 0; a < PR; ++a) {
-      if constexpr (!INTERLEAVED) {
-        *reinterpret_cast<double2*>(u + (r0 + a) * n + c0) = make_double2(uf[a][0], uf[a][1]);
-        *reinterpret_cast<double2*>(v + (r0 + a) * n + c0) = make_double2(vf[a][0], vf[a][1]);
+    for (int h = 0; h < NBLK; ++h) {
+      const int a0 = h * HR;
+      double uf[HR][2], vf[HR][2];
+#pragma unroll
+      for (int la = 0; la < HR; ++la) {
+        const double2 wu = *reinterpret_cast<const double2*>(us + (r0 + a0 + la) * n + c0);   // written by this same thread above
+        const double2 wv = *reinterpret_cast<const double2*>(vs + (r0 + a0 + la) * n + c0);
+        uf[la][0] = wu.x; uf[la][1] = wu.y; vf[la][0] = wv.x; vf[la][1] = wv.y;
       }
-      const size_t o = ((size_t)(r0 + a) * n + c0) * 2;
-      const double2 w0 = *reinterpret_cast<const double2*>(uref + o), w1 = *reinterpret_cast<const double2*>(uref + o + 2);
-      *reinterpret_cast<double2*>(obs + o) = make_double2(uf[a][0], vf[a][0]);
-      *reinterpret_cast<double2*>(obs + o + 2) = make_double2(uf[a][1], vf[a][1]);
-      // accumulation order of gen_back: cells in index order, du^2 then dv^2 (the reduction order across lanes differs: rtol 1e-12)
-      const double d0 = uf[a][0] - w0.x, d1 = vf[a][0] - w0.y, d2 = uf[a][1] - w1.x, d3 = vf[a][1] - w1.y;
-      acc += d0 * d0;
-      acc += d1 * d1;
-      acc += d2 * d2;
-      acc += d3 * d3;
+#pragma unroll
+      for (int la = 0; la < HR; ++la) {
+        const int a = a0 + la;
+        const double pl = dpp_shr_f64(pf[a][1]), pr = dpp_shl_f64(pf[a][0]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const double pw = (k == 0) ? pl : pf[a][0], pe = (k == 1) ? pr : pf[a][1];
+          const double ps = (a == 0) ? pt[k] : pf[a - 1][k], pn = (a == PR - 1) ? pb[k] : pf[a + 1][k];
+          const double dpdx = div_c(pe - pw, S.two_dx, S.inv_two_dx);
+          const double dpdy = div_c(pn - ps, S.two_dy, S.inv_two_dy);
+          const bool edge = edge_cell(a, k);
+          uf[la][k] = edge ? uf[la][k] : uf[la][k] - S.dt_over_rho * dpdx;
+          vf[la][k] = edge ? vf[la][k] : vf[la][k] - S.dt_over_rho * dpdy;
+        }
+      }
+      apply_bc_rows<HR, 2, double>(uf, E, C.bc, 0, act, C.action_dim, r0 + a0, c0, h == 0, h == NBLK - 1);
+      apply_bc_rows<HR, 2, double>(vf, E, C.bc, 1, act, C.action_dim, r0 + a0, c0, h == 0, h == NBLK - 1);
+#pragma unroll
+      for (int la = 0; la < HR; ++la) {
+        const int a = a0 + la;
+        if constexpr (!INTERLEAVED) {
+          *reinterpret_cast<double2*>(u + (r0 + a) * n + c0) = make_double2(uf[la][0], uf[la][1]);
+          *reinterpret_cast<double2*>(v + (r0 + a) * n + c0) = make_double2(vf[la][0], vf[la][1]);
+        }
+        const size_t o = ((size_t)(r0 + a) * n + c0) * 2;
+        const double2 w0 = *reinterpret_cast<const double2*>(uref + o), w1 = *reinterpret_cast<const double2*>(uref + o + 2);
+        *reinterpret_cast<double2*>(obs + o) = make_double2(uf[la][0], vf[la][0]);
+        *reinterpret_cast<double2*>(obs + o + 2) = make_double2(uf[la][1], vf[la][1]);
+        // accumulation order of gen_back: cells in index order, du^2 then dv^2 (the reduction order across lanes differs: rtol 1e-12)
+        const double d0 = uf[la][0] - w0.x, d1 = vf[la][0] - w0.y, d2 = uf[la][1] - w1.x, d3 = vf[la][1] - w1.y;
+        acc += d0 * d0;
+        acc += d1 * d1;
+        acc += d2 * d2;
+        acc += d3 * d3;
+      }
+      asm volatile("" : "+v"(acc));
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   const double ss = block_sum<double>(acc, lds);
