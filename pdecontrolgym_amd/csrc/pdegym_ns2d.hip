@@ -496,6 +496,10 @@ struct TileCfg {
   static constexpr int N = 32 * PC;                      // grid side (== 16 * PR)
   static constexpr int BUF = 2 * NT;                     // vectors per halo buffer (top edges, bottom edges)
   static constexpr int LDS_BYTES = 2 * BUF * PC * 4;     // two buffers
+  // rows of u* that wait in LDS (one PC-wide vector per thread and row) instead of the caller's scratch while the
+  // pressure solve runs: 128x128 -> 5 of 8 rows = 40 KB, so that two workgroups (2 x 72 KB) still share a CU's 160 KB
+  static constexpr int PARK_ROWS = (PR == 8 && PC == 4) ? 5 : 0;
+  static constexpr int PARK_BYTES = PARK_ROWS * NT * PC * 4;
   static_assert(16 * PR == 32 * PC, "square grids only");
 };
 
@@ -1070,7 +1074,15 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
     // ---- apply_boundary(u*, v*) (:140) ----
     apply_bc_patch<PR, PC>(uf, E, C.bc, 0, act, C.action_dim, r0, c0);
     apply_bc_patch<PR, PC>(vf, E, C.bc, 1, act, C.action_dim, r0, c0);
-    store_patch<PR, PC>(uf, us, n, r0, c0);
+    {
+      using V = typename VecOf<PC>::type;
+      V* park = reinterpret_cast<V*>(smem_raw + TileCfg<PR, PC>::LDS_BYTES);
+#pragma unroll
+      for (int a = 0; a < PR; ++a) {
+        if (a < TileCfg<PR, PC>::PARK_ROWS) park[a * 512 + tid] = pack_row<PC>(uf[a]);      // read back by this thread only
+        else *reinterpret_cast<V*>(us + ((r0 + a) * n + c0)) = pack_row<PC>(uf[a]);
+      }
+    }
     store_patch<PR, PC>(vf, vs, n, r0, c0);
     // ---- rhs (:101-103), pre-multiplied by 0.25*dx*dy (:108) ----
     {
@@ -1164,7 +1176,10 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
       using V = typename VecOf<PC>::type;
 #pragma unroll
       for (int la = 0; la < HR; ++la) {     // written by this same thread above
-        unpack_row<PC>(*reinterpret_cast<const V*>(us + ((r0 + a0 + la) * n + c0)), uf[la]);
+        if (a0 + la < TileCfg<PR, PC>::PARK_ROWS)
+          unpack_row<PC>(reinterpret_cast<const V*>(smem_raw + TileCfg<PR, PC>::LDS_BYTES)[(a0 + la) * 512 + tid], uf[la]);
+        else
+          unpack_row<PC>(*reinterpret_cast<const V*>(us + ((r0 + a0 + la) * n + c0)), uf[la]);
         unpack_row<PC>(*reinterpret_cast<const V*>(vs + ((r0 + a0 + la) * n + c0)), vf[la]);
       }
 #pragma unroll
@@ -2251,7 +2266,14 @@ int ns_step_launch(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, i
   if constexpr (sizeof(T) == 4) {
     // register-tiled float32 path for the square grids it is instantiated for (BASELINE config 4 is 128x128)
     if (!pdegym_force_generic() && C.nx == C.ny && (C.nx == 128 || C.nx == 64)) {
-      constexpr int lds128 = TileCfg<8, 4>::LDS_BYTES, lds64 = TileCfg<4, 2>::LDS_BYTES;
+      constexpr int lds128 = TileCfg<8, 4>::LDS_BYTES + TileCfg<8, 4>::PARK_BYTES, lds64 = TileCfg<4, 2>::LDS_BYTES;
+      if (C.nx == 128) {   // 72 KB of dynamic LDS: above the 64 KB a kernel gets without asking
+        static signed char attr_i[pdegym::kMaxDevices] = {}, attr_s[pdegym::kMaxDevices] = {};
+        const bool ok = buf->state_in
+            ? pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&ns_tile_step<8, 4, true>), lds128, attr_i)
+            : pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&ns_tile_step<8, 4, false>), lds128, attr_s);
+        if (!ok) return pdegym::fail(-4, "cannot raise the dynamic LDS limit of ns_tile_step");
+      }
       // state_in given -> the velocity state is the previous observation and u, v are not written (if the caller
       // also passed u, v they are simply left untouched)
       const bool inter = buf->state_in != nullptr;
