@@ -1710,6 +1710,8 @@ __device__ __forceinline__ void jacobi_sweep_f64(double (&ph)[PR + 1][2], const 
   }
 }
 
+constexpr int kF64HaloBytes = 2 * 2 * 1024 * 16;            // two buffers x (top, bottom) x one double2 per thread
+constexpr int kF64ParkRows = 5;                             // 5 x 16 KB next to the 64 KB of halo buffers: 144 of the CU's 160 KB
 template <bool INTERLEAVED>
 __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<double> S, NSPtrs<double> P, int B) {
   constexpr int n = 128, ncell = n * n, PR = 8;
@@ -1795,9 +1797,12 @@ __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<do
     // ---- apply_boundary(u*, v*) (:140) ----
     apply_bc_patch_f64<PR>(uf, E, C.bc, 0, act, C.action_dim, r0, c0);
     apply_bc_patch_f64<PR>(vf, E, C.bc, 1, act, C.action_dim, r0, c0);
+    // kF64ParkRows rows of u* wait in LDS (behind the halo buffers) instead of the caller's scratch
+    double2* park = reinterpret_cast<double2*>(smem_raw + kF64HaloBytes);
 #pragma unroll
     for (int a = 0; a < PR; ++a) {
-      *reinterpret_cast<double2*>(us + (r0 + a) * n + c0) = make_double2(uf[a][0], uf[a][1]);
+      if (a < kF64ParkRows) park[a * 1024 + tid] = make_double2(uf[a][0], uf[a][1]);
+      else *reinterpret_cast<double2*>(us + (r0 + a) * n + c0) = make_double2(uf[a][0], uf[a][1]);
       *reinterpret_cast<double2*>(vs + (r0 + a) * n + c0) = make_double2(vf[a][0], vf[a][1]);
     }
     // ---- rhs (:101-103) times dx dy (:108) ----
@@ -1865,7 +1870,9 @@ __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<do
       double uf[HR][2], vf[HR][2];
 #pragma unroll
       for (int la = 0; la < HR; ++la) {
-        const double2 wu = *reinterpret_cast<const double2*>(us + (r0 + a0 + la) * n + c0);   // written by this same thread above
+        const double2 wu = (a0 + la < kF64ParkRows)
+                               ? reinterpret_cast<const double2*>(smem_raw + kF64HaloBytes)[(a0 + la) * 1024 + tid]
+                               : *reinterpret_cast<const double2*>(us + (r0 + a0 + la) * n + c0);   // written by this same thread above
         const double2 wv = *reinterpret_cast<const double2*>(vs + (r0 + a0 + la) * n + c0);
         uf[la][0] = wu.x; uf[la][1] = wu.y; vf[la][0] = wv.x; vf[la][1] = wv.y;
       }
@@ -2291,7 +2298,7 @@ int ns_step_launch(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, i
   if constexpr (sizeof(T) == 8) {
     // register-tiled float64 path for 128x128 (BASELINE config 4 at the reference's own precision)
     if (!pdegym_force_generic() && C.nx == 128 && C.ny == 128) {
-      constexpr int lds_bytes = 2 * 2 * 1024 * 16;
+      constexpr int lds_bytes = kF64HaloBytes + kF64ParkRows * 1024 * 16;
       static signed char attr_a[pdegym::kMaxDevices] = {}, attr_b[pdegym::kMaxDevices] = {};
       if (buf->state_in) {
         if (!pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&ns_tile_step_f64<true>), lds_bytes, attr_a))
