@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PDEGYM_ABI_VERSION 8
+#define PDEGYM_ABI_VERSION 9
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
 #define PDEGYM_MAX_N1D 2048      /* nodes per 1D row kept in registers by the wave-per-instance kernels */
@@ -327,6 +327,39 @@ int pdegym_tumor_advance(const pdegym_params_tumor* prm, const pdegym_bufs_tumor
  * remaining = total_dosage, days = (0,0,0,0,-1). */
 int pdegym_tumor_reset_masked(const pdegym_params_tumor* prm, const pdegym_bufs_tumor* buf, const double* init,
                               int64_t init_stride, const uint8_t* mask, int32_t B, void* stream);
+
+/* ---- policy network on the device (the caller of env.step inside an on-device rollout) ------------------------------
+ * The reference evaluates an SB3 "MlpPolicy" (two hidden layers of 64 tanh units by default) between two env.step calls:
+ * model = PPO("MlpPolicy", env) / model.predict(obs), examples/transportPDE/transport1Dppo.py:88-90 and
+ * transport1DtestAlgorithm.py (the RL controllers).  pdegym_mlp_forward evaluates such a network for B observation rows
+ * in ONE launch (float32; weights in a blocked transpose of torch.nn.Linear.weight W[out_dim, in_dim]:
+ * w[(k / 4) * out_dim * 4 + n * 4 + k % 4] = W[n][k], zero-padded to a multiple of four k, 16-byte aligned -- one 16-byte
+ * load per lane brings four consecutive inputs of its neuron and a wave's load is contiguous), optionally clamping the
+ * output to the action box, so that policy + step + auto-reset of a rollout are two launches per env-step.
+ * Summation order is k ascending with the bias added last (not a BLAS order): float32-rounding agreement with torch. */
+#define PDEGYM_MLP_MAX_LAYERS 4
+#define PDEGYM_MLP_MAX_WIDTH 256   /* widest layer output                          */
+#define PDEGYM_MLP_MAX_INPUT 8192  /* widest observation row (first layer in_dim)  */
+enum { PDEGYM_MLP_IDENTITY = 0, PDEGYM_MLP_TANH = 1, PDEGYM_MLP_RELU = 2 };
+
+typedef struct {
+  const float* w;      /* [ceil(in_dim / 4), out_dim, 4] blocked transpose, see above  */
+  const float* b;      /* [out_dim] or NULL                                         */
+  int32_t in_dim, out_dim;
+  int32_t act;         /* PDEGYM_MLP_* applied to this layer's output               */
+  int32_t reserved_;
+} pdegym_mlp_layer;
+
+typedef struct {
+  int32_t n_layers;    /* 1 .. PDEGYM_MLP_MAX_LAYERS                                 */
+  int32_t clamp;       /* nonzero: the last layer's output is clamped to [lo, hi]   */
+  float lo, hi;
+  pdegym_mlp_layer layer[PDEGYM_MLP_MAX_LAYERS];
+} pdegym_mlp;
+
+/* y[b, :] = net(x[b, :]) for b < B; x_stride / y_stride = floats between consecutive rows (>= the row lengths). */
+int pdegym_mlp_forward(const pdegym_mlp* net, const float* x, int64_t x_stride, float* y, int64_t y_stride, int32_t B,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,8 @@ for _id, _entry in _IDS.items():
 
 from pde_control_gym.vector import PDEVecEnv, make_vec  # noqa: E402
 from pde_control_gym.rollout import DeviceRollout  # noqa: E402
+from pdecontrolgym_amd.policy import FusedMLP  # noqa: E402
 from pde_control_gym import export  # noqa: E402
 from pde_control_gym.vector_gymnasium import GymnasiumVectorAdapter  # noqa: E402
 
-__all__ = ["make", "register", "make_vec", "PDEVecEnv", "DeviceRollout", "HAVE_GYMNASIUM", "export", "GymnasiumVectorAdapter"]
+__all__ = ["make", "register", "make_vec", "PDEVecEnv", "DeviceRollout", "FusedMLP", "HAVE_GYMNASIUM", "export", "GymnasiumVectorAdapter"]

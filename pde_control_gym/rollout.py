@@ -10,7 +10,8 @@ from __future__ import annotations
 
 
 class DeviceRollout:
-    """``policy``: callable mapping an observation tensor [B, obs_dim] to actions [B] (or [B, 1]) on the same device.
+    """``policy``: callable mapping an observation tensor [B, obs_dim] to actions [B] (or [B, 1]) on the same device -- any
+    torch module, or a ``pdecontrolgym_amd.FusedMLP`` (Linear/Tanh/ReLU stack evaluated, clamped and stored in ONE launch).
     Buffers: ``obs[T+1, B, D]``, ``actions[T, B]``, ``rewards[T, B]``, ``terminated[T, B]``, ``truncated[T, B]``."""
 
     def __init__(self, venv, policy, n_steps: int, use_graph: bool = True, action_low: float = -1.0, action_high: float = 1.0):
@@ -60,10 +61,14 @@ class DeviceRollout:
     def _steps(self, core, torch):
         if self._ns:        # slot 0 of the rollout buffer is the input state of the first step (not the engine's own buffer,
             core.t["obs"] = self.obs[0]        # which a graph warm-up run leaves in its end state)
+        fused = hasattr(self.policy, "forward_into") and self.obs.dtype == torch.float32
         for t in range(self.T):
-            with torch.no_grad():
-                a = self.policy(self.obs[t]).reshape(self.actions[t].shape).clamp(self.lo, self.hi)
-            self.actions[t].copy_(a)
+            if fused:       # pdecontrolgym_amd.FusedMLP: forward pass + action clamp in one launch, written into slot t
+                self.policy.forward_into(self.obs[t], self.actions[t], clamp=(self.lo, self.hi))
+            else:
+                with torch.no_grad():
+                    a = self.policy(self.obs[t]).reshape(self.actions[t].shape).clamp(self.lo, self.hi)
+                self.actions[t].copy_(a)
             if self._ns:
                 # Navier-Stokes: the observation IS the state, so slot t of the rollout buffer is also the next step's input
                 core.step(self.actions[t], out_obs=self.obs[t + 1], out_reward=self.rewards[t], out_terminated=self.terminated[t])
@@ -82,6 +87,8 @@ class DeviceRollout:
         """Roll T steps from ``first_obs`` (default: the environment's current observation). Returns self."""
         import torch
         core = self.venv.core
+        if hasattr(self.policy, "refresh"):      # FusedMLP: pick up optimizer updates before the graph is (re)played
+            self.policy.refresh()
         self.obs[0].copy_((core.t["obs"] if self._direct or "obs" in core.t else core.t["u"]) if first_obs is None else first_obs)
         if not self.use_graph:
             self._body()

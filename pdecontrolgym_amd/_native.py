@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 RING = 128
 LOOKBACK = 100
 MAX_N1D = 8192
@@ -29,8 +29,10 @@ EXPORTS = [
     "pdegym_reset1d_masked", "pdegym_rownorm2_f32", "pdegym_selftest_quotient", "pdegym_ns2d_step_f32", "pdegym_ns2d_step_f64",
     "pdegym_ns2d_solve_pressure_f32", "pdegym_ns2d_solve_pressure_f64", "pdegym_ns2d_reset_masked_f32",
     "pdegym_ns2d_reset_masked_f64", "pdegym_traffic_step", "pdegym_traffic_reset_masked",
-    "pdegym_tumor_step", "pdegym_tumor_advance", "pdegym_tumor_reset_masked",
+    "pdegym_tumor_step", "pdegym_tumor_advance", "pdegym_tumor_reset_masked", "pdegym_mlp_forward",
 ]
+MLP_MAX_LAYERS, MLP_MAX_WIDTH, MLP_MAX_INPUT = 4, 256, 8192
+MLP_IDENTITY, MLP_TANH, MLP_RELU = 0, 1, 2
 
 
 class Params1D(C.Structure):
@@ -99,6 +101,16 @@ class BufsTumor(C.Structure):
                                           "t1_log")]
 
 
+class MlpLayer(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("in_dim", C.c_int32), ("out_dim", C.c_int32), ("act", C.c_int32),
+                ("reserved_", C.c_int32)]
+
+
+class Mlp(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("clamp", C.c_int32), ("lo", C.c_float), ("hi", C.c_float),
+                ("layer", MlpLayer * MLP_MAX_LAYERS)]
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -150,6 +162,8 @@ def load():
     lib.pdegym_tumor_reset_masked.argtypes = [C.POINTER(ParamsTumor), C.POINTER(BufsTumor), C.c_void_p, C.c_int64, C.c_void_p,
                                               C.c_int32, C.c_void_p]
     lib.pdegym_tumor_reset_masked.restype = C.c_int
+    lib.pdegym_mlp_forward.argtypes = [C.POINTER(Mlp), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+    lib.pdegym_mlp_forward.restype = C.c_int
     if lib.pdegym_abi_version() != ABI_VERSION:
         raise NativeError(f"ABI mismatch: library {lib.pdegym_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

@@ -208,6 +208,17 @@ class HipBackend:
         N.check(self.lib.pdegym_tumor_reset_masked(C.byref(P), C.byref(bufs), N.dptr(init, torch.float64), stride, m, B,
                                                    N.current_stream_ptr(T["u"].device)), "pdegym_tumor_reset_masked")
 
+    # ---- policy network ----------------------------------------------------------------------------
+    @_on_device_of("x")
+    def mlp_forward(self, net: N.Mlp, x, y, B: int):
+        """y[b] = net(x[b]) for b < B: x [B, in_dim], y [B, out_dim] float32 rows (row stride = stride(0))."""
+        import torch
+        for t_, name in ((x, "x"), (y, "y")):
+            if not t_.is_cuda or t_.dtype != torch.float32 or t_.dim() != 2 or t_.stride(1) != 1:
+                raise N.NativeError(f"mlp_forward: {name} must be a float32 HIP tensor [B, width] with unit inner stride")
+        N.check(self.lib.pdegym_mlp_forward(C.byref(net), x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), B,
+                                            N.current_stream_ptr(x.device)), "pdegym_mlp_forward")
+
 
 _default = None
 

@@ -1,0 +1,242 @@
+// pdegym_mlp.hip -- fused forward pass of a small multi-layer perceptron policy (see include/pdegym.h: pdegym_mlp_forward).
+//
+// The caller on the other side of env.step(): the reference trains SB3 "MlpPolicy" networks (two hidden layers of 64 tanh
+// units by default, examples/transportPDE/transport1Dppo.py:88-90) and evaluates them once per env-step.  Inside an
+// on-device rollout (pde_control_gym.DeviceRollout) that evaluation was 3 GEMM + 3 tanh + clamp + copy launches -- 29 us
+// per step next to a 20 us environment step at C2 -- so the whole forward pass is ONE launch here.  The arithmetic is
+// tiny (85 MFLOP at B = 4096); what decides the time is operand delivery and the number of dependent memory round trips.
+//
+// Mapping (the one GEMM-shaped piece of the project -> MFMA): a workgroup of four waves owns 16 observation rows for all
+// layers; wave w computes the 16 x 16 output tiles w, w + 4, w + 8, ... of a layer with v_mfma_f32_16x16x4_f32 (float32 in,
+// float32 accumulate).  Per 16 reduction indices a lane supplies ONE float4 of the layer input (row l % 16, inputs
+// 4 (l / 16) .. + 3, read from LDS: the observation rows are staged there once, hidden activations are written there by
+// the previous layer) and ONE float4 of weights per tile (blocked layout wq[k / 4][neuron][k % 4]: a wave's load is four
+// contiguous 256-byte pieces) for four MFMAs -- 1/8 float per FMA, against 1.25 for a VALU formulation whose wave-uniform
+// inputs have to be broadcast (the first versions: LDS broadcast reads and the texture addresser bound them at 12-17 us).
+// Weight loads run a software pipeline of 64 reduction indices (a wave is alone on its SIMD).  Accumulation order is that
+// of the MFMA (k in groups of four, ascending), bias added last: deterministic, but not the summation order of a BLAS GEMM
+// -- results match torch within float32 rounding (tests: rtol 2e-5, atol 4e-6 on O(1) values).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "pdegym.h"
+#include "pdegym_common.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kRows = 16;                   // observation rows per workgroup (the M of the MFMA tile)
+constexpr int kMaxWidth = PDEGYM_MLP_MAX_WIDTH;
+constexpr int kMaxTiles = kMaxWidth / 64;   // 16-neuron tiles per wave (four waves share a layer's tiles round-robin)
+constexpr int kXChunk = 512;                // observation entries per row staged in LDS at a time
+constexpr int kLdx = kXChunk + 4;           // LDS row strides: 16-byte aligned, and 16 rows x one float4 hit 64 distinct banks
+constexpr int kLdh = kMaxWidth + 4;
+constexpr int kStage = 4;                   // k-blocks (of 16 inputs) per software-pipeline stage
+
+__device__ __forceinline__ float activate(float v, int act) {
+  if (act == PDEGYM_MLP_TANH) return tanhf(v);
+  if (act == PDEGYM_MLP_RELU) return v > 0.f ? v : 0.f;
+  return v;
+}
+
+// weights of k-blocks kb0 .. kb0 + kStage - 1 for this lane: group g = 4 kb + l / 16 of the blocked matrix, neuron n (already
+// clamped to the layer width); groups past the end of the (zero-padded) matrix read as zero
+template <int NT>
+__device__ __forceinline__ void load_w(v4f (&w)[kStage][NT], const v4f* __restrict__ wq, int H, int ngroups, int kb0, int lg,
+                                       const int (&col)[NT]) {
+#pragma unroll
+  for (int s = 0; s < kStage; ++s) {
+    const int g = 4 * (kb0 + s) + lg;
+    const bool ok = g < ngroups;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const v4f v = wq[(ok ? g : ngroups - 1) * H + col[t]];
+      w[s][t] = ok ? v : (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void mma_stage(v4f (&acc)[NT], const v4f (&w)[kStage][NT], const float* in_row, int kb0, int nblk, int lg) {
+#pragma unroll
+  for (int s = 0; s < kStage; ++s) {
+    if (kb0 + s < nblk) {     // wave-uniform
+      const v4f a = *reinterpret_cast<const v4f*>(in_row + 16 * (kb0 + s) + 4 * lg);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[s][t].x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[s][t].y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[s][t].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[s][t].w, acc[t], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// acc[t] += in[16 rows, nblk k-blocks] x W^T for this wave's NT tiles; in_row = this lane's input row in LDS (index 0 = first
+// input of the chunk), gofs = k-block offset of the chunk within the weight matrix.  wa: the first stage's weights, loaded
+// by the caller BEFORE it waited for the inputs (the barrier after staging / after the previous layer's epilogue).
+template <int NT>
+__device__ __forceinline__ void reduce_blocks(v4f (&acc)[NT], v4f (&wa)[kStage][NT], const v4f* __restrict__ wq, int H, int ngroups,
+                                              int gofs, int nblk, const float* in_row, int lg, const int (&col)[NT]) {
+  v4f wb[kStage][NT];
+  int kb = 0;
+  while (true) {
+    const bool more_b = kb + kStage < nblk;
+    if (more_b) load_w<NT>(wb, wq, H, ngroups, gofs + kb + kStage, lg, col);
+    mma_stage<NT>(acc, wa, in_row, kb, nblk, lg);
+    kb += kStage;
+    if (!more_b) break;
+    const bool more_a = kb + kStage < nblk;
+    if (more_a) load_w<NT>(wa, wq, H, ngroups, gofs + kb + kStage, lg, col);
+    mma_stage<NT>(acc, wb, in_row, kb, nblk, lg);
+    kb += kStage;
+    if (!more_a) break;
+  }
+}
+
+template <int NT>   // NT = 16-neuron tiles per wave = ceil(width of the widest layer / 64)
+__global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const float* __restrict__ x, long long x_stride,
+                                                          float* __restrict__ y, long long y_stride, int B) {
+  // LDS: activations ping-pong between hb0 and hb1; the staged observation chunk shares its space with hb1 (first written
+  // by the second layer, when the observations are no longer needed)
+  __shared__ __attribute__((aligned(16))) float hb0[kRows * kLdh];
+  __shared__ __attribute__((aligned(16))) float xs[kRows * kLdx];
+  static_assert(kLdx >= kLdh, "hb1 lives inside the observation staging area");
+  auto hbuf = [&](int i) -> float* { return i ? xs : hb0; };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;      // MFMA operand lane = (row or neuron li, k-slot lg)
+  const int row0 = blockIdx.x * kRows;
+
+  // weights of the first pipeline stage of the coming layer: requested before the barrier that publishes its inputs
+  v4f wfirst[kStage][NT];
+  auto tile_cols = [&](int H, int (&col)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = 16 * (wave + 4 * t) + li;
+      col[t] = n < H ? n : H - 1;
+    }
+  };
+  {
+    int col0[NT];
+    tile_cols(N.layer[0].out_dim, col0);
+    if (16 * wave < N.layer[0].out_dim)
+      load_w<NT>(wfirst, reinterpret_cast<const v4f*>(N.layer[0].w), N.layer[0].out_dim, (N.layer[0].in_dim + 3) >> 2, 0, lg, col0);
+  }
+
+  for (int l = 0; l < N.n_layers; ++l) {
+    const pdegym_mlp_layer L = N.layer[l];
+    const int K = L.in_dim, H = L.out_dim;
+    const int ngroups = (K + 3) >> 2;
+    const v4f* __restrict__ wq = reinterpret_cast<const v4f*>(L.w);
+    int col[NT];
+    tile_cols(H, col);
+    v4f acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    const bool any_tile = 16 * wave < H;      // this wave has at least one tile of the layer
+    if (l == 0) {
+      for (int c0 = 0; c0 < K; c0 += kXChunk) {
+        const int clen = (K - c0) < kXChunk ? (K - c0) : kXChunk;
+        const int cpad = (clen + 15) & ~15;
+        // stage the chunk: wave w copies rows 4 w .. 4 w + 3, a wave-wide load = 64 consecutive entries of one row; all
+        // the loads of a thread are issued before the first LDS store.  Rows past the batch and entries past K read as zero.
+        {
+          float v[4][kXChunk / 64];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * wave + rr;
+            const bool row_ok = row0 + r < B;
+            const float* src = x + (long long)(row_ok ? row0 + r : 0) * x_stride + c0;
+#pragma unroll
+            for (int i = 0; i < kXChunk / 64; ++i) {
+              const int c = lane + 64 * i;
+              v[rr][i] = (row_ok && c < clen) ? src[c] : 0.f;
+            }
+          }
+          if (c0 > 0 && any_tile) load_w<NT>(wfirst, wq, H, ngroups, c0 / 16, lg, col);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int i = 0; i < kXChunk / 64; ++i) {
+              const int c = lane + 64 * i;
+              if (c < cpad) xs[(4 * wave + rr) * kLdx + c] = v[rr][i];
+            }
+        }
+        __syncthreads();
+        if (any_tile) reduce_blocks<NT>(acc, wfirst, wq, H, ngroups, c0 / 16, cpad / 16, xs + li * kLdx, lg, col);
+        __syncthreads();
+      }
+    } else {
+      const float* hin = hbuf((l + 1) & 1);       // written by layer l - 1, zero beyond its width up to a multiple of 16
+      if (any_tile) reduce_blocks<NT>(acc, wfirst, wq, H, ngroups, 0, (K + 15) >> 4, hin + li * kLdh, lg, col);
+    }
+    const bool last = l == N.n_layers - 1;
+    if (!last) {      // the next layer's first weights travel while this layer's epilogue runs
+      const pdegym_mlp_layer Ln = N.layer[l + 1];
+      int coln[NT];
+      tile_cols(Ln.out_dim, coln);
+      if (16 * wave < Ln.out_dim)
+        load_w<NT>(wfirst, reinterpret_cast<const v4f*>(Ln.w), Ln.out_dim, (Ln.in_dim + 3) >> 2, 0, lg, coln);
+    }
+    // bias, activation; D[i = 4 lg + v][j = li] of tile t.  Hidden layers go to LDS, zero-padded to a multiple of 16 columns.
+    float* hout = hbuf(l & 1);
+    const int Hpad = (H + 15) & ~15;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = 16 * (wave + 4 * t) + li;
+      if (n < Hpad) {
+        const float bias = (L.b && n < H) ? L.b[n] : 0.f;
+        const float av[4] = {acc[t].x, acc[t].y, acc[t].z, acc[t].w};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int r = 4 * lg + v;
+          float o = n < H ? activate(av[v] + bias, L.act) : 0.f;
+          if (last) {
+            if (N.clamp) o = fminf(fmaxf(o, N.lo), N.hi);
+            if (n < H && row0 + r < B) y[(long long)(row0 + r) * y_stride + n] = o;
+          } else {
+            hout[r * kLdh + n] = o;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int pdegym_mlp_forward(const pdegym_mlp* net, const float* x, int64_t x_stride, float* y, int64_t y_stride, int32_t B,
+                                  void* stream) {
+  if (!net || !x || !y) return pdegym::fail(-3, "null pointer");
+  if (B < 0) return pdegym::fail(-2, "B must be >= 0");
+  if (net->n_layers < 1 || net->n_layers > PDEGYM_MLP_MAX_LAYERS) return pdegym::fail(-2, "n_layers must be 1..4");
+  for (int l = 0; l < net->n_layers; ++l) {
+    const pdegym_mlp_layer& L = net->layer[l];
+    if (!L.w) return pdegym::fail(-3, "null weight pointer");
+    if (L.in_dim < 1 || L.out_dim < 1) return pdegym::fail(-2, "layer dimensions must be >= 1");
+    if (L.out_dim > PDEGYM_MLP_MAX_WIDTH) return pdegym::fail(-2, "layer wider than PDEGYM_MLP_MAX_WIDTH");
+    if (l == 0 && L.in_dim > PDEGYM_MLP_MAX_INPUT) return pdegym::fail(-2, "observation wider than PDEGYM_MLP_MAX_INPUT");
+    if (l > 0 && L.in_dim != net->layer[l - 1].out_dim) return pdegym::fail(-2, "layer input size does not match the previous layer");
+    if (L.act < PDEGYM_MLP_IDENTITY || L.act > PDEGYM_MLP_RELU) return pdegym::fail(-2, "unknown activation");
+  }
+  if (x_stride < net->layer[0].in_dim || y_stride < net->layer[net->n_layers - 1].out_dim)
+    return pdegym::fail(-2, "row stride shorter than the row");
+  if (net->clamp && !(net->lo <= net->hi)) return pdegym::fail(-2, "clamp bounds must satisfy lo <= hi");
+  if (B == 0) return 0;
+  int width = 0;
+  for (int l = 0; l < net->n_layers; ++l) width = net->layer[l].out_dim > width ? net->layer[l].out_dim : width;
+  const dim3 grid((B + kRows - 1) / kRows), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const long long xs = x_stride, ys = y_stride;
+  switch ((width + 63) / 64) {
+    case 1: hipLaunchKernelGGL(mlp_forward_kernel<1>, grid, block, 0, st, *net, x, xs, y, ys, B); break;
+    case 2: hipLaunchKernelGGL(mlp_forward_kernel<2>, grid, block, 0, st, *net, x, xs, y, ys, B); break;
+    case 3: hipLaunchKernelGGL(mlp_forward_kernel<3>, grid, block, 0, st, *net, x, xs, y, ys, B); break;
+    default: hipLaunchKernelGGL(mlp_forward_kernel<4>, grid, block, 0, st, *net, x, xs, y, ys, B); break;
+  }
+  return pdegym::check_launch("mlp_forward");
+}

@@ -259,3 +259,26 @@ class FakeBackend:
         T["stage"][m] = 0
         T["remaining"][m] = P.total_dosage
         T["days"][m] = torch.tensor([0, 0, 0, 0, -1], dtype=torch.int32)
+
+    def mlp_forward(self, net, x, y, B):
+        """CPU double of pdegym_mlp_forward: float32 accumulation over k in ascending order, bias last, like the kernel."""
+        import ctypes
+        import numpy as np
+        import torch
+        h = x[:B].detach().cpu().numpy().astype(np.float32)
+        for i in range(net.n_layers):
+            L = net.layer[i]
+            k4 = (L.in_dim + 3) // 4
+            blk = np.ctypeslib.as_array(ctypes.cast(L.w, ctypes.POINTER(ctypes.c_float)), (k4, L.out_dim, 4))
+            w = blk.transpose(1, 0, 2).reshape(L.out_dim, 4 * k4)[:, :L.in_dim]
+            acc = np.zeros((h.shape[0], L.out_dim), np.float32)
+            for k in range(L.in_dim):     # an fma is exact before its single rounding: emulate with a double product
+                acc = (acc.astype(np.float64) + h[:, k:k + 1].astype(np.float64) * w[:, k][None, :].astype(np.float64)).astype(np.float32)
+            if L.b:
+                acc = acc + np.ctypeslib.as_array(ctypes.cast(L.b, ctypes.POINTER(ctypes.c_float)), (L.out_dim,))[None, :]
+            h = np.tanh(acc) if L.act == 1 else (np.maximum(acc, 0) if L.act == 2 else acc)
+            h = h.astype(np.float32)
+        if net.clamp:
+            h = np.clip(h, net.lo, net.hi)
+        y[:B].copy_(torch.from_numpy(h))
+

@@ -1,0 +1,177 @@
+"""FusedMLP (pdegym_mlp_forward): one-launch forward pass of an SB3-style MLP policy.
+
+GPU tests compare the HIP kernel with the torch module it wraps (float32 rounding tolerance: the kernel sums k in ascending
+order with FMAs, a BLAS GEMM does not); CPU tests drive the host wrapper through the oracle-backed double."""
+import numpy as np
+import pytest
+import torch
+
+from pdecontrolgym_amd import _native as N
+from pdecontrolgym_amd.policy import FusedMLP
+
+
+def _mlp(sizes, acts, bias=True, seed=0):
+    torch.manual_seed(seed)
+    mods = []
+    for i in range(len(sizes) - 1):
+        mods.append(torch.nn.Linear(sizes[i], sizes[i + 1], bias=bias))
+        if acts[i] == "tanh":
+            mods.append(torch.nn.Tanh())
+        elif acts[i] == "relu":
+            mods.append(torch.nn.ReLU())
+    return torch.nn.Sequential(*mods)
+
+
+SHAPES = [
+    ([257, 64, 64, 1], ["tanh", "tanh", "tanh"]),          # SB3 MlpPolicy on the C2 observation, squashed output
+    ([513, 64, 64, 1], ["tanh", "tanh", None]),            # C3 observation, linear head
+    ([101, 128, 2], ["relu", None]),
+    ([7, 256, 200, 33, 3], ["tanh", "relu", "tanh", None]),  # four layers, ragged widths
+    ([1, 1], [None]),
+    ([300, 65, 1], ["tanh", "tanh"]),                      # width just above one neuron tile
+]
+
+
+def test_struct_layout_matches_header():
+    import ctypes as C
+    assert C.sizeof(N.MlpLayer) == 32 and C.sizeof(N.Mlp) == 16 + 4 * 32
+    assert N.Mlp.layer.offset == 16 and N.MlpLayer.in_dim.offset == 16
+
+
+def test_rejects_unsupported_modules():
+    with pytest.raises(ValueError):
+        FusedMLP(torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Sigmoid()), backend=object())
+    with pytest.raises(ValueError):
+        FusedMLP(torch.nn.Sequential(torch.nn.Tanh(), torch.nn.Linear(4, 4)), backend=object())
+    with pytest.raises(ValueError):
+        FusedMLP(torch.nn.Sequential(torch.nn.Linear(4, 300)), backend=object())
+    with pytest.raises(ValueError):
+        FusedMLP(torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.Linear(9, 1)), backend=object())
+    with pytest.raises(ValueError):
+        FusedMLP(torch.nn.Sequential(*[torch.nn.Linear(4, 4) for _ in range(5)]), backend=object())
+    with pytest.raises(ValueError):
+        FusedMLP(torch.nn.Sequential(torch.nn.Linear(4, 4)).double(), backend=object())
+    with pytest.raises(ValueError):
+        FusedMLP(torch.nn.Sequential(torch.nn.Linear(4, 1)), clamp=(1.0, -1.0), backend=object())
+
+
+@pytest.mark.parametrize("sizes,acts", SHAPES[:4])
+def test_host_wrapper_with_cpu_double(sizes, acts):
+    from tests.fake_backend import FakeBackend
+    net = _mlp(sizes, acts)
+    pol = FusedMLP(net, clamp=(-1.0, 1.0), backend=FakeBackend())
+    x = torch.randn(37, sizes[0])
+    with torch.no_grad():
+        want = net(x).clamp(-1, 1)
+    got = pol(x)
+    assert got.shape == (37, sizes[-1])
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
+    out = torch.zeros(37, sizes[-1])
+    assert pol.forward_into(x, out, clamp=None) is out
+    with torch.no_grad():
+        np.testing.assert_allclose(out.numpy(), net(x).numpy(), rtol=2e-5, atol=2e-6)
+    with pytest.raises(ValueError):
+        pol(torch.randn(5, sizes[0] + 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes,acts", SHAPES)
+@pytest.mark.parametrize("B", [1, 16, 37, 4096])
+def test_fused_mlp_matches_torch_on_gpu(sizes, acts, B):
+    net = _mlp(sizes, acts, seed=B).cuda()
+    pol = FusedMLP(net)
+    x = torch.randn(B, sizes[0], device="cuda") * 2
+    with torch.no_grad():
+        want = net(x)
+    got = pol(x)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=4e-6)
+    # clamp fused, no bias, rows taken from a larger buffer (row stride > row length), output into a [B] view
+    net2 = _mlp(sizes[:-1] + [1], acts, bias=False, seed=B + 1).cuda()
+    pol2 = FusedMLP(net2, clamp=(-0.25, 0.5))
+    big = torch.randn(B, sizes[0] + 5, device="cuda")
+    out = torch.full((B,), 7.0, device="cuda")
+    pol2.forward_into(big[:, :sizes[0]], out)
+    with torch.no_grad():
+        want2 = net2(big[:, :sizes[0]]).clamp(-0.25, 0.5).reshape(B)
+    np.testing.assert_allclose(out.cpu().numpy(), want2.cpu().numpy(), rtol=2e-5, atol=4e-6)
+
+
+@pytest.mark.gpu
+def test_fused_mlp_sees_in_place_parameter_updates_and_rejects_bad_calls():
+    net = _mlp([33, 64, 1], ["tanh", None]).cuda()
+    pol = FusedMLP(net)
+    x = torch.randn(50, 33, device="cuda")
+    a = pol(x).clone()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(0.5)
+        want = net(x)
+    b = pol(x)
+    assert not torch.allclose(a, b)
+    np.testing.assert_allclose(b.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=4e-6)
+    with pytest.raises(N.NativeError):
+        pol(x.double())
+    with pytest.raises(N.NativeError):
+        pol(x.cpu())
+
+
+@pytest.mark.gpu
+def test_c_abi_validation_of_mlp_descriptor():
+    import ctypes as C
+    lib = N.load()
+    w = torch.zeros(1, 4, 4, device="cuda")     # blocked transpose [ceil(in_dim / 4), out_dim, 4]
+    net = N.Mlp()
+    net.n_layers = 1
+    net.layer[0].w, net.layer[0].in_dim, net.layer[0].out_dim = w.data_ptr(), 4, 4
+    x = torch.zeros(2, 4, device="cuda")
+    y = torch.zeros(2, 4, device="cuda")
+    call = lambda: lib.pdegym_mlp_forward(C.byref(net), x.data_ptr(), 4, y.data_ptr(), 4, 2, None)
+    assert call() == 0
+    net.n_layers = 5
+    assert call() == -2
+    net.n_layers = 1
+    net.layer[0].out_dim = 257
+    assert call() == -2
+    net.layer[0].out_dim = 4
+    net.layer[0].act = 9
+    assert call() == -2
+    net.layer[0].act = 0
+    net.clamp, net.lo, net.hi = 1, 1.0, -1.0
+    assert call() == -2
+    net.clamp = 0
+    net.layer[0].w = None
+    assert call() == -3
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_device_rollout_with_fused_policy_equals_torch_policy():
+    """The rollout driven by FusedMLP (policy + clamp + store in one launch) follows the same trajectory as the torch module
+    within the float32 agreement of the two forward passes, in eager mode and replayed from a hipGraph."""
+    import pde_control_gym
+    from pde_control_gym import DeviceRollout, FusedMLP as Exported
+    from pde_control_gym.src import TunedReward1D
+    assert Exported is FusedMLP
+    B, T, nx = 64, 6, 64
+    dx = 1.0 / nx
+    dt = 0.25 * dx * dx
+    beta = np.full(nx + 1, 3.0, np.float32)
+    p = {"T": 40 * 5 * dt, "dt": dt, "X": 1, "dx": dx, "reward_class": TunedReward1D(40 * 5, -1e3, 3e2), "normalize": True,
+         "sensing_loc": "full", "control_type": "Dirchilet", "sensing_type": None, "sensing_noise_func": None,
+         "limit_pde_state_size": True, "max_state_value": 1e10, "max_control_value": 5, "control_sample_rate": 5 * dt,
+         "batched_reset_func": lambda idx, nx_: (np.random.default_rng(3).uniform(1, 2, (len(idx), 1)).astype(np.float32)
+                                                 * np.ones((1, nx_ + 1), np.float32), np.tile(beta, (len(idx), 1)))}
+    net = _mlp([nx + 1, 64, 64, 1], ["tanh", "tanh", "tanh"], seed=5).cuda()
+    runs = {}
+    for name, pol, graph in (("torch", net, False), ("fused", FusedMLP(net), False), ("fused_graph", FusedMLP(net), True)):
+        venv = pde_control_gym.make_vec("PDEControlGym-ReactionDiffusionPDE1D", num_envs=B, **p)
+        venv.reset_tensor()
+        venv.enable_fused_auto_reset()
+        ro = DeviceRollout(venv, pol, T, use_graph=graph).run()
+        torch.cuda.synchronize()
+        runs[name] = (ro.actions.cpu().numpy().copy(), ro.obs.cpu().numpy().copy(), ro.rewards.cpu().numpy().copy())
+    for name in ("fused", "fused_graph"):
+        for got, want in zip(runs[name], runs["torch"]):
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+    for got, want in zip(runs["fused_graph"], runs["fused"]):
+        np.testing.assert_array_equal(got, want)
