@@ -41,6 +41,10 @@ print(f"PDEVecEnv: obs {tuple(obs_t.shape)} on {obs_t.device}, mean reward {rew_
 policy = torch.nn.Sequential(torch.nn.Linear(100, 64), torch.nn.Tanh(), torch.nn.Linear(64, 1), torch.nn.Tanh()).cuda()
 rollout = pde_control_gym.DeviceRollout(venv, policy, n_steps=8).run()
 print(f"DeviceRollout: buffers obs {tuple(rollout.obs.shape)}, rewards {tuple(rollout.rewards.shape)}")
+# the same network as ONE launch per step (forward pass + action clamp + store), reading the module's own parameters
+fused = pde_control_gym.FusedMLP(policy)
+rollout = pde_control_gym.DeviceRollout(venv, fused, n_steps=8).run()
+print(f"DeviceRollout + FusedMLP: actions in [{rollout.actions.min().item():.3f}, {rollout.actions.max().item():.3f}]")
 
 # ---- 4. Navier-Stokes, the parameter dictionary of examples/NavierStokes/NS2Dppo.py:36-50 ---------------------------------
 bc = {"upper": ["Controllable", "Dirchilet"], "lower": ["Dirchilet", "Dirchilet"], "left": ["Dirchilet", "Dirchilet"],
