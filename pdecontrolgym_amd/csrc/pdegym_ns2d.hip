@@ -2054,6 +2054,239 @@ __global__ __launch_bounds__(1024) void ns256_back_pred(NSConst C, NSScal<float>
   if (threadIdx.x == 0) sc[2 * ncell + rb] = ss;   // partial sum of this 16-row band (rq is dead by now)
 }
 
+// ================================================================================================
+// Small grids (the reference's shipped example: 21 x 21, K = 2000 sweeps, float64 -- examples/NavierStokes/NS2Dppo.py):
+// one LANE per grid column, the column's ny cells in registers, floor(64 / nx) instances side by side in one wave.
+// East / West neighbours are the adjacent lanes (DPP wave shifts), North / South neighbours are registers of the same
+// lane: no LDS, no barriers -- a sweep is ~16 instructions per row for up to three instances, against one workgroup barrier
+// per sweep and instance in ns_generic_step (whose 2000 barriers are what its 0.7 ms per env-step consist of).
+// Lanes of neighbouring instances never feed each other: only interior columns 1 .. nx-2 are updated by stencils, and their
+// neighbours are columns 0 .. nx-1 of the same instance.  Pressure walls: the reference's four Neumann copies make every
+// wall cell equal its nearest interior cell after each sweep, so from the second sweep on a stencil next to a wall reads
+// the cell's own old value instead of the wall (first sweep: the walls as given); the walls are written out once at the end.
+// Same expression trees as ns_generic_step<T> (IEEE division for double) -> bit-identical fields (tested against the goldens
+// of the reference and the generic kernel); the reward is summed per column then over the instance's lanes in order.
+// ================================================================================================
+__device__ __forceinline__ float lane_from_left(float v) { return lane_left(v); }
+__device__ __forceinline__ float lane_from_right(float v) { return lane_right(v); }
+__device__ __forceinline__ double lane_from_left(double v) { return dpp_shr_f64(v); }
+__device__ __forceinline__ double lane_from_right(double v) { return dpp_shl_f64(v); }
+// A lane shift must execute with every lane of the wave active: when its only use is a per-lane select (edge lanes keep
+// their value, the lanes next to a wall substitute their own), the compiler may fold the shift into the selecting lanes'
+// branch, and a DPP read from a lane that is masked off returns 0.  The empty asm pins the shift where it is written.
+template <typename T>
+__device__ __forceinline__ T pinned_from_left(T v) {
+  T r = lane_from_left(v);
+  asm volatile("" : "+v"(r));
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ T pinned_from_right(T v) {
+  T r = lane_from_right(v);
+  asm volatile("" : "+v"(r));
+  return r;
+}
+
+template <typename T, int NY>     // NY = C.ny exactly: every row index below is a compile-time constant
+__global__ __launch_bounds__(64, (sizeof(T) == 8 ? 2 : 3)) void ns_col_step(NSConst C, NSScal<T> S, NSPtrs<T> P, int B) {
+  __shared__ T red[64];
+  static_assert(NY >= 3, "a grid has at least one interior row");
+  const int nx = C.nx, ncell = nx * NY;
+  const int lane = threadIdx.x;
+  const int G = 64 / nx;
+  const int g = lane / nx;
+  const int live_g = g < G ? g : G - 1;
+  const int j = g < G ? lane - g * nx : nx - 1;                 // idle lanes shadow a valid cell and never store
+  const int b_raw = blockIdx.x * G + live_g;
+  const bool live = g < G && b_raw < B;
+  const int b = b_raw < B ? b_raw : B - 1;
+  const bool lef = j == 0, rig = j == nx - 1, icol = !lef && !rig;
+  const T* act = P.action + (size_t)b * C.action_dim;
+  const T* sin = P.state_in ? P.state_in + (size_t)b * ncell * 2 : nullptr;
+  T* ug = P.u ? P.u + (size_t)b * ncell : nullptr;
+  T* vg = P.v ? P.v + (size_t)b * ncell : nullptr;
+  T* us = P.scratch + (size_t)b * 4 * ncell;
+  T* vs = us + ncell;
+  auto aval = [&](int idx) -> T { return C.action_dim == 1 ? act[0] : act[idx]; };
+
+  // apply_boundary (navier_stokes2D.py:76-90) on a column-per-lane field: lower / upper rule on every lane's end cells, then
+  // the left / right rule on the edge lanes, which for a Neumann edge copies the (already ruled) neighbouring column
+  auto apply_bc = [&](T (&f)[NY], int comp) {
+    const int cl = C.bc[PDEGYM_EDGE_LOWER][comp], cu = C.bc[PDEGYM_EDGE_UPPER][comp];
+    f[0] = (cl == PDEGYM_BC_NEUMANN) ? f[1] : ((cl == PDEGYM_BC_DIRICHLET) ? (T)0 : aval(j));
+    f[NY - 1] = (cu == PDEGYM_BC_NEUMANN) ? f[NY - 2] : ((cu == PDEGYM_BC_DIRICHLET) ? (T)0 : aval(j));
+    const int cL = C.bc[PDEGYM_EDGE_LEFT][comp], cR = C.bc[PDEGYM_EDGE_RIGHT][comp];
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const T from_r = pinned_from_right(f[i]), from_l = pinned_from_left(f[i]);
+      const T vl = (cL == PDEGYM_BC_NEUMANN) ? from_r : ((cL == PDEGYM_BC_DIRICHLET) ? (T)0 : aval(i));
+      const T vr = (cR == PDEGYM_BC_NEUMANN) ? from_l : ((cR == PDEGYM_BC_DIRICHLET) ? (T)0 : aval(i));
+      f[i] = lef ? vl : (rig ? vr : f[i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  T u[NY], v[NY];
+#pragma unroll
+  for (int i = 0; i < NY; ++i) {
+    const int c = i * nx + j;
+    if (sin) { u[i] = sin[2 * c]; v[i] = sin[2 * c + 1]; }
+    else { u[i] = ug[c]; v[i] = vg[c]; }
+  }
+  // ---- predictor (navier_stokes2D.py:130-138), in place with the old row below carried along ----
+  {
+    T pu = u[0], pv = v[0];
+#pragma unroll
+    for (int i = 1; i < NY - 1; ++i) {
+      const T uc = u[i], vc = v[i];
+      const T uw = pinned_from_left(uc), ue = pinned_from_right(uc), vw = pinned_from_left(vc), ve = pinned_from_right(vc);
+      const T usn = pu, vsn = pv, unn = u[i + 1], vnn = v[i + 1];
+      const T dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx), dudy = div_c(unn - usn, S.two_dy, S.inv_two_dy);
+      const T dvdx = div_c(ve - vw, S.two_dx, S.inv_two_dx), dvdy = div_c(vnn - vsn, S.two_dy, S.inv_two_dy);
+      const T lapu = div_c((((uw + usn) - (T)4 * uc) + ue) + unn, S.dxdy, S.inv_dxdy);
+      const T lapv = div_c((((vw + vsn) - (T)4 * vc) + ve) + vnn, S.dxdy, S.inv_dxdy);
+      const T un = uc + S.dt * (((-uc) * dudx - vc * dudy) + S.nu * lapu);
+      const T vn = vc + S.dt * (((-uc) * dvdx - vc * dvdy) + S.nu * lapv);
+      u[i] = icol ? un : uc;
+      v[i] = icol ? vn : vc;
+      pu = uc;
+      pv = vc;
+      __builtin_amdgcn_sched_barrier(0);      // one row at a time: interleaved rows multiply the live temporaries
+    }
+  }
+  apply_bc(u, 0);
+  apply_bc(v, 1);
+  // ---- rhs (:101-103) times dx dy (:108); u*, v* wait in the caller's scratch during the sweeps ----
+  T rq[NY];
+#pragma unroll
+  for (int i = 0; i < NY; ++i) {
+    rq[i] = (T)0;
+    if (live) { us[i * nx + j] = u[i]; vs[i * nx + j] = v[i]; }
+    if (i >= 1 && i < NY - 1) {
+      const T ue = pinned_from_right(u[i]), uw = pinned_from_left(u[i]);
+      const T dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx);
+      const T dvdy = div_c(v[i + 1] - v[i - 1], S.two_dy, S.inv_two_dy);
+      const T r = S.rho_over_dt * (dudx + dvdy);
+      if constexpr (sizeof(T) == 4) rq[i] = icol ? jacobi_rhs_term(S.dxdy, r) : 0.f;
+      else rq[i] = icol ? S.dxdy * r : (T)0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- K Jacobi sweeps (:104-114) ----
+  T p[NY];
+  {
+    const T* pg = P.p + (size_t)b * ncell;
+#pragma unroll
+    for (int i = 0; i < NY; ++i) p[i] = pg[i * nx + j];
+  }
+  // FIRST: the walls as given (edge lanes and rows 0, NY-1 hold them); afterwards a stencil next to a wall reads the cell's
+  // own old value (= what the Neumann copies of the previous sweep left in the wall).  Edge lanes run the same arithmetic on
+  // whatever their neighbours hold: nothing reads them until the walls are written out after the last sweep.
+  const bool next_to_left = j == 1, next_to_right = j == nx - 2;
+  auto sweep = [&](auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    T below = p[0];                      // old value of the row below
+#pragma unroll
+    for (int i = 1; i < NY - 1; ++i) {
+      const T cur = p[i];
+      const T wl = pinned_from_left(cur), er = pinned_from_right(cur);
+      const T w = (!FIRST && next_to_left) ? cur : wl;
+      const T e = (!FIRST && next_to_right) ? cur : er;
+      const T sv = (!FIRST && i == 1) ? cur : below;
+      const T nv = (!FIRST && i == NY - 2) ? cur : p[i + 1];
+      const T s4 = ((w + sv) + e) + nv;
+      T val;
+      if constexpr (sizeof(T) == 4) val = jacobi_update(s4, rq[i]);
+      else val = (T)0.25 * (s4 - rq[i]);
+      p[i] = FIRST ? (icol ? val : cur) : val;
+      below = cur;
+    }
+  };
+  if (C.iters > 0) {
+    sweep(std::true_type{});
+    for (int it = 1; it < C.iters; ++it) sweep(std::false_type{});
+    // the four Neumann copies of the last sweep (:110-113): every wall cell = its nearest interior cell
+    p[0] = p[1];
+    p[NY - 1] = p[NY - 2];
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const T from_r = pinned_from_right(p[i]), from_l = pinned_from_left(p[i]);
+      p[i] = lef ? from_r : (rig ? from_l : p[i]);
+    }
+  }
+  {
+    T* pd = (P.p_out ? P.p_out : P.p) + (size_t)b * ncell;
+#pragma unroll
+    for (int i = 0; i < NY; ++i)
+      if (live) pd[i * nx + j] = p[i];
+  }
+  // ---- corrector (:143-146), observation, reward ----
+#pragma unroll
+  for (int i = 0; i < NY; ++i) {
+    u[i] = us[i * nx + j];      // written by this same lane above (idle lanes: never written, never used)
+    v[i] = vs[i * nx + j];
+  }
+#pragma unroll
+  for (int i = 1; i < NY - 1; ++i) {
+    const T pe = pinned_from_right(p[i]), pw = pinned_from_left(p[i]);
+    const T dpdx = div_c(pe - pw, S.two_dx, S.inv_two_dx);
+    const T dpdy = div_c(p[i + 1] - p[i - 1], S.two_dy, S.inv_two_dy);
+    u[i] = icol ? u[i] - S.dt_over_rho * dpdx : u[i];
+    v[i] = icol ? v[i] - S.dt_over_rho * dpdy : v[i];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  apply_bc(u, 0);
+  apply_bc(v, 1);
+  const int t = P.time_index[b] + 1;
+  const int tr = t < C.nt_ref ? t : C.nt_ref - 1;
+  const T* uref = P.U_ref + (size_t)tr * ncell * 2;
+  T* obs = P.obs + (size_t)b * ncell * 2;
+  T acc = 0;
+#pragma unroll
+  for (int i = 0; i < NY; ++i) {
+    const int c = i * nx + j;
+    if (live) {
+      if (ug) { ug[c] = u[i]; vg[c] = v[i]; }
+      obs[2 * c] = u[i];
+      obs[2 * c + 1] = v[i];
+    }
+    const T du = u[i] - uref[2 * c], dv = v[i] - uref[2 * c + 1];
+    acc += du * du;
+    acc += dv * dv;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  red[lane] = acc;
+  __syncthreads();
+  if (live && j == 0) {
+    T ss = 0;
+    for (int k = 0; k < nx; ++k) ss += red[lane + k];
+    T asq = 0;
+    const T aref = P.action_ref[tr];
+    for (int k = 0; k < C.action_dim; ++k) {
+      const T d = act[k] - aref;
+      asq += d * d;
+    }
+    P.reward[b] = (((T)-0.5 * ss) / (T)nx) / (T)NY - S.gamma_half * asq;
+    P.time_index[b] = t;
+    P.terminated[b] = (t >= C.nt - 1) ? 1 : 0;
+  }
+}
+
+// The column kernel is instantiated for the grid height of the reference's shipped example (21 rows; any width up to 64).
+// One wave works through all K sweeps of its (up to three) instances alone: in float64 a lone instance finishes sooner on
+// the workgroup-per-instance kernel (seven waves per instance; 0.77 vs 0.98 ms per env-step at K = 2000), so batches below
+// PDEGYM_NS_COL_MIN_BATCH (default: 512 for float64, 1 for float32, where the two are equal at B = 1) stay there.
+template <typename T>
+bool launch_ns_col(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int B, hipStream_t st) {
+  if (C.nx < 3 || C.nx > 64 || C.ny != 21) return false;
+  const char* e = std::getenv("PDEGYM_NS_COL_MIN_BATCH");
+  const int min_batch = e ? std::atoi(e) : (sizeof(T) == 8 ? 512 : 1);
+  if (B < min_batch) return false;
+  const int G = 64 / C.nx;
+  hipLaunchKernelGGL((ns_col_step<T, 21>), dim3((B + G - 1) / G), dim3(64), 0, st, C, S, P, B);
+  return true;
+}
+
 template <typename T, int LDSJ>
 __global__ __launch_bounds__(1024) void ns_generic_pressure(NSConst C, NSScal<T> S, const T* ug, const T* vg, const T* p_in,
                                                              T* p_out, T* scratch, int B) {
@@ -2180,6 +2413,10 @@ int fill(const pdegym_params_ns2d* prm, NSConst& C, NSScal<T>& S) {
 }
 
 // PDEGYM_NS_GENERIC=1 in the environment routes float32 steps through ns_generic (A/B testing of the tiled path)
+inline bool pdegym_ns_no_col() {          // PDEGYM_NS_NO_COL=1: small grids take ns_generic_step (A/B and tests)
+  const char* e = std::getenv("PDEGYM_NS_NO_COL");
+  return e && e[0] == '1';
+}
 inline bool pdegym_force_generic() {
   const char* e = getenv("PDEGYM_NS_GENERIC");
   return e && e[0] == '1';
@@ -2270,6 +2507,9 @@ int ns_step_launch(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, i
               (const T*)buf->U_ref, (const T*)buf->action_ref, (T*)buf->obs, (T*)buf->reward, buf->terminated,
               (const T*)buf->state_in, (T*)buf->p_out};
   if (buf->p_out && buf->p_out == buf->p) return pdegym::fail(-3, "p_out must not alias p");
+  // small grids: one lane per column, up to three instances per wave, no barriers (ns_col_step)
+  if (!pdegym_force_generic() && !pdegym_ns_no_col() && launch_ns_col<T>(C, S, P, B, (hipStream_t)stream))
+    return pdegym::check_launch("ns2d_col_step");
   if constexpr (sizeof(T) == 4) {
     // register-tiled float32 path for the square grids it is instantiated for (BASELINE config 4 is 128x128)
     if (!pdegym_force_generic() && C.nx == C.ny && (C.nx == 128 || C.nx == 64)) {

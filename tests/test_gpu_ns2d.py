@@ -444,3 +444,92 @@ def test_ns_c5_grid_256_parity():
     obs, r, te = env32.step(a32)
     np.testing.assert_allclose(obs.cpu().numpy().astype(np.float64), o_ref, rtol=1e-5, atol=2e-6 * np.abs(o_ref).max())
     np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-4)
+
+
+def _rect_case(ny, nx, B, K, seed, bc, action_dim=1):
+    rng = np.random.default_rng(seed)
+    dx, dy = 1.0 / (nx - 1), 1.0 / (ny - 1)
+    dt = 0.2 * 0.5 * min(dx, dy) ** 2 / 0.1
+    nt = 8
+    Xg, Yg = np.meshgrid(np.linspace(0, 1, nx), np.linspace(0, 1, ny))
+    u0 = np.stack([np.sin(2 * np.pi * Xg * rng.uniform(0.5, 2)) * np.cos(np.pi * Yg) + rng.uniform(-1, 1) for _ in range(B)])
+    v0 = np.stack([np.cos(np.pi * Xg) * np.sin(2 * np.pi * Yg * rng.uniform(0.5, 2)) + rng.uniform(-1, 1) for _ in range(B)])
+    p0 = rng.uniform(-1, 1, (B, ny, nx))
+    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dy, boundary_condition=bc, U_ref=rng.uniform(-1, 1, (nt, ny, nx, 2)),
+              action_ref=rng.uniform(1, 3, nt), gamma=0.1, maximum_pressure_iteration=K, action_dim=action_dim)
+    acts = rng.uniform(2, 4, (3, B, action_dim))
+    return kw, u0, v0, p0, acts
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("nx,B,K,interleaved,per_node", [(21, 1, 7, True, False), (21, 7, 2, True, True), (21, 64, 33, False, False),
+                                                         (21, 4, 1, False, True), (3, 5, 4, True, False), (10, 13, 1, True, False),
+                                                         (22, 3, 0, True, False), (32, 5, 9, False, False), (33, 2, 5, True, False),
+                                                         (64, 3, 6, True, False)])     # per-node actions need a square grid
+def test_ns_column_kernel_equals_workgroup_kernel_bitwise(dtype, nx, B, K, interleaved, per_node):
+    """ns_col_step (21 rows, one lane per column, floor(64 / nx) instances per wave, no barriers) against ns_generic_step:
+    identical velocity, pressure, flags; rewards to the rounding of a different summation order.  Ragged batches (idle lane
+    groups), the first / later sweep forms (K = 0, 1, 2, more), mixed boundary conditions with scalar and per-node actions."""
+    import os
+    from pdecontrolgym_amd.batch2d import NSBatch2D
+    td = getattr(torch, dtype)
+    adim = 21 if per_node else 1
+    kw, u0, v0, p0, acts = _rect_case(21, nx, B, K, 900 + nx + K, BC_MIX, adim)
+    outs = []
+    for col in (True, False):
+        os.environ["PDEGYM_NS_COL_MIN_BATCH"] = "0"
+        os.environ["PDEGYM_NS_NO_COL"] = "0" if col else "1"
+        try:
+            env = NSBatch2D(num_envs=B, device="cuda", dtype=td, interleaved_state=interleaved, **kw)
+            env.reset(u0, v0, p0)
+            res = []
+            for a in acts:
+                obs, r, te = env.step(a)
+                res.append((obs.cpu().numpy().copy(), env.p.cpu().numpy().copy(), env.u.cpu().numpy().copy(),
+                            env.time_index.cpu().numpy().copy(), te.cpu().numpy().copy(), r.cpu().numpy().copy()))
+            outs.append(res)
+        finally:
+            os.environ.pop("PDEGYM_NS_COL_MIN_BATCH", None)
+            os.environ["PDEGYM_NS_NO_COL"] = "0"
+    for a, b in zip(*outs):
+        for x, y in zip(a[:-1], b[:-1]):
+            np.testing.assert_array_equal(x, y)
+        np.testing.assert_allclose(a[-1], b[-1], rtol=1e-5 if dtype == "float32" else 1e-12)
+
+
+def test_ns_column_kernel_reproduces_target_npz_and_oracle(golden_ns):
+    """The reference's shipped example (21 x 21, K = 2000, float64) on the column kernel: the committed target.npz frames bit for
+    bit (B = 5: two waves, the second with one live lane group), and a random mixed-boundary case against the oracle."""
+    import os
+    from oracle import pde_oracle as po
+    os.environ["PDEGYM_NS_COL_MIN_BATCH"] = "0"
+    try:
+        g = golden_ns["N1"]
+        B = 5
+        kw = dict(T=0.2, dt=1e-3, X=1, dx=0.05, Y=1, dy=0.05, boundary_condition=NS_BC, U_ref=np.zeros((200, 21, 21, 2)),
+                  action_ref=2.0 * np.ones(1000), gamma=0.1)
+        env = _mk(kw, B, torch.float64)
+        env.reset(g.u0, g.v0, np.zeros((21, 21)))
+        keep = set(int(k) for k in g.keep)
+        for t in range(1, 200):
+            obs, r, te = env.step(np.full(B, g.actions[t - 1]))
+            if t in keep:
+                o = obs.cpu().numpy()
+                for b in (0, 2, B - 1):
+                    np.testing.assert_array_equal(o[b, :, :, 0], g[f"u{t}"], err_msg=f"u frame {t}")
+                    np.testing.assert_array_equal(o[b, :, :, 1], g[f"v{t}"], err_msg=f"v frame {t}")
+        assert te.cpu().numpy().all()
+        np.testing.assert_array_equal(env.p.cpu().numpy()[3], g.p_final)
+        kw, u0, v0, p0, acts = _random_case(21, 5, 7, 121, BC_MIX, 1)
+        orc = po.NavierStokesOracle(**kw)
+        env = _mk(kw, 5, torch.float64)
+        orc.reset(u0, v0, p0)
+        env.reset(u0, v0, p0)
+        for a in acts:
+            o_ref, r_ref, te_ref, _ = orc.step(a)
+            obs, r, te = env.step(a)
+            np.testing.assert_array_equal(obs.cpu().numpy(), o_ref)
+            np.testing.assert_array_equal(env.p.cpu().numpy(), orc.p)
+            np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-12)
+    finally:
+        os.environ.pop("PDEGYM_NS_COL_MIN_BATCH", None)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time the reference's shipped NavierStokes2D example configuration (NS2Dppo.py: 21x21, K=2000 Jacobi sweeps, float64)
-with the LDS-resident Jacobi and with the global-memory loop:  python tools/bench_ns_example.py"""
+with the column-per-lane kernel (ns_col_step) and with the workgroup-per-instance kernel:  python tools/bench_ns_example.py
+(PDEGYM_NS_COL_MIN_BATCH=0 in the environment forces the column kernel at every batch size)"""
 import os
 import sys
 import time
@@ -15,8 +16,8 @@ BC = {"upper": ["Controllable", "Dirchilet"], "lower": ["Dirchilet", "Dirchilet"
       "right": ["Dirchilet", "Dirchilet"]}
 
 
-def run(B, no_lds, steps=50, n=21, K=2000, dtype=torch.float64):
-    os.environ["PDEGYM_NS_NO_LDS_JACOBI"] = "1" if no_lds else "0"
+def run(B, no_col, steps=20, n=21, K=2000, dtype=torch.float64):
+    os.environ["PDEGYM_NS_NO_COL"] = "1" if no_col else "0"
     nt = 200
     env = NSBatch2D(T=0.2, dt=1e-3, X=1, dx=1 / (n - 1), Y=1, dy=1 / (n - 1), boundary_condition=BC, U_ref=np.zeros((nt, n, n, 2)),
                     action_ref=2 * np.ones(nt), gamma=0.1, maximum_pressure_iteration=K, num_envs=B, device="cuda", dtype=dtype)
@@ -35,6 +36,8 @@ def run(B, no_lds, steps=50, n=21, K=2000, dtype=torch.float64):
 
 
 if __name__ == "__main__":
-    for B in (1, 64, 1024, 8192):
-        a, b = run(B, False), run(B, True)
-        print(f"21x21 K=2000 f64 B={B}: LDS {a*1e3:.3f} ms/step ({B/a:.0f} env-steps/s) | global {b*1e3:.3f} ms/step ({B/b:.0f} env-steps/s)")
+    for dtype in (torch.float64, torch.float32):
+        for B in (1, 1024, 3072, 8192, 32768):
+            a, b = run(B, False, dtype=dtype), run(B, True, dtype=dtype)
+            print(f"21x21 K=2000 {str(dtype)[6:]} B={B}: column kernel (B >= PDEGYM_NS_COL_MIN_BATCH) {a*1e3:.3f} ms/step ({B/a:.0f} env-steps/s)"
+                  f" | workgroup kernel {b*1e3:.3f} ms/step ({B/b:.0f} env-steps/s)")
