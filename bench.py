@@ -334,11 +334,12 @@ class BrainTumor:
                 "substeps_per_env_step": 1, "reward": "BrainTumorReward", "parallelism": "independent instances, no collective"}
 
 
-from bench_ns2d import NavierStokesC4, NavierStokesC4B4096, NavierStokesC4F64, NavierStokesC5  # noqa: E402
+from bench_ns2d import NavierStokesC4, NavierStokesC4B4096, NavierStokesC4F64, NavierStokesC5, NavierStokesExample  # noqa: E402
 WORKLOADS["ns2d_c4"] = NavierStokesC4
 WORKLOADS["ns2d_c4_f64"] = NavierStokesC4F64
 WORKLOADS["ns2d_c4_b4096"] = NavierStokesC4B4096
 WORKLOADS["ns2d_c5"] = NavierStokesC5
+WORKLOADS["ns2d_example"] = NavierStokesExample
 WORKLOADS["traffic_arz"] = TrafficARZ
 WORKLOADS["brain_tumor"] = BrainTumor
 
@@ -543,7 +544,7 @@ def main():
                 continue
             try:
                 w2 = cls(device, 99)
-                n2 = max(40, args.steps // 2) if name not in ("ns2d_c4_b4096", "ns2d_c5") else 20
+                n2 = max(40, args.steps // 2) if name not in ("ns2d_c4_b4096", "ns2d_c5", "ns2d_example") else 20
                 r2 = run_workload(w2, n2, max(5, args.warmup // 2), 1, graph=use_graph, repeats=3)
                 rf = roofline_block(w2, name, r2["step_ms_events"], True)
                 also[name] = {"value": w2.units_per_step() * n2 / r2["seconds"], "unit": "env-steps/s", "ms_per_step": r2["seconds"] / n2 * 1e3,

@@ -78,3 +78,11 @@ class NavierStokesC4B4096(NavierStokesC4):
     """BASELINE.json's metric string names "NS2D 128x128, batch 4096": configs[3] at eight times its batch on one GPU."""
     name = "NavierStokes2D 128x128 K=50 B=4096 fp32 (BASELINE metric string)"
     B = 4096
+
+
+class NavierStokesExample(NavierStokesC4):
+    """The reference's own shipped NavierStokes2D configuration (examples/NavierStokes/NS2Dppo.py:36-50: 21 x 21 grid, 2000 Jacobi
+    sweeps per env-step, float64) at a batch that fills the chip: one lane per grid column, three instances per wave."""
+    name = "NavierStokes2D 21x21 K=2000 B=8192 fp64 (the reference's shipped example configuration)"
+    n, B, K = 21, 8192, 2000
+    dtype = "f64"
