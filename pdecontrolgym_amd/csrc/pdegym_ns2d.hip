@@ -2088,7 +2088,7 @@ __device__ __forceinline__ T pinned_from_right(T v) {
 }
 
 template <typename T, int NY>     // NY = C.ny exactly: every row index below is a compile-time constant
-__global__ __launch_bounds__(64, (sizeof(T) == 8 ? 2 : 3)) void ns_col_step(NSConst C, NSScal<T> S, NSPtrs<T> P, int B) {
+__global__ __launch_bounds__(64, (sizeof(T) == 8 || NY > 21 ? 2 : 3)) void ns_col_step(NSConst C, NSScal<T> S, NSPtrs<T> P, int B) {
   __shared__ T red[64];
   static_assert(NY >= 3, "a grid has at least one interior row");
   const int nx = C.nx, ncell = nx * NY;
@@ -2272,19 +2272,27 @@ __global__ __launch_bounds__(64, (sizeof(T) == 8 ? 2 : 3)) void ns_col_step(NSCo
   }
 }
 
-// The column kernel is instantiated for the grid height of the reference's shipped example (21 rows; any width up to 64).
-// One wave works through all K sweeps of its (up to three) instances alone: in float64 a lone instance finishes sooner on
-// the workgroup-per-instance kernel (seven waves per instance; 0.77 vs 0.98 ms per env-step at K = 2000), so batches below
-// PDEGYM_NS_COL_MIN_BATCH (default: 512 for float64, 1 for float32, where the two are equal at B = 1) stay there.
+// The column kernel is instantiated for the grid height of the reference's shipped example (21 rows) and a few neighbours
+// (11, 16, 26, 31); any width up to 64.  One wave works through all K sweeps of its (up to three) instances alone: in
+// float64 a lone instance finishes sooner on the workgroup-per-instance kernel (seven waves per instance; 0.77 vs 0.98 ms per
+// env-step at 21 x 21, K = 2000), so batches below PDEGYM_NS_COL_MIN_BATCH (default: 1024 for float64, 1 for float32, where
+// the two kernels are equal at B = 1) stay there.
 template <typename T>
 bool launch_ns_col(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int B, hipStream_t st) {
-  if (C.nx < 3 || C.nx > 64 || C.ny != 21) return false;
+  if (C.nx < 3 || C.nx > 64) return false;
   const char* e = std::getenv("PDEGYM_NS_COL_MIN_BATCH");
-  const int min_batch = e ? std::atoi(e) : (sizeof(T) == 8 ? 512 : 1);
+  const int min_batch = e ? std::atoi(e) : (sizeof(T) == 8 ? 1024 : 1);
   if (B < min_batch) return false;
   const int G = 64 / C.nx;
-  hipLaunchKernelGGL((ns_col_step<T, 21>), dim3((B + G - 1) / G), dim3(64), 0, st, C, S, P, B);
-  return true;
+  const dim3 grid((B + G - 1) / G), block(64);
+  switch (C.ny) {
+    case 11: hipLaunchKernelGGL((ns_col_step<T, 11>), grid, block, 0, st, C, S, P, B); return true;
+    case 16: hipLaunchKernelGGL((ns_col_step<T, 16>), grid, block, 0, st, C, S, P, B); return true;
+    case 21: hipLaunchKernelGGL((ns_col_step<T, 21>), grid, block, 0, st, C, S, P, B); return true;
+    case 26: hipLaunchKernelGGL((ns_col_step<T, 26>), grid, block, 0, st, C, S, P, B); return true;
+    case 31: hipLaunchKernelGGL((ns_col_step<T, 31>), grid, block, 0, st, C, S, P, B); return true;
+    default: return false;
+  }
 }
 
 template <typename T, int LDSJ>

@@ -497,6 +497,35 @@ def test_ns_column_kernel_equals_workgroup_kernel_bitwise(dtype, nx, B, K, inter
         np.testing.assert_allclose(a[-1], b[-1], rtol=1e-5 if dtype == "float32" else 1e-12)
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("ny,nx,B,K", [(11, 11, 7, 5), (16, 30, 5, 3), (26, 26, 4, 6), (31, 64, 2, 4), (31, 8, 9, 2)])
+def test_ns_column_kernel_other_heights_bitwise(dtype, ny, nx, B, K):
+    """The other instantiated grid heights (11, 16, 26, 31 rows) against the workgroup kernel."""
+    import os
+    from pdecontrolgym_amd.batch2d import NSBatch2D
+    td = getattr(torch, dtype)
+    kw, u0, v0, p0, acts = _rect_case(ny, nx, B, K, 700 + ny + nx, BC_MIX, 1)
+    outs = []
+    for col in (True, False):
+        os.environ["PDEGYM_NS_COL_MIN_BATCH"] = "0"
+        os.environ["PDEGYM_NS_NO_COL"] = "0" if col else "1"
+        try:
+            env = NSBatch2D(num_envs=B, device="cuda", dtype=td, **kw)
+            env.reset(u0, v0, p0)
+            res = []
+            for a in acts:
+                obs, r, te = env.step(a)
+                res.append((obs.cpu().numpy().copy(), env.p.cpu().numpy().copy(), r.cpu().numpy().copy()))
+            outs.append(res)
+        finally:
+            os.environ.pop("PDEGYM_NS_COL_MIN_BATCH", None)
+            os.environ["PDEGYM_NS_NO_COL"] = "0"
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        np.testing.assert_allclose(a[2], b[2], rtol=1e-5 if dtype == "float32" else 1e-12)
+
+
 def test_ns_column_kernel_reproduces_target_npz_and_oracle(golden_ns):
     """The reference's shipped example (21 x 21, K = 2000, float64) on the column kernel: the committed target.npz frames bit for
     bit (B = 5: two waves, the second with one live lane group), and a random mixed-boundary case against the oracle."""

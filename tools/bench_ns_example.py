@@ -36,6 +36,13 @@ def run(B, no_col, steps=20, n=21, K=2000, dtype=torch.float64):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:       # other grid sizes: python tools/bench_ns_example.py 11 16 26 31   (K = 200, B = 8192)
+        for n in map(int, sys.argv[1:]):
+            for dtype in (torch.float64, torch.float32):
+                for B in (512, 8192):
+                    a, b = run(B, False, n=n, K=200, dtype=dtype), run(B, True, n=n, K=200, dtype=dtype)
+                    print(f"{n}x{n} K=200 {str(dtype)[6:]} B={B}: column kernel {a*1e3:.3f} ms/step | workgroup kernel {b*1e3:.3f} ms/step")
+        sys.exit(0)
     for dtype in (torch.float64, torch.float32):
         for B in (1, 1024, 3072, 8192, 32768):
             a, b = run(B, False, dtype=dtype), run(B, True, dtype=dtype)
