@@ -354,11 +354,14 @@ typedef struct {
   int32_t n_layers;    /* 1 .. PDEGYM_MLP_MAX_LAYERS                                 */
   int32_t clamp;       /* nonzero: the last layer's output is clamped to [lo, hi]   */
   float lo, hi;
+  int32_t x_f64;       /* nonzero: x holds float64 rows (TrafficPDE1D, BrainTumor1D, float64 NavierStokes2D observations),
+                          rounded to float32 as they are read -- what SB3 does before it evaluates its policy           */
+  int32_t y_f64;       /* nonzero: y receives float64 (the float32 result widened: those environments' action dtype)   */
   pdegym_mlp_layer layer[PDEGYM_MLP_MAX_LAYERS];
 } pdegym_mlp;
 
-/* y[b, :] = net(x[b, :]) for b < B; x_stride / y_stride = floats between consecutive rows (>= the row lengths). */
-int pdegym_mlp_forward(const pdegym_mlp* net, const float* x, int64_t x_stride, float* y, int64_t y_stride, int32_t B,
+/* y[b, :] = net(x[b, :]) for b < B; x_stride / y_stride = ELEMENTS between consecutive rows (>= the row lengths). */
+int pdegym_mlp_forward(const pdegym_mlp* net, const void* x, int64_t x_stride, void* y, int64_t y_stride, int32_t B,
                        void* stream);
 
 #ifdef __cplusplus

@@ -61,7 +61,7 @@ class DeviceRollout:
     def _steps(self, core, torch):
         if self._ns:        # slot 0 of the rollout buffer is the input state of the first step (not the engine's own buffer,
             core.t["obs"] = self.obs[0]        # which a graph warm-up run leaves in its end state)
-        fused = hasattr(self.policy, "forward_into") and self.obs.dtype == torch.float32
+        fused = hasattr(self.policy, "forward_into") and self.obs.dtype in (torch.float32, torch.float64)
         for t in range(self.T):
             if fused:       # pdecontrolgym_amd.FusedMLP: forward pass + action clamp in one launch, written into slot t
                 self.policy.forward_into(self.obs[t], self.actions[t], clamp=(self.lo, self.hi))

@@ -211,11 +211,13 @@ class HipBackend:
     # ---- policy network ----------------------------------------------------------------------------
     @_on_device_of("x")
     def mlp_forward(self, net: N.Mlp, x, y, B: int):
-        """y[b] = net(x[b]) for b < B: x [B, in_dim], y [B, out_dim] float32 rows (row stride = stride(0))."""
+        """y[b] = net(x[b]) for b < B: x [B, in_dim], y [B, out_dim] rows (row stride = stride(0)); float32, or float64 with
+        net.x_f64 / net.y_f64 set (the caller sets them from the tensors' dtypes)."""
         import torch
-        for t_, name in ((x, "x"), (y, "y")):
-            if not t_.is_cuda or t_.dtype != torch.float32 or t_.dim() != 2 or t_.stride(1) != 1:
-                raise N.NativeError(f"mlp_forward: {name} must be a float32 HIP tensor [B, width] with unit inner stride")
+        for t_, name, f64 in ((x, "x", net.x_f64), (y, "y", net.y_f64)):
+            want = torch.float64 if f64 else torch.float32
+            if not t_.is_cuda or t_.dtype != want or t_.dim() != 2 or t_.stride(1) != 1:
+                raise N.NativeError(f"mlp_forward: {name} must be a {want} HIP tensor [B, width] with unit inner stride")
         N.check(self.lib.pdegym_mlp_forward(C.byref(net), x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), B,
                                             N.current_stream_ptr(x.device)), "pdegym_mlp_forward")
 

@@ -97,9 +97,9 @@ __device__ __forceinline__ void reduce_blocks(v4f (&acc)[NT], v4f (&wa)[kStage][
   }
 }
 
-template <int NT>   // NT = 16-neuron tiles per wave = ceil(width of the widest layer / 64)
-__global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const float* __restrict__ x, long long x_stride,
-                                                          float* __restrict__ y, long long y_stride, int B) {
+template <int NT, typename TX, typename TY>   // NT = 16-neuron tiles per wave = ceil(width of the widest layer / 64)
+__global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX* __restrict__ x, long long x_stride,
+                                                          TY* __restrict__ y, long long y_stride, int B) {
   // LDS: activations ping-pong between hb0 and hb1; the staged observation chunk shares its space with hb1 (first written
   // by the second layer, when the observations are no longer needed)
   __shared__ __attribute__((aligned(16))) float hb0[kRows * kLdh];
@@ -149,11 +149,11 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const fl
           for (int rr = 0; rr < 4; ++rr) {
             const int r = 4 * wave + rr;
             const bool row_ok = row0 + r < B;
-            const float* src = x + (long long)(row_ok ? row0 + r : 0) * x_stride + c0;
+            const TX* src = x + (long long)(row_ok ? row0 + r : 0) * x_stride + c0;
 #pragma unroll
             for (int i = 0; i < kXChunk / 64; ++i) {
               const int c = lane + 64 * i;
-              v[rr][i] = (row_ok && c < clen) ? src[c] : 0.f;
+              v[rr][i] = (row_ok && c < clen) ? (float)src[c] : 0.f;
             }
           }
           if (c0 > 0 && any_tile) load_w<NT>(wfirst, wq, H, ngroups, c0 / 16, lg, col);
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const fl
           float o = n < H ? activate(av[v] + bias, L.act) : 0.f;
           if (last) {
             if (N.clamp) o = fminf(fmaxf(o, N.lo), N.hi);
-            if (n < H && row0 + r < B) y[(long long)(row0 + r) * y_stride + n] = o;
+            if (n < H && row0 + r < B) y[(long long)(row0 + r) * y_stride + n] = (TY)o;
           } else {
             hout[r * kLdh + n] = o;
           }
@@ -209,7 +209,20 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const fl
 
 }  // namespace
 
-extern "C" int pdegym_mlp_forward(const pdegym_mlp* net, const float* x, int64_t x_stride, float* y, int64_t y_stride, int32_t B,
+template <typename TX, typename TY>
+static void launch_mlp(const pdegym_mlp* net, const void* x, long long xs, void* y, long long ys, int B, int width, hipStream_t st) {
+  const dim3 grid((B + kRows - 1) / kRows), block(256);
+  const TX* xp = static_cast<const TX*>(x);
+  TY* yp = static_cast<TY*>(y);
+  switch ((width + 63) / 64) {
+    case 1: hipLaunchKernelGGL((mlp_forward_kernel<1, TX, TY>), grid, block, 0, st, *net, xp, xs, yp, ys, B); break;
+    case 2: hipLaunchKernelGGL((mlp_forward_kernel<2, TX, TY>), grid, block, 0, st, *net, xp, xs, yp, ys, B); break;
+    case 3: hipLaunchKernelGGL((mlp_forward_kernel<3, TX, TY>), grid, block, 0, st, *net, xp, xs, yp, ys, B); break;
+    default: hipLaunchKernelGGL((mlp_forward_kernel<4, TX, TY>), grid, block, 0, st, *net, xp, xs, yp, ys, B); break;
+  }
+}
+
+extern "C" int pdegym_mlp_forward(const pdegym_mlp* net, const void* x, int64_t x_stride, void* y, int64_t y_stride, int32_t B,
                                   void* stream) {
   if (!net || !x || !y) return pdegym::fail(-3, "null pointer");
   if (B < 0) return pdegym::fail(-2, "B must be >= 0");
@@ -229,14 +242,11 @@ extern "C" int pdegym_mlp_forward(const pdegym_mlp* net, const float* x, int64_t
   if (B == 0) return 0;
   int width = 0;
   for (int l = 0; l < net->n_layers; ++l) width = net->layer[l].out_dim > width ? net->layer[l].out_dim : width;
-  const dim3 grid((B + kRows - 1) / kRows), block(256);
   hipStream_t st = (hipStream_t)stream;
   const long long xs = x_stride, ys = y_stride;
-  switch ((width + 63) / 64) {
-    case 1: hipLaunchKernelGGL(mlp_forward_kernel<1>, grid, block, 0, st, *net, x, xs, y, ys, B); break;
-    case 2: hipLaunchKernelGGL(mlp_forward_kernel<2>, grid, block, 0, st, *net, x, xs, y, ys, B); break;
-    case 3: hipLaunchKernelGGL(mlp_forward_kernel<3>, grid, block, 0, st, *net, x, xs, y, ys, B); break;
-    default: hipLaunchKernelGGL(mlp_forward_kernel<4>, grid, block, 0, st, *net, x, xs, y, ys, B); break;
-  }
+  if (net->x_f64 && net->y_f64) launch_mlp<double, double>(net, x, xs, y, ys, B, width, st);
+  else if (net->x_f64) launch_mlp<double, float>(net, x, xs, y, ys, B, width, st);
+  else if (net->y_f64) launch_mlp<float, double>(net, x, xs, y, ys, B, width, st);
+  else launch_mlp<float, float>(net, x, xs, y, ys, B, width, st);
   return pdegym::check_launch("mlp_forward");
 }

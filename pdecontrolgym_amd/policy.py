@@ -77,8 +77,9 @@ class FusedMLP:
                     self._seen[i] = w._version
         return self
 
-    def _net(self, clamp) -> N.Mlp:
+    def _net(self, clamp, x_f64=False, y_f64=False) -> N.Mlp:
         net = N.Mlp()
+        net.x_f64, net.y_f64 = int(x_f64), int(y_f64)
         net.n_layers = len(self.layers)
         net.clamp = 0 if clamp is None else 1
         net.lo, net.hi = (0.0, 0.0) if clamp is None else clamp
@@ -90,7 +91,9 @@ class FusedMLP:
 
     def forward_into(self, obs, out, clamp="default"):
         """out[b, :] = net(obs[b, :]); ``obs`` [B, in_dim] (any trailing shape that flattens to in_dim), ``out`` [B, out_dim]
-        or [B] when out_dim == 1; both float32 on the parameters' device.  Returns ``out``."""
+        or [B] when out_dim == 1, on the parameters' device.  float64 observations (traffic, tumour, float64 Navier-Stokes)
+        are rounded to float32 as they are read and a float64 ``out`` receives the widened float32 result -- the casts SB3
+        makes around its float32 policy.  Returns ``out``."""
         B = obs.shape[0]
         x = obs.reshape(B, -1)
         if x.shape[1] != self.in_dim:
@@ -101,10 +104,14 @@ class FusedMLP:
         import torch
         if not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
             self.refresh()
-        self.backend.mlp_forward(self._net(self.clamp if clamp == "default" else clamp), x, y, B)
+        for t_, name in ((x, "obs"), (y, "out")):
+            if t_.dtype not in (torch.float32, torch.float64):
+                raise N.NativeError(f"FusedMLP: {name} must be float32 or float64, got {t_.dtype}")
+        net = self._net(self.clamp if clamp == "default" else clamp, x.dtype == torch.float64, y.dtype == torch.float64)
+        self.backend.mlp_forward(net, x, y, B)
         return out
 
     def __call__(self, obs):
         import torch
-        out = torch.empty(obs.shape[0], self.out_dim, dtype=torch.float32, device=obs.device)
+        out = torch.empty(obs.shape[0], self.out_dim, dtype=obs.dtype, device=obs.device)
         return self.forward_into(obs, out)

@@ -265,7 +265,7 @@ class FakeBackend:
         import ctypes
         import numpy as np
         import torch
-        h = x[:B].detach().cpu().numpy().astype(np.float32)
+        h = x[:B].detach().cpu().numpy().astype(np.float32)       # float64 observations are rounded on the way in
         for i in range(net.n_layers):
             L = net.layer[i]
             k4 = (L.in_dim + 3) // 4
@@ -280,5 +280,5 @@ class FakeBackend:
             h = h.astype(np.float32)
         if net.clamp:
             h = np.clip(h, net.lo, net.hi)
-        y[:B].copy_(torch.from_numpy(h))
+        y[:B].copy_(torch.from_numpy(h).to(y.dtype))
 

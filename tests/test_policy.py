@@ -34,8 +34,8 @@ SHAPES = [
 
 def test_struct_layout_matches_header():
     import ctypes as C
-    assert C.sizeof(N.MlpLayer) == 32 and C.sizeof(N.Mlp) == 16 + 4 * 32
-    assert N.Mlp.layer.offset == 16 and N.MlpLayer.in_dim.offset == 16
+    assert C.sizeof(N.MlpLayer) == 32 and C.sizeof(N.Mlp) == 24 + 4 * 32
+    assert N.Mlp.layer.offset == 24 and N.Mlp.x_f64.offset == 16 and N.MlpLayer.in_dim.offset == 16
 
 
 def test_rejects_unsupported_modules():
@@ -110,9 +110,19 @@ def test_fused_mlp_sees_in_place_parameter_updates_and_rejects_bad_calls():
     assert not torch.allclose(a, b)
     np.testing.assert_allclose(b.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=4e-6)
     with pytest.raises(N.NativeError):
-        pol(x.double())
+        pol(x.half())
     with pytest.raises(N.NativeError):
         pol(x.cpu())
+    # float64 observations / actions (traffic, tumour, float64 Navier-Stokes): rounded on the way in, widened on the way out
+    xd = x.double() * (1 + 1e-12)
+    got = pol(xd)
+    assert got.dtype == torch.float64
+    with torch.no_grad():
+        want64 = net(xd.float()).double()
+    np.testing.assert_allclose(got.cpu().numpy(), want64.cpu().numpy(), rtol=2e-5, atol=4e-6)
+    out32 = torch.zeros(50, 1, device="cuda")
+    pol.forward_into(xd, out32)
+    np.testing.assert_array_equal(out32.cpu().numpy(), got.float().cpu().numpy())
 
 
 @pytest.mark.gpu

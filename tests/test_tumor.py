@@ -297,3 +297,33 @@ def test_tumor_device_rollout_graph_equals_eager():
         for x, y in zip(a, b):
             assert torch.equal(x, y)
     assert outs[0][2][3].any() or outs[0][2][4].any() or outs[0][1][3].any() or outs[0][1][4].any() or True
+
+
+@pytest.mark.gpu
+def test_tumor_device_rollout_with_fused_policy_on_float64_observations():
+    """FusedMLP on the tumour environment's float64 observations (rounded to float32 as they are read, the action widened
+    back): same rollout as the torch module wrapped in the casts SB3 makes, within the float32 agreement of the two forward
+    passes; the replayed graph equals the eager run bit for bit."""
+    import numpy as np
+    import pde_control_gym
+    from pde_control_gym import FusedMLP
+    from pde_control_gym.src import BrainTumorReward
+    kw = dict(T=600, reward_class=BrainTumorReward(), reset_init_condition_func=tumor_ic, **KW)
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Linear(201, 32), torch.nn.Tanh(), torch.nn.Linear(32, 1), torch.nn.Tanh()).cuda()
+    with torch.no_grad():
+        net[0].weight.mul_(1e-5)                    # cell densities are O(1e5)
+    runs = {}
+    for name, pol, graph in (("torch", lambda o: net(o.float()).double(), False), ("fused", FusedMLP(net), False),
+                             ("fused_graph", FusedMLP(net), True)):
+        venv = pde_control_gym.make_vec("PDEControlGym-BrainTumor1D", num_envs=64, weekends=True, **kw)
+        venv.benchmark()
+        venv.reset_tensor()
+        ro = pde_control_gym.DeviceRollout(venv, pol, n_steps=6, use_graph=graph, action_low=0.0, action_high=1.0).run()
+        torch.cuda.synchronize()
+        runs[name] = [x.cpu().numpy().copy() for x in (ro.actions, ro.obs, ro.rewards)]
+    assert runs["fused"][0].dtype == np.float64
+    for got, want in zip(runs["fused"], runs["torch"]):
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)
+    for got, want in zip(runs["fused_graph"], runs["fused"]):
+        np.testing.assert_array_equal(got, want)
