@@ -29,7 +29,7 @@ def ns_case(rng, idx):
     adim = int(rng.choice([1, 1, n]))
     bc = {e: [str(rng.choice(BCS)), str(rng.choice(BCS))] for e in ("upper", "lower", "left", "right")}
     # non-square grids and cells: nx = round(X/dx + 1) columns, ny = round(Y/dy + 1) rows (base_env_2d.py:27-36)
-    m = n if rng.random() < 0.5 else int(rng.choice([3, 4, 5, 9, 16, 21, 33, 64, 65]))
+    m = n if rng.random() < 0.5 else int(rng.choice([3, 4, 5, 9, 11, 16, 21, 21, 26, 31, 33, 64, 65]))
     dx = 1.0 / (n - 1)
     dy = (1.0 if rng.random() < 0.6 else 0.5) / (m - 1)
     Yl = dy * (m - 1)
@@ -53,6 +53,11 @@ def ns_case(rng, idx):
               action_ref=rng.uniform(1, 3, nt), gamma=float(rng.choice([0.1, 0.0, 2.0])), maximum_pressure_iteration=K, viscosity=nu,
               density=float(rng.choice([1.0, 2.0])))
     desc = f"#{idx} ns nx={n} ny={m} K={K} B={B} adim={adim} nt={nt} inter={inter} ic={style} bc={bc}"
+    # grids of 11 / 16 / 21 / 26 / 31 rows and up to 64 columns: half of the cases on the column-per-lane kernel (which float64
+    # batches this small would not reach by themselves), half on the workgroup kernel -- the switch is read at every launch
+    col = rng.random() < 0.5
+    os.environ["PDEGYM_NS_COL_MIN_BATCH"] = "0" if col else "1000000"
+    desc += f" col={col}"
     orc = po.NavierStokesOracle(**kw)
     env = NSBatch2D(num_envs=B, device="cuda", dtype=torch.float64, interleaved_state=inter, action_dim=adim, **kw)
     orc.reset(u0, v0, p0)
@@ -65,6 +70,7 @@ def ns_case(rng, idx):
         assert bits_equal(env.p.cpu().numpy(), orc.p), desc + f" step {i}: p"
         assert np.allclose(r.cpu().numpy(), r_ref, rtol=1e-12, atol=1e-300), desc + f" step {i}: reward {r.cpu().numpy()} {r_ref}"
         assert np.array_equal(te.cpu().numpy().astype(bool), te_ref), desc + f" step {i}: terminate"
+    os.environ.pop("PDEGYM_NS_COL_MIN_BATCH", None)
     # float32: tiled kernel == generic kernel for the sizes the tiled path exists for
     if n == m and n in (64, 128):
         outs = []
