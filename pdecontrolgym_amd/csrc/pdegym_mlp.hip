@@ -134,8 +134,12 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX
     int col[NT];
     tile_cols(H, col);
     v4f acc[NT];
+    float bias[NT];       // requested before the reduction: its latency hides behind the MFMAs instead of delaying the epilogue
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) {
+      acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+      bias[t] = (L.b && 16 * (wave + 4 * t) + li < H) ? L.b[col[t]] : 0.f;
+    }
     const bool any_tile = 16 * wave < H;      // this wave has at least one tile of the layer
     if (l == 0) {
       for (int c0 = 0; c0 < K; c0 += kXChunk) {
@@ -188,12 +192,11 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX
     for (int t = 0; t < NT; ++t) {
       const int n = 16 * (wave + 4 * t) + li;
       if (n < Hpad) {
-        const float bias = (L.b && n < H) ? L.b[n] : 0.f;
         const float av[4] = {acc[t].x, acc[t].y, acc[t].z, acc[t].w};
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int r = 4 * lg + v;
-          float o = n < H ? activate(av[v] + bias, L.act) : 0.f;
+          float o = n < H ? activate(av[v] + bias[t], L.act) : 0.f;
           if (last) {
             if (N.clamp) o = fminf(fmaxf(o, N.lo), N.hi);
             if (n < H && row0 + r < B) y[(long long)(row0 + r) * y_stride + n] = (TY)o;
