@@ -133,6 +133,36 @@ class Parabolic1D:
                 "reward": "TunedReward1D", "auto_reset": "fused", "parallelism": "independent instances, no collective"}
 
 
+class ParabolicPolicyLoop(Parabolic1D):
+    """SURVEY section 8f rank 1: the C2 environment with its controller in the loop -- an SB3-style MlpPolicy (257-64-64-1, tanh;
+    transport1Dppo.py:88-90) evaluated on the observation of the previous step by pdegym_mlp_forward (one launch: forward pass,
+    action clamp, store), then the env-step with fused auto-reset: two launches per env-step, nothing on the host."""
+    name = "ReactionDiffusionPDE1D nx=256 B=4096 S=100 with a 257-64-64-1 tanh MLP policy in the loop (FusedMLP + env-step)"
+
+    def prepare(self, total_steps):
+        import torch
+        from pdecontrolgym_amd.policy import FusedMLP
+        super().prepare(total_steps)
+        torch.manual_seed(0)
+        n = self.env.n
+        net = torch.nn.Sequential(torch.nn.Linear(n, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(),
+                                  torch.nn.Linear(64, 1), torch.nn.Tanh()).to(self.device)
+        self.policy = FusedMLP(net, clamp=(-1.0, 1.0))
+        self.act = torch.zeros(self.B, dtype=torch.float32, device=self.device)
+        self.obs = self.env.t["obs"]
+
+    def step(self):
+        self.policy.forward_into(self.obs, self.act)
+        out = self.env.step(self.act)
+        self.obs = out[0]
+        return out
+
+    def config(self):
+        c = super().config()
+        c["policy"] = "MLP 257-64-64-1 tanh, float32, pdegym_mlp_forward (MFMA), clamp to [-1, 1] fused"
+        return c
+
+
 class Transport1D(Parabolic1D):
     """BASELINE config 3 shape: TransportPDE1D nx=512, dt=0.5dx, S=100, B=16384/GPU (the reference has no
     Burgers env)."""
@@ -335,6 +365,7 @@ class BrainTumor:
 
 
 from bench_ns2d import NavierStokesC4, NavierStokesC4B4096, NavierStokesC4F64, NavierStokesC5, NavierStokesExample  # noqa: E402
+WORKLOADS["parabolic_c2_policy_loop"] = ParabolicPolicyLoop
 WORKLOADS["ns2d_c4"] = NavierStokesC4
 WORKLOADS["ns2d_c4_f64"] = NavierStokesC4F64
 WORKLOADS["ns2d_c4_b4096"] = NavierStokesC4B4096
