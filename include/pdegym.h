@@ -357,6 +357,9 @@ typedef struct {
   int32_t x_f64;       /* nonzero: x holds float64 rows (TrafficPDE1D, BrainTumor1D, float64 NavierStokes2D observations),
                           rounded to float32 as they are read -- what SB3 does before it evaluates its policy           */
   int32_t y_f64;       /* nonzero: y receives float64 (the float32 result widened: those environments' action dtype)   */
+  const float* noise;  /* [B, out_dim] float32 or NULL: added to the last layer's output before the clamp -- the exploration
+                          noise of a stochastic policy (SB3's Gaussian MlpPolicy samples mean + std * eps), drawn by the caller */
+  int64_t noise_stride; /* floats between consecutive rows of noise                                                     */
   pdegym_mlp_layer layer[PDEGYM_MLP_MAX_LAYERS];
 } pdegym_mlp;
 

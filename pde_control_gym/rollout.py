@@ -12,9 +12,11 @@ from __future__ import annotations
 class DeviceRollout:
     """``policy``: callable mapping an observation tensor [B, obs_dim] to actions [B] (or [B, 1]) on the same device -- any
     torch module, or a ``pdecontrolgym_amd.FusedMLP`` (Linear/Tanh/ReLU stack evaluated, clamped and stored in ONE launch).
-    Buffers: ``obs[T+1, B, D]``, ``actions[T, B]``, ``rewards[T, B]``, ``terminated[T, B]``, ``truncated[T, B]``."""
+    Buffers: ``obs[T+1, B, D]``, ``actions[T, B]``, ``rewards[T, B]``, ``terminated[T, B]``, ``truncated[T, B]``; with
+    ``action_noise=True`` also ``action_noise[T, B]`` (float32), added to the policy output of step t before the clamp."""
 
-    def __init__(self, venv, policy, n_steps: int, use_graph: bool = True, action_low: float = -1.0, action_high: float = 1.0):
+    def __init__(self, venv, policy, n_steps: int, use_graph: bool = True, action_low: float = -1.0, action_high: float = 1.0,
+                 action_noise: bool = False):
         import torch
         kind = getattr(venv, "kind", "tumor")
         self.venv, self.policy, self.T = venv, policy, int(n_steps)
@@ -34,6 +36,10 @@ class DeviceRollout:
         self.rewards = torch.zeros(self.T, B, dtype=dt, device=dev)
         self.terminated = torch.zeros(self.T, B, dtype=torch.uint8, device=dev)
         self.truncated = torch.zeros(self.T, B, dtype=torch.uint8, device=dev)
+        # exploration noise of a stochastic policy: slot t is added to the policy output of step t before the clamp.  The
+        # caller fills the buffer in place before each run() (e.g. ``ro.action_noise.normal_().mul_(std)``): a replayed graph
+        # reads the new draws.
+        self.action_noise = torch.zeros_like(self.actions, dtype=torch.float32) if action_noise else None
         self.use_graph = bool(use_graph) and dev.type == "cuda"
         self._graph = None
 
@@ -63,11 +69,15 @@ class DeviceRollout:
             core.t["obs"] = self.obs[0]        # which a graph warm-up run leaves in its end state)
         fused = hasattr(self.policy, "forward_into") and self.obs.dtype in (torch.float32, torch.float64)
         for t in range(self.T):
-            if fused:       # pdecontrolgym_amd.FusedMLP: forward pass + action clamp in one launch, written into slot t
-                self.policy.forward_into(self.obs[t], self.actions[t], clamp=(self.lo, self.hi))
+            nz = self.action_noise[t] if self.action_noise is not None else None
+            if fused:       # pdecontrolgym_amd.FusedMLP: forward pass (+ noise) + action clamp in one launch, written into slot t
+                self.policy.forward_into(self.obs[t], self.actions[t], clamp=(self.lo, self.hi), noise=nz)
             else:
                 with torch.no_grad():
-                    a = self.policy(self.obs[t]).reshape(self.actions[t].shape).clamp(self.lo, self.hi)
+                    a = self.policy(self.obs[t]).reshape(self.actions[t].shape)
+                    if nz is not None:
+                        a = a + nz.to(a.dtype)
+                    a = a.clamp(self.lo, self.hi)
                 self.actions[t].copy_(a)
             if self._ns:
                 # Navier-Stokes: the observation IS the state, so slot t of the rollout buffer is also the next step's input

@@ -108,7 +108,8 @@ class MlpLayer(C.Structure):
 
 class Mlp(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("clamp", C.c_int32), ("lo", C.c_float), ("hi", C.c_float),
-                ("x_f64", C.c_int32), ("y_f64", C.c_int32), ("layer", MlpLayer * MLP_MAX_LAYERS)]
+                ("x_f64", C.c_int32), ("y_f64", C.c_int32), ("noise", C.c_void_p), ("noise_stride", C.c_int64),
+                ("layer", MlpLayer * MLP_MAX_LAYERS)]
 
 
 class NativeError(RuntimeError):

@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX
           const int r = 4 * lg + v;
           float o = n < H ? activate(av[v] + bias[t], L.act) : 0.f;
           if (last) {
+            if (N.noise && n < H && row0 + r < B) o += N.noise[(long long)(row0 + r) * N.noise_stride + n];
             if (N.clamp) o = fminf(fmaxf(o, N.lo), N.hi);
             if (n < H && row0 + r < B) y[(long long)(row0 + r) * y_stride + n] = (TY)o;
           } else {
@@ -242,6 +243,7 @@ extern "C" int pdegym_mlp_forward(const pdegym_mlp* net, const void* x, int64_t 
   if (x_stride < net->layer[0].in_dim || y_stride < net->layer[net->n_layers - 1].out_dim)
     return pdegym::fail(-2, "row stride shorter than the row");
   if (net->clamp && !(net->lo <= net->hi)) return pdegym::fail(-2, "clamp bounds must satisfy lo <= hi");
+  if (net->noise && net->noise_stride < net->layer[net->n_layers - 1].out_dim) return pdegym::fail(-2, "noise row stride shorter than the row");
   if (B == 0) return 0;
   int width = 0;
   for (int l = 0; l < net->n_layers; ++l) width = net->layer[l].out_dim > width ? net->layer[l].out_dim : width;

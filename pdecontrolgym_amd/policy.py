@@ -89,11 +89,12 @@ class FusedMLP:
             L.in_dim, L.out_dim, L.act = int(w.shape[1]), int(w.shape[0]), act
         return net
 
-    def forward_into(self, obs, out, clamp="default"):
+    def forward_into(self, obs, out, clamp="default", noise=None):
         """out[b, :] = net(obs[b, :]); ``obs`` [B, in_dim] (any trailing shape that flattens to in_dim), ``out`` [B, out_dim]
         or [B] when out_dim == 1, on the parameters' device.  float64 observations (traffic, tumour, float64 Navier-Stokes)
         are rounded to float32 as they are read and a float64 ``out`` receives the widened float32 result -- the casts SB3
-        makes around its float32 policy.  Returns ``out``."""
+        makes around its float32 policy.  ``noise`` (float32, same shape as the action): added to the network output before
+        the clamp -- the caller's pre-scaled exploration noise of a Gaussian policy.  Returns ``out``."""
         B = obs.shape[0]
         x = obs.reshape(B, -1)
         if x.shape[1] != self.in_dim:
@@ -108,6 +109,11 @@ class FusedMLP:
             if t_.dtype not in (torch.float32, torch.float64):
                 raise N.NativeError(f"FusedMLP: {name} must be float32 or float64, got {t_.dtype}")
         net = self._net(self.clamp if clamp == "default" else clamp, x.dtype == torch.float64, y.dtype == torch.float64)
+        if noise is not None:       # exploration noise, added before the clamp (float32 [B, out_dim] or [B] when out_dim == 1)
+            nz = noise.reshape(B, self.out_dim)
+            if nz.dtype != torch.float32 or nz.device != x.device or nz.stride(1) != 1 or nz.data_ptr() != noise.data_ptr():
+                raise ValueError("noise must be a float32 tensor on the observations' device, viewable as [B, out_dim]")
+            net.noise, net.noise_stride = nz.data_ptr(), nz.stride(0)
         self.backend.mlp_forward(net, x, y, B)
         return out
 

@@ -278,6 +278,9 @@ class FakeBackend:
                 acc = acc + np.ctypeslib.as_array(ctypes.cast(L.b, ctypes.POINTER(ctypes.c_float)), (L.out_dim,))[None, :]
             h = np.tanh(acc) if L.act == 1 else (np.maximum(acc, 0) if L.act == 2 else acc)
             h = h.astype(np.float32)
+        if net.noise:
+            nz = np.ctypeslib.as_array(ctypes.cast(net.noise, ctypes.POINTER(ctypes.c_float)), (h.shape[0], int(net.noise_stride)))
+            h = h + nz[:, :h.shape[1]]
         if net.clamp:
             h = np.clip(h, net.lo, net.hi)
         y[:B].copy_(torch.from_numpy(h).to(y.dtype))

@@ -193,3 +193,20 @@ def test_quickstart_example_runs():
     r = subprocess.run([sys.executable, os.path.join(root, "examples", "quickstart.py")], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("quickstart ok"), r.stdout[-2000:]
+
+
+def test_ppo_example_trains_on_device():
+    """examples/train_ppo_device.py: PPO whose rollouts are one hipGraph replay each (FusedMLP actor with exploration noise +
+    env-step with fused auto-reset) and whose updates are ordinary torch autograd on the same module; a short run has to
+    improve the episode return of the unstable reaction-diffusion plant."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "train_ppo_device.py")
+    spec = importlib.util.spec_from_file_location("train_ppo_device", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hist = mod.main(iterations=14, B=1024, quiet=True)
+    first = hist[0]["episode_return"]
+    last = sum(h["episode_return"] for h in hist[-3:]) / 3
+    assert last > first + 15.0, (first, last)
+    assert hist[-1]["mean_norm"] < hist[0]["mean_norm"]

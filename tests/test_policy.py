@@ -34,8 +34,8 @@ SHAPES = [
 
 def test_struct_layout_matches_header():
     import ctypes as C
-    assert C.sizeof(N.MlpLayer) == 32 and C.sizeof(N.Mlp) == 24 + 4 * 32
-    assert N.Mlp.layer.offset == 24 and N.Mlp.x_f64.offset == 16 and N.MlpLayer.in_dim.offset == 16
+    assert C.sizeof(N.MlpLayer) == 32 and C.sizeof(N.Mlp) == 40 + 4 * 32
+    assert N.Mlp.layer.offset == 40 and N.Mlp.x_f64.offset == 16 and N.Mlp.noise.offset == 24 and N.MlpLayer.in_dim.offset == 16
 
 
 def test_rejects_unsupported_modules():
@@ -123,6 +123,21 @@ def test_fused_mlp_sees_in_place_parameter_updates_and_rejects_bad_calls():
     out32 = torch.zeros(50, 1, device="cuda")
     pol.forward_into(xd, out32)
     np.testing.assert_array_equal(out32.cpu().numpy(), got.float().cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_fused_mlp_exploration_noise_before_clamp():
+    net = _mlp([40, 64, 2], ["tanh", None]).cuda()
+    pol = FusedMLP(net, clamp=(-0.5, 0.5))
+    x = torch.randn(70, 40, device="cuda")
+    nz = torch.randn(70, 2, device="cuda") * 0.3
+    out = torch.zeros(70, 2, device="cuda")
+    pol.forward_into(x, out, noise=nz)
+    with torch.no_grad():
+        want = (net(x) + nz).clamp(-0.5, 0.5)
+    np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=4e-6)
+    with pytest.raises(ValueError):
+        pol.forward_into(x, out, noise=nz.double())
 
 
 @pytest.mark.gpu
