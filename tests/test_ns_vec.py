@@ -106,3 +106,35 @@ def test_ns_device_rollout_equals_stepping_by_hand(bk):
         assert torch.equal(o0, o) and torch.equal(r0, r) and torch.equal(t0, t)
         assert torch.equal(n0, nx)                 # the engine continues from the rollout's last state
     assert t0.sum() > 0                            # an episode boundary was crossed
+
+
+@pytest.mark.gpu
+def test_ns_device_rollout_with_fused_policy():
+    """FusedMLP on the flattened float64 Navier-Stokes observation (21 x 21 x 2 = 882 inputs, rounded to float32 as they are
+    read; lid action in [2, 4] through the fused clamp): same rollout as the wrapped torch module within the float32 agreement
+    of the forward passes, and the graph replay equals the eager run bit for bit."""
+    import pde_control_gym
+    from pde_control_gym import DeviceRollout, FusedMLP
+    n, B, nt, K, T = 21, 6, 7, 6, 9
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(n * n * 2, 32), torch.nn.Tanh(), torch.nn.Linear(32, 1)).cuda()
+    with torch.no_grad():
+        net[-1].bias.fill_(3.0)
+    runs = {}
+    for name, pol, graph in (("torch", lambda o: net(o.reshape(o.shape[0], -1).float()).double(), False),
+                             ("fused", FusedMLP(net), False), ("fused_graph", FusedMLP(net), True)):
+        rng = np.random.default_rng(3)
+        p = _params(n, nt, K, rng, "float64")
+        pools = [rng.uniform(-1, 1, (2 * B, n, n)) for _ in range(3)]
+        p["reset_init_condition_func"] = lambda X: (pools[0][0], pools[1][0], pools[2][0])
+        venv = pde_control_gym.make_vec("PDEControlGym-NavierStokes2D", num_envs=B, **p)
+        venv.core.reset(*[pool[:B] for pool in pools])
+        venv.enable_fused_auto_reset(tuple(pools))
+        ro = DeviceRollout(venv, pol, T, use_graph=graph, action_low=2.0, action_high=4.0).run()
+        torch.cuda.synchronize()
+        runs[name] = [x.cpu().numpy().copy() for x in (ro.actions, ro.obs, ro.rewards)]
+    assert runs["fused"][0].min() >= 2.0 and runs["fused"][0].max() <= 4.0 and runs["fused"][0].std() > 0
+    for got, want in zip(runs["fused"], runs["torch"]):
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)
+    for got, want in zip(runs["fused_graph"], runs["fused"]):
+        np.testing.assert_array_equal(got, want)
