@@ -448,3 +448,38 @@ def test_device_rollout_eager_matches_manual_loop():
         np.testing.assert_array_equal(ro.obs[t + 1].numpy(), obs.numpy())
         np.testing.assert_array_equal(ro.rewards[t].numpy(), r.numpy())
         np.testing.assert_array_equal(ro.actions[t].numpy(), a.numpy())
+
+
+def test_device_rollout_with_fused_policy_and_exploration_noise_on_cpu_double():
+    """Host logic of the fused-policy rollout (pdegym_mlp_forward stands in as the CPU double): the policy output plus the
+    caller's noise, clamped, lands in the action buffer; the next run picks up in-place parameter updates (refresh)."""
+    import torch
+    from pde_control_gym import DeviceRollout
+    from pdecontrolgym_amd.policy import FusedMLP
+    from tests.fake_backend import FakeBackend
+    B, T = 3, 5
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(100, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1))
+    env = _vec(B)
+    env.reset_tensor()
+    ro = DeviceRollout(env, FusedMLP(net, backend=FakeBackend()), T, use_graph=False, action_noise=True)
+    ro.action_noise.normal_().mul_(0.3)
+    ro.run()
+    env2 = _vec(B)
+    obs = env2.reset_tensor()
+    for t in range(T):
+        with torch.no_grad():
+            a = (net(obs).reshape(B) + ro.action_noise[t]).clamp(-1, 1)
+        np.testing.assert_allclose(ro.actions[t].numpy(), a.numpy(), rtol=2e-5, atol=2e-6)
+        obs, r, te, tr = env2.step_tensor(ro.actions[t])          # follow the rollout's own actions: everything else is bitwise
+        np.testing.assert_array_equal(ro.obs[t + 1].numpy(), obs.numpy())
+        np.testing.assert_array_equal(ro.rewards[t].numpy(), r.numpy())
+    before = ro.actions.clone()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(-1.0)
+    ro.action_noise.zero_()
+    ro.run()
+    assert not torch.equal(before, ro.actions)
+    with torch.no_grad():
+        np.testing.assert_allclose(ro.actions[0].numpy(), net(ro.obs[0]).reshape(B).clamp(-1, 1).numpy(), rtol=2e-5, atol=2e-6)
