@@ -22,6 +22,32 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// Neighbouring lanes of a double: two v_mov_b32_dpp each (wave_shl / wave_shr; the lane without a source reads 0, which no
+// valid node ever uses).  The empty asm pins the shift where it is written: folded into a branch that masks lanes off (the
+// inner update runs on lanes 1 .. M-2 only), a DPP read from a masked-off neighbour would return 0.  ds_bpermute
+// (__shfl_up / __shfl_down, what this kernel used first) costs an LDS round trip per shuffle.
+__device__ __forceinline__ double lane_next(double v) {        // lane i <- lane i + 1
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x130, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xf, 0xf, true);
+  double r = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+  asm volatile("" : "+v"(r));
+  return r;
+}
+__device__ __forceinline__ double lane_prev(double v) {        // lane i <- lane i - 1
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x138, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xf, 0xf, true);
+  double r = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+  asm volatile("" : "+v"(r));
+  return r;
+}
+__device__ __forceinline__ double lane_value(double v, int l) {   // l: wave-uniform
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
 __device__ __forceinline__ double Veq(double vm, double rm, double rho) { return vm * (1 - rho / rm); }  // :270-272
 __device__ __forceinline__ double F_r(double vm, double rm, double rho, double y) { return y + rho * Veq(vm, rm, rho); }
 __device__ __forceinline__ double F_y(double vm, double rm, double rho, double y) { return y * (y / rho + Veq(vm, rm, rho)); }
@@ -56,17 +82,17 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pde
   if (time < P.T) {                               // :172  (time does not change inside the loop)
     for (int s = 0; s < P.control_freq; ++s) {
       // boundary conditions :174-190
-      const double r1 = __shfl(r, 1), rm2 = __shfl(r, M - 2);
+      const double r1 = lane_value(r, 1), rm2 = lane_value(r, M - 2);
       if (lane == 0) { r = r1; y = q_in - r * Veq(vm, rm, r); }
       if (lane == M - 1) { r = rm2; y = q_out - r * Veq(vm, rm, r); }
       // nodal fluxes and the "plus" midpoint (:201-216)
       const double fr = F_r(vm, rm, r, y), fy = F_y(vm, rm, r, y);
-      const double r_p = __shfl_down(r, 1), y_p = __shfl_down(y, 1), fr_p = __shfl_down(fr, 1), fy_p = __shfl_down(fy, 1);
+      const double r_p = lane_next(r), y_p = lane_next(y), fr_p = lane_next(fr), fy_p = lane_next(fy);
       const double r_pm = 0.5 * (r_p + r) - c1 * (fr_p - fr);
       const double y_pm = (0.5 * (y_p + y) - c1 * (fy_p - fy)) - c2 * (y_p + y);
       const double Frp = F_r(vm, rm, r_pm, y_pm), Fyp = F_y(vm, rm, r_pm, y_pm);
       // the "minus" midpoint of node j is the "plus" midpoint of node j-1
-      const double Frm = __shfl_up(Frp, 1), Fym = __shfl_up(Fyp, 1), y_mm = __shfl_up(y_pm, 1);
+      const double Frm = lane_prev(Frp), Fym = lane_prev(Fyp), y_mm = lane_prev(y_pm);
       if (lane >= 1 && lane <= M - 2) {           // inner update :219-223
         r = r - c3 * (Frp - Frm);
         y = y - (c3 * (Fyp - Fym) + c4 * (y_pm + y_mm));
