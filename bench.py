@@ -338,17 +338,27 @@ class BrainTumor:
         self.init = torch.as_tensor(0.8 * 1e5 * np.exp(-0.25 * (xs ** 2)), dtype=torch.float64, device=device)
         self.env.set_benchmark(363.0)
 
+    COHORT_DAYS = 350      # untreated patients die around day 363 (t_benchmark): a cohort is replaced before anyone has
+
     def prepare(self, total_steps):
         import torch
         self.actions = (torch.rand(min(total_steps, 64), self.B, generator=self.gen, dtype=torch.float64) * 0.05).to(self.device)
         self.env.reset(self.init)
-        self.i = 0
+        self.i = self.day = 0
+
+    def begin_region(self):
+        """Called by run_workload at the start of every timed region (inside the captured graph, so that each replay starts
+        with it): a fresh cohort.  A finished patient costs nothing (the kernel returns at once), so a region that ran on into
+        days where everyone is dead would report a throughput that no live cohort has."""
+        self.env.reset(self.init)
+        self.day = 0
 
     def step(self):
-        if self.i and self.i % 599 == 0:           # every patient has reached day T: start the next cohort
+        if self.day and self.day % self.COHORT_DAYS == 0:      # long regions: the next cohort
             self.env.reset(self.init)
         out = self.env.step(self.actions[self.i % self.actions.shape[0]])
         self.i += 1
+        self.day += 1
         return out
 
     def units_per_step(self):
@@ -417,6 +427,7 @@ def run_workload(wl, steps, warmup, world, graph=False, repeats=REPEATS):
     import torch
     from pdecontrolgym_amd.sharding import max_over_ranks
     extra = min(steps, 50)
+    begin = getattr(wl, "begin_region", lambda: None)     # workloads with finite episodes and no auto-reset restart here
     wl.prepare(warmup + ((repeats + 2) * steps) + extra)
     for _ in range(warmup):
         wl.step()
@@ -430,6 +441,7 @@ def run_workload(wl, steps, warmup, world, graph=False, repeats=REPEATS):
             wl.step()                       # warm the side stream
             wl.i -= 1
             with torch.cuda.graph(g, stream=side):
+                begin()
                 for _ in range(steps):
                     wl.step()
         torch.cuda.current_stream().wait_stream(side)
@@ -438,6 +450,7 @@ def run_workload(wl, steps, warmup, world, graph=False, repeats=REPEATS):
             regions.append(_timed(g.replay, world))
     else:
         def loop():
+            begin()
             for _ in range(steps):
                 wl.step()
         for _ in range(repeats):
@@ -448,6 +461,7 @@ def run_workload(wl, steps, warmup, world, graph=False, repeats=REPEATS):
     el, (el_local, ev_ms) = maxes[med], regions[med]
     # per-launch duration with HIP events on the launch stream (outside the timed regions)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(extra)]
+    begin()
     for a, b in evs:
         a.record()
         wl.step()

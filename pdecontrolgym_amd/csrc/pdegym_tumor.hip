@@ -86,14 +86,29 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tumor_step_kernel(pdegy
   // "rightmost node at or above a threshold" (:106-121) = highest set bit of a wave ballot, chunk of 64 nodes by chunk:
   // scalar results without a shuffle reduction
   int t2_idx = -1;
-  for (int i0 = 0; i0 < nx; i0 += kWave) {
-    const int i = i0 + lane;
-    double v = -1.0;
-    if (i < nx) {
-      v = g[i];
-      cur[i] = v;
+  if (nx <= 4 * kWave) {       // rows of up to 256 nodes (the shipped 201): the four loads of a lane are issued together
+    double v4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = c * kWave + lane;
+      v4[c] = i < nx ? g[i] : -1.0;
     }
-    t2_idx = rightmost(__ballot(i < nx && v >= P.thr_t2), i0, t2_idx);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = c * kWave + lane;
+      if (i < nx) cur[i] = v4[c];
+      if (c * kWave < nx) t2_idx = rightmost(__ballot(i < nx && v4[c] >= P.thr_t2), c * kWave, t2_idx);
+    }
+  } else {
+    for (int i0 = 0; i0 < nx; i0 += kWave) {
+      const int i = i0 + lane;
+      double v = -1.0;
+      if (i < nx) {
+        v = g[i];
+        cur[i] = v;
+      }
+      t2_idx = rightmost(__ballot(i < nx && v >= P.thr_t2), i0, t2_idx);
+    }
   }
   double remaining = Bf.remaining[inst];
   int32_t* days = Bf.days + (size_t)inst * PDEGYM_TUMOR_DAYS;
