@@ -500,6 +500,8 @@ def roofline_block(wl, key, step_ms, default_config):
         out = {"bound": "hbm", "achieved": eff, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
                "note": "no committed counters for this batch / sub-step count: achieved is the EFFECTIVE streaming-model bandwidth"}
     out["traffic"] = hbm["bytes_per_step"] if hbm else None
+    if ctr and ctr.get("round"):
+        src = f"round {ctr['round']}: " + (src or "")
     out.update({"valu_issue": valu, "hbm": hbm, "step_ms": step_ms, "counters_source": src,
                 "kernels_per_step": (ctr or {}).get("kernels"),
                 "effective_streaming_GBps": alg / t / 1e9, "effective_streaming_frac_of_hbm_peak": alg / t / 1e9 / HBM_PEAK_GBPS,

@@ -105,7 +105,8 @@ def is_step_kernel(name):
     return not ("at::native" in name or "reset" in name or "Functor" in name or "elementwise" in name)
 
 
-latest = {"source": f"profiles/{tag}_summary.json: rocprofv3 --pmc, separate passes for FETCH_SIZE, WRITE_SIZE and the SQ group; "
+latest = {"source": "profiles/<round>_summary.json of each workload's `round` (tools/profile_round.sh -> tools/summarize_profiles.py): "
+                    "rocprofv3 --pmc, separate passes for FETCH_SIZE, WRITE_SIZE and the SQ group; "
                     "HBM bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (MI355X_MICROARCH.md: gfx950 tallies 128-byte reads at 64 bytes); "
                     "per-step = total over all launches of the step's kernels / number of steps",
           "workloads": {}}
@@ -139,14 +140,15 @@ for wl in DOM:
                 kernels[k]["avg_ns"] = float(r["AverageNs"])
     if per:
         per["kernels"] = kernels
+        per["round"] = tag
         latest["workloads"][wl] = per
 if latest["workloads"]:
     prev_path = os.path.join(dst, "counters_latest.json")
     if os.path.exists(prev_path):       # keep workloads that this round did not re-profile
         try:
             prev = json.load(open(prev_path))
-            for k, v in prev.get("workloads", {}).items():
-                latest["workloads"].setdefault(k, dict(v, stale_from=prev.get("source", "")[:40]))
+            for k, v in prev.get("workloads", {}).items():      # a workload keeps the round it was last profiled in
+                latest["workloads"].setdefault(k, v)
         except Exception:
             pass
     with open(prev_path, "w") as fh:
