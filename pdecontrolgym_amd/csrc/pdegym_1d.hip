@@ -55,15 +55,40 @@ __device__ __forceinline__ float from_right_lane(float v, float edge) {
 #endif
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+// Wave-wide reductions on DPP (result in every lane).  __shfl_xor compiles to ds_bpermute_b32, an LDS round trip per step:
+// six dependent ones per reduction, four reductions per env-step on the critical path of a wave's prologue / epilogue.
+// Steps: the lane pair, the quad (quad_perm), the half row and the row (row_half_mirror / row_mirror: lane i pairs with
+// lane 7-i / 15-i), then lane 15 of rows 0 and 2 into rows 1 and 3 (row_bcast:15) and lane 31 into rows 2, 3
+// (row_bcast:31): lane 63 holds the total, v_readlane hands it to everybody.  A fixed order (deterministic), not the
+// butterfly's -- norms and rewards were never bitwise against a BLAS dot product anyway (tests: rtol 1e-6).
+template <typename Op>
+__device__ __forceinline__ float wave_reduce(float v, float identity, Op op) {
+  auto dpp = [&](float x, const int ctrl_tag) {
+    const int xi = __builtin_bit_cast(int, x), idn = __builtin_bit_cast(int, identity);
+    int r;
+    switch (ctrl_tag) {
+      case 0: r = __builtin_amdgcn_update_dpp(idn, xi, 0xB1, 0xf, 0xf, false); break;    // quad_perm:[1,0,3,2]
+      case 1: r = __builtin_amdgcn_update_dpp(idn, xi, 0x4E, 0xf, 0xf, false); break;    // quad_perm:[2,3,0,1]
+      case 2: r = __builtin_amdgcn_update_dpp(idn, xi, 0x141, 0xf, 0xf, false); break;   // row_half_mirror
+      case 3: r = __builtin_amdgcn_update_dpp(idn, xi, 0x140, 0xf, 0xf, false); break;   // row_mirror
+      case 4: r = __builtin_amdgcn_update_dpp(idn, xi, 0x142, 0xa, 0xf, false); break;   // row_bcast:15 -> rows 1, 3
+      default: r = __builtin_amdgcn_update_dpp(idn, xi, 0x143, 0xc, 0xf, false); break;  // row_bcast:31 -> rows 2, 3
+    }
+    return __builtin_bit_cast(float, r);
+  };
+  v = op(v, dpp(v, 0));
+  v = op(v, dpp(v, 1));
+  v = op(v, dpp(v, 2));
+  v = op(v, dpp(v, 3));
+  v = op(v, dpp(v, 4));
+  v = op(v, dpp(v, 5));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+__device__ __forceinline__ float wave_sum(float v) {
+  return wave_reduce(v, 0.0f, [](float a, float b) { return a + b; });
+}
+__device__ __forceinline__ float wave_max(float v) {      // callers pass magnitudes: 0 is the identity
+  return wave_reduce(v, 0.0f, [](float a, float b) { return fmaxf(a, b); });
 }
 
 // value of slot s when lane l holds slots [l*EPL, l*EPL+EPL)
