@@ -562,3 +562,30 @@ def test_ns_column_kernel_reproduces_target_npz_and_oracle(golden_ns):
             np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-12)
     finally:
         os.environ.pop("PDEGYM_NS_COL_MIN_BATCH", None)
+
+
+def test_ns_column_kernel_default_dispatch_large_batch():
+    """Without any switch a float64 batch of >= 1024 instances on a 21-row grid takes the column kernel (float32: any batch);
+    a full-size batch (1030 instances: the last wave has one live lane group) equals the workgroup kernel bit for bit."""
+    import os
+    from pdecontrolgym_amd.batch2d import NSBatch2D
+    B = 1030
+    kw, u0, v0, p0, acts = _rect_case(21, 21, B, 5, 4321, BC_MIX, 1)
+    outs = []
+    for no_col in ("0", "1"):
+        os.environ.pop("PDEGYM_NS_COL_MIN_BATCH", None)
+        os.environ["PDEGYM_NS_NO_COL"] = no_col
+        try:
+            env = NSBatch2D(num_envs=B, device="cuda", dtype=torch.float64, **kw)
+            env.reset(u0, v0, p0)
+            res = []
+            for a in acts[:2]:
+                obs, r, te = env.step(a)
+                res.append((obs.cpu().numpy().copy(), env.p.cpu().numpy().copy(), r.cpu().numpy().copy()))
+            outs.append(res)
+        finally:
+            os.environ["PDEGYM_NS_NO_COL"] = "0"
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        np.testing.assert_allclose(a[2], b[2], rtol=1e-12)
