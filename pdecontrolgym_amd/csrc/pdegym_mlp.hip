@@ -126,7 +126,20 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX
       load_w<NT>(wfirst, reinterpret_cast<const v4f*>(N.layer[0].w), N.layer[0].out_dim, (N.layer[0].in_dim + 3) >> 2, 0, lg, col0);
   }
 
-  for (int l = 0; l < N.n_layers; ++l) {
+  // biases of every layer up front (their pointers and the loads are off the critical path of the layers); the layer loop
+  // is unrolled over the at most four layers so that the descriptors are read with constant offsets at kernel start
+  float bias_all[PDEGYM_MLP_MAX_LAYERS][NT];
+#pragma unroll
+  for (int l = 0; l < PDEGYM_MLP_MAX_LAYERS; ++l) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = 16 * (wave + 4 * t) + li;
+      bias_all[l][t] = (l < N.n_layers && N.layer[l].b && n < N.layer[l].out_dim) ? N.layer[l].b[n] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < PDEGYM_MLP_MAX_LAYERS; ++l) {
+    if (l >= N.n_layers) break;
     const pdegym_mlp_layer L = N.layer[l];
     const int K = L.in_dim, H = L.out_dim;
     const int ngroups = (K + 3) >> 2;
@@ -134,13 +147,19 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX
     int col[NT];
     tile_cols(H, col);
     v4f acc[NT];
-    float bias[NT];       // requested before the reduction: its latency hides behind the MFMAs instead of delaying the epilogue
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
-      bias[t] = (L.b && 16 * (wave + 4 * t) + li < H) ? L.b[col[t]] : 0.f;
-    }
+    for (int t = 0; t < NT; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
     const bool any_tile = 16 * wave < H;      // this wave has at least one tile of the layer
+    const bool last = l == N.n_layers - 1;
+    // the NEXT layer's first weights are requested now: they travel while this layer is reduced
+    v4f wnext[kStage][NT];
+    if (!last) {
+      const pdegym_mlp_layer Ln = N.layer[l + 1];
+      int coln[NT];
+      tile_cols(Ln.out_dim, coln);
+      if (16 * wave < Ln.out_dim)
+        load_w<NT>(wnext, reinterpret_cast<const v4f*>(Ln.w), Ln.out_dim, (Ln.in_dim + 3) >> 2, 0, lg, coln);
+    }
     if (l == 0) {
       for (int c0 = 0; c0 < K; c0 += kXChunk) {
         const int clen = (K - c0) < kXChunk ? (K - c0) : kXChunk;
@@ -177,13 +196,11 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX
       const float* hin = hbuf((l + 1) & 1);       // written by layer l - 1, zero beyond its width up to a multiple of 16
       if (any_tile) reduce_blocks<NT>(acc, wfirst, wq, H, ngroups, 0, (K + 15) >> 4, hin + li * kLdh, lg, col);
     }
-    const bool last = l == N.n_layers - 1;
-    if (!last) {      // the next layer's first weights travel while this layer's epilogue runs
-      const pdegym_mlp_layer Ln = N.layer[l + 1];
-      int coln[NT];
-      tile_cols(Ln.out_dim, coln);
-      if (16 * wave < Ln.out_dim)
-        load_w<NT>(wfirst, reinterpret_cast<const v4f*>(Ln.w), Ln.out_dim, (Ln.in_dim + 3) >> 2, 0, lg, coln);
+    if (!last) {
+#pragma unroll
+      for (int s2 = 0; s2 < kStage; ++s2)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wfirst[s2][t] = wnext[s2][t];
     }
     // bias, activation; D[i = 4 lg + v][j = li] of tile t.  Hidden layers go to LDS, zero-padded to a multiple of 16 columns.
     float* hout = hbuf(l & 1);
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int r = 4 * lg + v;
-          float o = n < H ? activate(av[v] + bias[t], L.act) : 0.f;
+          float o = n < H ? activate(av[v] + bias_all[l][t], L.act) : 0.f;
           if (last) {
             if (N.noise && n < H && row0 + r < B) o += N.noise[(long long)(row0 + r) * N.noise_stride + n];
             if (N.clamp) o = fminf(fmaxf(o, N.lo), N.hi);
