@@ -1736,7 +1736,6 @@ __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<do
 
   double rq[PR][2];     // dx dy rhs, kept for all sweeps
   {
-    double uf[PR][2], vf[PR][2];
     auto load_row = [&](int grow, double (&ru)[2], double (&rv)[2]) {
       if constexpr (INTERLEAVED) {
         const double2* row = reinterpret_cast<const double2*>(sin + ((size_t)grow * n + c0) * 2);
@@ -1748,80 +1747,101 @@ __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<do
         ru[0] = wu.x; ru[1] = wu.y; rv[0] = wv.x; rv[1] = wv.y;
       }
     };
-    // ---- predictor (navier_stokes2D.py:130-138): rows in order, the old row above is carried along ----
-    // The patch is loaded and predicted in two blocks of PR/2 rows (the second block's loads are issued after the first
-    // block's arithmetic): with all eight rows in flight next to the stencil temporaries the compiler spilled half the
-    // patch to scratch memory (~190 bytes per lane written and read back through HBM).  The old rows just above / below
-    // the patch come straight from the state in global memory (the neighbouring thread's own rows: L2 hits) instead of
-    // an LDS exchange.  Domain-edge threads read a valid row whose values are never used.
+    // ---- predictor (:130-138), apply_boundary(u*, v*) (:140), rhs (:101-103, :108) as a ROW PIPELINE ----
+    // Iteration a: load the old row a+1, predict row a, finalise row a-1 (boundary rule), store it (u* partly in LDS, v* in the
+    // caller's scratch) and form dx dy rhs of row a-2, whose stencil reaches the finalised rows a-3 ... a-1.  A row's values
+    // are dead two iterations after they are made, so next to rq only a five-row window is live -- with the whole patch of
+    // u, v, u*, v* in flight around the division-heavy stencil the compiler spilled ~190 bytes per lane to scratch memory
+    // (HBM traffic both ways).  The old rows just above / below the patch come straight from the state in global memory (the
+    // neighbouring thread's own rows: L2 hits); domain-edge threads read a valid row whose values are never used.
+    // The lower / upper rule of apply_boundary reads the RAW prediction of row 1 / row PR-2 (those passes run before the
+    // left / right passes, navier_stokes2D.py:76-90), the left / right rule is row-local: finalise() applies them in that order.
     {
-      constexpr int HB = PR / 2;
-      double pu[2], pv[2], ub[2], vb[2];
-      load_row(E.top ? r0 : r0 - 1, pu, pv);
+      double old_p[2][2], old_c[2][2], old_n[2][2];       // [field u / v][column]: old rows a-1, a, a+1
+      double raw_u[PR][2], raw_v[PR][2], fin_u[PR][2], fin_v[PR][2];
+      double2* park = reinterpret_cast<double2*>(smem_raw + kF64HaloBytes);
+      auto aval = [&](int idx) -> double { return C.action_dim == 1 ? act[0] : act[idx]; };
+      auto finalise = [&](int i) {
 #pragma unroll
-      for (int a = 0; a <= HB; ++a) load_row(r0 + a, uf[a], vf[a]);
-#pragma unroll
-      for (int a = 0; a < PR; ++a) {
-        if (a == HB) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int a2 = HB + 1; a2 < PR; ++a2) load_row(r0 + a2, uf[a2], vf[a2]);
-          load_row(E.bot ? r0 + PR - 1 : r0 + PR, ub, vb);
+        for (int comp = 0; comp < 2; ++comp) {
+          const double (&raw)[PR][2] = comp == 0 ? raw_u : raw_v;
+          double (&fin)[PR][2] = comp == 0 ? fin_u : fin_v;
+          double t0 = raw[i][0], t1 = raw[i][1];
+          if (i == 0 && E.top) {
+            const int c = C.bc[PDEGYM_EDGE_LOWER][comp];
+            t0 = (c == PDEGYM_BC_NEUMANN) ? raw[1][0] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0 : aval(c0));
+            t1 = (c == PDEGYM_BC_NEUMANN) ? raw[1][1] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0 : aval(c0 + 1));
+          }
+          if (i == PR - 1 && E.bot) {
+            const int c = C.bc[PDEGYM_EDGE_UPPER][comp];
+            t0 = (c == PDEGYM_BC_NEUMANN) ? raw[PR - 2][0] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0 : aval(c0));
+            t1 = (c == PDEGYM_BC_NEUMANN) ? raw[PR - 2][1] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0 : aval(c0 + 1));
+          }
+          if (E.lef) {
+            const int c = C.bc[PDEGYM_EDGE_LEFT][comp];
+            t0 = (c == PDEGYM_BC_NEUMANN) ? t1 : ((c == PDEGYM_BC_DIRICHLET) ? 0.0 : aval(r0 + i));
+          }
+          if (E.rig) {
+            const int c = C.bc[PDEGYM_EDGE_RIGHT][comp];
+            t1 = (c == PDEGYM_BC_NEUMANN) ? t0 : ((c == PDEGYM_BC_DIRICHLET) ? 0.0 : aval(r0 + i));
+          }
+          fin[i][0] = t0;
+          fin[i][1] = t1;
         }
-        const double cu[2] = {uf[a][0], uf[a][1]}, cv[2] = {vf[a][0], vf[a][1]};
-        const double ul = dpp_shr_f64(cu[1]), ur = dpp_shl_f64(cu[0]), vl = dpp_shr_f64(cv[1]), vr = dpp_shl_f64(cv[0]);
+        if (i < kF64ParkRows) park[i * 1024 + tid] = make_double2(fin_u[i][0], fin_u[i][1]);
+        else *reinterpret_cast<double2*>(us + (r0 + i) * n + c0) = make_double2(fin_u[i][0], fin_u[i][1]);
+        *reinterpret_cast<double2*>(vs + (r0 + i) * n + c0) = make_double2(fin_v[i][0], fin_v[i][1]);
+      };
+      auto rhs_row = [&](int i, const double (&vbelow)[2], const double (&vabove)[2]) {
+        const double ul = dpp_shr_f64(fin_u[i][1]), ur = dpp_shl_f64(fin_u[i][0]);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          const double uc = cu[k], vc = cv[k];
-          const double uw = (k == 0) ? ul : cu[0], ue = (k == 1) ? ur : cu[1];
-          const double vw = (k == 0) ? vl : cv[0], ve = (k == 1) ? vr : cv[1];
-          const double usn = pu[k], vsn = pv[k];
-          const double unn = (a == PR - 1) ? ub[k] : uf[a + 1][k];
-          const double vnn = (a == PR - 1) ? vb[k] : vf[a + 1][k];
-          const double dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx), dudy = div_c(unn - usn, S.two_dy, S.inv_two_dy);
-          const double dvdx = div_c(ve - vw, S.two_dx, S.inv_two_dx), dvdy = div_c(vnn - vsn, S.two_dy, S.inv_two_dy);
-          const double lapu = div_c((((uw + usn) - 4.0 * uc) + ue) + unn, S.dxdy, S.inv_dxdy);
-          const double lapv = div_c((((vw + vsn) - 4.0 * vc) + ve) + vnn, S.dxdy, S.inv_dxdy);
-          const double un = uc + S.dt * (((-uc) * dudx - vc * dudy) + S.nu * lapu);
-          const double vn = vc + S.dt * (((-uc) * dvdx - vc * dvdy) + S.nu * lapv);
-          const bool edge = edge_cell(a, k);
-          uf[a][k] = edge ? uc : un;
-          vf[a][k] = edge ? vc : vn;
-        }
-        pu[0] = cu[0]; pu[1] = cu[1]; pv[0] = cv[0]; pv[1] = cv[1];
-#ifdef PDEGYM_F64_ROW_BARRIER
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-      }
-    }
-    // ---- apply_boundary(u*, v*) (:140) ----
-    apply_bc_patch_f64<PR>(uf, E, C.bc, 0, act, C.action_dim, r0, c0);
-    apply_bc_patch_f64<PR>(vf, E, C.bc, 1, act, C.action_dim, r0, c0);
-    // kF64ParkRows rows of u* wait in LDS (behind the halo buffers) instead of the caller's scratch
-    double2* park = reinterpret_cast<double2*>(smem_raw + kF64HaloBytes);
-#pragma unroll
-    for (int a = 0; a < PR; ++a) {
-      if (a < kF64ParkRows) park[a * 1024 + tid] = make_double2(uf[a][0], uf[a][1]);
-      else *reinterpret_cast<double2*>(us + (r0 + a) * n + c0) = make_double2(uf[a][0], uf[a][1]);
-      *reinterpret_cast<double2*>(vs + (r0 + a) * n + c0) = make_double2(vf[a][0], vf[a][1]);
-    }
-    // ---- rhs (:101-103) times dx dy (:108) ----
-    {
-      double vt[2], vb[2];
-      halo_tb_f64(vf[0], vf[PR - 1], vt, vb, lds, xc, tid, ty);
-#pragma unroll
-      for (int a = 0; a < PR; ++a) {
-        const double ul = dpp_shr_f64(uf[a][1]), ur = dpp_shl_f64(uf[a][0]);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const double uw = (k == 0) ? ul : uf[a][0], ue = (k == 1) ? ur : uf[a][1];
-          const double vsn = (a == 0) ? vt[k] : vf[a - 1][k], vnn = (a == PR - 1) ? vb[k] : vf[a + 1][k];
+          const double uw = (k == 0) ? ul : fin_u[i][0], ue = (k == 1) ? ur : fin_u[i][1];
           const double dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx);
-          const double dvdy = div_c(vnn - vsn, S.two_dy, S.inv_two_dy);
+          const double dvdy = div_c(vabove[k] - vbelow[k], S.two_dy, S.inv_two_dy);
           const double r = S.rho_over_dt * (dudx + dvdy);
-          rq[a][k] = edge_cell(a, k) ? 0.0 : S.dxdy * r;
+          rq[i][k] = edge_cell(i, k) ? 0.0 : S.dxdy * r;
         }
+      };
+      load_row(E.top ? r0 : r0 - 1, old_p[0], old_p[1]);
+      load_row(r0, old_c[0], old_c[1]);
+#pragma unroll
+      for (int a = 0; a < PR; ++a) {
+        load_row((a == PR - 1 && E.bot) ? r0 + PR - 1 : r0 + a + 1, old_n[0], old_n[1]);
+        {
+          const double (&cu)[2] = old_c[0], (&cv)[2] = old_c[1];
+          const double ul = dpp_shr_f64(cu[1]), ur = dpp_shl_f64(cu[0]), vl = dpp_shr_f64(cv[1]), vr = dpp_shl_f64(cv[0]);
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const double uc = cu[k], vc = cv[k];
+            const double uw = (k == 0) ? ul : cu[0], ue = (k == 1) ? ur : cu[1];
+            const double vw = (k == 0) ? vl : cv[0], ve = (k == 1) ? vr : cv[1];
+            const double usn = old_p[0][k], vsn = old_p[1][k], unn = old_n[0][k], vnn = old_n[1][k];
+            const double dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx), dudy = div_c(unn - usn, S.two_dy, S.inv_two_dy);
+            const double dvdx = div_c(ve - vw, S.two_dx, S.inv_two_dx), dvdy = div_c(vnn - vsn, S.two_dy, S.inv_two_dy);
+            const double lapu = div_c((((uw + usn) - 4.0 * uc) + ue) + unn, S.dxdy, S.inv_dxdy);
+            const double lapv = div_c((((vw + vsn) - 4.0 * vc) + ve) + vnn, S.dxdy, S.inv_dxdy);
+            const double un = uc + S.dt * (((-uc) * dudx - vc * dudy) + S.nu * lapu);
+            const double vn = vc + S.dt * (((-uc) * dvdx - vc * dvdy) + S.nu * lapv);
+            const bool edge = edge_cell(a, k);
+            raw_u[a][k] = edge ? uc : un;
+            raw_v[a][k] = edge ? vc : vn;
+          }
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) { old_p[f][k] = old_c[f][k]; old_c[f][k] = old_n[f][k]; }
+        if (a >= 1) finalise(a - 1);
+        if (a >= 3) rhs_row(a - 2, fin_v[a - 3], fin_v[a - 1]);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      finalise(PR - 1);
+      rhs_row(PR - 2, fin_v[PR - 3], fin_v[PR - 1]);
+      double vt[2], vb[2];
+      halo_tb_f64(fin_v[0], fin_v[PR - 1], vt, vb, lds, xc, tid, ty);
+      rhs_row(0, vt, fin_v[1]);
+      rhs_row(PR - 1, fin_v[PR - 2], vb);
     }
   }
 
