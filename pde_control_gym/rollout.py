@@ -120,7 +120,8 @@ class DeviceRollout:
             with torch.cuda.stream(side):
                 self._body()                               # warm-up on the side stream (allocator, lazy init)
                 for k, v in snapshot.items():
-                    core.t[k].copy_(v)                     # ... then rewind the environment state
+                    if core.t[k].shape == v.shape:         # (an input slot such as the traffic engine's "action" may have been rebound)
+                        core.t[k].copy_(v)                 # ... then rewind the environment state
                 for k, v in extra.items():
                     getattr(self.venv, k).copy_(v)
                 self._graph = torch.cuda.CUDAGraph()
@@ -128,7 +129,8 @@ class DeviceRollout:
                     self._body()
             torch.cuda.current_stream().wait_stream(side)
             for k, v in snapshot.items():
-                core.t[k].copy_(v)
+                if core.t[k].shape == v.shape:
+                    core.t[k].copy_(v)
             for k, v in extra.items():
                 getattr(self.venv, k).copy_(v)
         self._graph.replay()

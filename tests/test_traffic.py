@@ -120,3 +120,33 @@ def test_traffic_vecenv_on_test_double():
     obs, rew, dones, infos = venv.step(qs[:, None] * 1.05)
     assert obs.shape == (5, 102) and rew.shape == (5,) and not dones.any()
     assert venv.observation_space.shape == (102,) and venv.action_space.shape == (1,)
+
+
+@pytest.mark.gpu
+def test_traffic_device_rollout_with_fused_policy():
+    """DeviceRollout on TrafficPDE1D with FusedMLP reading the float64 observation (102 entries) and writing the float64
+    outlet command (policy output scaled into the action box by the clamp): same rollout as the wrapped torch module within
+    the float32 agreement of the forward passes; the graph replay equals the eager run bit for bit."""
+    import pde_control_gym
+    from pde_control_gym import DeviceRollout, FusedMLP
+    from pde_control_gym.src import TrafficARZReward
+    torch = pytest.importorskip("torch")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(102, 32), torch.nn.Tanh(), torch.nn.Linear(32, 1)).cuda()
+    with torch.no_grad():
+        net[-1].bias.fill_(4.6)                     # around the steady-state flow q_s
+    runs = {}
+    for name, pol, graph in (("torch", lambda o: net(o.float()).double(), False), ("fused", FusedMLP(net), False),
+                             ("fused_graph", FusedMLP(net), True)):
+        random.seed(0)
+        venv = pde_control_gym.make_vec("PDEControlGym-TrafficPDE1D", num_envs=96, reward_class=TrafficARZReward(),
+                                        simulation_type="outlet", limit_pde_state_size=True, control_freq=2, **BASE)
+        venv.reset_tensor()
+        ro = DeviceRollout(venv, pol, 8, use_graph=graph, action_low=3.0, action_high=6.0).run()
+        torch.cuda.synchronize()
+        runs[name] = [x.cpu().numpy().copy() for x in (ro.actions, ro.obs, ro.rewards)]
+    assert runs["fused"][0].dtype == np.float64 and runs["fused"][0].std() > 0
+    for got, want in zip(runs["fused"], runs["torch"]):
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-7)
+    for got, want in zip(runs["fused_graph"], runs["fused"]):
+        np.testing.assert_array_equal(got, want)
