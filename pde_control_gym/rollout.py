@@ -12,7 +12,7 @@ from __future__ import annotations
 class DeviceRollout:
     """``policy``: callable mapping an observation tensor [B, obs_dim] to actions [B] (or [B, 1]) on the same device -- any
     torch module, or a ``pdecontrolgym_amd.FusedMLP`` (Linear/Tanh/ReLU stack evaluated, clamped and stored in ONE launch).
-    Buffers: ``obs[T+1, B, D]``, ``actions[T, B]``, ``rewards[T, B]``, ``terminated[T, B]``, ``truncated[T, B]``; with
+    Buffers: ``obs[T+1, B, D]``, ``actions[T, B]`` (``[T, B, action_dim]`` for Navier-Stokes and two-command traffic), ``rewards[T, B]``, ``terminated[T, B]``, ``truncated[T, B]``; with
     ``action_noise=True`` also ``action_noise[T, B]`` (float32), added to the policy output of step t before the clamp."""
 
     def __init__(self, venv, policy, n_steps: int, use_graph: bool = True, action_low: float = -1.0, action_high: float = 1.0,
@@ -31,8 +31,8 @@ class DeviceRollout:
         B, dev, dt = core.num_envs, core.device, cur.dtype
         oshape = tuple(cur.shape[1:])                                # (D,) for the 1D engines, (ny, nx, 2) for Navier-Stokes
         self.obs = torch.zeros((self.T + 1, B) + oshape, dtype=dt, device=dev)
-        adim = core.action_dim if self._ns else 1
-        self.actions = torch.zeros((self.T, B) + ((adim,) if self._ns else ()), dtype=dt, device=dev)
+        adim = int(getattr(core, "action_dim", 1))      # Navier-Stokes: its action_dim; traffic 'both': inlet and outlet command
+        self.actions = torch.zeros((self.T, B) + ((adim,) if (self._ns or adim > 1) else ()), dtype=dt, device=dev)
         self.rewards = torch.zeros(self.T, B, dtype=dt, device=dev)
         self.terminated = torch.zeros(self.T, B, dtype=torch.uint8, device=dev)
         self.truncated = torch.zeros(self.T, B, dtype=torch.uint8, device=dev)

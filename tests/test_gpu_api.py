@@ -210,3 +210,46 @@ def test_ppo_example_trains_on_device():
     last = sum(h["episode_return"] for h in hist[-3:]) / 3
     assert last > first + 15.0, (first, last)
     assert hist[-1]["mean_norm"] < hist[0]["mean_norm"]
+
+
+@pytest.mark.parametrize("family", ["burgers", "traffic"])
+def test_device_rollout_graph_equals_eager_other_families(family):
+    """Graph replay == eager loop for the remaining environment families (the Burgers extension on the transport kernel; the
+    traffic engine, whose action slot is rebound by every step)."""
+    import pde_control_gym
+    from pde_control_gym import DeviceRollout
+    from pde_control_gym.src import TunedReward1D
+    torch.manual_seed(0)
+    outs = []
+    for graph in (False, True):
+        if family == "burgers":
+            p = _transport_params(T=0.0400, dt=1e-4, control_sample_rate=30e-4, reward_class=TunedReward1D(400, -1e3, 3e2))
+            rng = np.random.default_rng(5)
+            p["reset_init_condition_func"] = lambda nx: np.ones(nx) * rng.uniform(0.2, 0.6)
+            venv = pde_control_gym.make_vec("PDEControlGym-BurgersPDE1D", num_envs=48, **p)
+            venv.reset_tensor()
+            venv.enable_fused_auto_reset()
+            pol = torch.nn.Sequential(torch.nn.Linear(100, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1), torch.nn.Tanh()).cuda()
+            lo, hi = -1.0, 1.0
+        else:
+            import random
+            from pde_control_gym.src import TrafficARZReward
+            random.seed(0)
+            venv = pde_control_gym.make_vec("PDEControlGym-TrafficPDE1D", num_envs=48, reward_class=TrafficARZReward(),
+                                            simulation_type="both", limit_pde_state_size=True, control_freq=2, T=240, dt=0.25, X=500, dx=10)
+            venv.reset_tensor()
+            torch.manual_seed(2)
+            lin = torch.nn.Linear(102, 2).double().cuda()
+            pol = lambda o: 4.6 + 0.5 * torch.tanh(lin(o))             # noqa: E731
+            lo, hi = 3.0, 6.0
+        torch.manual_seed(1)
+        if family == "burgers":
+            for q in pol.parameters():
+                torch.nn.init.normal_(q, std=0.2)
+        ro = DeviceRollout(venv, pol, 16, use_graph=graph, action_low=lo, action_high=hi).run()
+        ro.run()
+        torch.cuda.synchronize()
+        outs.append([x.cpu().numpy().copy() for x in (ro.obs, ro.actions, ro.rewards, ro.terminated, ro.truncated)])
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    assert np.isfinite(outs[0][2]).all()
