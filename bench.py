@@ -9,8 +9,10 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
 A "step" = one env-step of EVERY instance of the batch = one launch of the fused step kernel
 (S PDE sub-steps + norms + reward + observation + auto-reset), inputs already resident in HBM.
 Default workload = BASELINE.json configs[1]: ReactionDiffusionPDE1D ("Parabolic1D") nx=256, batch 4096
-per GPU, fp32, S=100 sub-steps per env-step.  Other workloads: --workload
-transport_c3 | ns2d_c4 (reported as their own line; the default run adds them under "also").
+per GPU, fp32, S=100 sub-steps per env-step (SURVEY.md section 8d).  Other workloads (--workload NAME prints NAME's own line;
+the default run adds all of them under "also"): transport_c3, burgers_c3 (extension), parabolic_c2_policy_loop (C2 with its MLP
+controller evaluated on the device every step), ns2d_c4, ns2d_c4_f64, ns2d_c4_b4096, ns2d_c5, ns2d_example (the reference's
+shipped 21x21 K=2000 float64 configuration), traffic_arz, brain_tumor.
 
 Prints ONE JSON line (rank 0).
 """
