@@ -2293,7 +2293,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 8 || NY > 21 ? 2 : 3)) void ns_co
 }
 
 // The column kernel is instantiated for the grid height of the reference's shipped example (21 rows) and a few neighbours
-// (11, 16, 26, 31); any width up to 64.  One wave works through all K sweeps of its (up to three) instances alone: in
+// (8, 11, 16, 26, 31, 32); any width up to 64.  One wave works through all K sweeps of its (up to three) instances alone: in
 // float64 a lone instance finishes sooner on the workgroup-per-instance kernel (seven waves per instance; 0.77 vs 0.98 ms per
 // env-step at 21 x 21, K = 2000), so batches below PDEGYM_NS_COL_MIN_BATCH (default: 1024 for float64, 1 for float32, where
 // the two kernels are equal at B = 1) stay there.
@@ -2306,11 +2306,13 @@ bool launch_ns_col(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int
   const int G = 64 / C.nx;
   const dim3 grid((B + G - 1) / G), block(64);
   switch (C.ny) {
+    case 8: hipLaunchKernelGGL((ns_col_step<T, 8>), grid, block, 0, st, C, S, P, B); return true;
     case 11: hipLaunchKernelGGL((ns_col_step<T, 11>), grid, block, 0, st, C, S, P, B); return true;
     case 16: hipLaunchKernelGGL((ns_col_step<T, 16>), grid, block, 0, st, C, S, P, B); return true;
     case 21: hipLaunchKernelGGL((ns_col_step<T, 21>), grid, block, 0, st, C, S, P, B); return true;
     case 26: hipLaunchKernelGGL((ns_col_step<T, 26>), grid, block, 0, st, C, S, P, B); return true;
     case 31: hipLaunchKernelGGL((ns_col_step<T, 31>), grid, block, 0, st, C, S, P, B); return true;
+    case 32: hipLaunchKernelGGL((ns_col_step<T, 32>), grid, block, 0, st, C, S, P, B); return true;
     default: return false;
   }
 }

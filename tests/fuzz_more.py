@@ -29,7 +29,7 @@ def ns_case(rng, idx):
     adim = int(rng.choice([1, 1, n]))
     bc = {e: [str(rng.choice(BCS)), str(rng.choice(BCS))] for e in ("upper", "lower", "left", "right")}
     # non-square grids and cells: nx = round(X/dx + 1) columns, ny = round(Y/dy + 1) rows (base_env_2d.py:27-36)
-    m = n if rng.random() < 0.5 else int(rng.choice([3, 4, 5, 9, 11, 16, 21, 21, 26, 31, 33, 64, 65]))
+    m = n if rng.random() < 0.5 else int(rng.choice([3, 4, 5, 8, 9, 11, 16, 21, 21, 26, 31, 32, 33, 64, 65]))
     dx = 1.0 / (n - 1)
     dy = (1.0 if rng.random() < 0.6 else 0.5) / (m - 1)
     Yl = dy * (m - 1)
@@ -53,7 +53,7 @@ def ns_case(rng, idx):
               action_ref=rng.uniform(1, 3, nt), gamma=float(rng.choice([0.1, 0.0, 2.0])), maximum_pressure_iteration=K, viscosity=nu,
               density=float(rng.choice([1.0, 2.0])))
     desc = f"#{idx} ns nx={n} ny={m} K={K} B={B} adim={adim} nt={nt} inter={inter} ic={style} bc={bc}"
-    # grids of 11 / 16 / 21 / 26 / 31 rows and up to 64 columns: half of the cases on the column-per-lane kernel (which float64
+    # grids of 8 / 11 / 16 / 21 / 26 / 31 / 32 rows and up to 64 columns: half of the cases on the column-per-lane kernel (which float64
     # batches this small would not reach by themselves), half on the workgroup kernel -- the switch is read at every launch
     col = rng.random() < 0.5
     os.environ["PDEGYM_NS_COL_MIN_BATCH"] = "0" if col else "1000000"

@@ -498,9 +498,10 @@ def test_ns_column_kernel_equals_workgroup_kernel_bitwise(dtype, nx, B, K, inter
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
-@pytest.mark.parametrize("ny,nx,B,K", [(11, 11, 7, 5), (16, 30, 5, 3), (26, 26, 4, 6), (31, 64, 2, 4), (31, 8, 9, 2)])
+@pytest.mark.parametrize("ny,nx,B,K", [(11, 11, 7, 5), (16, 30, 5, 3), (26, 26, 4, 6), (31, 64, 2, 4), (31, 8, 9, 2), (8, 8, 11, 4),
+                                       (32, 32, 3, 5)])
 def test_ns_column_kernel_other_heights_bitwise(dtype, ny, nx, B, K):
-    """The other instantiated grid heights (11, 16, 26, 31 rows) against the workgroup kernel."""
+    """The other instantiated grid heights (8, 11, 16, 26, 31, 32 rows) against the workgroup kernel."""
     import os
     from pdecontrolgym_amd.batch2d import NSBatch2D
     td = getattr(torch, dtype)
