@@ -31,8 +31,10 @@ constexpr int kRows = 16;                   // observation rows per workgroup (t
 constexpr int kMaxWidth = PDEGYM_MLP_MAX_WIDTH;
 constexpr int kMaxTiles = kMaxWidth / 64;   // 16-neuron tiles per wave (four waves share a layer's tiles round-robin)
 constexpr int kXChunk = 512;                // observation entries per row staged in LDS at a time
-constexpr int kLdx = kXChunk + 4;           // LDS row strides: 16-byte aligned, and 16 rows x one float4 hit 64 distinct banks
-constexpr int kLdh = kMaxWidth + 4;
+// LDS row strides are (a multiple of 64) + 4 floats: 16-byte aligned rows, and 16 rows x one float4 hit 64 distinct banks.
+// The staging area is sized by the launch for the layer widths at hand (dynamic LDS): a 257-64-64-1 policy takes 25 KB per
+// workgroup instead of the 50 KB of the largest shapes, so four workgroups share a CU when the batch is large.
+__host__ __device__ constexpr int lds_stride(int width) { return ((width + 63) / 64) * 64 + 4; }
 constexpr int kStage = 4;                   // k-blocks (of 16 inputs) per software-pipeline stage
 
 __device__ __forceinline__ float activate(float v, int act) {
@@ -99,12 +101,14 @@ __device__ __forceinline__ void reduce_blocks(v4f (&acc)[NT], v4f (&wa)[kStage][
 
 template <int NT, typename TX, typename TY>   // NT = 16-neuron tiles per wave = ceil(width of the widest layer / 64)
 __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX* __restrict__ x, long long x_stride,
-                                                          TY* __restrict__ y, long long y_stride, int B) {
+                                                          TY* __restrict__ y, long long y_stride, int B, int ldx) {
   // LDS: activations ping-pong between hb0 and hb1; the staged observation chunk shares its space with hb1 (first written
   // by the second layer, when the observations are no longer needed)
-  __shared__ __attribute__((aligned(16))) float hb0[kRows * kLdh];
-  __shared__ __attribute__((aligned(16))) float xs[kRows * kLdx];
-  static_assert(kLdx >= kLdh, "hb1 lives inside the observation staging area");
+  extern __shared__ __attribute__((aligned(16))) float mlp_smem[];
+  constexpr int kLdh = lds_stride(64 * NT);
+  const int kLdx = ldx;                              // >= kLdh (the launch takes the larger of the two)
+  float* const hb0 = mlp_smem;
+  float* const xs = mlp_smem + kRows * kLdh;
   auto hbuf = [&](int i) -> float* { return i ? xs : hb0; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;      // MFMA operand lane = (row or neuron li, k-slot lg)
@@ -230,16 +234,24 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX
 
 }  // namespace
 
+template <int NT, typename TX, typename TY>
+static void launch_mlp_nt(const pdegym_mlp* net, const TX* xp, long long xs, TY* yp, long long ys, int B, hipStream_t st) {
+  const int kin = net->layer[0].in_dim < kXChunk ? net->layer[0].in_dim : kXChunk;
+  const int ldh = lds_stride(64 * NT);
+  const int ldx = lds_stride(kin) > ldh ? lds_stride(kin) : ldh;
+  const size_t lds_bytes = (size_t)kRows * (ldh + ldx) * sizeof(float);         // <= 50 KB: below the 64 KB that need no opt-in
+  hipLaunchKernelGGL((mlp_forward_kernel<NT, TX, TY>), dim3((B + kRows - 1) / kRows), dim3(256), lds_bytes, st, *net, xp, xs, yp, ys, B, ldx);
+}
+
 template <typename TX, typename TY>
 static void launch_mlp(const pdegym_mlp* net, const void* x, long long xs, void* y, long long ys, int B, int width, hipStream_t st) {
-  const dim3 grid((B + kRows - 1) / kRows), block(256);
   const TX* xp = static_cast<const TX*>(x);
   TY* yp = static_cast<TY*>(y);
   switch ((width + 63) / 64) {
-    case 1: hipLaunchKernelGGL((mlp_forward_kernel<1, TX, TY>), grid, block, 0, st, *net, xp, xs, yp, ys, B); break;
-    case 2: hipLaunchKernelGGL((mlp_forward_kernel<2, TX, TY>), grid, block, 0, st, *net, xp, xs, yp, ys, B); break;
-    case 3: hipLaunchKernelGGL((mlp_forward_kernel<3, TX, TY>), grid, block, 0, st, *net, xp, xs, yp, ys, B); break;
-    default: hipLaunchKernelGGL((mlp_forward_kernel<4, TX, TY>), grid, block, 0, st, *net, xp, xs, yp, ys, B); break;
+    case 1: launch_mlp_nt<1, TX, TY>(net, xp, xs, yp, ys, B, st); break;
+    case 2: launch_mlp_nt<2, TX, TY>(net, xp, xs, yp, ys, B, st); break;
+    case 3: launch_mlp_nt<3, TX, TY>(net, xp, xs, yp, ys, B, st); break;
+    default: launch_mlp_nt<4, TX, TY>(net, xp, xs, yp, ys, B, st); break;
   }
 }
 

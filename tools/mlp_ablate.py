@@ -2,7 +2,7 @@ import sys, os, time
 sys.path.insert(0, os.getcwd())
 import torch
 from pdecontrolgym_amd.policy import FusedMLP
-B = 4096
+B = int(os.environ.get("MLP_B", 4096))
 L = torch.nn.Linear
 def seq(*m): return torch.nn.Sequential(*m).cuda()
 T = torch.nn.Tanh
