@@ -133,6 +133,12 @@ typedef struct pdegym_bufs1d {
   int32_t* reset_count;     /* optional [B] in/out: restarts of each instance so far (k above); NULL = always row b  */
   int32_t reset_pool_rows;  /* rows of reset_init / reset_beta (0 = B)                                            */
   int32_t reserved_;
+  /* With full-state sensing the observation IS the row (hyperbolic.py:72-75, parabolic.py:74-77).  state_in, when non-NULL
+   * (needs sensing == PDEGYM_SENSE_FULL and history == NULL): the rows are READ from state_in [B, n] -- the obs buffer of the
+   * previous call -- and the new rows are written to obs only; u is not touched and may be NULL.  One row store per instance
+   * and env-step instead of two; obs must not alias state_in (double-buffer the observations).  pdegym_reset1d_masked with
+   * u == NULL likewise writes the reset rows to obs only. */
+  const float* state_in;
 } pdegym_bufs1d;
 
 int pdegym_abi_version(void);

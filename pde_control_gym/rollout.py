@@ -53,7 +53,9 @@ class DeviceRollout:
             core.t["p_out"] = None
         try:
             self._steps(core, torch)
-            if self._ns:    # the observation IS the Navier-Stokes state: leave it in the engine's own buffer, not in slot T
+            if self._ns or getattr(core, "state_in_obs", False):
+                # the observation IS the state (Navier-Stokes; the 1D engines with full-state sensing): leave it in the engine's
+                # own buffer, not in slot T
                 own["obs"].copy_(self.obs[self.T])
         finally:
             if pingpong:
@@ -63,10 +65,14 @@ class DeviceRollout:
             # (graph-safe: only Python references change)
             for k, v in own.items():
                 core.t[k] = v
+            if getattr(core, "state_in_obs", False):
+                core.t["u"] = core.t["obs"]
 
     def _steps(self, core, torch):
-        if self._ns:        # slot 0 of the rollout buffer is the input state of the first step (not the engine's own buffer,
-            core.t["obs"] = self.obs[0]        # which a graph warm-up run leaves in its end state)
+        if self._ns or getattr(core, "state_in_obs", False):
+            # slot 0 of the rollout buffer is the input state of the first step (not the engine's own buffer, which a graph
+            # warm-up run leaves in its end state)
+            core.t["obs"] = self.obs[0]
         fused = hasattr(self.policy, "forward_into") and self.obs.dtype in (torch.float32, torch.float64)
         for t in range(self.T):
             nz = self.action_noise[t] if self.action_noise is not None else None

@@ -51,7 +51,8 @@ class Bufs1D(C.Structure):
                 ("reward", C.c_void_p), ("norm_now", C.c_void_p), ("norm_back", C.c_void_p),
                 ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("history", C.c_void_p),
                 ("reset_init", C.c_void_p), ("final_obs", C.c_void_p), ("reset_beta", C.c_void_p),
-                ("reset_count", C.c_void_p), ("reset_pool_rows", C.c_int32), ("reserved_", C.c_int32)]
+                ("reset_count", C.c_void_p), ("reset_pool_rows", C.c_int32), ("reserved_", C.c_int32),
+                ("state_in", C.c_void_p)]
 
 
 class ParamsNS2D(C.Structure):

@@ -46,7 +46,11 @@ class HipBackend:
     def _bufs1d(T) -> N.Bufs1D:
         import torch
         b = N.Bufs1D()
-        b.u = N.dptr(T["u"], torch.float32)
+        si = T.get("state_in")
+        if si is not None:       # the rows live in the (double-buffered) observation tensors: read from the previous one
+            b.state_in, b.u = N.dptr(si, torch.float32), None
+        else:
+            b.u = N.dptr(T["u"], torch.float32) if T.get("u") is not None else None
         b.beta = N.dptr(T["beta"])                 # float32, or float64 in the reference's mixed-precision mode (P.beta_f64)
         b.beta_stride = 0 if T["beta"].dim() == 1 else T["beta"].stride(0)
         b.action = N.dptr(T["action"])             # float32, or float64 when P.action_kind != ACTION_F32
@@ -72,7 +76,7 @@ class HipBackend:
             raise N.NativeError("reset_beta needs a per-instance beta [B, n] and the shape of reset_init")
         return b
 
-    @_on_device_of("u")
+    @_on_device_of("obs")
     def step1d(self, kind: str, P: N.Params1D, T: dict, B: int):
         import torch
         fn = self.lib.pdegym_transport_step if kind == "transport" else self.lib.pdegym_parabolic_step
@@ -81,15 +85,15 @@ class HipBackend:
         if T["action"].dtype != (torch.float32 if P.action_kind == N.ACTION_F32 else torch.float64):
             raise N.NativeError(f"action is {T['action'].dtype} but params.action_kind = {P.action_kind}")
         bufs = self._bufs1d(T)
-        N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["u"].device)), f"pdegym_{kind}_step")
+        N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["obs"].device)), f"pdegym_{kind}_step")
 
-    @_on_device_of("u")
+    @_on_device_of("obs")
     def reset1d(self, P: N.Params1D, T: dict, init, mask, B: int):
         import torch
         bufs = self._bufs1d(T)
         m = N.dptr(mask, torch.uint8) if mask is not None else None
         N.check(self.lib.pdegym_reset1d_masked(C.byref(P), C.byref(bufs), N.dptr(init, torch.float32), m, B,
-                                               N.current_stream_ptr(T["u"].device)), "pdegym_reset1d_masked")
+                                               N.current_stream_ptr(T["obs"].device)), "pdegym_reset1d_masked")
 
     @_on_device_of("u")
     def rownorm2(self, rows, out):

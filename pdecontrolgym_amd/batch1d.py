@@ -62,7 +62,7 @@ class PDEBatch1D:
                  control_type: str = "Dirchilet", sensing_loc: str = "full", sensing_type="Dirchilet",
                  normalize: bool = False, max_control_value: float = 20, limit_pde_state_size: bool = False,
                  max_state_value: float = 1e10, reward: RewardSpec | None = None, num_envs: int = 1,
-                 device="cuda", backend=None, record_history: bool = False, flux: str = "linear"):
+                 device="cuda", backend=None, record_history: bool = False, state_in_obs: bool = True, flux: str = "linear"):
         import torch
         assert kind in ("transport", "parabolic")
         if flux not in ("linear", "burgers") or (flux == "burgers" and kind != "transport"):
@@ -132,6 +132,13 @@ class PDEBatch1D:
         self._obs = [torch.zeros(B, self.obs_dim, dtype=f32, device=dev) for _ in range(2)]
         self._flip = 0
         self.t["obs"] = self._obs[0]
+        # Full-state sensing: the observation IS the row (hyperbolic.py:72-75), so the state lives only in the observation
+        # tensors -- a step reads the previous observation (bufs.state_in) and writes the next one, one row store instead of
+        # two.  ``t["u"]`` then names the CURRENT observation tensor (rebound after every step / reset).
+        self.state_in_obs = self.sensing == N.SENSE_FULL and not record_history and state_in_obs
+        self.t["state_in"] = None
+        if self.state_in_obs:
+            self.t["u"] = self.t["obs"]
 
     # ---- state accessors ---------------------------------------------------------------------------
     @property
@@ -176,7 +183,11 @@ class PDEBatch1D:
             # masked reset writes into the CURRENT obs buffer so untouched instances keep their observation
         else:
             self._next_obs()
+        if self.state_in_obs:
+            self.t["u"] = None                      # the reset rows go to the observation buffer only
         self.backend.reset1d(self.params, self.t, init, mask, self.num_envs)
+        if self.state_in_obs:
+            self.t["u"] = self.t["obs"]
         return self.t["obs"]
 
     def enable_auto_reset(self, init_pool, keep_final_obs: bool = True, beta_pool=None):
@@ -223,14 +234,23 @@ class PDEBatch1D:
         a = action.to(device=self.device, dtype=adt).reshape(self.num_envs).contiguous()
         self.t["action"] = a
         self.params.action_kind = action_kind
+        prev = self.t["obs"]
         if out_obs is not None:
             self.t["obs"] = out_obs.view(self.num_envs, self.obs_dim)
         else:
             self._next_obs()
+            if self.state_in_obs and self.t["obs"] is prev:   # never write the observation over the state it is computed from
+                self._next_obs()
+        if self.state_in_obs:
+            if self.t["obs"].data_ptr() == prev.data_ptr():
+                raise ValueError("out_obs must not be the tensor that holds the current observation (it is the state)")
+            self.t["state_in"], self.t["u"] = prev, None
         for key, out in (("reward", out_reward), ("terminated", out_terminated), ("truncated", out_truncated)):
             if out is not None:
                 self.t[key] = out
         self.backend.step1d(self.kind, self.params, self.t, self.num_envs)
+        if self.state_in_obs:
+            self.t["u"] = self.t["obs"]
         return self.t["obs"], self.t["reward"], self.t["terminated"], self.t["truncated"]
 
     # ---- roofline bookkeeping ---------------------------------------------
@@ -240,5 +260,6 @@ class PDEBatch1D:
         return self.substeps * 12 * self.n + 4 * self.n + 16
 
     def compulsory_bytes_per_env_step(self) -> int:
-        """What the fused kernel must move: row in, beta in, row out, obs out (+ scalars)."""
-        return 4 * self.n * 3 + 4 * self.obs_dim + 64
+        """What the fused kernel must move: row in, beta in, row out, obs out (+ scalars); with the state in the observation
+        tensors the row is written once."""
+        return 4 * self.n * (2 if self.state_in_obs else 3) + 4 * self.obs_dim + 64

@@ -419,16 +419,18 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
 #ifdef PDEGYM_TIMING
   const unsigned long long tmk = __builtin_amdgcn_s_memtime() + (unsigned long long)(n == 0x7fffffff);  // kernarg arrived
 #endif
-  float* urow = Bf.u + (size_t)inst * n;
+  // state_in given: the row comes from the previous call's observation and goes to obs only (include/pdegym.h)
+  const float* urow_in = (Bf.state_in ? Bf.state_in : Bf.u) + (size_t)inst * n;
+  float* urow = Bf.state_in ? nullptr : Bf.u + (size_t)inst * n;
   const bool beta64 = M64 && P.beta_f64;
   // float32 beta row; in the mixed-precision mode with a float64 beta it is read as double below (beta then stays zero)
-  const float* brow = beta64 ? urow : static_cast<const float*>(Bf.beta) + (size_t)inst * Bf.beta_stride;
+  const float* brow = beta64 ? urow_in : static_cast<const float*>(Bf.beta) + (size_t)inst * Bf.beta_stride;
   float* ring = Bf.ring + (size_t)inst * PDEGYM_RING;
   float* hist = (HIST && Bf.history) ? Bf.history + (size_t)inst * P.nt * n : nullptr;
 
   Row<EPL> R;
   float beta[EPL];
-  load_row<EPL, PARABOLIC>(R, beta, urow, brow, n, lane);
+  load_row<EPL, PARABOLIC>(R, beta, urow_in, brow, n, lane);
   double b64[M64 ? EPL : 1];
   if constexpr (M64) {
     const double* brow64 = static_cast<const double*>(Bf.beta) + (size_t)inst * Bf.beta_stride;
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
       // inf/NaN somewhere (or a squared overflow): 0*inf may have leaked into a frozen slot -> redo exactly
       exact = !(fabsf(norm_now) <= 3.4028234663852886e38f);
       if (exact) {
-        load_row<EPL, PARABOLIC>(R, beta, urow, brow, n, lane);
+        load_row<EPL, PARABOLIC>(R, beta, urow_in, brow, n, lane);
         R.t = t_in;
         R.k = (t_in + PDEGYM_LOOKBACK) % S;
         R.bsum = bsum_in;
@@ -579,7 +581,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
     Bf.truncated[inst] = truncate ? 1 : 0;
   }
   if (!auto_reset) {
-    if (nsub > 0) {
+    if (nsub > 0 && urow) {
       if (PARABOLIC && lane == 0) urow[0] = R.bl;
 #pragma unroll
       for (int e = 0; e < EPL; ++e)
@@ -608,11 +610,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
     }
     if (Bf.reset_count && lane == 0) Bf.reset_count[inst] += 1;
     R.bl = PARABOLIC ? irow[0] : 0.f;
-    if (PARABOLIC && lane == 0) urow[0] = R.bl;
+    if (PARABOLIC && lane == 0 && urow) urow[0] = R.bl;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
       R.x[e] = (s0 + e < ns) ? irow[J0 + s0 + e] : 0.f;
-      if (s0 + e < ns) urow[J0 + s0 + e] = R.x[e];
+      if (s0 + e < ns && urow) urow[J0 + s0 + e] = R.x[e];
     }
     if constexpr (HIST) {
       if (hist)
@@ -667,14 +669,15 @@ __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, p
   const int n = P.n;
   float* cur = wl;
   float* nxt = wl + n;
-  float* urow = Bf.u + (size_t)inst * n;
+  const float* urow_in = (Bf.state_in ? Bf.state_in : Bf.u) + (size_t)inst * n;      // include/pdegym.h: state_in
+  float* urow = Bf.state_in ? nullptr : Bf.u + (size_t)inst * n;
   const bool beta64 = M64 && P.beta_f64;
   const float* brow = static_cast<const float*>(Bf.beta) + (beta64 ? 0 : (size_t)inst * Bf.beta_stride);
   const double* brow64 = static_cast<const double*>(Bf.beta) + (beta64 ? (size_t)inst * Bf.beta_stride : 0);
   float* ring = Bf.ring + (size_t)inst * PDEGYM_RING;
   float* hist = Bf.history ? Bf.history + (size_t)inst * P.nt * n : nullptr;
   const bool neumann = P.control_type == PDEGYM_CONTROL_NEUMANN;
-  for (int j = lane; j < n; j += kWave) cur[j] = urow[j];
+  for (int j = lane; j < n; j += kWave) cur[j] = urow_in[j];
   const int t_in = Bf.time_index[inst];
   const int S = P.substeps > 0 ? P.substeps : 1;
   int nsub = P.nt - 1 - t_in;
@@ -812,7 +815,7 @@ __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, p
     Bf.truncated[inst] = truncate ? 1 : 0;
   }
   if (!auto_reset) {
-    if (nsub > 0)
+    if (nsub > 0 && urow)
       for (int j = lane; j < n; j += kWave) urow[j] = cur[j];
     emit_obs(Bf.obs, cur);
     if (lane == 0) {
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, p
     for (int j = lane; j < n; j += kWave) {
       const float v = irow[j];
       nxt[j] = v;
-      urow[j] = v;
+      if (urow) urow[j] = v;
     }
     if (hist)
       for (size_t q = lane; q < (size_t)P.nt * n; q += kWave) hist[q] = (q < (size_t)n) ? irow[q] : 0.f;
@@ -864,11 +867,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void reset1d_kernel(pdegym_p
   if (mask && !mask[inst]) return;
   const int n = P.n;
   const float* src = init + (size_t)inst * n;
-  float* urow = Bf.u + (size_t)inst * n;
+  float* urow = Bf.u ? Bf.u + (size_t)inst * n : nullptr;      // NULL: the state lives in the observation buffers
   float ss = 0.f;
   for (int j = lane; j < n; j += kWave) {
     const float v = src[j];
-    urow[j] = v;
+    if (urow) urow[j] = v;
     if (P.sensing == PDEGYM_SENSE_FULL) Bf.obs[(size_t)inst * n + j] = v;
     ss += v * v;
   }
@@ -951,9 +954,14 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
   const pdegym_params1d& P = *prm;
   if (P.n < 3 || P.n > PDEGYM_MAX_N1D_WIDE) return pdegym::fail(-2, "n must be in [3, 8192] for the 1D kernels");
   if (P.nt < 2) return pdegym::fail(-2, "nt must be >= 2");
-  if (!buf->u || !buf->beta || !buf->action || !buf->time_index || !buf->bsum || !buf->ring || !buf->obs ||
+  if ((!buf->u && !buf->state_in) || !buf->beta || !buf->action || !buf->time_index || !buf->bsum || !buf->ring || !buf->obs ||
       !buf->norm_now || !buf->norm_back || !buf->terminated || !buf->truncated)
     return pdegym::fail(-3, "null device buffer");
+  if (buf->state_in) {
+    if (P.sensing != PDEGYM_SENSE_FULL) return pdegym::fail(-2, "state_in needs full-state sensing (the observation is the row)");
+    if (buf->history) return pdegym::fail(-2, "state_in cannot be combined with a history buffer");
+    if (buf->state_in == buf->obs) return pdegym::fail(-3, "state_in must not alias obs (double-buffer the observations)");
+  }
   if (P.reward_kind != PDEGYM_REWARD_NONE && !buf->reward) return pdegym::fail(-3, "null reward buffer");
   hipStream_t st = (hipStream_t)stream;
   if (P.action_kind < PDEGYM_ACTION_F32 || P.action_kind > PDEGYM_ACTION_WEAK) return pdegym::fail(-2, "bad action_kind");
@@ -1020,6 +1028,7 @@ int pdegym_reset1d_masked(const pdegym_params1d* prm, const pdegym_bufs1d* buf, 
   if (!prm || !buf || !init) return pdegym::fail(-1, "null params/bufs/init");
   if (B <= 0) return 0;
   if (prm->n < 3) return pdegym::fail(-2, "n must be >= 3");
+  if (!buf->u && prm->sensing != PDEGYM_SENSE_FULL) return pdegym::fail(-3, "u may only be NULL with full-state sensing (rows go to obs)");
   const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
   hipLaunchKernelGGL(reset1d_kernel, grid, block, 0, (hipStream_t)stream, *prm, *buf, init, mask, B);
   if (buf->history) {

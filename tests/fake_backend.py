@@ -43,7 +43,8 @@ class FakeBackend:
     def _load(self, orc, T, B):
         orc.B = B
         orc.beta = self._beta(T, B)
-        orc.row = T["u"].numpy().copy()
+        src = T["state_in"] if T.get("state_in") is not None else (T["u"] if T.get("u") is not None else T["obs"])
+        orc.row = src.numpy().copy()                 # state_in: the previous observation is the state (include/pdegym.h)
         orc.time_index = T["time_index"].numpy().astype(np.int64)
         orc.bsum = T["bsum"].numpy().copy()
         orc.ring = T["ring"].numpy().copy()
@@ -52,7 +53,8 @@ class FakeBackend:
             orc.hist = T["history"].numpy()          # shares memory with the tensor: rows are written in place
 
     def _store(self, orc, T):
-        T["u"].copy_(torch.from_numpy(orc.row))
+        if T.get("u") is not None:
+            T["u"].copy_(torch.from_numpy(orc.row))
         T["time_index"].copy_(torch.from_numpy(orc.time_index.astype(np.int32)))
         T["bsum"].copy_(torch.from_numpy(orc.bsum))
         T["ring"].copy_(torch.from_numpy(orc.ring))

@@ -610,3 +610,78 @@ def test_transport_quotient_equals_ieee_division(dx):
         rc = lib.pdegym_selftest_quotient(arr.data_ptr(), dx32, 1.0 / dx32, mism.data_ptr(), arr.numel(), N.current_stream_ptr())
         assert rc == 0
         assert int(mism.item()) == 0
+
+
+@pytest.mark.parametrize("kind,nx,S,beta64", [("parabolic", 256, 100, False), ("transport", 100, 30, False), ("transport", 3000, 4, False),
+                                              ("parabolic", 64, 10, True), ("transport", 700, 3, True)])
+def test_state_in_observation_mode_equals_separate_state(kind, nx, S, beta64):
+    """Full-state sensing: the rows live in the double-buffered observation tensors (bufs.state_in: one row store per env-step
+    instead of two).  Bit for bit the separate-state engine across episode ends with the fused auto-reset (initial-condition and
+    beta pools), a masked reset in between, the register / LDS-resident / mixed-precision kernels; the observation returned by
+    step k is still intact after step k+1."""
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
+    B = 7
+    dx = 1.0 / nx
+    dt = 0.25 * dx * dx if kind == "parabolic" else 0.5 * dx
+    nsteps = 9
+    kw = dict(T=5 * S * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type="Dirchilet", sensing_loc="full",
+              sensing_type=None, normalize=True, max_control_value=5.0, limit_pde_state_size=True, max_state_value=1e6)
+    rng = np.random.default_rng(nx + S)
+    envs = []
+    for mode in (True, False):
+        e = PDEBatch1D(kind, reward=RewardSpec(N.REWARD_TUNED1D, int(round(kw["T"] / dt)), -1e3, 3e2), num_envs=B, device="cuda",
+                       state_in_obs=mode, **kw)
+        assert e.state_in_obs == mode
+        envs.append(e)
+    n = envs[0].n
+    bdt = np.float64 if beta64 else np.float32
+    init = rng.uniform(1, 3, (B, n)).astype(np.float32)
+    beta = rng.uniform(-2, 2, (B, n)).astype(bdt)
+    pool_i = rng.uniform(1, 3, (3 * B, n)).astype(np.float32)
+    pool_b = rng.uniform(-2, 2, (3 * B, n)).astype(bdt)
+    acts = rng.uniform(-1, 1, (nsteps, B)).astype(np.float32)
+    outs = []
+    for e in envs:
+        o0 = e.reset(torch.tensor(init), torch.tensor(beta))
+        e.enable_auto_reset(torch.tensor(pool_i), keep_final_obs=True, beta_pool=torch.tensor(pool_b))
+        res = [o0.cpu().numpy().copy()]
+        prev, prev_copy = None, None
+        for k in range(nsteps):
+            if k == 4:
+                m = torch.tensor([1, 0, 0, 1, 0, 0, 1], dtype=torch.uint8)
+                e.reset(torch.tensor(init[::-1].copy()), mask=m)
+                prev = None                                  # a masked reset rewrites the current observation in place
+            obs, r, te, tr = e.step(torch.tensor(acts[k]))
+            if prev is not None:
+                np.testing.assert_array_equal(prev.cpu().numpy(), prev_copy)      # step k's observation survives step k+1
+            prev, prev_copy = obs, obs.cpu().numpy().copy()
+            res.append((obs.cpu().numpy().copy(), e.u.cpu().numpy().copy(), r.cpu().numpy().copy(), te.cpu().numpy().copy(),
+                        tr.cpu().numpy().copy(), e.time_index.cpu().numpy().copy(), e.t["final_obs"].cpu().numpy().copy(),
+                        e.t["beta"].cpu().numpy().copy()))
+        outs.append(res)
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    ended = 0
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(a[0], a[1])          # the observation IS the row
+        ended += int(a[3].sum() + a[4].sum())
+    assert ended > 0
+
+
+def test_state_in_abi_validation():
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D
+    env = PDEBatch1D("transport", 1, 1e-3, 1, 1e-2, 0.01, num_envs=2, device="cuda")
+    env.reset(torch.ones(2, 100), torch.ones(2, 100))
+    assert env.state_in_obs and env.u is env.t["obs"]
+    with pytest.raises(ValueError, match="out_obs"):
+        env.step(torch.zeros(2), out_obs=env.t["obs"])
+    env.params.sensing = N.SENSE_LAST                # state_in with a scalar observation: refused by the C side
+    with pytest.raises(N.NativeError, match="state_in"):
+        env.step(torch.zeros(2))
+    env.params.sensing = N.SENSE_FULL
+    env.step(torch.zeros(2))
+    hist = PDEBatch1D("transport", 1, 1e-3, 1, 1e-2, 0.01, num_envs=2, device="cuda", record_history=True)
+    assert not hist.state_in_obs                      # the history mode keeps its own state rows
