@@ -597,7 +597,8 @@ def main():
                 r2 = run_workload(w2, n2, max(5, args.warmup // 2), 1, graph=use_graph, repeats=3)
                 rf = roofline_block(w2, name, r2["step_ms_events"], True)
                 also[name] = {"value": w2.units_per_step() * n2 / r2["seconds"], "unit": "env-steps/s", "ms_per_step": r2["seconds"] / n2 * 1e3,
-                              "dtype": w2.dtype, "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "step_ms")},
+                              "dtype": w2.dtype, "timed_regions_s": r2["all_regions_s"],
+                              "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "step_ms")},
                               "config": w2.config()}
                 del w2
             except Exception as ex:  # keep the headline line alive
