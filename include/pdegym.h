@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PDEGYM_ABI_VERSION 9
+#define PDEGYM_ABI_VERSION 10
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
 #define PDEGYM_MAX_N1D 2048      /* nodes per 1D row kept in registers by the wave-per-instance kernels */
@@ -146,6 +146,27 @@ const char* pdegym_last_error(void);
 
 int pdegym_transport_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int32_t B, void* stream);
 int pdegym_parabolic_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int32_t B, void* stream);
+
+/* T env-steps in ONE launch (the on-device rollout of SURVEY.md section 8f rank 1 without a kernel boundary per step).
+ * Step t reads the rows from obs slot t, the commands from actions row t, and writes obs slot t + 1, rewards / terminated /
+ * truncated row t; everything else (beta, time_index, bsum, ring, norm_now, norm_back, the auto-reset pools, final_obs,
+ * reset_count) comes from the pdegym_bufs1d of the call and behaves as in T consecutive pdegym_*_step calls with state_in --
+ * the results are bit-identical to those calls.  bufs->u / state_in / obs / action / reward / terminated / truncated / history
+ * are ignored.  Needs sensing == PDEGYM_SENSE_FULL, Dirichlet actuation, float32 beta and actions, n <= 2048. */
+typedef struct pdegym_rollout1d {
+  int32_t T;                /* env-steps per call                                                              */
+  int32_t reserved_;
+  float* obs;               /* [T + 1, B, n]  slot 0 = the input rows; slots 1 .. T are written                 */
+  const float* actions;     /* [T, B]                                                                          */
+  float* rewards;           /* [T, B]  (may be NULL with PDEGYM_REWARD_NONE)                                   */
+  uint8_t* terminated;      /* [T, B]                                                                          */
+  uint8_t* truncated;       /* [T, B]                                                                          */
+} pdegym_rollout1d;
+
+int pdegym_transport_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const pdegym_rollout1d* ro, int32_t B,
+                             void* stream);
+int pdegym_parabolic_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const pdegym_rollout1d* ro, int32_t B,
+                             void* stream);
 
 /* Where mask[b] != 0 (or mask == NULL): u[b] = init[b], beta untouched, time_index = 0, bsum = |init[b,-1]|,
  * ring[b, 0] = ||init[b]|| , obs[b] = sensing(init[b]).  (hyperbolic.py:214-227) */

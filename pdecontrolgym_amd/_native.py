@@ -11,10 +11,11 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 RING = 128
 LOOKBACK = 100
 MAX_N1D = 8192
+MAX_N1D_REG = 2048      # rows kept in registers (PDEGYM_MAX_N1D); the rollout kernel handles these
 
 CONTROL = {"Dirchilet": 0, "Neumann": 1}
 FLUX_LINEAR, FLUX_BURGERS = 0, 1
@@ -30,6 +31,7 @@ EXPORTS = [
     "pdegym_ns2d_solve_pressure_f32", "pdegym_ns2d_solve_pressure_f64", "pdegym_ns2d_reset_masked_f32",
     "pdegym_ns2d_reset_masked_f64", "pdegym_traffic_step", "pdegym_traffic_reset_masked",
     "pdegym_tumor_step", "pdegym_tumor_advance", "pdegym_tumor_reset_masked", "pdegym_mlp_forward",
+    "pdegym_transport_rollout", "pdegym_parabolic_rollout",
 ]
 MLP_MAX_LAYERS, MLP_MAX_WIDTH, MLP_MAX_INPUT = 4, 256, 8192
 MLP_IDENTITY, MLP_TANH, MLP_RELU = 0, 1, 2
@@ -53,6 +55,11 @@ class Bufs1D(C.Structure):
                 ("reset_init", C.c_void_p), ("final_obs", C.c_void_p), ("reset_beta", C.c_void_p),
                 ("reset_count", C.c_void_p), ("reset_pool_rows", C.c_int32), ("reserved_", C.c_int32),
                 ("state_in", C.c_void_p)]
+
+
+class Rollout1D(C.Structure):
+    _fields_ = [("T", C.c_int32), ("reserved_", C.c_int32), ("obs", C.c_void_p), ("actions", C.c_void_p),
+                ("rewards", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p)]
 
 
 class ParamsNS2D(C.Structure):
@@ -135,6 +142,9 @@ def load():
     for name in ("pdegym_transport_step", "pdegym_parabolic_step"):
         f = getattr(lib, name)
         f.argtypes = [C.POINTER(Params1D), C.POINTER(Bufs1D), C.c_int32, C.c_void_p]
+        f.restype = C.c_int
+    for f in (lib.pdegym_transport_rollout, lib.pdegym_parabolic_rollout):
+        f.argtypes = [C.POINTER(Params1D), C.POINTER(Bufs1D), C.POINTER(Rollout1D), C.c_int32, C.c_void_p]
         f.restype = C.c_int
     lib.pdegym_reset1d_masked.argtypes = [C.POINTER(Params1D), C.POINTER(Bufs1D), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.pdegym_reset1d_masked.restype = C.c_int

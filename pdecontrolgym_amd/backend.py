@@ -88,6 +88,25 @@ class HipBackend:
         N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["obs"].device)), f"pdegym_{kind}_step")
 
     @_on_device_of("obs")
+    def rollout1d(self, kind: str, P: N.Params1D, T: dict, obs, actions, rewards, terminated, truncated, B: int):
+        """T env-steps in one launch (pdegym_*_rollout): ``obs`` [T+1, B, n] (slot 0 = input rows), ``actions`` / ``rewards`` /
+        ``terminated`` / ``truncated`` [T, B]."""
+        import torch
+        fn = self.lib.pdegym_transport_rollout if kind == "transport" else self.lib.pdegym_parabolic_rollout
+        steps = int(actions.shape[0])
+        if tuple(obs.shape) != (steps + 1, B, P.n) or not obs.is_contiguous():
+            raise N.NativeError(f"rollout obs must be a contiguous [{steps + 1}, {B}, {P.n}] tensor, got {tuple(obs.shape)}")
+        for name, x in (("actions", actions), ("rewards", rewards), ("terminated", terminated), ("truncated", truncated)):
+            if tuple(x.shape) != (steps, B) or not x.is_contiguous():
+                raise N.NativeError(f"rollout {name} must be a contiguous [{steps}, {B}] tensor, got {tuple(x.shape)}")
+        bufs = self._bufs1d({**T, "state_in": None, "u": None, "history": None})
+        ro = N.Rollout1D()
+        ro.T = steps
+        ro.obs, ro.actions, ro.rewards = N.dptr(obs, torch.float32), N.dptr(actions, torch.float32), N.dptr(rewards, torch.float32)
+        ro.terminated, ro.truncated = N.dptr(terminated, torch.uint8), N.dptr(truncated, torch.uint8)
+        N.check(fn(C.byref(P), C.byref(bufs), C.byref(ro), B, N.current_stream_ptr(obs.device)), f"pdegym_{kind}_rollout")
+
+    @_on_device_of("obs")
     def reset1d(self, P: N.Params1D, T: dict, init, mask, B: int):
         import torch
         bufs = self._bufs1d(T)

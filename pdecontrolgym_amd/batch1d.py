@@ -253,6 +253,25 @@ class PDEBatch1D:
             self.t["u"] = self.t["obs"]
         return self.t["obs"], self.t["reward"], self.t["terminated"], self.t["truncated"]
 
+    def can_rollout(self) -> bool:
+        """True when ``rollout`` applies: the observation is the row (full-state sensing, no history), Dirichlet actuation,
+        float32 operands, register-resident rows."""
+        return bool(self.state_in_obs and self.params.control_type != N.CONTROL["Neumann"] and not self.params.beta_f64
+                    and self.n <= N.MAX_N1D_REG and hasattr(self.backend, "rollout1d"))
+
+    def rollout(self, obs, actions, rewards, terminated, truncated):
+        """T env-steps in ONE launch (include/pdegym.h: pdegym_*_rollout): step t reads the rows from ``obs[t]`` and the
+        commands from ``actions[t]``, writes ``obs[t + 1]``, ``rewards[t]``, ``terminated[t]``, ``truncated[t]`` -- bit-identical
+        to T calls of ``step(actions[t], out_obs=obs[t + 1], ...)`` from the state in ``obs[0]``, fused auto-reset included.
+        Afterwards the engine's current observation (its state) is a copy of ``obs[T]``."""
+        if not self.can_rollout():
+            raise ValueError("rollout needs full-state sensing without history, Dirichlet actuation and float32 operands")
+        self.params.action_kind = N.ACTION_F32
+        self.backend.rollout1d(self.kind, self.params, self.t, obs, actions, rewards, terminated, truncated, self.num_envs)
+        self.t["obs"].copy_(obs[-1])
+        self.t["u"] = self.t["obs"]
+        return obs, rewards, terminated, truncated
+
     # ---- roofline bookkeeping (SURVEY.md section 8d) ---------------------------------------------
     def algorithmic_bytes_per_env_step(self) -> int:
         """Streaming model: each sub-step reads the previous row and beta and writes the new row

@@ -404,13 +404,12 @@ __device__ __forceinline__ void load_row(Row<EPL>& R, float (&beta)[EPL], const 
   R.bl = PARABOLIC ? urow[0] : 0.f;
 }
 
+// One env-step of one instance by one wave: the body of step1d_kernel, and of every iteration of rollout1d_kernel.
 template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false, bool M64 = false>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_params1d P, pdegym_bufs1d Bf, int B) {
+__device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdegym_bufs1d& Bf, const int B, const int inst,
+                                            const int lane) {
   constexpr int J0 = PARABOLIC ? 1 : 0;
   constexpr bool kFast = !NEUMANN && !HIST && !M64;
-  const int lane = threadIdx.x & (kWave - 1);
-  const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (inst >= B) return;  // wave-uniform
 #ifdef PDEGYM_TIMING
   const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
   const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
@@ -642,6 +641,44 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
     dbg[9] = (unsigned int)(tmk - tm0);
   }
 #endif
+}
+
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false, bool M64 = false>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_params1d P, pdegym_bufs1d Bf, int B) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (inst >= B) return;  // wave-uniform
+  step1d_body<EPL, PARABOLIC, NEUMANN, HIST, BURGERS, M64>(P, Bf, B, inst, lane);
+}
+
+// T env-steps of one instance by one wave in ONE launch (pdegym_*_rollout): iteration t is exactly the step kernel's body with
+// the row read from observation slot t and written to slot t + 1, action / reward / flags taken from / written to row t of
+// the [T, B] rollout arrays -- so every value equals what T separate step calls produce, bit for bit.  What it removes is
+// the kernel boundary between env-steps: no dispatch gap, no L2 invalidate (the row a wave wrote is re-read from its own
+// CU's cache path), and the waves of a SIMD drift apart instead of finishing in two generations.
+template <int EPL, bool PARABOLIC, bool BURGERS>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void rollout1d_kernel(pdegym_params1d P, pdegym_bufs1d Bf, pdegym_rollout1d Ro,
+                                                                         int B) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (inst >= B) return;  // wave-uniform
+  const size_t slot = (size_t)B * P.n;
+  for (int t = 0; t < Ro.T; ++t) {
+    pdegym_bufs1d S = Bf;
+    S.u = nullptr;
+    S.history = nullptr;
+    S.state_in = Ro.obs + (size_t)t * slot;
+    S.obs = Ro.obs + (size_t)(t + 1) * slot;
+    S.action = Ro.actions + (size_t)t * B;
+    S.reward = Ro.rewards + (size_t)t * B;
+    S.terminated = Ro.terminated + (size_t)t * B;
+    S.truncated = Ro.truncated + (size_t)t * B;
+    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false>(P, S, B, inst, lane);
+    // lane 0's stores (node 0 of a parabolic row, time index, |u| sum, norm ring) are read by the whole wave in the next
+    // iteration: make them visible first
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
 }
 
 
@@ -1009,9 +1046,58 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
   }
 }
 
+template <bool PARABOLIC, bool BURGERS = false>
+int launch_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const pdegym_rollout1d* ro, int B, void* stream) {
+  if (!prm || !buf || !ro) return pdegym::fail(-1, "null params/bufs/rollout");
+  if (B <= 0 || ro->T <= 0) return 0;
+  const pdegym_params1d& P = *prm;
+  if (P.n < 3 || P.n > PDEGYM_MAX_N1D) return pdegym::fail(-2, "rollout: n must be in [3, 2048] (register-resident rows)");
+  if (P.nt < 2) return pdegym::fail(-2, "nt must be >= 2");
+  if (P.sensing != PDEGYM_SENSE_FULL) return pdegym::fail(-2, "rollout needs full-state sensing (slot t of obs is the state of step t)");
+  if (P.control_type == PDEGYM_CONTROL_NEUMANN) return pdegym::fail(-2, "rollout: Neumann actuation is not supported");
+  if (P.beta_f64 || P.action_kind != PDEGYM_ACTION_F32) return pdegym::fail(-2, "rollout: float32 beta and actions only");
+  if (buf->history) return pdegym::fail(-2, "rollout cannot record a history buffer");
+  if (!buf->beta || !buf->time_index || !buf->bsum || !buf->ring || !buf->norm_now || !buf->norm_back)
+    return pdegym::fail(-3, "null device buffer");
+  if (!ro->obs || !ro->actions || !ro->terminated || !ro->truncated) return pdegym::fail(-3, "null rollout buffer");
+  if (P.reward_kind != PDEGYM_REWARD_NONE && !ro->rewards) return pdegym::fail(-3, "null reward buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+  const int nslots = P.n - (PARABOLIC ? 1 : 0);
+  const int epl = (nslots + kWave - 1) / kWave;
+  auto go = [&](auto tag) {
+    constexpr int E = decltype(tag)::value;
+    hipLaunchKernelGGL((rollout1d_kernel<E, PARABOLIC, BURGERS>), grid, block, 0, st, P, *buf, *ro, B);
+  };
+  // the same slots-per-lane choice as launch_step: the norm reductions (hence rewards) depend on the layout
+  if (epl <= 1) go(std::integral_constant<int, 1>{});
+  else if (epl <= 2) go(std::integral_constant<int, 2>{});
+  else if (epl <= 3) go(std::integral_constant<int, 3>{});
+  else if (epl <= 4) go(std::integral_constant<int, 4>{});
+  else if (epl <= 5) go(std::integral_constant<int, 5>{});
+  else if (epl <= 6) go(std::integral_constant<int, 6>{});
+  else if (epl <= 8) go(std::integral_constant<int, 8>{});
+  else if (epl <= 12) go(std::integral_constant<int, 12>{});
+  else if (epl <= 16) go(std::integral_constant<int, 16>{});
+  else if (epl <= 24) go(std::integral_constant<int, 24>{});
+  else go(std::integral_constant<int, 32>{});
+  return pdegym::check_launch("rollout1d");
+}
+
 }  // namespace
 
 extern "C" {
+
+int pdegym_transport_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const pdegym_rollout1d* ro, int32_t B,
+                             void* stream) {
+  if (prm && prm->flux == PDEGYM_FLUX_BURGERS) return launch_rollout<false, true>(prm, buf, ro, B, stream);
+  return launch_rollout<false, false>(prm, buf, ro, B, stream);
+}
+
+int pdegym_parabolic_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const pdegym_rollout1d* ro, int32_t B,
+                             void* stream) {
+  return launch_rollout<true>(prm, buf, ro, B, stream);
+}
 
 int pdegym_transport_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int32_t B, void* stream) {
   // flux = PDEGYM_FLUX_BURGERS is an extension that the reference does not have

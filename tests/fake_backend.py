@@ -87,6 +87,14 @@ class FakeBackend:
                     T["reset_count"][dm] += 1
                 self.reset1d(P, T, T["reset_init"][rows].contiguous(), torch.from_numpy(done.astype(np.uint8)), B, _keep_flags=True)
 
+    def rollout1d(self, kind, P, T, obs, actions, rewards, terminated, truncated, B):
+        # the C ABI's contract: T step calls with the row read from slot t and written to slot t + 1
+        for t in range(actions.shape[0]):
+            S = dict(T)
+            S.update(state_in=obs[t], u=None, obs=obs[t + 1], action=actions[t], reward=rewards[t], terminated=terminated[t],
+                     truncated=truncated[t], history=None)
+            self.step1d(kind, P, S, B)
+
     def reset1d(self, P, T, init, mask, B, _keep_flags=False):
         orc = self._orc1d(P)
         m = np.ones(B, dtype=bool) if mask is None else mask.numpy().astype(bool)

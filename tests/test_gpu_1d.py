@@ -685,3 +685,71 @@ def test_state_in_abi_validation():
     env.step(torch.zeros(2))
     hist = PDEBatch1D("transport", 1, 1e-3, 1, 1e-2, 0.01, num_envs=2, device="cuda", record_history=True)
     assert not hist.state_in_obs                      # the history mode keeps its own state rows
+
+
+@pytest.mark.parametrize("kind,nx,S,burgers", [("parabolic", 256, 100, False), ("transport", 100, 30, False), ("transport", 512, 20, True),
+                                               ("parabolic", 40, 7, False), ("transport", 1500, 3, False)])
+def test_rollout_kernel_equals_step_calls_bitwise(kind, nx, S, burgers):
+    """pdegym_*_rollout (T env-steps in one launch, the row never leaves the wave's cache path) against T step calls: every
+    observation slot, reward, flag, the time index, |u| sum, norm ring, restart counters, redrawn beta rows and the kept
+    terminal observations agree bit for bit, across episode ends with the fused auto-reset."""
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
+    B, T = 9, 11
+    dx = 1.0 / nx
+    dt = 0.25 * dx * dx if kind == "parabolic" else 0.5 * dx
+    kw = dict(T=4 * S * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type="Dirchilet", sensing_loc="full",
+              sensing_type=None, normalize=True, max_control_value=5.0, limit_pde_state_size=True, max_state_value=1e6)
+    if burgers:
+        kw["flux"] = "burgers"
+    rng = np.random.default_rng(nx * 7 + S)
+    envs = [PDEBatch1D(kind, reward=RewardSpec(N.REWARD_TUNED1D, int(round(kw["T"] / dt)), -1e3, 3e2), num_envs=B, device="cuda", **kw)
+            for _ in range(2)]
+    n = envs[0].n
+    init = rng.uniform(0.5, 2, (B, n)).astype(np.float32)
+    beta = rng.uniform(-2, 2, (B, n)).astype(np.float32)
+    pool_i = rng.uniform(0.5, 2, (2 * B, n)).astype(np.float32)
+    pool_b = rng.uniform(-2, 2, (2 * B, n)).astype(np.float32)
+    acts = torch.tensor(rng.uniform(-1, 1, (T, B)).astype(np.float32), device="cuda")
+    bufs = []
+    for e in envs:
+        assert e.can_rollout()
+        e.reset(torch.tensor(init), torch.tensor(beta))
+        e.enable_auto_reset(torch.tensor(pool_i), keep_final_obs=True, beta_pool=torch.tensor(pool_b))
+        obs = torch.zeros(T + 1, B, n, device="cuda")
+        obs[0].copy_(e.t["obs"])
+        bufs.append((obs, torch.zeros(T, B, device="cuda"), torch.zeros(T, B, dtype=torch.uint8, device="cuda"),
+                     torch.zeros(T, B, dtype=torch.uint8, device="cuda")))
+    # (a) T step calls through the rollout buffers
+    e, (obs, rew, te, tr) = envs[0], bufs[0]
+    e.t["obs"] = obs[0]
+    e.t["u"] = obs[0]
+    for t in range(T):
+        e.step(acts[t], out_obs=obs[t + 1], out_reward=rew[t], out_terminated=te[t], out_truncated=tr[t])
+    # (b) one rollout launch
+    e2, (obs2, rew2, te2, tr2) = envs[1], bufs[1]
+    e2.rollout(obs2, acts, rew2, te2, tr2)
+    for a, b in ((obs, obs2), (rew, rew2), (te, te2), (tr, tr2)):
+        np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    for k in ("time_index", "bsum", "ring", "reset_count", "beta", "final_obs", "norm_now", "norm_back"):
+        np.testing.assert_array_equal(e.t[k].cpu().numpy(), e2.t[k].cpu().numpy(), err_msg=k)
+    np.testing.assert_array_equal(e2.t["obs"].cpu().numpy(), obs2[T].cpu().numpy())
+    assert int(te.sum() + tr.sum()) > 0
+    # the engine carries on from slot T with ordinary step calls
+    o_a = e.step(acts[0])[0].cpu().numpy()
+    o_b = e2.step(acts[0])[0].cpu().numpy()
+    np.testing.assert_array_equal(o_a, o_b)
+
+
+def test_rollout_abi_validation():
+    from pdecontrolgym_amd.batch1d import PDEBatch1D
+    env = PDEBatch1D("transport", 1, 1e-3, 1, 1e-2, 0.01, num_envs=2, device="cuda", sensing_loc="opposite", sensing_type="Dirchilet")
+    assert not env.can_rollout()
+    with pytest.raises(ValueError):
+        env.rollout(None, None, None, None, None)
+    env = PDEBatch1D("transport", 1, 1e-3, 1, 1e-2, 0.01, num_envs=2, device="cuda", sensing_loc="full", sensing_type=None)
+    env.reset(torch.ones(2, 100), torch.ones(2, 100))
+    n = env.n
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device="cuda")   # noqa: E731
+    with pytest.raises(Exception, match="obs"):
+        env.rollout(z(4, 2, n), z(4, 2), z(4, 2), z(4, 2, dt=torch.uint8), z(4, 2, dt=torch.uint8))   # T + 1 slots needed

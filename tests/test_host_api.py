@@ -483,3 +483,42 @@ def test_device_rollout_with_fused_policy_and_exploration_noise_on_cpu_double():
     assert not torch.equal(before, ro.actions)
     with torch.no_grad():
         np.testing.assert_allclose(ro.actions[0].numpy(), net(ro.obs[0]).reshape(B).clamp(-1, 1).numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_engine_rollout_equals_step_loop_on_the_cpu_double():
+    """PDEBatch1D.rollout (pdegym_*_rollout on the GPU) is T step calls through the rollout buffers: host-side contract on the
+    oracle-backed double, with fused auto-reset."""
+    import torch
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
+    B, T, nx, S = 3, 7, 20, 5
+    dx = 1.0 / nx
+    dt = 0.25 * dx * dx
+    kw = dict(T=3 * S * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type="Dirchilet", sensing_loc="full",
+              sensing_type=None, normalize=True, max_control_value=5.0, limit_pde_state_size=True, max_state_value=1e6)
+    rng = np.random.default_rng(5)
+    outs = []
+    for mode in ("steps", "rollout"):
+        e = PDEBatch1D("parabolic", reward=RewardSpec(N.REWARD_TUNED1D, int(round(kw["T"] / dt)), -1e3, 3e2), num_envs=B,
+                       device="cpu", backend=FakeBackend(), **kw)
+        n = e.n
+        rng = np.random.default_rng(5)
+        e.reset(torch.tensor(rng.uniform(1, 2, (B, n)).astype(np.float32)), torch.tensor(rng.uniform(-1, 1, (B, n)).astype(np.float32)))
+        e.enable_auto_reset(torch.tensor(rng.uniform(1, 2, (2 * B, n)).astype(np.float32)), keep_final_obs=True)
+        acts = torch.tensor(rng.uniform(-1, 1, (T, B)).astype(np.float32))
+        obs = torch.zeros(T + 1, B, n)
+        obs[0].copy_(e.t["obs"])
+        rew, te, tr = torch.zeros(T, B), torch.zeros(T, B, dtype=torch.uint8), torch.zeros(T, B, dtype=torch.uint8)
+        if mode == "steps":
+            e.t["obs"] = obs[0]
+            e.t["u"] = obs[0]
+            for t in range(T):
+                e.step(acts[t], out_obs=obs[t + 1], out_reward=rew[t], out_terminated=te[t], out_truncated=tr[t])
+        else:
+            assert e.can_rollout()
+            e.rollout(obs, acts, rew, te, tr)
+            assert torch.equal(e.t["obs"], obs[T])
+        outs.append((obs, rew, te, tr, e.t["time_index"].clone(), e.t["reset_count"].clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert int(outs[0][2].sum()) > 0
