@@ -157,10 +157,16 @@ typedef struct pdegym_rollout1d {
   int32_t T;                /* env-steps per call                                                              */
   int32_t reserved_;
   float* obs;               /* [T + 1, B, n]  slot 0 = the input rows; slots 1 .. T are written                 */
-  const float* actions;     /* [T, B]                                                                          */
+  float* actions;           /* [T, B]  read; with a policy: WRITTEN (the command the policy issued, after noise and clamp) */
   float* rewards;           /* [T, B]  (may be NULL with PDEGYM_REWARD_NONE)                                   */
   uint8_t* terminated;      /* [T, B]                                                                          */
   uint8_t* truncated;       /* [T, B]                                                                          */
+  /* Optional policy (HOST pointer, read during the call; see pdegym_mlp below): evaluated INSIDE the launch on observation
+   * slot t -- the caller of env.step of an SB3 rollout (transport1Dppo.py:88-90) without a launch of its own.  Layers of up
+   * to 64 units, first in_dim == n, one output; the whole network must fit into 160 KB of LDS next to 16 observation rows
+   * (n <= 513).  noise, when given, is [T, B] (row t, instance b at noise[(t * B + b) * noise_stride]), added before the
+   * clamp.  Same arithmetic as pdegym_mlp_forward except for the order of the additions inside a group of 16 inputs. */
+  const struct pdegym_mlp_s* policy;
 } pdegym_rollout1d;
 
 int pdegym_transport_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const pdegym_rollout1d* ro, int32_t B,
@@ -377,7 +383,7 @@ typedef struct {
   int32_t reserved_;
 } pdegym_mlp_layer;
 
-typedef struct {
+typedef struct pdegym_mlp_s {
   int32_t n_layers;    /* 1 .. PDEGYM_MLP_MAX_LAYERS                                 */
   int32_t clamp;       /* nonzero: the last layer's output is clamped to [lo, hi]   */
   float lo, hi;

@@ -13,10 +13,11 @@ class DeviceRollout:
     """``policy``: callable mapping an observation tensor [B, obs_dim] to actions [B] (or [B, 1]) on the same device -- any
     torch module, or a ``pdecontrolgym_amd.FusedMLP`` (Linear/Tanh/ReLU stack evaluated, clamped and stored in ONE launch).
     Buffers: ``obs[T+1, B, D]``, ``actions[T, B]`` (``[T, B, action_dim]`` for Navier-Stokes and two-command traffic), ``rewards[T, B]``, ``terminated[T, B]``, ``truncated[T, B]``; with
-    ``action_noise=True`` also ``action_noise[T, B]`` (float32), added to the policy output of step t before the clamp."""
+    ``action_noise=True`` also ``action_noise[T, B]`` (float32), added to the policy output of step t before the clamp.
+    ``one_launch``: see the constructor (1D engines with full-state sensing + a small ``FusedMLP``: the rollout is ONE kernel)."""
 
     def __init__(self, venv, policy, n_steps: int, use_graph: bool = True, action_low: float = -1.0, action_high: float = 1.0,
-                 action_noise: bool = False):
+                 action_noise: bool = False, one_launch=None):
         import torch
         kind = getattr(venv, "kind", "tumor")
         self.venv, self.policy, self.T = venv, policy, int(n_steps)
@@ -40,12 +41,23 @@ class DeviceRollout:
         # caller fills the buffer in place before each run() (e.g. ``ro.action_noise.normal_().mul_(std)``): a replayed graph
         # reads the new draws.
         self.action_noise = torch.zeros_like(self.actions, dtype=torch.float32) if action_noise else None
+        # transport / reaction-diffusion with full-state sensing and a small FusedMLP: the WHOLE rollout is one kernel launch
+        # (pdegym_*_rollout with the policy inside: no kernel boundary between env-steps, none between policy and step).
+        # one_launch=None: whenever it applies; True: required; False: T x (policy launch + step launch) as for the others.
+        fits = bool(hasattr(core, "policy_fits_rollout") and core.policy_fits_rollout(policy) and dt == torch.float32)
+        if one_launch and not fits:
+            raise ValueError("one_launch=True needs a 1D engine with full-state sensing and a FusedMLP of <= 64-unit layers")
+        self.one_launch = fits if one_launch is None else bool(one_launch)
         self.use_graph = bool(use_graph) and dev.type == "cuda"
         self._graph = None
 
     def _body(self):
         import torch
         core = self.venv.core
+        if self.one_launch:
+            core.rollout(self.obs, self.actions, self.rewards, self.terminated, self.truncated, policy=self.policy,
+                         clamp=(self.lo, self.hi), noise=self.action_noise)
+            return
         own = {k: core.t[k] for k in ("reward", "terminated", "truncated", "obs") if k in core.t} if self._direct else {}
         pingpong = self._ns and getattr(core, "_p_pingpong", False)
         if pingpong:        # keep the pressure in ONE tensor while the steps are baked into a graph (the C side copies it home)

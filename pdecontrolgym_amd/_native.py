@@ -59,7 +59,7 @@ class Bufs1D(C.Structure):
 
 class Rollout1D(C.Structure):
     _fields_ = [("T", C.c_int32), ("reserved_", C.c_int32), ("obs", C.c_void_p), ("actions", C.c_void_p),
-                ("rewards", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p)]
+                ("rewards", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("policy", C.c_void_p)]
 
 
 class ParamsNS2D(C.Structure):

@@ -88,9 +88,10 @@ class HipBackend:
         N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["obs"].device)), f"pdegym_{kind}_step")
 
     @_on_device_of("obs")
-    def rollout1d(self, kind: str, P: N.Params1D, T: dict, obs, actions, rewards, terminated, truncated, B: int):
+    def rollout1d(self, kind: str, P: N.Params1D, T: dict, obs, actions, rewards, terminated, truncated, B: int, policy=None):
         """T env-steps in one launch (pdegym_*_rollout): ``obs`` [T+1, B, n] (slot 0 = input rows), ``actions`` / ``rewards`` /
-        ``terminated`` / ``truncated`` [T, B]."""
+        ``terminated`` / ``truncated`` [T, B].  ``policy``: an ``N.Mlp`` descriptor evaluated inside the launch (``actions`` is
+        then an output; its ``noise``, if set, is [T, B])."""
         import torch
         fn = self.lib.pdegym_transport_rollout if kind == "transport" else self.lib.pdegym_parabolic_rollout
         steps = int(actions.shape[0])
@@ -104,6 +105,7 @@ class HipBackend:
         ro.T = steps
         ro.obs, ro.actions, ro.rewards = N.dptr(obs, torch.float32), N.dptr(actions, torch.float32), N.dptr(rewards, torch.float32)
         ro.terminated, ro.truncated = N.dptr(terminated, torch.uint8), N.dptr(truncated, torch.uint8)
+        ro.policy = C.addressof(policy) if policy is not None else None
         N.check(fn(C.byref(P), C.byref(bufs), C.byref(ro), B, N.current_stream_ptr(obs.device)), f"pdegym_{kind}_rollout")
 
     @_on_device_of("obs")

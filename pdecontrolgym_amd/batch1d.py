@@ -259,15 +259,41 @@ class PDEBatch1D:
         return bool(self.state_in_obs and self.params.control_type != N.CONTROL["Neumann"] and not self.params.beta_f64
                     and self.n <= N.MAX_N1D_REG and hasattr(self.backend, "rollout1d"))
 
-    def rollout(self, obs, actions, rewards, terminated, truncated):
+    def policy_fits_rollout(self, policy) -> bool:
+        """Whether ``policy`` (a ``FusedMLP``) can be evaluated inside the rollout kernel: observation rows of at most 513
+        nodes as its input, layers of at most 64 units, one output, and weights + 16 observation rows within 160 KB of LDS."""
+        if not (self.can_rollout() and hasattr(policy, "layers") and hasattr(policy, "_net")):
+            return False
+        dims = [(int(w.shape[1]), int(w.shape[0])) for w, _, _ in policy.layers]
+        if dims[0][0] != self.n or self.n > 513 or dims[-1][1] != 1 or any(o > 64 for _, o in dims):
+            return False
+        floats = sum(((i + 3) // 4) * 4 * o + 64 for i, o in dims) + 16 * (((self.n + 3) // 4) * 4 + 128)
+        return 4 * floats <= 160 * 1024
+
+    def rollout(self, obs, actions, rewards, terminated, truncated, policy=None, clamp="default", noise=None):
         """T env-steps in ONE launch (include/pdegym.h: pdegym_*_rollout): step t reads the rows from ``obs[t]`` and the
         commands from ``actions[t]``, writes ``obs[t + 1]``, ``rewards[t]``, ``terminated[t]``, ``truncated[t]`` -- bit-identical
         to T calls of ``step(actions[t], out_obs=obs[t + 1], ...)`` from the state in ``obs[0]``, fused auto-reset included.
-        Afterwards the engine's current observation (its state) is a copy of ``obs[T]``."""
+        Afterwards the engine's current observation (its state) is a copy of ``obs[T]``.
+
+        ``policy`` (a ``FusedMLP`` with layers of at most 64 units and one output, see ``policy_fits_rollout``): evaluated
+        inside the launch on ``obs[t]``; ``actions[t]`` then RECEIVES the command (after ``noise[t]`` [T, B] float32 and the
+        clamp), as ``policy.forward_into(obs[t], actions[t], clamp, noise[t])`` would have written it."""
         if not self.can_rollout():
             raise ValueError("rollout needs full-state sensing without history, Dirichlet actuation and float32 operands")
         self.params.action_kind = N.ACTION_F32
-        self.backend.rollout1d(self.kind, self.params, self.t, obs, actions, rewards, terminated, truncated, self.num_envs)
+        net = None
+        if policy is not None:
+            if not self.policy_fits_rollout(policy):
+                raise ValueError("this policy cannot run inside the rollout kernel (see policy_fits_rollout)")
+            net = policy._net(policy.clamp if clamp == "default" else clamp)
+            if noise is not None:
+                import torch
+                if noise.dtype != torch.float32 or tuple(noise.shape) != tuple(actions.shape) or not noise.is_contiguous():
+                    raise ValueError("noise must be a contiguous float32 [T, B] tensor")
+                net.noise, net.noise_stride = noise.data_ptr(), 1
+        self.backend.rollout1d(self.kind, self.params, self.t, obs, actions, rewards, terminated, truncated, self.num_envs,
+                               policy=net)
         self.t["obs"].copy_(obs[-1])
         self.t["u"] = self.t["obs"]
         return obs, rewards, terminated, truncated

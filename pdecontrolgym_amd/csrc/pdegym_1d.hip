@@ -407,7 +407,7 @@ __device__ __forceinline__ void load_row(Row<EPL>& R, float (&beta)[EPL], const 
 // One env-step of one instance by one wave: the body of step1d_kernel, and of every iteration of rollout1d_kernel.
 template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false, bool M64 = false>
 __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdegym_bufs1d& Bf, const int B, const int inst,
-                                            const int lane) {
+                                            const int lane, const float* command = nullptr) {
   constexpr int J0 = PARABOLIC ? 1 : 0;
   constexpr bool kFast = !NEUMANN && !HIST && !M64;
 #ifdef PDEGYM_TIMING
@@ -443,7 +443,8 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
   nsub = nsub < P.substeps ? nsub : P.substeps;
   nsub = nsub > 0 ? nsub : 0;
   const bool act64 = M64 && P.action_kind != PDEGYM_ACTION_F32;
-  const float a = act64 ? 0.f : static_cast<const float*>(Bf.action)[inst];
+  // command: the control input computed inside the launch (rollout kernel with its policy) instead of bufs.action
+  const float a = command ? *command : (act64 ? 0.f : static_cast<const float*>(Bf.action)[inst]);
   const double a64 = act64 ? static_cast<const double*>(Bf.action)[inst] : 0.0;
   R.t = t_in;
   R.k = (t_in + PDEGYM_LOOKBACK) % S;
@@ -1046,6 +1047,115 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
   }
 }
 
+// ---- the policy inside the rollout kernel --------------------------------------------------------------------------------
+// A workgroup of 16 waves (16 instances, one CU's worth at four waves per SIMD) keeps ONE copy of the network in LDS for the
+// whole launch; every wave evaluates it for its own instance at the start of each env-step, on its own clock -- no barrier
+// after the weights are staged, so the waves of a SIMD keep drifting apart as in rollout1d_kernel.  Lane j owns neuron j
+// (layers of up to 64 units): per four inputs one 16-byte broadcast read of the layer input and one 16-byte read of the
+// lane's weights (the ABI's blocked transpose, copied verbatim), four fused multiply-adds; k ascending in ONE chain from
+// zero, bias added last -- the summation order pdegym_mlp_forward documents, up to the MFMA's order inside a group of 16.
+constexpr int kPolicyWaves = 16;
+constexpr int kPolicyMaxWidth = 64;
+constexpr int kPolicyMaxLdsBytes = 160 * 1024;
+
+__host__ __device__ inline int policy_xpad(int n) { return (n + 3) & ~3; }
+// floats of LDS: per layer its blocked weights and a bias row of 64, then per wave the padded observation row and two
+// hidden rows of 64
+__host__ __device__ inline int policy_lds_floats(const pdegym_mlp& N, int n) {
+  int f = 0;
+  for (int l = 0; l < N.n_layers; ++l) f += ((N.layer[l].in_dim + 3) >> 2) * 4 * N.layer[l].out_dim + kPolicyMaxWidth;
+  return f + kPolicyWaves * (policy_xpad(n) + 2 * kPolicyMaxWidth);
+}
+
+__device__ __forceinline__ float policy_activate(float v, int act) {
+  if (act == PDEGYM_MLP_TANH) return tanhf(v);
+  if (act == PDEGYM_MLP_RELU) return v > 0.f ? v : 0.f;
+  return v;
+}
+
+template <int EPL, bool PARABOLIC, bool BURGERS>
+__global__ __launch_bounds__(kWave* kPolicyWaves) void rollout1d_policy_kernel(pdegym_params1d P, pdegym_bufs1d Bf, pdegym_rollout1d Ro,
+                                                                               pdegym_mlp N, int B) {
+  extern __shared__ __attribute__((aligned(16))) float pol_smem[];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int inst = blockIdx.x * kPolicyWaves + wave;
+  const int n = P.n, xpad = policy_xpad(n);
+  // stage the network once
+  int woff[PDEGYM_MLP_MAX_LAYERS], boff[PDEGYM_MLP_MAX_LAYERS];
+  int off = 0;
+#pragma unroll
+  for (int l = 0; l < PDEGYM_MLP_MAX_LAYERS; ++l) {
+    woff[l] = boff[l] = 0;
+    if (l < N.n_layers) {
+      const int nw = ((N.layer[l].in_dim + 3) >> 2) * 4 * N.layer[l].out_dim;
+      woff[l] = off;
+      boff[l] = off + nw;
+      for (int i = threadIdx.x; i < nw; i += kWave * kPolicyWaves) pol_smem[off + i] = N.layer[l].w[i];
+      for (int i = threadIdx.x; i < kPolicyMaxWidth; i += kWave * kPolicyWaves)
+        pol_smem[off + nw + i] = (N.layer[l].b && i < N.layer[l].out_dim) ? N.layer[l].b[i] : 0.f;
+      off += nw + kPolicyMaxWidth;
+    }
+  }
+  __syncthreads();
+  if (inst >= B) return;  // wave-uniform, after the only barrier
+  float* const xw = pol_smem + off + wave * (xpad + 2 * kPolicyMaxWidth);
+  float* const hw = xw + xpad;
+  const size_t slot = (size_t)B * n;
+  for (int t = 0; t < Ro.T; ++t) {
+    // observation of this instance (slot t) -> LDS, zero-padded to a multiple of four
+    const float* xrow = Ro.obs + (size_t)t * slot + (size_t)inst * n;
+    for (int j = lane; j < xpad; j += kWave) xw[j] = j < n ? xrow[j] : 0.f;
+    wave_lds_sync();
+    const float* in = xw;
+    int K = n;
+    float out = 0.f;
+#pragma unroll
+    for (int l = 0; l < PDEGYM_MLP_MAX_LAYERS; ++l) {
+      if (l < N.n_layers) {
+        const int H = N.layer[l].out_dim, ng = (K + 3) >> 2;
+        const int jj = lane < H ? lane : H - 1;
+        const float4* W = reinterpret_cast<const float4*>(pol_smem + woff[l]) + jj;
+        const float4* X = reinterpret_cast<const float4*>(in);
+        float acc = 0.f;
+        for (int kb = 0; kb < ng; ++kb) {
+          const float4 xv = X[kb], wv = W[(size_t)kb * H];
+          acc = __builtin_fmaf(xv.x, wv.x, acc);
+          acc = __builtin_fmaf(xv.y, wv.y, acc);
+          acc = __builtin_fmaf(xv.z, wv.z, acc);
+          acc = __builtin_fmaf(xv.w, wv.w, acc);
+        }
+        const float o = policy_activate(acc + pol_smem[boff[l] + jj], N.layer[l].act);
+        if (l == N.n_layers - 1) {
+          out = o;
+        } else {
+          float* hl = hw + (l & 1) * kPolicyMaxWidth;
+          hl[lane] = lane < H ? o : 0.f;      // zero beyond the layer width: the next layer reads whole groups of four
+          wave_lds_sync();
+          in = hl;
+          K = H;
+        }
+      }
+    }
+    float a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, out)));   // neuron 0 of the last layer
+    if (N.noise) a += N.noise[((size_t)t * B + inst) * N.noise_stride];
+    if (N.clamp) a = fminf(fmaxf(a, N.lo), N.hi);
+    if (lane == 0) Ro.actions[(size_t)t * B + inst] = a;
+
+    pdegym_bufs1d S = Bf;
+    S.u = nullptr;
+    S.history = nullptr;
+    S.state_in = Ro.obs + (size_t)t * slot;
+    S.obs = Ro.obs + (size_t)(t + 1) * slot;
+    S.action = Ro.actions + (size_t)t * B;
+    S.reward = Ro.rewards + (size_t)t * B;
+    S.terminated = Ro.terminated + (size_t)t * B;
+    S.truncated = Ro.truncated + (size_t)t * B;
+    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false>(P, S, B, inst, lane, &a);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
 template <bool PARABOLIC, bool BURGERS = false>
 int launch_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const pdegym_rollout1d* ro, int B, void* stream) {
   if (!prm || !buf || !ro) return pdegym::fail(-1, "null params/bufs/rollout");
@@ -1062,9 +1172,44 @@ int launch_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const p
   if (!ro->obs || !ro->actions || !ro->terminated || !ro->truncated) return pdegym::fail(-3, "null rollout buffer");
   if (P.reward_kind != PDEGYM_REWARD_NONE && !ro->rewards) return pdegym::fail(-3, "null reward buffer");
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
   const int nslots = P.n - (PARABOLIC ? 1 : 0);
   const int epl = (nslots + kWave - 1) / kWave;
+  if (ro->policy) {
+    const pdegym_mlp& N = *ro->policy;
+    if (N.n_layers < 1 || N.n_layers > PDEGYM_MLP_MAX_LAYERS) return pdegym::fail(-2, "policy: n_layers must be 1..4");
+    for (int l = 0; l < N.n_layers; ++l) {
+      const pdegym_mlp_layer& L = N.layer[l];
+      if (!L.w) return pdegym::fail(-3, "policy: null weight pointer");
+      if (L.in_dim != (l ? N.layer[l - 1].out_dim : P.n)) return pdegym::fail(-2, "policy: layer input size must match the row / the previous layer");
+      if (L.out_dim < 1 || L.out_dim > kPolicyMaxWidth) return pdegym::fail(-2, "policy inside the rollout kernel: layers of 1..64 units");
+      if (L.act < PDEGYM_MLP_IDENTITY || L.act > PDEGYM_MLP_RELU) return pdegym::fail(-2, "policy: unknown activation");
+    }
+    if (N.layer[N.n_layers - 1].out_dim != 1) return pdegym::fail(-2, "policy: the 1D environments take one command per instance");
+    if (N.x_f64 || N.y_f64) return pdegym::fail(-2, "policy inside the rollout kernel: float32 observations and commands");
+    if (N.clamp && !(N.lo <= N.hi)) return pdegym::fail(-2, "policy: clamp bounds must satisfy lo <= hi");
+    if (N.noise && N.noise_stride < 1) return pdegym::fail(-2, "policy: noise stride must be >= 1");
+    if (epl > 8) return pdegym::fail(-2, "policy inside the rollout kernel: rows of up to 513 nodes");
+    const int lds_bytes = policy_lds_floats(N, P.n) * (int)sizeof(float);
+    if (lds_bytes > kPolicyMaxLdsBytes) return pdegym::fail(-2, "policy inside the rollout kernel: the network does not fit into 160 KB of LDS");
+    const dim3 pgrid((B + kPolicyWaves - 1) / kPolicyWaves), pblock(kWave * kPolicyWaves);
+    bool ok = true;
+    auto gop = [&](auto tag) {
+      constexpr int E = decltype(tag)::value;
+      static signed char attr[pdegym::kMaxDevices] = {};
+      ok = pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&rollout1d_policy_kernel<E, PARABOLIC, BURGERS>), kPolicyMaxLdsBytes, attr);
+      if (ok) hipLaunchKernelGGL((rollout1d_policy_kernel<E, PARABOLIC, BURGERS>), pgrid, pblock, lds_bytes, st, P, *buf, *ro, N, B);
+    };
+    if (epl <= 1) gop(std::integral_constant<int, 1>{});
+    else if (epl <= 2) gop(std::integral_constant<int, 2>{});
+    else if (epl <= 3) gop(std::integral_constant<int, 3>{});
+    else if (epl <= 4) gop(std::integral_constant<int, 4>{});
+    else if (epl <= 5) gop(std::integral_constant<int, 5>{});
+    else if (epl <= 6) gop(std::integral_constant<int, 6>{});
+    else gop(std::integral_constant<int, 8>{});
+    if (!ok) return pdegym::fail(-4, "cannot raise the dynamic LDS limit of rollout1d_policy_kernel");
+    return pdegym::check_launch("rollout1d_policy");
+  }
+  const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
   auto go = [&](auto tag) {
     constexpr int E = decltype(tag)::value;
     hipLaunchKernelGGL((rollout1d_kernel<E, PARABOLIC, BURGERS>), grid, block, 0, st, P, *buf, *ro, B);

@@ -87,9 +87,17 @@ class FakeBackend:
                     T["reset_count"][dm] += 1
                 self.reset1d(P, T, T["reset_init"][rows].contiguous(), torch.from_numpy(done.astype(np.uint8)), B, _keep_flags=True)
 
-    def rollout1d(self, kind, P, T, obs, actions, rewards, terminated, truncated, B):
-        # the C ABI's contract: T step calls with the row read from slot t and written to slot t + 1
+    def rollout1d(self, kind, P, T, obs, actions, rewards, terminated, truncated, B, policy=None):
+        # the C ABI's contract: T step calls with the row read from slot t and written to slot t + 1 (and the policy, when
+        # given, evaluated on slot t first)
+        import ctypes as C
         for t in range(actions.shape[0]):
+            if policy is not None:
+                net = type(policy)()
+                C.memmove(C.addressof(net), C.addressof(policy), C.sizeof(policy))
+                if policy.noise:
+                    net.noise = policy.noise + 4 * t * B * policy.noise_stride
+                self.mlp_forward(net, obs[t], actions[t].view(B, 1), B)
             S = dict(T)
             S.update(state_in=obs[t], u=None, obs=obs[t + 1], action=actions[t], reward=rewards[t], terminated=terminated[t],
                      truncated=truncated[t], history=None)

@@ -200,3 +200,90 @@ def test_device_rollout_with_fused_policy_equals_torch_policy():
             np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
     for got, want in zip(runs["fused_graph"], runs["fused"]):
         np.testing.assert_array_equal(got, want)
+
+
+def _rd_env(B, nx, S, horizon, kind="PDEControlGym-ReactionDiffusionPDE1D", seed=3):
+    import pde_control_gym
+    from pde_control_gym.src import TunedReward1D
+    dx = 1.0 / nx
+    dt = 0.25 * dx * dx if "Reaction" in kind else 0.5 * dx
+    nodes = nx + 1 if "Reaction" in kind else nx
+    beta = np.full(nodes, 3.0, np.float32)
+    p = {"T": horizon * S * dt, "dt": dt, "X": 1, "dx": dx, "reward_class": TunedReward1D(horizon * S, -1e3, 3e2), "normalize": True,
+         "sensing_loc": "full", "control_type": "Dirchilet", "sensing_type": None, "sensing_noise_func": None,
+         "limit_pde_state_size": True, "max_state_value": 1e10, "max_control_value": 5, "control_sample_rate": S * dt,
+         "batched_reset_func": lambda idx, nx_: (np.random.default_rng(seed).uniform(1, 2, (len(idx), 1)).astype(np.float32)
+                                                 * np.ones((1, nodes), np.float32), np.tile(beta, (len(idx), 1)))}
+    venv = pde_control_gym.make_vec(kind, num_envs=B, **p)
+    venv.reset_tensor()
+    venv.enable_fused_auto_reset()
+    return venv
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,nx,S,B,sizes,acts", [
+    ("PDEControlGym-ReactionDiffusionPDE1D", 256, 20, 100, [257, 64, 64, 1], ["tanh", "tanh", "tanh"]),
+    ("PDEControlGym-ReactionDiffusionPDE1D", 64, 5, 37, [65, 48, 1], ["relu", None]),
+    ("PDEControlGym-TransportPDE1D", 100, 10, 16, [100, 64, 33, 20, 1], ["tanh", "relu", "tanh", "tanh"]),
+    ("PDEControlGym-TransportPDE1D", 512, 4, 5, [512, 32, 64, 1], ["tanh", "tanh", None]),
+    ("PDEControlGym-TransportPDE1D", 30, 3, 200, [30, 1], [None]),
+])
+def test_one_launch_rollout_with_policy_inside_equals_two_launches_per_step(kind, nx, S, B, sizes, acts):
+    """DeviceRollout(one_launch=True): policy + env-step + auto-reset of all T steps in ONE kernel (pdegym_*_rollout with a
+    policy) against the policy launch + step launch per env-step.  The environment arithmetic is identical; the two forward
+    passes differ in the order of the additions inside groups of 16 inputs (MFMA there, one fma chain here), so commands
+    agree to float32 rounding and the trajectories follow (tolerances below); episode ends and restarts coincide."""
+    from pde_control_gym import DeviceRollout
+    T = 9
+    net = _mlp(sizes, acts, seed=11).cuda()
+    with torch.no_grad():
+        net[0].weight.mul_(0.3)
+    runs = {}
+    for mode in (False, True):
+        venv = _rd_env(B, nx, S, horizon=4, kind=kind)
+        ro = DeviceRollout(venv, FusedMLP(net), T, action_low=-2.0, action_high=2.0, action_noise=True, one_launch=mode)
+        assert ro.one_launch == mode
+        ro.action_noise.copy_(torch.randn(T, B, generator=torch.Generator().manual_seed(1)).mul(0.3).cuda())
+        ro.run()
+        torch.cuda.synchronize()
+        runs[mode] = {k: getattr(ro, k).cpu().numpy().copy() for k in ("actions", "obs", "rewards", "terminated", "truncated")}
+        runs[mode]["time_index"] = venv.core.t["time_index"].cpu().numpy().copy()
+        runs[mode]["cur"] = venv.core.t["obs"].cpu().numpy().copy()
+        ro.run()                                   # the graph replays from the engine's new state
+        torch.cuda.synchronize()
+        runs[mode]["obs2"] = ro.obs.cpu().numpy().copy()
+    a, b = runs[True], runs[False]
+    np.testing.assert_allclose(a["actions"][0], b["actions"][0], rtol=2e-5, atol=4e-6)      # same input: forward passes only
+    for k in ("actions", "obs", "rewards", "cur", "obs2"):
+        np.testing.assert_allclose(a[k], b[k], rtol=1e-4, atol=2e-5, err_msg=k)
+    for k in ("terminated", "truncated", "time_index"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    np.testing.assert_array_equal(a["cur"], a["obs"][T])
+    np.testing.assert_array_equal(a["obs2"][0], a["cur"])
+    assert a["terminated"].sum() > 0
+    assert (np.abs(a["actions"]) == 2.0).sum() < a["actions"].size       # the clamp binds in places at most
+
+
+@pytest.mark.gpu
+def test_one_launch_rollout_falls_back_and_validates():
+    from pde_control_gym import DeviceRollout
+    venv = _rd_env(8, 64, 5, horizon=4)
+    wide = FusedMLP(_mlp([65, 128, 1], ["tanh", None]).cuda())
+    assert not venv.core.policy_fits_rollout(wide)
+    assert not DeviceRollout(venv, wide, 3).one_launch            # wider than 64 units: policy launch + step launch per env-step
+    with pytest.raises(ValueError):
+        DeviceRollout(venv, wide, 3, one_launch=True)
+    two_out = FusedMLP(_mlp([65, 16, 2], ["tanh", None]).cuda())
+    assert not venv.core.policy_fits_rollout(two_out)
+    assert not DeviceRollout(venv, torch.nn.Linear(65, 1).cuda(), 3).one_launch          # a plain torch module
+    # the C ABI itself refuses what the wrapper filters
+    core = venv.core
+    T, B, n = 3, 8, core.n
+    obs = torch.zeros(T + 1, B, n, device="cuda")
+    z = lambda dt: torch.zeros(T, B, dtype=dt, device="cuda")      # noqa: E731
+    with pytest.raises(N.NativeError, match="64 units"):
+        core.backend.rollout1d(core.kind, core.params, core.t, obs, z(torch.float32), z(torch.float32), z(torch.uint8), z(torch.uint8), B,
+                               policy=wide._net(None))
+    with pytest.raises(N.NativeError, match="one command"):
+        core.backend.rollout1d(core.kind, core.params, core.t, obs, z(torch.float32), z(torch.float32), z(torch.uint8), z(torch.uint8), B,
+                               policy=two_out._net(None))

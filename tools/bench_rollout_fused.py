@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """On-device rollout with the policy as a torch module vs pdecontrolgym_amd.FusedMLP (one launch for forward + clamp + store),
-replayed from one hipGraph; also the forward pass alone.  Usage: python tools/bench_rollout_fused.py [S]"""
+replayed from one hipGraph, vs the whole rollout as ONE launch (pdegym_*_rollout with the policy inside); also the forward pass alone.  Usage: python tools/bench_rollout_fused.py [S]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -22,11 +22,11 @@ p = {"T": 1000 * S * dt, "dt": dt, "X": 1, "dx": dx, "reward_class": TunedReward
 net = torch.nn.Sequential(torch.nn.Linear(nx + 1, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(),
                           torch.nn.Linear(64, 1), torch.nn.Tanh()).cuda()
 res = {}
-for name, pol in (("torch_module", net), ("fused_mlp", FusedMLP(net))):
+for name, pol, one in (("torch_module", net, False), ("fused_mlp", FusedMLP(net), False), ("one_launch", FusedMLP(net), True)):
     venv = pde_control_gym.make_vec("PDEControlGym-ReactionDiffusionPDE1D", num_envs=B, **p)
     venv.reset_tensor()
     venv.enable_fused_auto_reset()
-    ro = DeviceRollout(venv, pol, T, use_graph=True)
+    ro = DeviceRollout(venv, pol, T, use_graph=True, one_launch=one)
     ro.run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -39,7 +39,7 @@ for name, pol in (("torch_module", net), ("fused_mlp", FusedMLP(net))):
 x = torch.randn(B, nx + 1, device="cuda")
 out = torch.zeros(B, 1, device="cuda")
 fm = FusedMLP(net, clamp=(-1.0, 1.0))
-for name, fn in (("torch_module", lambda: out.copy_(net(x).clamp(-1, 1))), ("fused_mlp", lambda: fm.forward_into(x, out))):
+for name, fn in (("torch_module", lambda: out.copy_(net(x).clamp(-1, 1))), ("fused_mlp", lambda: fm.forward_into(x, out))):   # noqa: E501
     with torch.no_grad():
         fn()
         torch.cuda.synchronize()
