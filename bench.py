@@ -11,7 +11,8 @@ A "step" = one env-step of EVERY instance of the batch = one launch of the fused
 Default workload = BASELINE.json configs[1]: ReactionDiffusionPDE1D ("Parabolic1D") nx=256, batch 4096
 per GPU, fp32, S=100 sub-steps per env-step (SURVEY.md section 8d).  Other workloads (--workload NAME prints NAME's own line;
 the default run adds all of them under "also"): transport_c3, burgers_c3 (extension), parabolic_c2_policy_loop (C2 with its MLP
-controller evaluated on the device every step), ns2d_c4, ns2d_c4_f64, ns2d_c4_b4096, ns2d_c5, ns2d_example (the reference's
+controller evaluated on the device every step), parabolic_c2_rollout (the same loop as ONE kernel per 25 env-steps: here a
+"step" is one launch and `value` still counts env-steps), ns2d_c4, ns2d_c4_f64, ns2d_c4_b4096, ns2d_c5, ns2d_example (the reference's
 shipped 21x21 K=2000 float64 configuration), traffic_arz, brain_tumor.
 
 Prints ONE JSON line (rank 0).
@@ -165,6 +166,46 @@ class ParabolicPolicyLoop(Parabolic1D):
         return c
 
 
+class ParabolicRollout(ParabolicPolicyLoop):
+    """The same policy-in-the-loop rollout as ONE kernel per CHUNK env-steps (pdegym_parabolic_rollout with the policy inside,
+    include/pdegym.h): a bench "step" is one launch = CHUNK env-steps of every instance; `value` counts env-steps."""
+    CHUNK = 25
+    name = ("ReactionDiffusionPDE1D nx=256 B=4096 S=100, 257-64-64-1 tanh MLP policy, 25 env-steps per launch "
+            "(pdegym_parabolic_rollout: policy + env-step + auto-reset inside one kernel)")
+
+    def prepare(self, total_steps):
+        import torch
+        super().prepare(1)
+        T, B, n = self.CHUNK, self.B, self.env.n
+        self.robs = torch.zeros(T + 1, B, n, device=self.device)
+        self.robs[0].copy_(self.env.t["obs"])
+        self.ract = torch.zeros(T, B, device=self.device)
+        self.rrew = torch.zeros(T, B, device=self.device)
+        self.rte = torch.zeros(T, B, dtype=torch.uint8, device=self.device)
+        self.rtr = torch.zeros(T, B, dtype=torch.uint8, device=self.device)
+        assert self.env.policy_fits_rollout(self.policy)
+
+    def step(self):
+        self.env.rollout(self.robs, self.ract, self.rrew, self.rte, self.rtr, policy=self.policy)
+        self.robs[0].copy_(self.robs[self.CHUNK])         # the next chunk starts where this one ended
+        self.i += 1
+
+    def units_per_step(self):
+        return self.B * self.CHUNK
+
+    def algorithmic_bytes_per_step(self):
+        return super().algorithmic_bytes_per_step() * self.CHUNK
+
+    def compulsory_bytes_per_step(self):
+        return super().compulsory_bytes_per_step() * self.CHUNK
+
+    def config(self):
+        c = super().config()
+        c["policy"] = "MLP 257-64-64-1 tanh, float32, evaluated inside the rollout kernel (weights in LDS, one fma chain per neuron)"
+        c["env_steps_per_launch"] = self.CHUNK
+        return c
+
+
 class Transport1D(Parabolic1D):
     """BASELINE config 3 shape: TransportPDE1D nx=512, dt=0.5dx, S=100, B=16384/GPU (the reference has no
     Burgers env)."""
@@ -187,6 +228,8 @@ def cpu_port_rate(workload_key, seconds, seed=0):
     import numpy as np
     from oracle import pde_oracle as po
     rng = np.random.default_rng(seed)
+    if workload_key.startswith("parabolic_c2"):      # the policy-in-the-loop variants: the CPU port times the environment alone
+        workload_key = "parabolic_c2"
     if workload_key == "traffic_arz":
         env = po.TrafficOracle(240, 0.25, 500, 10, "outlet", 40, 0.16, 60, True, TrafficARZ.S)
         rs = [0.12]
@@ -378,6 +421,7 @@ class BrainTumor:
 
 from bench_ns2d import NavierStokesC4, NavierStokesC4B4096, NavierStokesC4F64, NavierStokesC5, NavierStokesExample  # noqa: E402
 WORKLOADS["parabolic_c2_policy_loop"] = ParabolicPolicyLoop
+WORKLOADS["parabolic_c2_rollout"] = ParabolicRollout
 WORKLOADS["ns2d_c4"] = NavierStokesC4
 WORKLOADS["ns2d_c4_f64"] = NavierStokesC4F64
 WORKLOADS["ns2d_c4_b4096"] = NavierStokesC4B4096

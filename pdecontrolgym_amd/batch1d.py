@@ -267,7 +267,7 @@ class PDEBatch1D:
         dims = [(int(w.shape[1]), int(w.shape[0])) for w, _, _ in policy.layers]
         if dims[0][0] != self.n or self.n > 513 or dims[-1][1] != 1 or any(o > 64 for _, o in dims):
             return False
-        floats = sum(((i + 3) // 4) * 4 * o + 64 for i, o in dims) + 16 * (((self.n + 3) // 4) * 4 + 128)
+        floats = sum((((i + 3) // 4) | 1) * 4 * o + 64 for i, o in dims) + 16 * (((self.n + 3) // 4) * 4 + 128)
         return 4 * floats <= 160 * 1024
 
     def rollout(self, obs, actions, rewards, terminated, truncated, policy=None, clamp="default", noise=None):

@@ -1052,18 +1052,21 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
 // whole launch; every wave evaluates it for its own instance at the start of each env-step, on its own clock -- no barrier
 // after the weights are staged, so the waves of a SIMD keep drifting apart as in rollout1d_kernel.  Lane j owns neuron j
 // (layers of up to 64 units): per four inputs one 16-byte broadcast read of the layer input and one 16-byte read of the
-// lane's weights (the ABI's blocked transpose, copied verbatim), four fused multiply-adds; k ascending in ONE chain from
+// lane's weights, four fused multiply-adds; k ascending in ONE chain from
 // zero, bias added last -- the summation order pdegym_mlp_forward documents, up to the MFMA's order inside a group of 16.
 constexpr int kPolicyWaves = 16;
 constexpr int kPolicyMaxWidth = 64;
 constexpr int kPolicyMaxLdsBytes = 160 * 1024;
 
 __host__ __device__ inline int policy_xpad(int n) { return (n + 3) & ~3; }
-// floats of LDS: per layer its blocked weights and a bias row of 64, then per wave the padded observation row and two
-// hidden rows of 64
+// In LDS a neuron's weights are contiguous -- [neuron][group of four inputs][4], the group count rounded up to an odd number
+// so that the 16-byte reads of 16 consecutive lanes (1 KB apart for 257 inputs) fall into distinct banks -- and every read of
+// the reduction loop is base + immediate offset.
+__host__ __device__ inline int policy_groups(int in_dim) { return ((in_dim + 3) >> 2) | 1; }
+// floats of LDS: per layer its weights and a bias row of 64, then per wave the padded observation row and two hidden rows of 64
 __host__ __device__ inline int policy_lds_floats(const pdegym_mlp& N, int n) {
   int f = 0;
-  for (int l = 0; l < N.n_layers; ++l) f += ((N.layer[l].in_dim + 3) >> 2) * 4 * N.layer[l].out_dim + kPolicyMaxWidth;
+  for (int l = 0; l < N.n_layers; ++l) f += policy_groups(N.layer[l].in_dim) * 4 * N.layer[l].out_dim + kPolicyMaxWidth;
   return f + kPolicyWaves * (policy_xpad(n) + 2 * kPolicyMaxWidth);
 }
 
@@ -1087,10 +1090,15 @@ __global__ __launch_bounds__(kWave* kPolicyWaves) void rollout1d_policy_kernel(p
   for (int l = 0; l < PDEGYM_MLP_MAX_LAYERS; ++l) {
     woff[l] = boff[l] = 0;
     if (l < N.n_layers) {
-      const int nw = ((N.layer[l].in_dim + 3) >> 2) * 4 * N.layer[l].out_dim;
+      const int H = N.layer[l].out_dim, ng = (N.layer[l].in_dim + 3) >> 2, ngo = policy_groups(N.layer[l].in_dim);
+      const int nw = ngo * 4 * H;
       woff[l] = off;
       boff[l] = off + nw;
-      for (int i = threadIdx.x; i < nw; i += kWave * kPolicyWaves) pol_smem[off + i] = N.layer[l].w[i];
+      // ABI layout [group][neuron][4] -> [neuron][group][4]; the padding group reads as zero
+      for (int i = threadIdx.x; i < nw; i += kWave * kPolicyWaves) {
+        const int e = i & 3, g = (i >> 2) % ngo, j = (i >> 2) / ngo;
+        pol_smem[off + i] = g < ng ? N.layer[l].w[((size_t)g * H + j) * 4 + e] : 0.f;
+      }
       for (int i = threadIdx.x; i < kPolicyMaxWidth; i += kWave * kPolicyWaves)
         pol_smem[off + nw + i] = (N.layer[l].b && i < N.layer[l].out_dim) ? N.layer[l].b[i] : 0.f;
       off += nw + kPolicyMaxWidth;
@@ -1114,11 +1122,24 @@ __global__ __launch_bounds__(kWave* kPolicyWaves) void rollout1d_policy_kernel(p
       if (l < N.n_layers) {
         const int H = N.layer[l].out_dim, ng = (K + 3) >> 2;
         const int jj = lane < H ? lane : H - 1;
-        const float4* W = reinterpret_cast<const float4*>(pol_smem + woff[l]) + jj;
+        const float4* W = reinterpret_cast<const float4*>(pol_smem + woff[l]) + (size_t)jj * policy_groups(K);
         const float4* X = reinterpret_cast<const float4*>(in);
         float acc = 0.f;
-        for (int kb = 0; kb < ng; ++kb) {
-          const float4 xv = X[kb], wv = W[(size_t)kb * H];
+        int kb = 0;
+        for (; kb + 4 <= ng; kb += 4) {          // eight reads in flight, then their sixteen fused multiply-adds
+          float4 xv[4], wv[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { xv[i] = X[kb + i]; wv[i] = W[kb + i]; }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc = __builtin_fmaf(xv[i].x, wv[i].x, acc);
+            acc = __builtin_fmaf(xv[i].y, wv[i].y, acc);
+            acc = __builtin_fmaf(xv[i].z, wv[i].z, acc);
+            acc = __builtin_fmaf(xv[i].w, wv[i].w, acc);
+          }
+        }
+        for (; kb < ng; ++kb) {
+          const float4 xv = X[kb], wv = W[kb];
           acc = __builtin_fmaf(xv.x, wv.x, acc);
           acc = __builtin_fmaf(xv.y, wv.y, acc);
           acc = __builtin_fmaf(xv.z, wv.z, acc);

@@ -42,7 +42,7 @@ def test_ctypes_structs_match_header_layout():
             out.extend(x.strip().lstrip("*").split("[")[0] for x in d.split(","))
         return out
 
-    for struct, mirror in (("pdegym_params1d", N.Params1D), ("pdegym_bufs1d", N.Bufs1D),
+    for struct, mirror in (("pdegym_params1d", N.Params1D), ("pdegym_bufs1d", N.Bufs1D), ("pdegym_rollout1d", N.Rollout1D),
                            ("pdegym_params_ns2d", N.ParamsNS2D), ("pdegym_bufs_ns2d", N.BufsNS2D)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
@@ -51,7 +51,7 @@ def test_ctypes_structs_match_header_layout():
             d = d.strip()
             if not d:
                 continue
-            d = re.sub(r"^(const\s+)?(int32_t|int64_t|uint8_t|float|double|void)\s*\*?", "", d).strip()
+            d = re.sub(r"^(const\s+)?(struct\s+\w+|int32_t|int64_t|uint8_t|float|double|void)\s*\*?", "", d).strip()
             decls.append(d)
         assert names(decls) == [f[0] for f in mirror._fields_], struct
 
