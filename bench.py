@@ -12,7 +12,7 @@ Default workload = BASELINE.json configs[1]: ReactionDiffusionPDE1D ("Parabolic1
 per GPU, fp32, S=100 sub-steps per env-step (SURVEY.md section 8d).  Other workloads (--workload NAME prints NAME's own line;
 the default run adds all of them under "also"): transport_c3, burgers_c3 (extension), parabolic_c2_policy_loop (C2 with its MLP
 controller evaluated on the device every step), parabolic_c2_rollout (the same loop as ONE kernel per 25 env-steps: here a
-"step" is one launch and `value` still counts env-steps), ns2d_c4, ns2d_c4_f64, ns2d_c4_b4096, ns2d_c5, ns2d_example (the reference's
+"step" is one launch and `value` still counts env-steps), parabolic_c2_open_loop_rollout (25 env-steps per launch, commands given ahead), ns2d_c4, ns2d_c4_f64, ns2d_c4_b4096, ns2d_c5, ns2d_example (the reference's
 shipped 21x21 K=2000 float64 configuration), traffic_arz, brain_tumor.
 
 Prints ONE JSON line (rank 0).
@@ -202,6 +202,43 @@ class ParabolicRollout(ParabolicPolicyLoop):
     def config(self):
         c = super().config()
         c["policy"] = "MLP 257-64-64-1 tanh, float32, evaluated inside the rollout kernel (weights in LDS, one fma chain per neuron)"
+        c["env_steps_per_launch"] = self.CHUNK
+        return c
+
+
+class ParabolicOpenLoopRollout(Parabolic1D):
+    """C2 with the commands of CHUNK env-steps handed over at once (an open-loop controller, or actions sampled ahead):
+    pdegym_parabolic_rollout without a policy, one launch per CHUNK env-steps, bit-identical to CHUNK step launches."""
+    CHUNK = 25
+    name = "ReactionDiffusionPDE1D nx=256 B=4096 S=100, 25 env-steps per launch (pdegym_parabolic_rollout, commands given ahead)"
+
+    def prepare(self, total_steps):
+        import torch
+        super().prepare(total_steps * self.CHUNK)
+        T, B, n = self.CHUNK, self.B, self.env.n
+        self.robs = torch.zeros(T + 1, B, n, device=self.device)
+        self.robs[0].copy_(self.env.t["obs"])
+        self.rrew = torch.zeros(T, B, device=self.device)
+        self.rte = torch.zeros(T, B, dtype=torch.uint8, device=self.device)
+        self.rtr = torch.zeros(T, B, dtype=torch.uint8, device=self.device)
+
+    def step(self):
+        T = self.CHUNK
+        self.env.rollout(self.robs, self.actions[self.i * T:(self.i + 1) * T], self.rrew, self.rte, self.rtr)
+        self.robs[0].copy_(self.robs[T])
+        self.i += 1
+
+    def units_per_step(self):
+        return self.B * self.CHUNK
+
+    def algorithmic_bytes_per_step(self):
+        return super().algorithmic_bytes_per_step() * self.CHUNK
+
+    def compulsory_bytes_per_step(self):
+        return super().compulsory_bytes_per_step() * self.CHUNK
+
+    def config(self):
+        c = super().config()
         c["env_steps_per_launch"] = self.CHUNK
         return c
 
@@ -422,6 +459,7 @@ class BrainTumor:
 from bench_ns2d import NavierStokesC4, NavierStokesC4B4096, NavierStokesC4F64, NavierStokesC5, NavierStokesExample  # noqa: E402
 WORKLOADS["parabolic_c2_policy_loop"] = ParabolicPolicyLoop
 WORKLOADS["parabolic_c2_rollout"] = ParabolicRollout
+WORKLOADS["parabolic_c2_open_loop_rollout"] = ParabolicOpenLoopRollout
 WORKLOADS["ns2d_c4"] = NavierStokesC4
 WORKLOADS["ns2d_c4_f64"] = NavierStokesC4F64
 WORKLOADS["ns2d_c4_b4096"] = NavierStokesC4B4096

@@ -687,15 +687,16 @@ def test_state_in_abi_validation():
     assert not hist.state_in_obs                      # the history mode keeps its own state rows
 
 
-@pytest.mark.parametrize("kind,nx,S,burgers", [("parabolic", 256, 100, False), ("transport", 100, 30, False), ("transport", 512, 20, True),
-                                               ("parabolic", 40, 7, False), ("transport", 1500, 3, False)])
-def test_rollout_kernel_equals_step_calls_bitwise(kind, nx, S, burgers):
+@pytest.mark.parametrize("kind,nx,S,burgers,B,T", [
+    ("parabolic", 256, 100, False, 9, 11), ("transport", 100, 30, False, 9, 11), ("transport", 512, 20, True, 9, 11),
+    ("parabolic", 40, 7, False, 9, 11), ("transport", 1500, 3, False, 9, 11),
+    ("transport", 3, 2, False, 1, 5), ("parabolic", 2, 1, False, 130, 9), ("parabolic", 2047, 2, False, 3, 6), ("transport", 64, 5, False, 5, 1)])
+def test_rollout_kernel_equals_step_calls_bitwise(kind, nx, S, burgers, B, T):
     """pdegym_*_rollout (T env-steps in one launch, the row never leaves the wave's cache path) against T step calls: every
     observation slot, reward, flag, the time index, |u| sum, norm ring, restart counters, redrawn beta rows and the kept
     terminal observations agree bit for bit, across episode ends with the fused auto-reset."""
     from pdecontrolgym_amd import _native as N
     from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
-    B, T = 9, 11
     dx = 1.0 / nx
     dt = 0.25 * dx * dx if kind == "parabolic" else 0.5 * dx
     kw = dict(T=4 * S * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type="Dirchilet", sensing_loc="full",
@@ -734,7 +735,7 @@ def test_rollout_kernel_equals_step_calls_bitwise(kind, nx, S, burgers):
     for k in ("time_index", "bsum", "ring", "reset_count", "beta", "final_obs", "norm_now", "norm_back"):
         np.testing.assert_array_equal(e.t[k].cpu().numpy(), e2.t[k].cpu().numpy(), err_msg=k)
     np.testing.assert_array_equal(e2.t["obs"].cpu().numpy(), obs2[T].cpu().numpy())
-    assert int(te.sum() + tr.sum()) > 0
+    assert T < 4 or int(te.sum() + tr.sum()) > 0
     # the engine carries on from slot T with ordinary step calls
     o_a = e.step(acts[0])[0].cpu().numpy()
     o_b = e2.step(acts[0])[0].cpu().numpy()
