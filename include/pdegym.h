@@ -289,6 +289,26 @@ typedef struct pdegym_bufs_traffic {
 } pdegym_bufs_traffic;
 
 int pdegym_traffic_step(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf, int32_t B, void* stream);
+
+/* T env-steps in ONE launch (M <= 64): step t takes the command(s) from actions row t and writes observation slot t + 1,
+ * rewards / done / truncated row t; r, y, time of the pdegym_bufs_traffic are read once and written back at the end
+ * (bufs->action / obs / reward / done / truncated are ignored).  Bit-identical to T pdegym_traffic_step calls; like them it
+ * keeps stepping a finished episode.  With a policy (HOST pointer; layers of <= 64 units, 2M inputs, action_stride outputs)
+ * the command of step t is computed inside the launch from observation slot t (slot 0 = the caller's current observation)
+ * rounded to float32, plus noise [T, B, action_stride] (row stride noise_stride), clamped, widened and stored to actions. */
+typedef struct pdegym_rollout_traffic {
+  int32_t T;
+  int32_t reserved_;
+  double* obs;              /* [T + 1, B, 2M]  slot 0 is read only by a policy; slots 1 .. T are written         */
+  double* actions;          /* [T, B, action_stride]  read, or written when a policy is given                   */
+  double* rewards;          /* [T, B]                                                                          */
+  uint8_t* done;            /* [T, B]                                                                          */
+  uint8_t* truncated;       /* [T, B]                                                                          */
+  const struct pdegym_mlp_s* policy;
+} pdegym_rollout_traffic;
+
+int pdegym_traffic_rollout(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf, const pdegym_rollout_traffic* ro,
+                           int32_t B, void* stream);
 /* Where mask[b] != 0 (or mask == NULL): rs[b] is taken as given, r = rs*profile, y = qs - vm r + vm/rm r^2, time = 0,
  * obs = (r, v).  profile[M] = sin(3 x/L pi)*0.1 + 1 is computed by the caller in NumPy (libm sin, bit parity). */
 int pdegym_traffic_reset_masked(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf, const double* profile,

@@ -41,12 +41,15 @@ class DeviceRollout:
         # caller fills the buffer in place before each run() (e.g. ``ro.action_noise.normal_().mul_(std)``): a replayed graph
         # reads the new draws.
         self.action_noise = torch.zeros_like(self.actions, dtype=torch.float32) if action_noise else None
-        # transport / reaction-diffusion with full-state sensing and a small FusedMLP: the WHOLE rollout is one kernel launch
-        # (pdegym_*_rollout with the policy inside: no kernel boundary between env-steps, none between policy and step).
+        # transport / reaction-diffusion with full-state sensing, or traffic, and a small FusedMLP: the WHOLE rollout is one
+        # kernel launch (pdegym_*_rollout with the policy inside: no kernel boundary between env-steps, none between policy and step).
         # one_launch=None: whenever it applies; True: required; False: T x (policy launch + step launch) as for the others.
-        fits = bool(hasattr(core, "policy_fits_rollout") and core.policy_fits_rollout(policy) and dt == torch.float32)
+        self._traffic = kind == "traffic"
+        fits = bool(hasattr(core, "policy_fits_rollout") and core.policy_fits_rollout(policy)
+                    and dt == (torch.float64 if self._traffic else torch.float32))
         if one_launch and not fits:
-            raise ValueError("one_launch=True needs a 1D engine with full-state sensing and a FusedMLP of <= 64-unit layers")
+            raise ValueError("one_launch=True needs a transport / reaction-diffusion engine with full-state sensing or a traffic "
+                             "engine of <= 64 nodes, and a FusedMLP of <= 64-unit layers")
         self.one_launch = fits if one_launch is None else bool(one_launch)
         self.use_graph = bool(use_graph) and dev.type == "cuda"
         self._graph = None
@@ -55,8 +58,11 @@ class DeviceRollout:
         import torch
         core = self.venv.core
         if self.one_launch:
-            core.rollout(self.obs, self.actions, self.rewards, self.terminated, self.truncated, policy=self.policy,
-                         clamp=(self.lo, self.hi), noise=self.action_noise)
+            acts, nz = self.actions, self.action_noise
+            if self._traffic and acts.dim() == 2:       # the traffic kernel takes [T, B, action_dim]
+                acts, nz = acts.unsqueeze(2), (nz.unsqueeze(2) if nz is not None else None)
+            core.rollout(self.obs, acts, self.rewards, self.terminated, self.truncated, policy=self.policy,
+                         clamp=(self.lo, self.hi), noise=nz)
             return
         own = {k: core.t[k] for k in ("reward", "terminated", "truncated", "obs") if k in core.t} if self._direct else {}
         pingpong = self._ns and getattr(core, "_p_pingpong", False)

@@ -31,7 +31,7 @@ EXPORTS = [
     "pdegym_ns2d_solve_pressure_f32", "pdegym_ns2d_solve_pressure_f64", "pdegym_ns2d_reset_masked_f32",
     "pdegym_ns2d_reset_masked_f64", "pdegym_traffic_step", "pdegym_traffic_reset_masked",
     "pdegym_tumor_step", "pdegym_tumor_advance", "pdegym_tumor_reset_masked", "pdegym_mlp_forward",
-    "pdegym_transport_rollout", "pdegym_parabolic_rollout",
+    "pdegym_transport_rollout", "pdegym_parabolic_rollout", "pdegym_traffic_rollout",
 ]
 MLP_MAX_LAYERS, MLP_MAX_WIDTH, MLP_MAX_INPUT = 4, 256, 8192
 MLP_IDENTITY, MLP_TANH, MLP_RELU = 0, 1, 2
@@ -90,6 +90,11 @@ class BufsTraffic(C.Structure):
     _fields_ = [("r", C.c_void_p), ("y", C.c_void_p), ("action", C.c_void_p), ("time", C.c_void_p), ("rs", C.c_void_p),
                 ("qs_clip", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
                 ("truncated", C.c_void_p), ("action_stride", C.c_int32), ("reserved_", C.c_int32)]
+
+
+class RolloutTraffic(C.Structure):
+    _fields_ = [("T", C.c_int32), ("reserved_", C.c_int32), ("obs", C.c_void_p), ("actions", C.c_void_p),
+                ("rewards", C.c_void_p), ("done", C.c_void_p), ("truncated", C.c_void_p), ("policy", C.c_void_p)]
 
 
 TUMOR_GROWTH, TUMOR_THERAPY, TUMOR_POST = range(3)
@@ -162,6 +167,8 @@ def load():
         f = getattr(lib, "pdegym_ns2d_reset_masked_" + sfx)
         f.argtypes = [C.POINTER(ParamsNS2D), C.POINTER(BufsNS2D), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         f.restype = C.c_int
+    lib.pdegym_traffic_rollout.argtypes = [C.POINTER(ParamsTraffic), C.POINTER(BufsTraffic), C.POINTER(RolloutTraffic), C.c_int32, C.c_void_p]
+    lib.pdegym_traffic_rollout.restype = C.c_int
     lib.pdegym_traffic_step.argtypes = [C.POINTER(ParamsTraffic), C.POINTER(BufsTraffic), C.c_int32, C.c_void_p]
     lib.pdegym_traffic_step.restype = C.c_int
     lib.pdegym_traffic_reset_masked.argtypes = [C.POINTER(ParamsTraffic), C.POINTER(BufsTraffic), C.c_void_p, C.c_void_p,

@@ -188,6 +188,29 @@ class HipBackend:
                 "pdegym_traffic_step")
 
     @_on_device_of("r")
+    def traffic_rollout(self, P: N.ParamsTraffic, T: dict, obs, actions, rewards, done, truncated, B: int, policy=None):
+        """T env-steps in one launch (pdegym_traffic_rollout): ``obs`` [T+1, B, 2M], ``actions`` [T, B, A] (A = 1 or 2; an output
+        when ``policy`` -- an ``N.Mlp`` descriptor, its ``noise`` [T, B, A] -- is given), ``rewards`` / ``done`` / ``truncated`` [T, B]."""
+        import torch
+        steps = int(actions.shape[0])
+        A = int(actions.shape[2])
+        if tuple(obs.shape) != (steps + 1, B, 2 * P.M) or not obs.is_contiguous():
+            raise N.NativeError(f"rollout obs must be a contiguous [{steps + 1}, {B}, {2 * P.M}] tensor, got {tuple(obs.shape)}")
+        if tuple(actions.shape) != (steps, B, A) or A not in (1, 2) or not actions.is_contiguous():
+            raise N.NativeError(f"rollout actions must be a contiguous [{steps}, {B}, 1 or 2] tensor, got {tuple(actions.shape)}")
+        for name, x in (("rewards", rewards), ("done", done), ("truncated", truncated)):
+            if tuple(x.shape) != (steps, B) or not x.is_contiguous():
+                raise N.NativeError(f"rollout {name} must be a contiguous [{steps}, {B}] tensor, got {tuple(x.shape)}")
+        bufs = self._bufs_traffic({**T, "action": actions[0]})
+        ro = N.RolloutTraffic()
+        ro.T = steps
+        ro.obs, ro.actions, ro.rewards = N.dptr(obs, torch.float64), N.dptr(actions, torch.float64), N.dptr(rewards, torch.float64)
+        ro.done, ro.truncated = N.dptr(done, torch.uint8), N.dptr(truncated, torch.uint8)
+        ro.policy = C.addressof(policy) if policy is not None else None
+        N.check(self.lib.pdegym_traffic_rollout(C.byref(P), C.byref(bufs), C.byref(ro), B, N.current_stream_ptr(obs.device)),
+                "pdegym_traffic_rollout")
+
+    @_on_device_of("r")
     def traffic_reset(self, P: N.ParamsTraffic, T: dict, profile, mask, B: int):
         import torch
         bufs = self._bufs_traffic(T)

@@ -74,6 +74,47 @@ class TrafficBatch:
         self.backend.traffic_reset(self.params, self.t, self.profile, mask, self.num_envs)
         return self.t["obs"]
 
+    def can_rollout(self) -> bool:
+        """``rollout`` needs the register-resident kernel (freeways of up to 64 nodes: the reference's grid has 51)."""
+        return self.M <= 64 and hasattr(self.backend, "traffic_rollout")
+
+    def policy_fits_rollout(self, policy) -> bool:
+        """Whether ``policy`` (a ``FusedMLP``) can run inside the rollout kernel: 2M inputs, layers of at most 64 units, one
+        output per command, weights + 16 observation rows within 160 KB of LDS."""
+        if not (self.can_rollout() and hasattr(policy, "layers") and hasattr(policy, "_net")):
+            return False
+        dims = [(int(w.shape[1]), int(w.shape[0])) for w, _, _ in policy.layers]
+        D = 2 * self.M
+        if dims[0][0] != D or dims[-1][1] != self.action_dim or any(o > 64 for _, o in dims):
+            return False
+        floats = sum((((i + 3) // 4) | 1) * 4 * o + 64 for i, o in dims) + 16 * (((D + 3) // 4) * 4 + 128)
+        return 4 * floats <= 160 * 1024
+
+    def rollout(self, obs, actions, rewards, done, truncated, policy=None, clamp="default", noise=None):
+        """T env-steps in ONE launch (include/pdegym.h: pdegym_traffic_rollout): step t takes ``actions[t]`` ([T, B, action_dim]),
+        writes ``obs[t + 1]`` ([T+1, B, 2M]), ``rewards[t]``, ``done[t]``, ``truncated[t]`` -- bit-identical to T ``step`` calls.
+        With ``policy`` (a ``FusedMLP``) the commands are computed inside the launch from ``obs[t]`` (``obs[0]`` = the current
+        observation, supplied by the caller) and written to ``actions``; ``noise`` [T, B, action_dim] float32 is added before
+        the clamp.  The engine's own observation / reward / flag tensors receive the values of the last step."""
+        if not self.can_rollout():
+            raise ValueError("rollout needs freeways of at most 64 nodes")
+        net = None
+        if policy is not None:
+            if not self.policy_fits_rollout(policy):
+                raise ValueError("this policy cannot run inside the rollout kernel (see policy_fits_rollout)")
+            net = policy._net(policy.clamp if clamp == "default" else clamp)
+            if noise is not None:
+                import torch
+                if noise.dtype != torch.float32 or tuple(noise.shape) != tuple(actions.shape) or not noise.is_contiguous():
+                    raise ValueError("noise must be a contiguous float32 tensor of the actions' shape")
+                net.noise, net.noise_stride = noise.data_ptr(), int(actions.shape[2])
+        self.backend.traffic_rollout(self.params, self.t, obs, actions, rewards, done, truncated, self.num_envs, policy=net)
+        self.t["obs"].copy_(obs[-1])
+        self.t["reward"].copy_(rewards[-1])
+        self.t["done"].copy_(done[-1])
+        self.t["truncated"].copy_(truncated[-1])
+        return obs, rewards, done, truncated
+
     def step(self, action):
         """action [B] / [B,1] (inlet, outlet) or [B,2] ('both'). Returns (obs [B,2M], reward, done, truncated)."""
         import torch

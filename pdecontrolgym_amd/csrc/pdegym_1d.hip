@@ -28,6 +28,7 @@
 
 #include "pdegym.h"
 #include "pdegym_common.h"
+#include "pdegym_policy.h"
 
 namespace {
 
@@ -1047,117 +1048,26 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
   }
 }
 
-// ---- the policy inside the rollout kernel --------------------------------------------------------------------------------
-// A workgroup of 16 waves (16 instances, one CU's worth at four waves per SIMD) keeps ONE copy of the network in LDS for the
-// whole launch; every wave evaluates it for its own instance at the start of each env-step, on its own clock -- no barrier
-// after the weights are staged, so the waves of a SIMD keep drifting apart as in rollout1d_kernel.  Lane j owns neuron j
-// (layers of up to 64 units): per four inputs one 16-byte broadcast read of the layer input and one 16-byte read of the
-// lane's weights, four fused multiply-adds; k ascending in ONE chain from
-// zero, bias added last -- the summation order pdegym_mlp_forward documents, up to the MFMA's order inside a group of 16.
-constexpr int kPolicyWaves = 16;
-constexpr int kPolicyMaxWidth = 64;
-constexpr int kPolicyMaxLdsBytes = 160 * 1024;
-
-__host__ __device__ inline int policy_xpad(int n) { return (n + 3) & ~3; }
-// In LDS a neuron's weights are contiguous -- [neuron][group of four inputs][4], the group count rounded up to an odd number
-// so that the 16-byte reads of 16 consecutive lanes (1 KB apart for 257 inputs) fall into distinct banks -- and every read of
-// the reduction loop is base + immediate offset.
-__host__ __device__ inline int policy_groups(int in_dim) { return ((in_dim + 3) >> 2) | 1; }
-// floats of LDS: per layer its weights and a bias row of 64, then per wave the padded observation row and two hidden rows of 64
-__host__ __device__ inline int policy_lds_floats(const pdegym_mlp& N, int n) {
-  int f = 0;
-  for (int l = 0; l < N.n_layers; ++l) f += policy_groups(N.layer[l].in_dim) * 4 * N.layer[l].out_dim + kPolicyMaxWidth;
-  return f + kPolicyWaves * (policy_xpad(n) + 2 * kPolicyMaxWidth);
-}
-
-__device__ __forceinline__ float policy_activate(float v, int act) {
-  if (act == PDEGYM_MLP_TANH) return tanhf(v);
-  if (act == PDEGYM_MLP_RELU) return v > 0.f ? v : 0.f;
-  return v;
-}
-
+// ---- the policy inside the rollout kernel (pdegym_policy.h) -----------------------------------------------------------------
 template <int EPL, bool PARABOLIC, bool BURGERS>
-__global__ __launch_bounds__(kWave* kPolicyWaves) void rollout1d_policy_kernel(pdegym_params1d P, pdegym_bufs1d Bf, pdegym_rollout1d Ro,
-                                                                               pdegym_mlp N, int B) {
+__global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy_kernel(pdegym_params1d P, pdegym_bufs1d Bf,
+                                                                                        pdegym_rollout1d Ro, pdegym_mlp N, int B) {
+  namespace pol = pdegym_policy;
   extern __shared__ __attribute__((aligned(16))) float pol_smem[];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  const int inst = blockIdx.x * kPolicyWaves + wave;
-  const int n = P.n, xpad = policy_xpad(n);
-  // stage the network once
-  int woff[PDEGYM_MLP_MAX_LAYERS], boff[PDEGYM_MLP_MAX_LAYERS];
-  int off = 0;
-#pragma unroll
-  for (int l = 0; l < PDEGYM_MLP_MAX_LAYERS; ++l) {
-    woff[l] = boff[l] = 0;
-    if (l < N.n_layers) {
-      const int H = N.layer[l].out_dim, ng = (N.layer[l].in_dim + 3) >> 2, ngo = policy_groups(N.layer[l].in_dim);
-      const int nw = ngo * 4 * H;
-      woff[l] = off;
-      boff[l] = off + nw;
-      // ABI layout [group][neuron][4] -> [neuron][group][4]; the padding group reads as zero
-      for (int i = threadIdx.x; i < nw; i += kWave * kPolicyWaves) {
-        const int e = i & 3, g = (i >> 2) % ngo, j = (i >> 2) / ngo;
-        pol_smem[off + i] = g < ng ? N.layer[l].w[((size_t)g * H + j) * 4 + e] : 0.f;
-      }
-      for (int i = threadIdx.x; i < kPolicyMaxWidth; i += kWave * kPolicyWaves)
-        pol_smem[off + nw + i] = (N.layer[l].b && i < N.layer[l].out_dim) ? N.layer[l].b[i] : 0.f;
-      off += nw + kPolicyMaxWidth;
-    }
-  }
-  __syncthreads();
-  if (inst >= B) return;  // wave-uniform, after the only barrier
-  float* const xw = pol_smem + off + wave * (xpad + 2 * kPolicyMaxWidth);
+  const int inst = blockIdx.x * pol::kWaves + wave;
+  const int n = P.n, xpad = pol::xpad(n);
+  const pol::Staged St = pol::stage(N, pol_smem);      // the launch's only barrier
+  if (inst >= B) return;  // wave-uniform
+  float* const xw = pol_smem + St.end + wave * (xpad + 2 * pol::kMaxWidth);
   float* const hw = xw + xpad;
   const size_t slot = (size_t)B * n;
   for (int t = 0; t < Ro.T; ++t) {
     // observation of this instance (slot t) -> LDS, zero-padded to a multiple of four
     const float* xrow = Ro.obs + (size_t)t * slot + (size_t)inst * n;
     for (int j = lane; j < xpad; j += kWave) xw[j] = j < n ? xrow[j] : 0.f;
-    wave_lds_sync();
-    const float* in = xw;
-    int K = n;
-    float out = 0.f;
-#pragma unroll
-    for (int l = 0; l < PDEGYM_MLP_MAX_LAYERS; ++l) {
-      if (l < N.n_layers) {
-        const int H = N.layer[l].out_dim, ng = (K + 3) >> 2;
-        const int jj = lane < H ? lane : H - 1;
-        const float4* W = reinterpret_cast<const float4*>(pol_smem + woff[l]) + (size_t)jj * policy_groups(K);
-        const float4* X = reinterpret_cast<const float4*>(in);
-        float acc = 0.f;
-        int kb = 0;
-        for (; kb + 4 <= ng; kb += 4) {          // eight reads in flight, then their sixteen fused multiply-adds
-          float4 xv[4], wv[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { xv[i] = X[kb + i]; wv[i] = W[kb + i]; }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            acc = __builtin_fmaf(xv[i].x, wv[i].x, acc);
-            acc = __builtin_fmaf(xv[i].y, wv[i].y, acc);
-            acc = __builtin_fmaf(xv[i].z, wv[i].z, acc);
-            acc = __builtin_fmaf(xv[i].w, wv[i].w, acc);
-          }
-        }
-        for (; kb < ng; ++kb) {
-          const float4 xv = X[kb], wv = W[kb];
-          acc = __builtin_fmaf(xv.x, wv.x, acc);
-          acc = __builtin_fmaf(xv.y, wv.y, acc);
-          acc = __builtin_fmaf(xv.z, wv.z, acc);
-          acc = __builtin_fmaf(xv.w, wv.w, acc);
-        }
-        const float o = policy_activate(acc + pol_smem[boff[l] + jj], N.layer[l].act);
-        if (l == N.n_layers - 1) {
-          out = o;
-        } else {
-          float* hl = hw + (l & 1) * kPolicyMaxWidth;
-          hl[lane] = lane < H ? o : 0.f;      // zero beyond the layer width: the next layer reads whole groups of four
-          wave_lds_sync();
-          in = hl;
-          K = H;
-        }
-      }
-    }
-    float a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, out)));   // neuron 0 of the last layer
+    pol::wave_lds_sync();
+    float a = pol::lane_value(pol::eval(N, St, pol_smem, xw, hw, n, lane), 0);      // neuron 0 of the last layer
     if (N.noise) a += N.noise[((size_t)t * B + inst) * N.noise_stride];
     if (N.clamp) a = fminf(fmaxf(a, N.lo), N.hi);
     if (lane == 0) Ro.actions[(size_t)t * B + inst] = a;
@@ -1197,27 +1107,16 @@ int launch_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const p
   const int epl = (nslots + kWave - 1) / kWave;
   if (ro->policy) {
     const pdegym_mlp& N = *ro->policy;
-    if (N.n_layers < 1 || N.n_layers > PDEGYM_MLP_MAX_LAYERS) return pdegym::fail(-2, "policy: n_layers must be 1..4");
-    for (int l = 0; l < N.n_layers; ++l) {
-      const pdegym_mlp_layer& L = N.layer[l];
-      if (!L.w) return pdegym::fail(-3, "policy: null weight pointer");
-      if (L.in_dim != (l ? N.layer[l - 1].out_dim : P.n)) return pdegym::fail(-2, "policy: layer input size must match the row / the previous layer");
-      if (L.out_dim < 1 || L.out_dim > kPolicyMaxWidth) return pdegym::fail(-2, "policy inside the rollout kernel: layers of 1..64 units");
-      if (L.act < PDEGYM_MLP_IDENTITY || L.act > PDEGYM_MLP_RELU) return pdegym::fail(-2, "policy: unknown activation");
-    }
-    if (N.layer[N.n_layers - 1].out_dim != 1) return pdegym::fail(-2, "policy: the 1D environments take one command per instance");
-    if (N.x_f64 || N.y_f64) return pdegym::fail(-2, "policy inside the rollout kernel: float32 observations and commands");
-    if (N.clamp && !(N.lo <= N.hi)) return pdegym::fail(-2, "policy: clamp bounds must satisfy lo <= hi");
-    if (N.noise && N.noise_stride < 1) return pdegym::fail(-2, "policy: noise stride must be >= 1");
+    if (const char* why = pdegym_policy::check(N, P.n, 1)) return pdegym::fail(-2, why);
+    if (N.x_f64 || N.y_f64) return pdegym::fail(-2, "policy inside the 1D rollout kernel: float32 observations and commands");
     if (epl > 8) return pdegym::fail(-2, "policy inside the rollout kernel: rows of up to 513 nodes");
-    const int lds_bytes = policy_lds_floats(N, P.n) * (int)sizeof(float);
-    if (lds_bytes > kPolicyMaxLdsBytes) return pdegym::fail(-2, "policy inside the rollout kernel: the network does not fit into 160 KB of LDS");
-    const dim3 pgrid((B + kPolicyWaves - 1) / kPolicyWaves), pblock(kWave * kPolicyWaves);
+    const int lds_bytes = pdegym_policy::lds_floats(N, P.n) * (int)sizeof(float);
+    const dim3 pgrid((B + pdegym_policy::kWaves - 1) / pdegym_policy::kWaves), pblock(kWave * pdegym_policy::kWaves);
     bool ok = true;
     auto gop = [&](auto tag) {
       constexpr int E = decltype(tag)::value;
       static signed char attr[pdegym::kMaxDevices] = {};
-      ok = pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&rollout1d_policy_kernel<E, PARABOLIC, BURGERS>), kPolicyMaxLdsBytes, attr);
+      ok = pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&rollout1d_policy_kernel<E, PARABOLIC, BURGERS>), pdegym_policy::kMaxLdsBytes, attr);
       if (ok) hipLaunchKernelGGL((rollout1d_policy_kernel<E, PARABOLIC, BURGERS>), pgrid, pblock, lds_bytes, st, P, *buf, *ro, N, B);
     };
     if (epl <= 1) gop(std::integral_constant<int, 1>{});

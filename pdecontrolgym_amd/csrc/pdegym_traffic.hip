@@ -10,6 +10,7 @@
 
 #include "pdegym.h"
 #include "pdegym_common.h"
+#include "pdegym_policy.h"
 
 namespace {
 
@@ -52,22 +53,21 @@ __device__ __forceinline__ double Veq(double vm, double rm, double rho) { return
 __device__ __forceinline__ double F_r(double vm, double rm, double rho, double y) { return y + rho * Veq(vm, rm, rho); }
 __device__ __forceinline__ double F_y(double vm, double rm, double rho, double y) { return y * (y / rho + Veq(vm, rm, rho)); }
 
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pdegym_params_traffic P, pdegym_bufs_traffic Bf, int B) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (inst >= B) return;
+// One env-step of one freeway held by one wave (M <= 64: node j in lane j): action clip, control_freq Lax-Wendroff sub-steps,
+// speed, reward, flags.  Shared by traffic_step_kernel and every iteration of traffic_rollout_kernel.
+struct TrafficStepOut {
+  double v, reward, vs;
+  bool done, trunc;
+};
+
+__device__ __forceinline__ TrafficStepOut traffic_step_wave(const pdegym_params_traffic& P, double& r, double& y, double& time,
+                                                            const double rs, const double qc, double a0, double a1, const int lane) {
   const int M = P.M;
   const bool in = lane < M;
   const double vm = P.vm, rm = P.rm, dt = P.dt, dx = P.dx;
-  double r = in ? Bf.r[(size_t)inst * M + lane] : 1.0;
-  double y = in ? Bf.y[(size_t)inst * M + lane] : 0.0;
-  const double rs = Bf.rs[inst];
   const double vs = Veq(vm, rm, rs);              // :66-72
   const double qs = rs * vs;
-  const double qc = Bf.qs_clip[inst];
   // action clip (:151-156) -- np.clip(a, low, high) = min(max(a, low), high)
-  const int astr = Bf.action_stride > 0 ? Bf.action_stride : 2;      // 1: one command per freeway (no second column to read)
-  double a0 = Bf.action[(size_t)inst * astr], a1 = astr > 1 ? Bf.action[(size_t)inst * astr + 1] : 0.0;
   const double lo = qc * 0.8, hi = 1.2 * qc;
   a0 = fmin(fmax(a0, lo), hi);
   a1 = fmin(fmax(a1, lo), hi);
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pde
   else if (P.sim == PDEGYM_TRAFFIC_INLET) { q_in = a0; q_out = qs; }
   else { q_in = qs; q_out = a0; }
 
-  double time = Bf.time[inst] + dt;               // :146
+  time = time + dt;                               // :146
   // Python evaluates these scalar sub-expressions before they meet an array (:201-222)
   const double c1 = dt / (2 * dx), c2 = 0.25 * dt / P.tau, c3 = dt / dx, c4 = 0.5 * dt / P.tau;
   if (time < P.T) {                               // :172  (time does not change inside the loop)
@@ -99,21 +99,27 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pde
       }
     }
   }
-  const double v = y / r + Veq(vm, rm, r);         // :227
+  TrafficStepOut o;
+  o.vs = vs;
+  o.v = y / r + Veq(vm, rm, r);                    // :227
   // reward (traffic_arz_reward.py:22)
-  const double dv = in ? v - vs : 0.0, dr = in ? r - rs : 0.0;
+  const double dv = in ? o.v - vs : 0.0, dr = in ? r - rs : 0.0;
   const double nv = sqrt(wave_sum_d(dv * dv)), nr = sqrt(wave_sum_d(dr * dr));
-  const double reward = -(nv / vs + nr / rs);
+  o.reward = -(nv / vs + nr / rs);
   const bool term = time >= P.T / dt;              // :106 (seconds compared with a step count -- kept)
   if (term) time = 0.0;
   bool trunc = false;
-  if (P.limit) trunc = __any(in && (v > vm || r > rm));
-  trunc = trunc || !__any(in && (dr != 0.0 || dv != 0.0));   // exact steady state (:127-128)
-  const bool done = (P.sim == PDEGYM_TRAFFIC_OUTLET_TRAIN) ? term : (term || reward > -0.00023);
-  if (in) {
-    Bf.r[(size_t)inst * M + lane] = r;
-    Bf.y[(size_t)inst * M + lane] = y;
-    double* o = Bf.obs + (size_t)inst * 2 * M;
+  if (P.limit) trunc = __any(in && (o.v > vm || r > rm));
+  o.trunc = trunc || !__any(in && (dr != 0.0 || dv != 0.0));   // exact steady state (:127-128)
+  o.done = (P.sim == PDEGYM_TRAFFIC_OUTLET_TRAIN) ? term : (term || o.reward > -0.00023);
+  return o;
+}
+
+// observation row of one freeway: (r, v), or ((r - rs)/rs, (v - vs)/vs) for outlet-train (:227-230)
+__device__ __forceinline__ void traffic_emit_obs(const pdegym_params_traffic& P, double* o, double r, double v, double rs, double vs,
+                                                 int lane) {
+  const int M = P.M;
+  if (lane < M) {
     if (P.sim == PDEGYM_TRAFFIC_OUTLET_TRAIN) {
       o[lane] = (r - rs) / rs;
       o[M + lane] = (v - vs) / vs;
@@ -122,12 +128,104 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pde
       o[M + lane] = v;
     }
   }
+}
+
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pdegym_params_traffic P, pdegym_bufs_traffic Bf, int B) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (inst >= B) return;
+  const int M = P.M;
+  const bool in = lane < M;
+  double r = in ? Bf.r[(size_t)inst * M + lane] : 1.0;
+  double y = in ? Bf.y[(size_t)inst * M + lane] : 0.0;
+  const double rs = Bf.rs[inst];
+  const int astr = Bf.action_stride > 0 ? Bf.action_stride : 2;      // 1: one command per freeway (no second column to read)
+  const double a0 = Bf.action[(size_t)inst * astr], a1 = astr > 1 ? Bf.action[(size_t)inst * astr + 1] : 0.0;
+  double time = Bf.time[inst];
+  const TrafficStepOut o = traffic_step_wave(P, r, y, time, rs, Bf.qs_clip[inst], a0, a1, lane);
+  if (in) {
+    Bf.r[(size_t)inst * M + lane] = r;
+    Bf.y[(size_t)inst * M + lane] = y;
+  }
+  traffic_emit_obs(P, Bf.obs + (size_t)inst * 2 * M, r, o.v, rs, o.vs, lane);
   if (lane == 0) {
     Bf.time[inst] = time;
-    Bf.reward[inst] = reward;
-    Bf.done[inst] = done ? 1 : 0;
-    Bf.truncated[inst] = trunc ? 1 : 0;
+    Bf.reward[inst] = o.reward;
+    Bf.done[inst] = o.done ? 1 : 0;
+    Bf.truncated[inst] = o.trunc ? 1 : 0;
   }
+}
+
+// T env-steps of one freeway by one wave in ONE launch (pdegym_traffic_rollout): (r, y) stay in registers across env-steps,
+// iteration t is traffic_step_wave with the command of row t, and writes observation slot t + 1, reward / done / truncated row
+// t -- bit-identical to T pdegym_traffic_step calls (a finished episode keeps running, as it does there: restarting is the
+// caller's business in this engine).  With a policy (pdegym_policy.h) the command of step t is computed inside the launch
+// from observation slot t rounded to float32 -- the cast SB3 makes in front of its float32 network -- widened back to
+// float64, plus noise, clamped, and stored to actions row t.
+__global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void traffic_rollout_kernel(pdegym_params_traffic P, pdegym_bufs_traffic Bf,
+                                                                                       pdegym_rollout_traffic Ro, pdegym_mlp N, int has_policy,
+                                                                                       int B) {
+  namespace pol = pdegym_policy;
+  extern __shared__ __attribute__((aligned(16))) float pol_smem[];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int inst = blockIdx.x * pol::kWaves + wave;
+  const int M = P.M, D = 2 * M, xpad = pol::xpad(D);
+  pol::Staged St = {};
+  if (has_policy) St = pol::stage(N, pol_smem);        // the launch's only barrier (uniform over the grid)
+  if (inst >= B) return;
+  float* const xw = pol_smem + St.end + wave * (xpad + 2 * pol::kMaxWidth);
+  float* const hw = xw + xpad;
+  const bool in = lane < M;
+  double r = in ? Bf.r[(size_t)inst * M + lane] : 1.0;
+  double y = in ? Bf.y[(size_t)inst * M + lane] : 0.0;
+  const double rs = Bf.rs[inst], qc = Bf.qs_clip[inst];
+  double time = Bf.time[inst];
+  const int A = Bf.action_stride > 0 ? Bf.action_stride : 2;
+  const size_t slot = (size_t)B * D;
+  for (int t = 0; t < Ro.T; ++t) {
+    double* arow = Ro.actions + ((size_t)t * B + inst) * A;
+    double a0, a1 = 0.0;
+    if (has_policy) {
+      const double* xrow = Ro.obs + (size_t)t * slot + (size_t)inst * D;
+      for (int j = lane; j < xpad; j += kWave) xw[j] = j < D ? (float)xrow[j] : 0.f;
+      pol::wave_lds_sync();
+      const float o = pol::eval(N, St, pol_smem, xw, hw, D, lane);
+      float c0 = pol::lane_value(o, 0), c1 = A > 1 ? pol::lane_value(o, 1) : 0.f;
+      if (N.noise) {
+        const float* nz = N.noise + ((size_t)t * B + inst) * N.noise_stride;
+        c0 += nz[0];
+        if (A > 1) c1 += nz[1];
+      }
+      if (N.clamp) {
+        c0 = fminf(fmaxf(c0, N.lo), N.hi);
+        c1 = fminf(fmaxf(c1, N.lo), N.hi);
+      }
+      a0 = (double)c0;
+      a1 = (double)c1;
+      if (lane == 0) {
+        arow[0] = a0;
+        if (A > 1) arow[1] = a1;
+      }
+    } else {
+      a0 = arow[0];
+      if (A > 1) a1 = arow[1];
+    }
+    const TrafficStepOut o = traffic_step_wave(P, r, y, time, rs, qc, a0, a1, lane);
+    traffic_emit_obs(P, Ro.obs + (size_t)(t + 1) * slot + (size_t)inst * D, r, o.v, rs, o.vs, lane);
+    if (lane == 0) {
+      Ro.rewards[(size_t)t * B + inst] = o.reward;
+      Ro.done[(size_t)t * B + inst] = o.done ? 1 : 0;
+      Ro.truncated[(size_t)t * B + inst] = o.trunc ? 1 : 0;
+    }
+    // the observation row just stored is read back (by other lanes) at the start of the next iteration
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  if (in) {
+    Bf.r[(size_t)inst * M + lane] = r;
+    Bf.y[(size_t)inst * M + lane] = y;
+  }
+  if (lane == 0) Bf.time[inst] = time;
 }
 
 // ---- rows of more than 64 nodes (finer grids than the reference notebook's M = 51): one wave still owns one freeway,
@@ -300,6 +398,30 @@ int pdegym_traffic_step(const pdegym_params_traffic* prm, const pdegym_bufs_traf
                        *prm, *buf, B);
   }
   return pdegym::check_launch("traffic_step");
+}
+
+int pdegym_traffic_rollout(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf, const pdegym_rollout_traffic* ro, int32_t B,
+                           void* stream) {
+  if (int rc = check(prm, buf)) return rc;
+  if (!ro) return pdegym::fail(-1, "null rollout descriptor");
+  if (B <= 0 || ro->T <= 0) return 0;
+  if (prm->M > kWave) return pdegym::fail(-2, "traffic rollout: freeways of up to 64 nodes (the register-resident kernel)");
+  if (!ro->obs || !ro->actions || !ro->rewards || !ro->done || !ro->truncated) return pdegym::fail(-3, "null rollout buffer");
+  const int A = buf->action_stride > 0 ? buf->action_stride : 2;
+  if (A > 2) return pdegym::fail(-2, "action_stride must be 1 or 2");
+  pdegym_mlp net = {};
+  size_t lds_bytes = 0;
+  if (ro->policy) {
+    net = *ro->policy;
+    if (const char* why = pdegym_policy::check(net, 2 * prm->M, A)) return pdegym::fail(-2, why);
+    lds_bytes = (size_t)pdegym_policy::lds_floats(net, 2 * prm->M) * sizeof(float);
+    static signed char attr[pdegym::kMaxDevices] = {};
+    if (!pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&traffic_rollout_kernel), pdegym_policy::kMaxLdsBytes, attr))
+      return pdegym::fail(-4, "cannot raise the dynamic LDS limit of traffic_rollout_kernel");
+  }
+  const dim3 grid((B + pdegym_policy::kWaves - 1) / pdegym_policy::kWaves), block(kWave * pdegym_policy::kWaves);
+  hipLaunchKernelGGL(traffic_rollout_kernel, grid, block, lds_bytes, (hipStream_t)stream, *prm, *buf, *ro, net, ro->policy ? 1 : 0, B);
+  return pdegym::check_launch("traffic_rollout");
 }
 
 int pdegym_traffic_reset_masked(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf, const double* profile,

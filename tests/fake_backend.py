@@ -197,6 +197,22 @@ class FakeBackend:
         T["done"].copy_(torch.from_numpy(d.astype(np.uint8)))
         T["truncated"].copy_(torch.from_numpy(t.astype(np.uint8)))
 
+    def traffic_rollout(self, P, T, obs, actions, rewards, done, truncated, B, policy=None):
+        # the C ABI's contract: T step calls (and the policy, when given, evaluated on slot t first)
+        import ctypes as C
+        A = actions.shape[2]
+        for t in range(actions.shape[0]):
+            if policy is not None:
+                net = type(policy)()
+                C.memmove(C.addressof(net), C.addressof(policy), C.sizeof(policy))
+                net.x_f64 = net.y_f64 = 1
+                if policy.noise:
+                    net.noise = policy.noise + 4 * t * B * policy.noise_stride
+                self.mlp_forward(net, obs[t], actions[t], B)
+            S = dict(T)
+            S.update(action=actions[t], obs=obs[t + 1], reward=rewards[t], done=done[t], truncated=truncated[t])
+            self.traffic_step(P, S, B)
+
     def traffic_reset(self, P, T, profile, mask, B):
         orc = self._orc_traffic()
         obs = orc.reset(T["rs"].numpy())

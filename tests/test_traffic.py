@@ -150,3 +150,81 @@ def test_traffic_device_rollout_with_fused_policy():
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-7)
     for got, want in zip(runs["fused_graph"], runs["fused"]):
         np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sim,cf,B,T", [("inlet", 1, 37, 12), ("outlet", 2, 64, 9), ("both", 1, 5, 30), ("outlet-train", 3, 130, 7),
+                                        ("outlet", 2, 1, 1)])
+def test_traffic_rollout_kernel_equals_step_calls_bitwise(sim, cf, B, T):
+    """pdegym_traffic_rollout (T env-steps in one launch, (r, y) in registers across steps) against T step calls: every
+    observation slot, reward, flag and the final r, y, time agree bit for bit."""
+    from pdecontrolgym_amd.batch_traffic import TrafficBatch
+    rng = np.random.default_rng(B + T)
+    rs = rng.choice([0.115, 0.12, 0.125], B)
+    qclip = rs * (40 * (1 - rs / 0.16))
+    nact = 2 if sim == "both" else 1
+    acts = torch.tensor(rng.uniform(0.7, 1.3, (T, B, nact)) * qclip[None, :, None], device="cuda")
+    res = []
+    for mode in ("steps", "rollout"):
+        env = TrafficBatch(0.5, 0.25, 500, 10, sim, 40, 0.16, 60, True, cf, num_envs=B, device="cuda")   # T/dt = 2 s: episodes end inside
+        env.set_action_bounds(qclip)
+        env.reset(rs)
+        obs = torch.zeros(T + 1, B, 2 * env.M, dtype=torch.float64, device="cuda")
+        obs[0].copy_(env.t["obs"])
+        rew = torch.zeros(T, B, dtype=torch.float64, device="cuda")
+        dn = torch.zeros(T, B, dtype=torch.uint8, device="cuda")
+        tr = torch.zeros(T, B, dtype=torch.uint8, device="cuda")
+        if mode == "steps":
+            for t in range(T):
+                o, r, d, tc = env.step(acts[t])
+                obs[t + 1].copy_(o), rew[t].copy_(r), dn[t].copy_(d), tr[t].copy_(tc)
+        else:
+            assert env.can_rollout()
+            env.rollout(obs, acts, rew, dn, tr)
+        res.append([x.cpu().numpy().copy() for x in (obs, rew, dn, tr, env.t["r"], env.t["y"], env.t["time"], env.t["obs"], env.t["reward"])])
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+    assert T < 9 or res[0][2].sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sim,sizes", [("outlet", [102, 32, 1]), ("both", [102, 64, 64, 2]), ("outlet-train", [102, 1])])
+def test_traffic_one_launch_rollout_with_policy_inside(sim, sizes):
+    """DeviceRollout on TrafficPDE1D as ONE kernel (policy evaluated inside pdegym_traffic_rollout on the float64 observation
+    rounded to float32) against policy launch + step launch per env-step: commands to float32 rounding, trajectories follow."""
+    import pde_control_gym
+    from pde_control_gym import DeviceRollout, FusedMLP
+    from pde_control_gym.src import TrafficARZReward
+    torch.manual_seed(1)
+    mods = []
+    for i in range(len(sizes) - 1):
+        mods.append(torch.nn.Linear(sizes[i], sizes[i + 1]))
+        if i < len(sizes) - 2:
+            mods.append(torch.nn.Tanh())
+    net = torch.nn.Sequential(*mods).cuda()
+    with torch.no_grad():
+        net[-1].bias.fill_(4.6 if sim != "outlet-train" else 4.0)
+    T, B = 10, 70
+    runs = {}
+    for mode in (False, True):
+        random.seed(0)
+        venv = pde_control_gym.make_vec("PDEControlGym-TrafficPDE1D", num_envs=B, reward_class=TrafficARZReward(),
+                                        simulation_type=sim, limit_pde_state_size=True, control_freq=2, **BASE)
+        venv.reset_tensor()
+        ro = DeviceRollout(venv, FusedMLP(net), T, action_low=3.0, action_high=6.0, action_noise=True, one_launch=mode)
+        assert ro.one_launch == mode
+        ro.action_noise.copy_(torch.randn(ro.action_noise.shape, generator=torch.Generator().manual_seed(2)).mul(0.05).cuda())
+        ro.run()
+        torch.cuda.synchronize()
+        runs[mode] = [x.cpu().numpy().copy() for x in (ro.actions, ro.obs, ro.rewards, ro.terminated, ro.truncated, venv.core.t["obs"],
+                                                       venv.core.t["time"])]
+    a, b = runs[True], runs[False]
+    assert a[0].dtype == np.float64 and a[0].std() > 0
+    np.testing.assert_allclose(a[0][0], b[0][0], rtol=2e-6, atol=1e-6)       # same observation: forward passes only
+    for x, y in zip(a[:3], b[:3]):
+        np.testing.assert_allclose(x, y, rtol=1e-4, atol=1e-6)
+    for x, y in zip(a[3:5], b[3:5]):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_allclose(a[5], b[5], rtol=1e-4, atol=1e-6)
+    np.testing.assert_array_equal(a[6], b[6])
+    np.testing.assert_array_equal(a[5], a[1][T])
