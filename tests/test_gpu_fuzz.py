@@ -47,3 +47,18 @@ def test_fuzz_other_kernels_against_oracle(which, count):
         d = fn(rng, k)
         done += d is not None and not d.endswith(")")
     assert done >= count // 2
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_fuzz_rollout_kernels_against_step_calls(seed):
+    """tests/fuzz_rollout.py: pdegym_*_rollout / pdegym_traffic_rollout == T step calls, bit for bit, for random shapes, reward
+    kinds, auto-reset pools and rollout lengths (the long run is `python tests/fuzz_rollout.py 600`)."""
+    import fuzz_rollout
+    rng = np.random.default_rng(seed)
+    n = {"1d": 0, "traffic": 0}
+    for _ in range(300):
+        which = "traffic" if rng.random() < 0.3 else "1d"
+        with np.errstate(all="ignore"):
+            d = fuzz_rollout.case_traffic(rng) if which == "traffic" else fuzz_rollout.case_1d(rng)
+        n[which] += d is not None
+    assert n["1d"] >= 150 and n["traffic"] >= 50
