@@ -5,9 +5,10 @@ The reference trains its RL controllers with SB3 on one environment per Python c
 (examples/ReactionDiffusionPDE/..., examples/transportPDE/transport1Dppo.py:77-90: PPO("MlpPolicy", env)).  This is the same
 algorithm in plain torch on the batched engine:
 
-  * rollout  -- ``DeviceRollout``: per env-step one ``pdegym_mlp_forward`` launch (actor mean + exploration noise + clamp,
-                written into the action buffer) and one env-step launch with fused auto-reset, the whole T-step rollout
-                replayed from one hipGraph;
+  * rollout  -- ``DeviceRollout``: the whole T-step rollout is ONE kernel launch (``pdegym_parabolic_rollout``: per env-step
+                the actor mean is evaluated inside the kernel from weights held in LDS, exploration noise added, the command
+                clamped and stored, then the env-step with fused auto-reset; bigger networks fall back to one
+                ``pdegym_mlp_forward`` launch + one env-step launch per step inside a hipGraph);
   * update   -- ordinary torch autograd on the same ``torch.nn.Sequential`` the rollout evaluates (``FusedMLP`` picks the new
                 weights up at the next ``run()``).
 
