@@ -15,6 +15,8 @@ nets = {
  "64-1 linear": seq(L(64,1)),
  "8-64 linear": seq(L(8,64)),
  "1025-64 linear": seq(L(1025,64)),
+ "257-256-256-1 relu (SAC actor shape)": seq(L(257,256),torch.nn.ReLU(),L(256,256),torch.nn.ReLU(),L(256,1),T()),
+ "257-128-128-1 tanh": seq(L(257,128),T(),L(128,128),T(),L(128,1)),
 }
 for name, net in nets.items():
     fm = FusedMLP(net)
@@ -31,4 +33,4 @@ for name, net in nets.items():
     t0 = time.perf_counter()
     for _ in range(5): g.replay()
     torch.cuda.synchronize()
-    print(f"{name:24s} {(time.perf_counter()-t0)/5/200*1e6:7.2f} us")
+    print(f"{name:40s} {(time.perf_counter()-t0)/5/200*1e6:7.2f} us")
