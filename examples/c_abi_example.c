@@ -133,6 +133,53 @@ int main(void) {
     fprintf(stderr, "two identical batches differ\n");
     return 7;
   }
+  /* The same episode as ONE launch: pdegym_parabolic_rollout reads the rows from observation slot t, the commands from
+   * actions row t, and writes slot t + 1 and row t of the reward / flag arrays -- bit-identical to the step calls above. */
+  {
+    pdegym_bufs1d Q;
+    memset(&Q, 0, sizeof Q);
+    pdegym_rollout1d R;
+    memset(&R, 0, sizeof R);
+    float h_acts[STEPS][B], h_rrew[STEPS][B], h_last[B * N];
+    for (int k = 0; k < STEPS; ++k) memcpy(h_acts[k], h_act, sizeof h_act);
+    float* d_init = (float*)dalloc(sizeof h_init);
+    R.T = STEPS;
+    R.obs = (float*)dalloc((size_t)(STEPS + 1) * sizeof h_init);
+    R.actions = (float*)dalloc(sizeof h_acts);
+    R.rewards = (float*)dalloc(sizeof h_rrew);
+    R.terminated = (uint8_t*)dalloc((size_t)STEPS * B);
+    R.truncated = (uint8_t*)dalloc((size_t)STEPS * B);
+    Q.u = NULL; /* full-state sensing: the rows live in the observation slots */
+    Q.obs = R.obs;
+    Q.beta = (const float*)dalloc(sizeof h_beta);
+    Q.action = R.actions;
+    Q.time_index = (int32_t*)dalloc(B * sizeof(int32_t));
+    Q.bsum = (double*)dalloc(B * sizeof(double));
+    Q.ring = (float*)dalloc((size_t)B * PDEGYM_RING * sizeof(float));
+    Q.reward = R.rewards;
+    Q.norm_now = (float*)dalloc(B * sizeof(float));
+    Q.norm_back = (float*)dalloc(B * sizeof(float));
+    Q.terminated = R.terminated;
+    Q.truncated = R.truncated;
+    if (!d_init || !R.obs || !R.actions || !R.rewards || !R.terminated || !R.truncated || !Q.beta || !Q.time_index || !Q.bsum ||
+        !Q.ring || !Q.norm_now || !Q.norm_back)
+      return 2;
+    CHECK_HIP(hipMemcpy(d_init, h_init, sizeof h_init, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy((void*)Q.beta, h_beta, sizeof h_beta, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(R.actions, h_acts, sizeof h_acts, hipMemcpyHostToDevice));
+    hipStream_t st;
+    CHECK_HIP(hipStreamCreate(&st));
+    CHECK_PDE(pdegym_reset1d_masked(&P, &Q, d_init, NULL, B, st)); /* writes observation slot 0 */
+    CHECK_PDE(pdegym_parabolic_rollout(&P, &Q, &R, B, st));
+    CHECK_HIP(hipMemcpyAsync(h_rrew, R.rewards, sizeof h_rrew, hipMemcpyDeviceToHost, st));
+    CHECK_HIP(hipMemcpyAsync(h_last, R.obs + (size_t)STEPS * B * N, sizeof h_last, hipMemcpyDeviceToHost, st));
+    CHECK_HIP(hipStreamSynchronize(st));
+    if (memcmp(h_rrew, h_rew[0], sizeof h_rrew) != 0 || memcmp(h_last, h_row[0], sizeof h_last) != 0) {
+      fprintf(stderr, "the one-launch rollout differs from the step calls\n");
+      return 8;
+    }
+    CHECK_HIP(hipStreamDestroy(st));
+  }
   printf("ok abi=%d rewards(step %d):", pdegym_abi_version(), STEPS);
   for (int b = 0; b < B; ++b) printf(" %.6g", h_rew[0][STEPS - 1][b]);
   printf("\n");

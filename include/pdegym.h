@@ -147,7 +147,9 @@ const char* pdegym_last_error(void);
 int pdegym_transport_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int32_t B, void* stream);
 int pdegym_parabolic_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int32_t B, void* stream);
 
-/* T env-steps in ONE launch (the on-device rollout of SURVEY.md section 8f rank 1 without a kernel boundary per step).
+/* T env-steps in ONE launch (the on-device rollout of SURVEY.md section 8f rank 1 without a kernel boundary per step):
+ * replaces the loop of env.step calls that SB3's model.learn() drives (examples/transportPDE/transport1Dppo.py:88-90,
+ * examples/reactionDiffusionPDE/reactionDiffusion1Dppo.py), i.e. T x (hyperbolic.py:126-194 / parabolic.py:126-189).
  * Step t reads the rows from obs slot t, the commands from actions row t, and writes obs slot t + 1, rewards / terminated /
  * truncated row t; everything else (beta, time_index, bsum, ring, norm_now, norm_back, the auto-reset pools, final_obs,
  * reset_count) comes from the pdegym_bufs1d of the call and behaves as in T consecutive pdegym_*_step calls with state_in --
@@ -290,7 +292,8 @@ typedef struct pdegym_bufs_traffic {
 
 int pdegym_traffic_step(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf, int32_t B, void* stream);
 
-/* T env-steps in ONE launch (M <= 64): step t takes the command(s) from actions row t and writes observation slot t + 1,
+/* T env-steps in ONE launch (M <= 64; T x traffic_arz_env.py:131-233, the loop of the reference's "RL control" notebook):
+ * step t takes the command(s) from actions row t and writes observation slot t + 1,
  * rewards / done / truncated row t; r, y, time of the pdegym_bufs_traffic are read once and written back at the end
  * (bufs->action / obs / reward / done / truncated are ignored).  Bit-identical to T pdegym_traffic_step calls; like them it
  * keeps stepping a finished episode.  With a policy (HOST pointer; layers of <= 64 units, 2M inputs, action_stride outputs)
