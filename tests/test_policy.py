@@ -254,6 +254,11 @@ def test_one_launch_rollout_with_policy_inside_equals_two_launches_per_step(kind
         runs[mode]["obs2"] = ro.obs.cpu().numpy().copy()
     a, b = runs[True], runs[False]
     np.testing.assert_allclose(a["actions"][0], b["actions"][0], rtol=2e-5, atol=4e-6)      # same input: forward passes only
+    # ... and against the torch module itself on the first observation slot (noise added before the clamp)
+    with torch.no_grad():
+        nz0 = torch.randn(T, B, generator=torch.Generator().manual_seed(1)).mul(0.3)[0].cuda()
+        want0 = (net(torch.tensor(a["obs"][0]).cuda()).reshape(B) + nz0).clamp(-2.0, 2.0).cpu().numpy()
+    np.testing.assert_allclose(a["actions"][0], want0, rtol=2e-5, atol=4e-6)
     for k in ("actions", "obs", "rewards", "cur", "obs2"):
         np.testing.assert_allclose(a[k], b[k], rtol=1e-4, atol=2e-5, err_msg=k)
     for k in ("terminated", "truncated", "time_index"):
