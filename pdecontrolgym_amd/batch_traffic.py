@@ -102,6 +102,9 @@ class TrafficBatch:
         if policy is not None:
             if not self.policy_fits_rollout(policy):
                 raise ValueError("this policy cannot run inside the rollout kernel (see policy_fits_rollout)")
+            import torch
+            if not (obs.is_cuda and torch.cuda.is_current_stream_capturing()):
+                policy.refresh()             # pick up in-place parameter updates (as FusedMLP.forward_into does)
             net = policy._net(policy.clamp if clamp == "default" else clamp)
             if noise is not None:
                 import torch

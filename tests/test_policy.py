@@ -292,3 +292,30 @@ def test_one_launch_rollout_falls_back_and_validates():
     with pytest.raises(N.NativeError, match="one command"):
         core.backend.rollout1d(core.kind, core.params, core.t, obs, z(torch.float32), z(torch.float32), z(torch.uint8), z(torch.uint8), B,
                                policy=two_out._net(None))
+
+
+@pytest.mark.gpu
+def test_engine_rollout_sees_in_place_weight_updates():
+    """PDEBatch1D.rollout(policy=...) re-transposes weights whose parameters changed since the last call (an optimizer step
+    between two rollouts), like FusedMLP.forward_into."""
+    venv = _rd_env(8, 64, 5, horizon=40)
+    core = venv.core
+    net = _mlp([65, 16, 1], ["tanh", None], seed=2).cuda()
+    pol = FusedMLP(net, clamp=(-3.0, 3.0))
+    T, B, n = 2, 8, core.n
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device="cuda")   # noqa: E731
+    obs, act = z(T + 1, B, n), z(T, B)
+    obs[0].copy_(core.t["obs"])
+    first = obs[0].clone()
+    core.rollout(obs, act, z(T, B), z(T, B, dt=torch.uint8), z(T, B, dt=torch.uint8), policy=pol)
+    with torch.no_grad():
+        want = net(first).reshape(B).clamp(-3, 3)
+        np.testing.assert_allclose(act[0].cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=4e-6)
+        net[-1].bias.add_(0.5)                                   # "optimizer step"
+        net[0].weight.mul_(1.5)
+    obs[0].copy_(first)
+    core.rollout(obs, act, z(T, B), z(T, B, dt=torch.uint8), z(T, B, dt=torch.uint8), policy=pol)
+    with torch.no_grad():
+        want2 = net(first).reshape(B).clamp(-3, 3)
+    np.testing.assert_allclose(act[0].cpu().numpy(), want2.cpu().numpy(), rtol=2e-5, atol=4e-6)
+    assert np.abs(want2.cpu().numpy() - want.cpu().numpy()).max() > 0.1
