@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PDEGYM_ABI_VERSION 10
+#define PDEGYM_ABI_VERSION 11
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
 #define PDEGYM_MAX_N1D 2048      /* nodes per 1D row kept in registers by the wave-per-instance kernels */
@@ -279,7 +279,8 @@ typedef struct pdegym_bufs_traffic {
   double* y;               /* [B, M] relative flow y = r (v - Veq(r)) (in/out)                              */
   const double* action;    /* [B, action_stride] inlet / outlet flux command; column 1 is used by 'both' only */
   double* time;            /* [B] simulated seconds ("time_index" of the reference) in/out                  */
-  const double* rs;        /* [B] steady-state density of each instance (vs, qs follow the equilibrium law) */
+  double* rs;              /* [B] steady-state density of each instance (vs, qs follow the equilibrium law); rewritten
+                              for an instance that the fused auto-reset restarts (reset_rs below)                     */
   const double* qs_clip;   /* [B] qs the action bounds [0.8 qs, 1.2 qs] were built from (:97-100)           */
   double* obs;             /* [B, 2M] out: (r, v), or ((r-rs)/rs, (v-vs)/vs) for outlet-train (:227-230)    */
   double* reward;          /* [B] out                                                                       */
@@ -288,6 +289,18 @@ typedef struct pdegym_bufs_traffic {
   int32_t action_stride;   /* elements between the commands of consecutive instances: 2 (or 0 = 2), or 1 for the
                               single-command simulation types (the caller's [B] / [B,1] tensor is used as it is)      */
   int32_t reserved_;
+  /* Fused VecEnv auto-reset (as for the 1D and NS engines): when reset_rs is non-NULL, an
+   * instance whose step ends done | truncated restarts INSIDE the same launch the way TrafficPDE1D.reset does
+   * (traffic_arz_env.py:245-260): its observation goes to final_obs (if given), then rs[b] := reset_rs[(b + k*B) mod
+   * reset_pool_rows] (k from reset_count: the reference redraws the steady state in 'outlet-train'), r = rs * profile,
+   * y = qs - vm r + vm/rm r^2, time = 0, and obs[b] is the first observation (r, v) of the new episode.  done / truncated /
+   * reward still report the finished step.  qs_clip (the construction-time action bounds) is left alone. */
+  const double* reset_rs;      /* optional [reset_pool_rows] steady-state densities of the coming episodes              */
+  const double* reset_profile; /* [M] sin(3 x/L pi)*0.1 + 1 as for pdegym_traffic_reset_masked (required with reset_rs)  */
+  double* final_obs;           /* optional [B, 2M]: last observation of the finished episode ("terminal_observation")   */
+  int32_t* reset_count;        /* optional [B] in/out: restarts so far; NULL = always pool row b mod reset_pool_rows     */
+  int32_t reset_pool_rows;     /* rows of reset_rs (0 = B)                                                              */
+  int32_t reserved2_;
 } pdegym_bufs_traffic;
 
 int pdegym_traffic_step(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf, int32_t B, void* stream);

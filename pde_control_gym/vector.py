@@ -184,15 +184,18 @@ class PDEVecEnv:
         return self.core.reset(init, beta)
 
     def enable_fused_auto_reset(self, init_pool=None, beta_pool=None, pool_episodes: int = 4):
-        """1D only: finished instances restart inside the step kernel (no host sync).  The reference calls BOTH reset
+        """Finished instances restart inside the step kernel (no host sync).  The reference calls BOTH reset
         callbacks at every reset (hyperbolic.py:207-209); here they are drawn ahead of time into pools of
         ``pool_episodes * num_envs`` rows (initial condition AND beta), and the k-th restart of instance b takes row
         (b + k*num_envs) mod rows.  Call ``refresh_pool()`` (any time between steps) to draw fresh rows; pass explicit
         ``init_pool`` / ``beta_pool`` tensors [P >= num_envs, n] to control them (``beta_pool=False`` keeps beta fixed)."""
         if self.kind == "ns2d":
             return self._enable_fused_auto_reset_ns(init_pool, min(int(pool_episodes), 2) if init_pool is None else 1)
-        if self.kind == "traffic":
-            raise NotImplementedError("fused auto-reset is implemented for the transport / reaction-diffusion / NS environments")
+        if self.kind == "traffic":       # pool of steady-state densities (redrawn per episode in 'outlet-train', :247-252)
+            rows = self.num_envs * max(1, int(pool_episodes))
+            self.core.enable_auto_reset(self._draw_rs(rows) if init_pool is None else init_pool)
+            self._fused_reset = True
+            return
         if getattr(self, "_host_reward", False):
             raise NotImplementedError("a host reward callback needs the finished trajectory: use the plain auto-reset of step()")
         if init_pool is None:
@@ -209,6 +212,10 @@ class PDEVecEnv:
         import torch
         if self.kind == "ns2d":
             return self._refresh_pool_ns(init_pool)
+        if self.kind == "traffic":
+            rr = self.core.t["reset_rs"]
+            rr.copy_(torch.as_tensor(self._draw_rs(rr.shape[0]) if init_pool is None else init_pool, dtype=rr.dtype, device=self.device))
+            return
         rows = self.core.t["reset_init"].shape[0]
         if init_pool is None:
             init_pool, drawn_beta = self._sample_1d(np.arange(rows))

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 RING = 128
 LOOKBACK = 100
 MAX_N1D = 8192
@@ -89,7 +89,9 @@ class ParamsTraffic(C.Structure):
 class BufsTraffic(C.Structure):
     _fields_ = [("r", C.c_void_p), ("y", C.c_void_p), ("action", C.c_void_p), ("time", C.c_void_p), ("rs", C.c_void_p),
                 ("qs_clip", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
-                ("truncated", C.c_void_p), ("action_stride", C.c_int32), ("reserved_", C.c_int32)]
+                ("truncated", C.c_void_p), ("action_stride", C.c_int32), ("reserved_", C.c_int32),
+                ("reset_rs", C.c_void_p), ("reset_profile", C.c_void_p), ("final_obs", C.c_void_p), ("reset_count", C.c_void_p),
+                ("reset_pool_rows", C.c_int32), ("reserved2_", C.c_int32)]
 
 
 class RolloutTraffic(C.Structure):

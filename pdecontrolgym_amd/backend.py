@@ -179,6 +179,12 @@ class HipBackend:
         b.done = N.dptr(T["done"], torch.uint8)
         b.truncated = N.dptr(T["truncated"], torch.uint8)
         b.action_stride = int(T["action"].shape[1]) if T["action"].dim() == 2 else 1
+        rr = T.get("reset_rs")
+        if rr is not None:           # fused auto-reset (include/pdegym.h)
+            b.reset_rs, b.reset_profile = N.dptr(rr, torch.float64), N.dptr(T["reset_profile"], torch.float64)
+            b.reset_pool_rows = int(rr.shape[0])
+            b.final_obs = N.dptr(T["final_obs"], torch.float64) if T.get("final_obs") is not None else None
+            b.reset_count = N.dptr(T["reset_count"], torch.int32) if T.get("reset_count") is not None else None
         return b
 
     @_on_device_of("r")

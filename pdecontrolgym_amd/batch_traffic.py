@@ -74,6 +74,22 @@ class TrafficBatch:
         self.backend.traffic_reset(self.params, self.t, self.profile, mask, self.num_envs)
         return self.t["obs"]
 
+    def enable_auto_reset(self, rs_pool, keep_final_obs: bool = True):
+        """Fused VecEnv auto-reset: an instance whose step ends done | truncated restarts inside the same launch (step and
+        rollout alike) the way ``TrafficPDE1D.reset`` does, with the steady-state density of pool row (b + k*B) mod P for its
+        k-th restart (``rs_pool`` [P]: the reference redraws it in 'outlet-train'); ``t['final_obs']`` keeps the last
+        observation of the finished episode."""
+        import torch
+        B, dev = self.num_envs, self.device
+        self.t["reset_rs"] = torch.as_tensor(rs_pool, dtype=torch.float64, device=dev).reshape(-1).contiguous()
+        self.t["reset_profile"] = self.profile
+        self.t["reset_count"] = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.t["final_obs"] = torch.zeros(B, 2 * self.M, dtype=torch.float64, device=dev) if keep_final_obs else None
+
+    def disable_auto_reset(self):
+        for k in ("reset_rs", "reset_profile", "reset_count", "final_obs"):
+            self.t.pop(k, None)
+
     def can_rollout(self) -> bool:
         """``rollout`` needs the register-resident kernel (freeways of up to 64 nodes: the reference's grid has 51)."""
         return self.M <= 64 and hasattr(self.backend, "traffic_rollout")

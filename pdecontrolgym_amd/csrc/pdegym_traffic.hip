@@ -130,6 +130,22 @@ __device__ __forceinline__ void traffic_emit_obs(const pdegym_params_traffic& P,
   }
 }
 
+// pool row of the k-th restart of instance b (include/pdegym.h)
+__device__ __forceinline__ int traffic_pool_row(const pdegym_bufs_traffic& Bf, int inst, int B) {
+  const int rows = Bf.reset_pool_rows > 0 ? Bf.reset_pool_rows : B;
+  const long long k = Bf.reset_count ? (long long)Bf.reset_count[inst] : 0;
+  return (int)(((long long)inst + k * B) % rows);
+}
+
+// TrafficPDE1D.reset of one node (traffic_arz_env.py:256-258; the expressions of traffic_reset_kernel)
+__device__ __forceinline__ void traffic_restart_node(const pdegym_params_traffic& P, double rs, double prof, double& r, double& y,
+                                                     double& v) {
+  const double vs = Veq(P.vm, P.rm, rs), qs = rs * vs;
+  r = rs * prof;
+  y = (qs * 1.0 - P.vm * r) + (P.vm / P.rm) * (r * r);
+  v = y / r + Veq(P.vm, P.rm, r);
+}
+
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pdegym_params_traffic P, pdegym_bufs_traffic Bf, int B) {
   const int lane = threadIdx.x & (kWave - 1);
   const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -143,6 +159,28 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pde
   const double a0 = Bf.action[(size_t)inst * astr], a1 = astr > 1 ? Bf.action[(size_t)inst * astr + 1] : 0.0;
   double time = Bf.time[inst];
   const TrafficStepOut o = traffic_step_wave(P, r, y, time, rs, Bf.qs_clip[inst], a0, a1, lane);
+  if (Bf.reset_rs && (o.done || o.trunc)) {       // fused auto-reset (wave-uniform)
+    if (Bf.final_obs) traffic_emit_obs(P, Bf.final_obs + (size_t)inst * 2 * M, r, o.v, rs, o.vs, lane);
+    const double rs_new = Bf.reset_rs[traffic_pool_row(Bf, inst, B)];
+    double v0 = 0.0;
+    if (in) {
+      traffic_restart_node(P, rs_new, Bf.reset_profile[lane], r, y, v0);
+      Bf.r[(size_t)inst * M + lane] = r;
+      Bf.y[(size_t)inst * M + lane] = y;
+      double* ob = Bf.obs + (size_t)inst * 2 * M;
+      ob[lane] = r;
+      ob[M + lane] = v0;
+    }
+    if (lane == 0) {
+      Bf.rs[inst] = rs_new;
+      if (Bf.reset_count) Bf.reset_count[inst] += 1;
+      Bf.time[inst] = 0.0;
+      Bf.reward[inst] = o.reward;
+      Bf.done[inst] = o.done ? 1 : 0;
+      Bf.truncated[inst] = o.trunc ? 1 : 0;
+    }
+    return;
+  }
   if (in) {
     Bf.r[(size_t)inst * M + lane] = r;
     Bf.y[(size_t)inst * M + lane] = y;
@@ -178,8 +216,11 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void traffic_rollout_
   const bool in = lane < M;
   double r = in ? Bf.r[(size_t)inst * M + lane] : 1.0;
   double y = in ? Bf.y[(size_t)inst * M + lane] : 0.0;
-  const double rs = Bf.rs[inst], qc = Bf.qs_clip[inst];
+  double rs = Bf.rs[inst];
+  const double qc = Bf.qs_clip[inst];
   double time = Bf.time[inst];
+  int restarts = 0;
+  const double prof = (Bf.reset_rs && in) ? Bf.reset_profile[lane] : 1.0;
   const int A = Bf.action_stride > 0 ? Bf.action_stride : 2;
   const size_t slot = (size_t)B * D;
   for (int t = 0; t < Ro.T; ++t) {
@@ -211,7 +252,23 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void traffic_rollout_
       if (A > 1) a1 = arow[1];
     }
     const TrafficStepOut o = traffic_step_wave(P, r, y, time, rs, qc, a0, a1, lane);
-    traffic_emit_obs(P, Ro.obs + (size_t)(t + 1) * slot + (size_t)inst * D, r, o.v, rs, o.vs, lane);
+    double* onext = Ro.obs + (size_t)(t + 1) * slot + (size_t)inst * D;
+    if (Bf.reset_rs && (o.done || o.trunc)) {     // fused auto-reset, as in traffic_step_kernel
+      if (Bf.final_obs) traffic_emit_obs(P, Bf.final_obs + (size_t)inst * D, r, o.v, rs, o.vs, lane);
+      const int rows = Bf.reset_pool_rows > 0 ? Bf.reset_pool_rows : B;
+      const long long k = (Bf.reset_count ? (long long)Bf.reset_count[inst] : 0) + restarts;
+      rs = Bf.reset_rs[(int)(((long long)inst + k * B) % rows)];
+      ++restarts;
+      double v0 = 0.0;
+      if (in) {
+        traffic_restart_node(P, rs, prof, r, y, v0);
+        onext[lane] = r;
+        onext[M + lane] = v0;
+      }
+      time = 0.0;
+    } else {
+      traffic_emit_obs(P, onext, r, o.v, rs, o.vs, lane);
+    }
     if (lane == 0) {
       Ro.rewards[(size_t)t * B + inst] = o.reward;
       Ro.done[(size_t)t * B + inst] = o.done ? 1 : 0;
@@ -225,7 +282,13 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void traffic_rollout_
     Bf.r[(size_t)inst * M + lane] = r;
     Bf.y[(size_t)inst * M + lane] = y;
   }
-  if (lane == 0) Bf.time[inst] = time;
+  if (lane == 0) {
+    Bf.time[inst] = time;
+    if (restarts) {
+      Bf.rs[inst] = rs;
+      if (Bf.reset_count) Bf.reset_count[inst] += restarts;
+    }
+  }
 }
 
 // ---- rows of more than 64 nodes (finer grids than the reference notebook's M = 51): one wave still owns one freeway,
@@ -337,6 +400,27 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_wide_kerne
   if (P.limit) trunc = __any(over);
   trunc = trunc || !__any(moved);
   const bool done = (P.sim == PDEGYM_TRAFFIC_OUTLET_TRAIN) ? term : (term || reward > -0.00023);
+  if (Bf.reset_rs && (done || trunc)) {           // fused auto-reset, as in traffic_step_kernel (each lane re-reads its own stores)
+    const double rs_new = Bf.reset_rs[traffic_pool_row(Bf, inst, B)];
+    double* fo = Bf.final_obs ? Bf.final_obs + (size_t)inst * 2 * M : nullptr;
+    for (int j = lane; j < M; j += kWave) {
+      if (fo) {
+        fo[j] = o[j];
+        fo[M + j] = o[M + j];
+      }
+      double r, y, v;
+      traffic_restart_node(P, rs_new, Bf.reset_profile[j], r, y, v);
+      Bf.r[(size_t)inst * M + j] = r;
+      Bf.y[(size_t)inst * M + j] = y;
+      o[j] = r;
+      o[M + j] = v;
+    }
+    time = 0.0;
+    if (lane == 0) {
+      Bf.rs[inst] = rs_new;
+      if (Bf.reset_count) Bf.reset_count[inst] += 1;
+    }
+  }
   if (lane == 0) {
     Bf.time[inst] = time;
     Bf.reward[inst] = reward;
@@ -377,6 +461,8 @@ int check(const pdegym_params_traffic* prm, const pdegym_bufs_traffic* buf) {
   if (prm->sim < 0 || prm->sim > 3) return pdegym::fail(-2, "bad simulation type");
   if (!buf->r || !buf->y || !buf->time || !buf->rs || !buf->qs_clip || !buf->obs || !buf->done || !buf->truncated)
     return pdegym::fail(-3, "null device buffer");
+  if (buf->reset_rs && !buf->reset_profile) return pdegym::fail(-3, "reset_rs needs reset_profile");
+  if (buf->reset_pool_rows < 0) return pdegym::fail(-2, "reset_pool_rows must be >= 0");
   return 0;
 }
 

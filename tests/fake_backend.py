@@ -196,6 +196,21 @@ class FakeBackend:
             T[k].copy_(torch.from_numpy(np.ascontiguousarray(v)))
         T["done"].copy_(torch.from_numpy(d.astype(np.uint8)))
         T["truncated"].copy_(torch.from_numpy(t.astype(np.uint8)))
+        if T.get("reset_rs") is not None:           # fused auto-reset (include/pdegym.h)
+            fin = d | t
+            if fin.any():
+                m = torch.from_numpy(fin)
+                if T.get("final_obs") is not None:
+                    T["final_obs"][m] = T["obs"][m]
+                cnt = T["reset_count"].numpy().astype(np.int64) if T.get("reset_count") is not None else np.zeros(B, dtype=np.int64)
+                rows = torch.from_numpy((np.arange(B) + cnt * B) % T["reset_rs"].shape[0])
+                T["rs"][m] = T["reset_rs"][rows][m]
+                if T.get("reset_count") is not None:
+                    T["reset_count"][m] += 1
+                keep = (T["done"].clone(), T["truncated"].clone())
+                self.traffic_reset(P, T, T["reset_profile"], m.to(torch.uint8), B)
+                T["done"].copy_(keep[0])
+                T["truncated"].copy_(keep[1])
 
     def traffic_rollout(self, P, T, obs, actions, rewards, done, truncated, B, policy=None):
         # the C ABI's contract: T step calls (and the policy, when given, evaluated on slot t first)

@@ -98,6 +98,9 @@ def case_traffic(rng):
     qclip = rs * (40 * (1 - rs / 0.16))
     nact = 2 if sim == "both" else 1
     acts = torch.tensor(rng.uniform(0.5, 1.5, (T, B, nact)) * qclip[None, :, None], device=DEV)
+    auto = bool(rng.random() < 0.6)
+    pool = rng.choice([0.115, 0.12, 0.125], int(rng.choice([1, B, 2 * B + 1])))
+    keep_final = bool(rng.random() < 0.7)
     outs = []
     for mode in ("steps", "rollout"):
         env = TrafficBatch(horizon, 0.25, X, 10, sim, 40, 0.16, 60, bool(rng.random() < 2), cf, num_envs=B, device=DEV)
@@ -105,6 +108,8 @@ def case_traffic(rng):
             return None
         env.set_action_bounds(qclip)
         env.reset(rs)
+        if auto:
+            env.enable_auto_reset(pool, keep_final_obs=keep_final)
         D = 2 * env.M
         obs = torch.zeros(T + 1, B, D, dtype=torch.float64, device=DEV)
         obs[0].copy_(env.t["obs"])
@@ -117,8 +122,9 @@ def case_traffic(rng):
                 obs[t + 1].copy_(o), rew[t].copy_(r), dn[t].copy_(d), tr[t].copy_(c)
         else:
             env.rollout(obs, acts, rew, dn, tr)
-        outs.append([k.clone() for k in (obs, rew, dn, tr, env.t["r"], env.t["y"], env.t["time"])])
-    desc = f"traffic {sim} cf={cf} B={B} T={T} X={X} horizon={horizon}"
+        outs.append([k.clone() for k in (obs, rew, dn, tr, env.t["r"], env.t["y"], env.t["time"], env.t["rs"])]
+                    + [env.t[k].clone() for k in ("reset_count", "final_obs") if env.t.get(k) is not None])
+    desc = f"traffic {sim} cf={cf} B={B} T={T} X={X} horizon={horizon} auto={auto} pool={len(pool)}"
     for i, (a, b) in enumerate(zip(*outs)):
         if not torch.equal(a.view(torch.uint8) if a.dtype != torch.uint8 else a, b.view(torch.uint8) if b.dtype != torch.uint8 else b):
             raise AssertionError(f"traffic rollout != steps (tensor {i}): {desc}")

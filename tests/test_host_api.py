@@ -44,7 +44,7 @@ def test_ctypes_structs_match_header_layout():
 
     for struct, mirror in (("pdegym_params1d", N.Params1D), ("pdegym_bufs1d", N.Bufs1D), ("pdegym_rollout1d", N.Rollout1D),
                            ("pdegym_params_ns2d", N.ParamsNS2D), ("pdegym_bufs_ns2d", N.BufsNS2D),
-                           ("pdegym_rollout_traffic", N.RolloutTraffic)):
+                           ("pdegym_rollout_traffic", N.RolloutTraffic), ("pdegym_bufs_traffic", N.BufsTraffic)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         decls = []

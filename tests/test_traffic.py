@@ -169,6 +169,8 @@ def test_traffic_rollout_kernel_equals_step_calls_bitwise(sim, cf, B, T):
         env = TrafficBatch(0.5, 0.25, 500, 10, sim, 40, 0.16, 60, True, cf, num_envs=B, device="cuda")   # T/dt = 2 s: episodes end inside
         env.set_action_bounds(qclip)
         env.reset(rs)
+        if B % 2 == 1:                                     # odd batches: with the fused auto-reset (pool of 2B + 1 steady states)
+            env.enable_auto_reset(np.random.default_rng(3).choice([0.115, 0.12, 0.125], 2 * B + 1))
         obs = torch.zeros(T + 1, B, 2 * env.M, dtype=torch.float64, device="cuda")
         obs[0].copy_(env.t["obs"])
         rew = torch.zeros(T, B, dtype=torch.float64, device="cuda")
@@ -181,7 +183,9 @@ def test_traffic_rollout_kernel_equals_step_calls_bitwise(sim, cf, B, T):
         else:
             assert env.can_rollout()
             env.rollout(obs, acts, rew, dn, tr)
-        res.append([x.cpu().numpy().copy() for x in (obs, rew, dn, tr, env.t["r"], env.t["y"], env.t["time"], env.t["obs"], env.t["reward"])])
+        res.append([x.cpu().numpy().copy() for x in (obs, rew, dn, tr, env.t["r"], env.t["y"], env.t["time"], env.t["obs"], env.t["reward"],
+                                                     env.t["rs"])]
+                   + [env.t[k].cpu().numpy().copy() for k in ("reset_count", "final_obs") if env.t.get(k) is not None])
     for a, b in zip(*res):
         np.testing.assert_array_equal(a, b)
     assert T < 9 or res[0][2].sum() > 0
@@ -228,3 +232,66 @@ def test_traffic_one_launch_rollout_with_policy_inside(sim, sizes):
     np.testing.assert_allclose(a[5], b[5], rtol=1e-4, atol=1e-6)
     np.testing.assert_array_equal(a[6], b[6])
     np.testing.assert_array_equal(a[5], a[1][T])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sim,X,cf,B", [("outlet-train", 500, 2, 37), ("inlet", 500, 1, 64), ("both", 1500, 1, 5), ("outlet", 630, 3, 9)])
+def test_traffic_fused_auto_reset_equals_host_driven_reset(sim, X, cf, B):
+    """bufs.reset_rs: an instance whose step ends done | truncated restarts inside the launch (TrafficPDE1D.reset: new steady
+    state from the pool, sine profile, time 0) -- bit for bit what a masked pdegym_traffic_reset_masked after the step does;
+    final_obs keeps the terminal observation; the register kernel (M = 51, 64) and the LDS one (M = 151)."""
+    from pdecontrolgym_amd.batch_traffic import TrafficBatch
+    rng = np.random.default_rng(B)
+    rs = rng.choice([0.115, 0.12, 0.125], B)
+    pool = rng.choice([0.115, 0.12, 0.125], 2 * B + 3)
+    qclip = rs * (40 * (1 - rs / 0.16))
+    nact = 2 if sim == "both" else 1
+    envs = [TrafficBatch(0.5, 0.25, X, 10, sim, 40, 0.16, 60, True, cf, num_envs=B, device="cuda") for _ in range(2)]   # T/dt = 2 s
+    for e in envs:
+        e.set_action_bounds(qclip)
+        e.reset(rs)
+    envs[0].enable_auto_reset(pool)
+    cnt = np.zeros(B, dtype=np.int64)
+    cur_rs = rs.copy()
+    ends = 0
+    for k in range(30):
+        a = torch.tensor(rng.uniform(0.7, 1.3, (B, nact)) * qclip[:, None], device="cuda")
+        o0, r0, d0, t0 = envs[0].step(a)
+        o1, r1, d1, t1 = envs[1].step(a)
+        fin = (d1.cpu().numpy() | t1.cpu().numpy()).astype(bool)
+        np.testing.assert_array_equal(r0.cpu().numpy(), r1.cpu().numpy())
+        np.testing.assert_array_equal(d0.cpu().numpy(), d1.cpu().numpy())
+        np.testing.assert_array_equal(t0.cpu().numpy(), t1.cpu().numpy())
+        last = o1.cpu().numpy().copy()
+        if fin.any():
+            ends += int(fin.sum())
+            np.testing.assert_array_equal(envs[0].t["final_obs"].cpu().numpy()[fin], last[fin])
+            cur_rs = np.where(fin, pool[(np.arange(B) + cnt * B) % len(pool)], cur_rs)
+            cnt += fin
+            o1 = envs[1].reset(cur_rs, mask=torch.tensor(fin.astype(np.uint8)))
+        for key in ("r", "y", "time", "rs"):
+            np.testing.assert_array_equal(envs[0].t[key].cpu().numpy(), envs[1].t[key].cpu().numpy(), err_msg=f"{key} step {k}")
+        np.testing.assert_array_equal(o0.cpu().numpy(), o1.cpu().numpy(), err_msg=f"obs step {k}")
+        np.testing.assert_array_equal(envs[0].t["reset_count"].cpu().numpy(), cnt)
+    assert ends > 0
+
+
+def test_traffic_vecenv_fused_auto_reset_on_test_double():
+    import pde_control_gym
+    from pde_control_gym.src import TrafficARZReward
+    random.seed(0)
+    kw = dict(BASE, T=0.5)
+    venv = pde_control_gym.make_vec("PDEControlGym-TrafficPDE1D", num_envs=4, device="cpu", backend=FakeBackend(),
+                                    reward_class=TrafficARZReward(), simulation_type="outlet-train", limit_pde_state_size=True,
+                                    control_freq=1, **kw)
+    venv.reset()
+    venv.enable_fused_auto_reset()
+    qs = venv.core.t["qs_clip"].numpy()
+    seen = 0
+    for _ in range(12):
+        obs, rew, dones, infos = venv.step(qs[:, None] * 1.05)
+        for i in np.nonzero(dones)[0]:
+            seen += 1
+            assert "terminal_observation" in infos[i] and infos[i]["terminal_observation"].shape == (102,)
+            assert venv.core.t["time"][i].item() == 0.0
+    assert seen > 0 and int(venv.core.t["reset_count"].sum()) == seen
