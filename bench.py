@@ -13,7 +13,7 @@ per GPU, fp32, S=100 sub-steps per env-step.  Other workl
 the default run adds all of them under "also"): transport_c3, burgers_c3 (extension), parabolic_c2_policy_loop (C2 with its MLP
 controller evaluated on the device every step), parabolic_c2_rollout (the same loop as ONE kernel per 25 env-steps: here a
 "step" is one launch and `value` still counts env-steps), parabolic_c2_open_loop_rollout (25 env-steps per launch, commands given ahead), ns2d_c4, ns2d_c4_f64, ns2d_c4_b4096, ns2d_c5, ns2d_example (the reference's
-shipped 21x21 K=2000 float64 configuration), traffic_arz, brain_tumor.
+shipped 21x21 K=2000 float64 configuration), traffic_arz, traffic_arz_rollout (25 env-steps per launch), brain_tumor.
 
 Prints ONE JSON line (rank 0).
 """
@@ -401,6 +401,42 @@ class TrafficARZ:
                 "substeps_per_env_step": self.S, "reward": "TrafficARZReward", "parallelism": "independent instances, no collective"}
 
 
+class TrafficARZRollout(TrafficARZ):
+    """The same freeways with the commands of CHUNK env-steps handed over at once: pdegym_traffic_rollout, one launch per CHUNK
+    env-steps with (r, y) in registers across them, bit-identical to CHUNK step launches; a bench "step" is one launch."""
+    CHUNK = 25
+    name = "TrafficPDE1D M=51 f64 B=16384 control_freq=2, 25 env-steps per launch (pdegym_traffic_rollout, commands given ahead)"
+
+    def prepare(self, total_steps):
+        import torch
+        super().prepare(total_steps * self.CHUNK)
+        T, B, M = self.CHUNK, self.B, self.env.M
+        f64 = torch.float64
+        self.robs = torch.zeros(T + 1, B, 2 * M, dtype=f64, device=self.device)
+        self.rrew = torch.zeros(T, B, dtype=f64, device=self.device)
+        self.rdn = torch.zeros(T, B, dtype=torch.uint8, device=self.device)
+        self.rtr = torch.zeros(T, B, dtype=torch.uint8, device=self.device)
+
+    def step(self):
+        T = self.CHUNK
+        self.env.rollout(self.robs, self.actions[self.i * T:(self.i + 1) * T], self.rrew, self.rdn, self.rtr)
+        self.i += 1
+
+    def units_per_step(self):
+        return self.B * self.CHUNK
+
+    def algorithmic_bytes_per_step(self):
+        return super().algorithmic_bytes_per_step() * self.CHUNK
+
+    def compulsory_bytes_per_step(self):
+        return super().compulsory_bytes_per_step() * self.CHUNK
+
+    def config(self):
+        c = super().config()
+        c["env_steps_per_launch"] = self.CHUNK
+        return c
+
+
 class BrainTumor:
     """BrainTumor1D (reference notebook configuration T=600, X=200, dt=dx=1, nx=201, float64,
     total_dosage=61.2), one simulated day per env-step, B=65536 patients with individual daily doses."""
@@ -466,6 +502,7 @@ WORKLOADS["ns2d_c4_b4096"] = NavierStokesC4B4096
 WORKLOADS["ns2d_c5"] = NavierStokesC5
 WORKLOADS["ns2d_example"] = NavierStokesExample
 WORKLOADS["traffic_arz"] = TrafficARZ
+WORKLOADS["traffic_arz_rollout"] = TrafficARZRollout
 WORKLOADS["brain_tumor"] = BrainTumor
 
 
