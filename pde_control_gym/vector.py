@@ -281,16 +281,33 @@ class PDEVecEnv:
     def step_async(self, actions):
         self._actions = actions
 
+    def _to_host(self, tensors):
+        """Device tensors -> fresh NumPy arrays through pinned staging buffers: the copies are queued back to back and the
+        stream is synchronised ONCE (``t.cpu()`` per tensor goes through pageable memory and synchronises every time)."""
+        import torch
+        if self.device.type != "cuda":
+            return [t.numpy().copy() for t in tensors]
+        pins = self.__dict__.setdefault("_pins", {})
+        out = []
+        for i, t in enumerate(tensors):
+            key = (i, tuple(t.shape), t.dtype)
+            if key not in pins:
+                pins[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            pins[key].copy_(t, non_blocking=True)
+            out.append(pins[key])
+        torch.cuda.current_stream(self.device).synchronize()
+        return [p.numpy().copy() for p in out]
+
     def step_wait(self):
         import torch
         a = torch.as_tensor(np.asarray(self._actions), device=self.device)
         if self.kind not in ("ns2d", "traffic"):
             a = a.reshape(self.num_envs)
         obs_t, r_t, te_t, tr_t = self.step_tensor(a)
-        obs = (obs_t.cpu().numpy() if self.kind == "traffic" else self._obs_np(obs_t)).copy()
-        rew = r_t.cpu().numpy().astype(np.float32)
-        te = te_t.cpu().numpy().astype(bool)
-        tr = tr_t.cpu().numpy().astype(bool)
+        obs, rew, te, tr = self._to_host([obs_t, r_t, te_t, tr_t])
+        if self.kind != "traffic":
+            obs = obs.astype(np.float32, copy=False)
+        rew, te, tr = rew.astype(np.float32), te.astype(bool), tr.astype(bool)
         dones = te | tr
         infos = [{} for _ in range(self.num_envs)]
         if dones.any():
