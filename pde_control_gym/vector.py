@@ -300,7 +300,19 @@ class PDEVecEnv:
 
     def step_wait(self):
         import torch
-        a = torch.as_tensor(np.asarray(self._actions), device=self.device)
+        a_np = np.asarray(self._actions)
+        if self.device.type == "cuda":        # upload through a pinned staging buffer (a pageable source makes the copy synchronous)
+            pins = self.__dict__.setdefault("_pins", {})
+            key = ("act", a_np.shape, a_np.dtype.str)
+            if key not in pins:
+                tdt = getattr(torch, a_np.dtype.name)          # float32 / float64 / int64 ...
+                pins[key] = (torch.empty(a_np.shape, dtype=tdt, pin_memory=True), torch.empty(a_np.shape, dtype=tdt, device=self.device))
+            pin, dev_a = pins[key]
+            pin.numpy()[...] = a_np
+            dev_a.copy_(pin, non_blocking=True)
+            a = dev_a
+        else:
+            a = torch.as_tensor(a_np, device=self.device)
         if self.kind not in ("ns2d", "traffic"):
             a = a.reshape(self.num_envs)
         obs_t, r_t, te_t, tr_t = self.step_tensor(a)
