@@ -6,8 +6,8 @@
 // per step next to a 20 us environment step at C2 -- so the whole forward pass is ONE launch here.  The arithmetic is
 // tiny (85 MFLOP at B = 4096); what decides the time is operand delivery and the number of dependent memory round trips.
 //
-// Mapping (the one GEMM-shaped piece of the project -> MFMA): a workgroup of four waves owns 16 observation rows for all
-// layers; wave w computes the 16 x 16 output tiles w, w + 4, w + 8, ... of a layer with v_mfma_f32_16x16x4_f32 (float32 in,
+// Mapping (the one GEMM-shaped piece of the project -> MFMA): a workgroup of four waves (8 / 16 for layers wider than 64 /
+// 128 units) owns 16 observation rows for all layers; wave w computes the 16 x 16 output tiles w, w + WV, ... of a layer with v_mfma_f32_16x16x4_f32 (float32 in,
 // float32 accumulate).  Per 16 reduction indices a lane supplies ONE float4 of the layer input (row l % 16, inputs
 // 4 (l / 16) .. + 3, read from LDS: the observation rows are staged there once, hidden activations are written there by
 // the previous layer) and ONE float4 of weights per tile (blocked layout wq[k / 4][neuron][k % 4]: a wave's load is four
@@ -29,7 +29,6 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kRows = 16;                   // observation rows per workgroup (the M of the MFMA tile)
 constexpr int kMaxWidth = PDEGYM_MLP_MAX_WIDTH;
-constexpr int kMaxTiles = kMaxWidth / 64;   // 16-neuron tiles per wave (four waves share a layer's tiles round-robin)
 constexpr int kXChunk = 512;                // observation entries per row staged in LDS at a time
 // LDS row strides are (a multiple of 64) + 4 floats: 16-byte aligned rows, and 16 rows x one float4 hit 64 distinct banks.
 // The staging area is sized by the launch for the layer widths at hand (dynamic LDS): a 257-64-64-1 policy takes 25 KB per
@@ -99,13 +98,18 @@ __device__ __forceinline__ void reduce_blocks(v4f (&acc)[NT], v4f (&wa)[kStage][
   }
 }
 
-template <int NT, typename TX, typename TY>   // NT = 16-neuron tiles per wave = ceil(width of the widest layer / 64)
-__global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX* __restrict__ x, long long x_stride,
+// NT = 16-neuron tiles per wave, WV = waves per workgroup: one tile per wave throughout -- 4 waves for layers of up to 64
+// units, 8 up to 128, 16 up to 256.  The reduction is bound by the latency of the weight stream, and more waves keep more
+// loads in flight per CU than fewer waves with more tiles each (257-256-256-1 at B = 4096: 27.7 us with 4 waves x 4 tiles,
+// 21.4 with 8 x 2, 19.2 with 16 x 1).
+template <int NT, int WV, typename TX, typename TY>
+__global__ __launch_bounds__(64 * WV) void mlp_forward_kernel(pdegym_mlp N, const TX* __restrict__ x, long long x_stride,
                                                           TY* __restrict__ y, long long y_stride, int B, int ldx) {
   // LDS: activations ping-pong between hb0 and hb1; the staged observation chunk shares its space with hb1 (first written
   // by the second layer, when the observations are no longer needed)
   extern __shared__ __attribute__((aligned(16))) float mlp_smem[];
-  constexpr int kLdh = lds_stride(64 * NT);
+  constexpr int kLdh = lds_stride(16 * WV * NT);
+  constexpr int kRowsPerWave = kRows / WV;        // observation rows a wave stages
   const int kLdx = ldx;                              // >= kLdh (the launch takes the larger of the two)
   float* const hb0 = mlp_smem;
   float* const xs = mlp_smem + kRows * kLdh;
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX
   auto tile_cols = [&](int H, int (&col)[NT]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int n = 16 * (wave + 4 * t) + li;
+      const int n = 16 * (wave + WV * t) + li;
       col[t] = n < H ? n : H - 1;
     }
   };
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX
   for (int l = 0; l < PDEGYM_MLP_MAX_LAYERS; ++l) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int n = 16 * (wave + 4 * t) + li;
+      const int n = 16 * (wave + WV * t) + li;
       bias_all[l][t] = (l < N.n_layers && N.layer[l].b && n < N.layer[l].out_dim) ? N.layer[l].b[n] : 0.f;
     }
   }
@@ -168,13 +172,13 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX
       for (int c0 = 0; c0 < K; c0 += kXChunk) {
         const int clen = (K - c0) < kXChunk ? (K - c0) : kXChunk;
         const int cpad = (clen + 15) & ~15;
-        // stage the chunk: wave w copies rows 4 w .. 4 w + 3, a wave-wide load = 64 consecutive entries of one row; all
+        // stage the chunk: wave w copies rows kRowsPerWave w .. + kRowsPerWave - 1, a wave-wide load = 64 consecutive entries of one row; all
         // the loads of a thread are issued before the first LDS store.  Rows past the batch and entries past K read as zero.
         {
-          float v[4][kXChunk / 64];
+          float v[kRowsPerWave][kXChunk / 64];
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int r = 4 * wave + rr;
+          for (int rr = 0; rr < kRowsPerWave; ++rr) {
+            const int r = kRowsPerWave * wave + rr;
             const bool row_ok = row0 + r < B;
             const TX* src = x + (long long)(row_ok ? row0 + r : 0) * x_stride + c0;
 #pragma unroll
@@ -185,11 +189,11 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX
           }
           if (c0 > 0 && any_tile) load_w<NT>(wfirst, wq, H, ngroups, c0 / 16, lg, col);
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr)
+          for (int rr = 0; rr < kRowsPerWave; ++rr)
 #pragma unroll
             for (int i = 0; i < kXChunk / 64; ++i) {
               const int c = lane + 64 * i;
-              if (c < cpad) xs[(4 * wave + rr) * kLdx + c] = v[rr][i];
+              if (c < cpad) xs[(kRowsPerWave * wave + rr) * kLdx + c] = v[rr][i];
             }
         }
         __syncthreads();
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX
     const int Hpad = (H + 15) & ~15;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int n = 16 * (wave + 4 * t) + li;
+      const int n = 16 * (wave + WV * t) + li;
       if (n < Hpad) {
         const float av[4] = {acc[t].x, acc[t].y, acc[t].z, acc[t].w};
 #pragma unroll
@@ -234,25 +238,23 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(pdegym_mlp N, const TX
 
 }  // namespace
 
-template <int NT, typename TX, typename TY>
+template <int NT, int WV, typename TX, typename TY>
 static void launch_mlp_nt(const pdegym_mlp* net, const TX* xp, long long xs, TY* yp, long long ys, int B, hipStream_t st) {
   const int kin = net->layer[0].in_dim < kXChunk ? net->layer[0].in_dim : kXChunk;
-  const int ldh = lds_stride(64 * NT);
+  const int ldh = lds_stride(16 * WV * NT);
   const int ldx = lds_stride(kin) > ldh ? lds_stride(kin) : ldh;
   const size_t lds_bytes = (size_t)kRows * (ldh + ldx) * sizeof(float);         // <= 50 KB: below the 64 KB that need no opt-in
-  hipLaunchKernelGGL((mlp_forward_kernel<NT, TX, TY>), dim3((B + kRows - 1) / kRows), dim3(256), lds_bytes, st, *net, xp, xs, yp, ys, B, ldx);
+  hipLaunchKernelGGL((mlp_forward_kernel<NT, WV, TX, TY>), dim3((B + kRows - 1) / kRows), dim3(64 * WV), lds_bytes, st, *net, xp, xs, yp, ys,
+                     B, ldx);
 }
 
 template <typename TX, typename TY>
 static void launch_mlp(const pdegym_mlp* net, const void* x, long long xs, void* y, long long ys, int B, int width, hipStream_t st) {
   const TX* xp = static_cast<const TX*>(x);
   TY* yp = static_cast<TY*>(y);
-  switch ((width + 63) / 64) {
-    case 1: launch_mlp_nt<1, TX, TY>(net, xp, xs, yp, ys, B, st); break;
-    case 2: launch_mlp_nt<2, TX, TY>(net, xp, xs, yp, ys, B, st); break;
-    case 3: launch_mlp_nt<3, TX, TY>(net, xp, xs, yp, ys, B, st); break;
-    default: launch_mlp_nt<4, TX, TY>(net, xp, xs, yp, ys, B, st); break;
-  }
+  if (width <= 64) launch_mlp_nt<1, 4, TX, TY>(net, xp, xs, yp, ys, B, st);
+  else if (width <= 128) launch_mlp_nt<1, 8, TX, TY>(net, xp, xs, yp, ys, B, st);
+  else launch_mlp_nt<1, 16, TX, TY>(net, xp, xs, yp, ys, B, st);
 }
 
 extern "C" int pdegym_mlp_forward(const pdegym_mlp* net, const void* x, int64_t x_stride, void* y, int64_t y_stride, int32_t B,
