@@ -1953,13 +1953,21 @@ __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<do
 template <int PR, int NTR>
 __global__ __launch_bounds__(64 * NTR, NTR / 4) void ns_slab_jacobi_rq(const float* p_src, size_t src_stride, float* p_dst,
                                                                       size_t dst_stride, const float* rq_base, size_t rq_stride,
-                                                                      int nsweeps, int B) {
+                                                                      int nsweeps, int B, int stagger) {
   constexpr int n = 256, PC = 4, NT = 64 * NTR, RS = 64, OWN = 128, ROWS = NTR * PR;
   static_assert(ROWS > OWN && ROWS <= n, "a slab is its own half plus halo rows of the other half");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* lds = reinterpret_cast<float*>(smem_raw);
   const int b = blockIdx.x >> 1, slab = blockIdx.x & 1;
   if (b >= B) return;
+  // One slab fills a CU, so the workgroups of the first generation would all load at once (256 x 360 KB in one burst at the
+  // HBM rate), sweep in step, and store at once; started in phases -- (stagger >> 8) + 1 of them inside each XCD, (stagger &
+  // 255) x ~1 us apart -- the later generations inherit the offsets and every CU's load / store phases meet an idle memory
+  // system instead (C5: 618 -> 600 us per 512 env-steps with 32 phases; profiles/r02_ab_c5_second_pass.txt).
+  if (stagger > 0 && blockIdx.x < 256) {
+    const int units = ((blockIdx.x >> 3) & (stagger >> 8)) * (stagger & 255);
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(32);
+  }
   const int tid = threadIdx.x, tx = tid & 63;
   const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: row offsets become scalar address arithmetic
   const int c0 = tx * PC;
@@ -2443,6 +2451,13 @@ int fill(const pdegym_params_ns2d* prm, NSConst& C, NSScal<T>& S) {
 }
 
 // PDEGYM_NS_GENERIC=1 in the environment routes float32 steps through ns_generic (A/B testing of the tiled path)
+// Phased start of the 256 x 256 Jacobi pass (ns_slab_jacobi_rq): (phases - 1) << 8 | microseconds between phases.  Default: 32
+// phases, 1 us apart, when the pass runs more than one generation of workgroups; PDEGYM_NS256_STAGGER overrides (0 = off).
+inline int pdegym_ns256_stagger(int workgroups) {
+  if (const char* e = getenv("PDEGYM_NS256_STAGGER")) return atoi(e);
+  return workgroups > 256 ? ((31 << 8) | 1) : 0;
+}
+
 inline bool pdegym_ns_no_col() {          // PDEGYM_NS_NO_COL=1: small grids take ns_generic_step (A/B and tests)
   const char* e = std::getenv("PDEGYM_NS_NO_COL");
   return e && e[0] == '1';
@@ -2611,7 +2626,7 @@ int ns_step_launch(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, i
           if (to_scratch) { dst = P.scratch + 3 * ncell; dst_stride = 4 * ncell; }
           else { dst = P.p_out ? P.p_out : P.p; dst_stride = ncell; }
           hipLaunchKernelGGL((ns_slab_jacobi_rq<kPR, kNTR>), dim3(2 * B), dim3(64 * kNTR), 2 * 2 * (64 * kNTR) * 16, st, src, src_stride, dst,
-                             dst_stride, P.scratch + 2 * ncell, 4 * ncell, nsw, B);
+                             dst_stride, P.scratch + 2 * ncell, 4 * ncell, nsw, B, pdegym_ns256_stagger(2 * B));
           src = dst;
           src_stride = dst_stride;
         }
