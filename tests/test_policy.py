@@ -319,3 +319,36 @@ def test_engine_rollout_sees_in_place_weight_updates():
         want2 = net(first).reshape(B).clamp(-3, 3)
     np.testing.assert_allclose(act[0].cpu().numpy(), want2.cpu().numpy(), rtol=2e-5, atol=4e-6)
     assert np.abs(want2.cpu().numpy() - want.cpu().numpy()).max() > 0.1
+
+
+def test_policy_fits_rollout_limits_on_cpu_double():
+    """Which policies DeviceRollout may hand to the rollout kernels (host-side rule = the C ABI's limits): layer widths, one
+    output per command, LDS budget, input size, and the engine's own conditions."""
+    from tests.fake_backend import FakeBackend
+    from pdecontrolgym_amd.batch1d import PDEBatch1D
+    from pdecontrolgym_amd.batch_traffic import TrafficBatch
+
+    def eng(nx, **kw):
+        dx = 1.0 / nx
+        return PDEBatch1D("parabolic", 100 * 0.25 * dx * dx, 0.25 * dx * dx, 1, dx, 5 * 0.25 * dx * dx, sensing_loc="full", sensing_type=None,
+                          num_envs=2, device="cpu", backend=FakeBackend(), **kw)
+
+    def pol(sizes):
+        return FusedMLP(_mlp(sizes, [None] * (len(sizes) - 1)), backend=object())
+
+    e = eng(256)
+    assert e.can_rollout() and e.policy_fits_rollout(pol([257, 64, 64, 1]))
+    assert not e.policy_fits_rollout(pol([257, 65, 1]))            # wider than a wave
+    assert not e.policy_fits_rollout(pol([257, 64, 2]))            # one command per instance
+    assert not e.policy_fits_rollout(pol([256, 64, 1]))            # input size != row length
+    assert not e.policy_fits_rollout(torch.nn.Linear(257, 1))      # not a FusedMLP
+    big = eng(512)
+    assert not big.policy_fits_rollout(pol([513, 64, 64, 1]))      # 131 KB of first-layer weights + 16 rows: over 160 KB
+    assert big.policy_fits_rollout(pol([513, 32, 64, 1]))
+    assert not eng(600).policy_fits_rollout(pol([601, 16, 1]))     # rows of more than 513 nodes
+    assert not eng(64, control_type="Neumann").can_rollout()
+    assert not eng(64, record_history=True).can_rollout()
+    tr = TrafficBatch(240, 0.25, 500, 10, "both", 40, 0.16, 60, True, 1, num_envs=2, device="cpu", backend=FakeBackend())
+    assert tr.can_rollout() and tr.policy_fits_rollout(pol([102, 64, 2])) and not tr.policy_fits_rollout(pol([102, 64, 1]))
+    wide = TrafficBatch(240, 0.25, 1000, 10, "inlet", 40, 0.16, 60, True, 1, num_envs=2, device="cpu", backend=FakeBackend())
+    assert wide.M == 101 and not wide.can_rollout()
