@@ -53,6 +53,23 @@ __device__ __forceinline__ double Veq(double vm, double rm, double rho) { return
 __device__ __forceinline__ double F_r(double vm, double rm, double rho, double y) { return y + rho * Veq(vm, rm, rho); }
 __device__ __forceinline__ double F_y(double vm, double rm, double rho, double y) { return y * (y / rho + Veq(vm, rm, rho)); }
 
+// Scalar sub-expressions that Python evaluates before they meet an array (traffic_arz_env.py:201-222, :106): formed ONCE on the
+// host in the same double arithmetic (IEEE division is correctly rounded on both sides, so the values are bit-identical to
+// forming them per wave on the device -- which cost five float64 divisions, a third of the step kernel's instructions).
+struct TrafficConsts {
+  double c1, c2, c3, c4;   // dt/(2 dx), 0.25 dt/tau, dt/dx, 0.5 dt/tau
+  double t_end;            // T/dt  (:106: seconds compared with a step count -- kept)
+};
+inline TrafficConsts traffic_consts(const pdegym_params_traffic& P) {
+  TrafficConsts K;
+  K.c1 = P.dt / (2 * P.dx);
+  K.c2 = 0.25 * P.dt / P.tau;
+  K.c3 = P.dt / P.dx;
+  K.c4 = 0.5 * P.dt / P.tau;
+  K.t_end = P.T / P.dt;
+  return K;
+}
+
 // One env-step of one freeway held by one wave (M <= 64: node j in lane j): action clip, control_freq Lax-Wendroff sub-steps,
 // speed, reward, flags.  Shared by traffic_step_kernel and every iteration of traffic_rollout_kernel.
 struct TrafficStepOut {
@@ -60,8 +77,9 @@ struct TrafficStepOut {
   bool done, trunc;
 };
 
-__device__ __forceinline__ TrafficStepOut traffic_step_wave(const pdegym_params_traffic& P, double& r, double& y, double& time,
-                                                            const double rs, const double qc, double a0, double a1, const int lane) {
+__device__ __forceinline__ TrafficStepOut traffic_step_wave(const pdegym_params_traffic& P, const TrafficConsts& K, double& r, double& y,
+                                                            double& time, const double rs, const double qc, double a0, double a1,
+                                                            const int lane) {
   const int M = P.M;
   const bool in = lane < M;
   const double vm = P.vm, rm = P.rm, dt = P.dt, dx = P.dx;
@@ -77,8 +95,7 @@ __device__ __forceinline__ TrafficStepOut traffic_step_wave(const pdegym_params_
   else { q_in = qs; q_out = a0; }
 
   time = time + dt;                               // :146
-  // Python evaluates these scalar sub-expressions before they meet an array (:201-222)
-  const double c1 = dt / (2 * dx), c2 = 0.25 * dt / P.tau, c3 = dt / dx, c4 = 0.5 * dt / P.tau;
+  const double c1 = K.c1, c2 = K.c2, c3 = K.c3, c4 = K.c4;
   if (time < P.T) {                               // :172  (time does not change inside the loop)
     for (int s = 0; s < P.control_freq; ++s) {
       // boundary conditions :174-190
@@ -106,7 +123,7 @@ __device__ __forceinline__ TrafficStepOut traffic_step_wave(const pdegym_params_
   const double dv = in ? o.v - vs : 0.0, dr = in ? r - rs : 0.0;
   const double nv = sqrt(wave_sum_d(dv * dv)), nr = sqrt(wave_sum_d(dr * dr));
   o.reward = -(nv / vs + nr / rs);
-  const bool term = time >= P.T / dt;              // :106 (seconds compared with a step count -- kept)
+  const bool term = time >= K.t_end;               // :106 (seconds compared with a step count -- kept)
   if (term) time = 0.0;
   bool trunc = false;
   if (P.limit) trunc = __any(in && (o.v > vm || r > rm));
@@ -146,7 +163,7 @@ __device__ __forceinline__ void traffic_restart_node(const pdegym_params_traffic
   v = y / r + Veq(P.vm, P.rm, r);
 }
 
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pdegym_params_traffic P, pdegym_bufs_traffic Bf, int B) {
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pdegym_params_traffic P, pdegym_bufs_traffic Bf, TrafficConsts K, int B) {
   const int lane = threadIdx.x & (kWave - 1);
   const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (inst >= B) return;
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pde
   const int astr = Bf.action_stride > 0 ? Bf.action_stride : 2;      // 1: one command per freeway (no second column to read)
   const double a0 = Bf.action[(size_t)inst * astr], a1 = astr > 1 ? Bf.action[(size_t)inst * astr + 1] : 0.0;
   double time = Bf.time[inst];
-  const TrafficStepOut o = traffic_step_wave(P, r, y, time, rs, Bf.qs_clip[inst], a0, a1, lane);
+  const TrafficStepOut o = traffic_step_wave(P, K, r, y, time, rs, Bf.qs_clip[inst], a0, a1, lane);
   if (Bf.reset_rs && (o.done || o.trunc)) {       // fused auto-reset (wave-uniform)
     if (Bf.final_obs) traffic_emit_obs(P, Bf.final_obs + (size_t)inst * 2 * M, r, o.v, rs, o.vs, lane);
     const double rs_new = Bf.reset_rs[traffic_pool_row(Bf, inst, B)];
@@ -201,8 +218,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pde
 // from observation slot t rounded to float32 -- the cast SB3 makes in front of its float32 network -- widened back to
 // float64, plus noise, clamped, and stored to actions row t.
 __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void traffic_rollout_kernel(pdegym_params_traffic P, pdegym_bufs_traffic Bf,
-                                                                                       pdegym_rollout_traffic Ro, pdegym_mlp N, int has_policy,
-                                                                                       int B) {
+                                                                                       pdegym_rollout_traffic Ro, pdegym_mlp N, TrafficConsts K,
+                                                                                       int has_policy, int B) {
   namespace pol = pdegym_policy;
   extern __shared__ __attribute__((aligned(16))) float pol_smem[];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void traffic_rollout_
       a0 = arow[0];
       if (A > 1) a1 = arow[1];
     }
-    const TrafficStepOut o = traffic_step_wave(P, r, y, time, rs, qc, a0, a1, lane);
+    const TrafficStepOut o = traffic_step_wave(P, K, r, y, time, rs, qc, a0, a1, lane);
     double* onext = Ro.obs + (size_t)(t + 1) * slot + (size_t)inst * D;
     if (Bf.reset_rs && (o.done || o.trunc)) {     // fused auto-reset, as in traffic_step_kernel
       if (Bf.final_obs) traffic_emit_obs(P, Bf.final_obs + (size_t)inst * D, r, o.v, rs, o.vs, lane);
@@ -299,7 +316,7 @@ __device__ __forceinline__ void wave_lds_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_wide_kernel(pdegym_params_traffic P, pdegym_bufs_traffic Bf, int B) {
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_wide_kernel(pdegym_params_traffic P, pdegym_bufs_traffic Bf, TrafficConsts K, int B) {
   extern __shared__ double tl[];
   const int lane = threadIdx.x & (kWave - 1);
   const int w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
@@ -332,7 +349,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_wide_kerne
   else if (P.sim == PDEGYM_TRAFFIC_INLET) { q_in = a0; q_out = qs; }
   else { q_in = qs; q_out = a0; }
   double time = Bf.time[inst] + dt;
-  const double c1 = dt / (2 * dx), c2 = 0.25 * dt / P.tau, c3 = dt / dx, c4 = 0.5 * dt / P.tau;
+  const double c1 = K.c1, c2 = K.c2, c3 = K.c3, c4 = K.c4;
   wave_lds_sync();
   if (time < P.T) {
     for (int s = 0; s < P.control_freq; ++s) {
@@ -394,7 +411,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_wide_kerne
   }
   const double nv = sqrt(wave_sum_d(sv)), nr = sqrt(wave_sum_d(sr));
   const double reward = -(nv / vs + nr / rs);
-  const bool term = time >= P.T / dt;
+  const bool term = time >= K.t_end;
   if (term) time = 0.0;
   bool trunc = false;
   if (P.limit) trunc = __any(over);
@@ -476,12 +493,12 @@ int pdegym_traffic_step(const pdegym_params_traffic* prm, const pdegym_bufs_traf
   if (B <= 0) return 0;
   if (prm->M <= kWave) {       // the reference's grid (M = 51): one node per lane, fields in registers
     const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-    hipLaunchKernelGGL(traffic_step_kernel, grid, block, 0, (hipStream_t)stream, *prm, *buf, B);
+    hipLaunchKernelGGL(traffic_step_kernel, grid, block, 0, (hipStream_t)stream, *prm, *buf, traffic_consts(*prm), B);
   } else {                     // finer grids: wave-private LDS rows, at most 56 KB per workgroup
     const int wpb = prm->M <= 256 ? 4 : (prm->M <= 512 ? 2 : 1);
     const dim3 grid((B + wpb - 1) / wpb), block(kWave * wpb);
     hipLaunchKernelGGL(traffic_step_wide_kernel, grid, block, (size_t)wpb * 7 * prm->M * sizeof(double), (hipStream_t)stream,
-                       *prm, *buf, B);
+                       *prm, *buf, traffic_consts(*prm), B);
   }
   return pdegym::check_launch("traffic_step");
 }
@@ -506,7 +523,7 @@ int pdegym_traffic_rollout(const pdegym_params_traffic* prm, const pdegym_bufs_t
       return pdegym::fail(-4, "cannot raise the dynamic LDS limit of traffic_rollout_kernel");
   }
   const dim3 grid((B + pdegym_policy::kWaves - 1) / pdegym_policy::kWaves), block(kWave * pdegym_policy::kWaves);
-  hipLaunchKernelGGL(traffic_rollout_kernel, grid, block, lds_bytes, (hipStream_t)stream, *prm, *buf, *ro, net, ro->policy ? 1 : 0, B);
+  hipLaunchKernelGGL(traffic_rollout_kernel, grid, block, lds_bytes, (hipStream_t)stream, *prm, *buf, *ro, net, traffic_consts(*prm), ro->policy ? 1 : 0, B);
   return pdegym::check_launch("traffic_rollout");
 }
 
