@@ -523,3 +523,13 @@ def test_engine_rollout_equals_step_loop_on_the_cpu_double():
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert int(outs[0][2].sum()) > 0
+
+
+def test_bench_docstring_names_every_workload():
+    """bench.py's module docstring is where the workloads are described: a workload added to WORKLOADS must be named there."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    missing = [k for k in bench.WORKLOADS if k not in (bench.__doc__ or "") and k != "parabolic_c2"]
+    assert not missing, missing
