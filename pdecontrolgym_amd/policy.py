@@ -63,6 +63,26 @@ class FusedMLP:
             backend = default_backend()
         self.backend = backend
 
+    @classmethod
+    def from_sb3(cls, policy, clamp=None, backend=None):
+        """The deterministic actor of a Stable-Baselines3 policy as a ``FusedMLP`` (duck-typed, SB3 itself is not imported):
+        ``ActorCriticPolicy`` (PPO / A2C ``MlpPolicy``): ``mlp_extractor.policy_net`` followed by ``action_net`` -- the mean of
+        the Gaussian, which SB3 clips to the action box (pass ``clamp``); ``SACPolicy`` / ``TD3Policy``: ``actor.latent_pi`` +
+        ``actor.mu`` with the tanh squashing of ``actor.forward(deterministic=True)``.  The wrapper shares the parameters
+        with ``policy`` (no copy), so ``model.learn()`` steps are picked up by ``refresh()``.  Observations must already be
+        flat vectors (``FlattenExtractor``), which is what ``MlpPolicy`` uses on these environments."""
+        import torch
+        if hasattr(policy, "mlp_extractor") and hasattr(policy, "action_net"):
+            mods = list(policy.mlp_extractor.policy_net) + [policy.action_net]
+        elif hasattr(policy, "actor") and hasattr(policy.actor, "mu"):
+            head = policy.actor.mu
+            mods = list(policy.actor.latent_pi) + (list(head) if isinstance(head, torch.nn.Sequential) else [head])
+            if not isinstance(mods[-1], torch.nn.Tanh):
+                mods.append(torch.nn.Tanh())          # SAC squashes the mean; TD3's mu already ends in Tanh
+        else:
+            raise ValueError("expected an SB3 ActorCriticPolicy (mlp_extractor + action_net) or SAC/TD3 policy (actor.latent_pi + actor.mu)")
+        return cls(torch.nn.Sequential(*mods), clamp=clamp, backend=backend)
+
     def refresh(self, force: bool = False):
         """Bring the transposed weight copies up to date with the module's parameters (in-place updates such as optimizer
         steps bump a tensor's version counter).  Not callable while a hipGraph is being captured."""

@@ -352,3 +352,24 @@ def test_policy_fits_rollout_limits_on_cpu_double():
     assert tr.can_rollout() and tr.policy_fits_rollout(pol([102, 64, 2])) and not tr.policy_fits_rollout(pol([102, 64, 1]))
     wide = TrafficBatch(240, 0.25, 1000, 10, "inlet", 40, 0.16, 60, True, 1, num_envs=2, device="cpu", backend=FakeBackend())
     assert wide.M == 101 and not wide.can_rollout()
+
+
+def test_from_sb3_duck_typed_policies():
+    """FusedMLP.from_sb3 picks the deterministic actor out of SB3-shaped policy objects (PPO: mlp_extractor.policy_net +
+    action_net; SAC: actor.latent_pi + actor.mu + tanh) and shares their parameters."""
+    import types
+    from tests.fake_backend import FakeBackend
+    torch.manual_seed(0)
+    pi = torch.nn.Sequential(torch.nn.Linear(9, 8), torch.nn.Tanh(), torch.nn.Linear(8, 8), torch.nn.Tanh())
+    ppo = types.SimpleNamespace(mlp_extractor=types.SimpleNamespace(policy_net=pi, value_net=torch.nn.Linear(9, 8)), action_net=torch.nn.Linear(8, 1))
+    f = FusedMLP.from_sb3(ppo, clamp=(-1.0, 1.0), backend=FakeBackend())
+    x = torch.randn(5, 9)
+    want = ppo.action_net(pi(x)).clamp(-1, 1)
+    np.testing.assert_allclose(f(x).numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-6)
+    assert f.layers[0][0] is pi[0].weight                       # shared parameters: training updates are seen after refresh()
+    lat = torch.nn.Sequential(torch.nn.Linear(9, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU())
+    sac = types.SimpleNamespace(actor=types.SimpleNamespace(latent_pi=lat, mu=torch.nn.Linear(16, 2)))
+    g = FusedMLP.from_sb3(sac, backend=FakeBackend())
+    np.testing.assert_allclose(g(x).numpy(), torch.tanh(sac.actor.mu(lat(x))).detach().numpy(), rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        FusedMLP.from_sb3(types.SimpleNamespace())
