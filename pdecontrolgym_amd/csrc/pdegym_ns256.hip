@@ -1,0 +1,431 @@
+// pdegym_ns256.hip -- NavierStokes2D on a 256 x 256 grid (BASELINE config 5), float32: ONE launch per env-step, one
+// workgroup per instance, one instance per CU.
+//
+// Reference semantics restated (environments2d/navier_stokes2D.py): predictor :130-138, apply_boundary :68-91 (called at
+// :140 and :146), solve_pressure :94-116 (right-hand side :101-103, sweeps :104-114), corrector :143-145, observation
+// :147-154, NSReward rewards/ns_reward.py:28.  Same expression trees as ns_generic_step<float> (pdegym_ns2d.hip): fields,
+// pressure and observations are bit-identical to it (tests/test_gpu_ns2d.py).
+//
+// Why one workgroup per instance.  p and 0.25 dx dy rhs of an instance are 2 x 256 KB; a CU has 512 KB of vector registers
+// and 160 KB of LDS.  Eight waves (two per SIMD, 256 registers per lane each) keep ALL of p (32 rows x 4 columns per lane =
+// 128 registers) and 20-22 of their 32 right-hand-side rows in registers; the other rows sit in wave-private LDS and
+// come back one ds_read_b128 per row and sweep, prefetched one two-row block ahead.  Nothing is recomputed (the earlier
+// two-slab pass did 1.41x the sweeps' work on halo rows) and nothing but the state, the pressure and the observation
+// crosses HBM:
+//   front   rows of the state -> predictor -> boundary rule -> 0.25 dx dy rhs       (a rolled row pipeline per wave,
+//           u*, v* exist only as a three-row window in registers)
+//   sweeps  K Jacobi sweeps on registers: left / right neighbours are lanes (DPP), the rows above / below a wave's block
+//           cross waves through a double-buffered 32 KB LDS area, one barrier per sweep (jacobi_sweep machinery of
+//           pdegym_ns_common.h: period-two row rotation, two-row in-place asm blocks)
+//   back    the predictor is evaluated again from the state rows (they are L2 / Infinity-Cache resident: 256 instances x
+//           512 KB are in flight), corrector, boundary rule, observation, reward partial sums
+// HBM traffic per env-step: read state + p, re-read state, write p + observation = 8 fields of 256 KB (the three-launch
+// pipeline it replaces moved 12 and its Jacobi pass ran at 3 waves per SIMD with one workgroup-wide burst of loads).
+#include <hip/hip_runtime.h>
+
+#include "pdegym.h"
+#include "pdegym_common.h"
+#include "pdegym_ns_common.h"
+
+namespace pdegym {
+namespace ns {
+namespace {
+
+constexpr int kN = 256, kCells = kN * kN;
+constexpr int kWaves = 8, kPR = kN / kWaves;      // 32 grid rows per wave, 4 columns per lane
+constexpr int kNT = 64 * kWaves;
+#ifndef PDEGYM_NS256_LDS_ROWS
+#define PDEGYM_NS256_LDS_ROWS 16
+#endif
+constexpr int kRL = PDEGYM_NS256_LDS_ROWS;        // right-hand-side rows per wave that live in LDS (even)
+constexpr int kRR = kPR - kRL;                    // rows in registers: the first kRR of the wave's block
+constexpr int kL0 = kRR;                          // first LDS row
+constexpr int kHaloBytes = 2 * 2 * kNT * 16;      // two buffers x (top rows, bottom rows) x one float4 per thread
+constexpr int kLdsBytes = kHaloBytes + kRL * kNT * 16;
+static_assert(kRL % 2 == 0 && kRL >= 2 && kRL < kPR && kRR % 2 == 0, "LDS rows come in two-row blocks");
+static_assert(kLdsBytes <= 160 * 1024, "LDS budget of one CU");
+
+__device__ __forceinline__ constexpr int rq_reg(int a) { return a; }
+
+// ---- state rows ---------------------------------------------------------------------------------------------------
+// (u, v) of columns 4 lane .. 4 lane + 3 of grid row `row` (clamped: rows outside the grid only feed values nobody reads)
+template <bool INTERLEAVED>
+__device__ __forceinline__ void load_state_row(const float* su, const float* sv, int row, int c0, float (&fu)[4], float (&fv)[4]) {
+  const int r = row < 0 ? 0 : (row > kN - 1 ? kN - 1 : row);
+  if constexpr (INTERLEAVED) {
+    const float4* q = reinterpret_cast<const float4*>(su + (r * kN + c0) * 2);
+    const float4 a = q[0], d = q[1];
+    fu[0] = a.x; fv[0] = a.y; fu[1] = a.z; fv[1] = a.w; fu[2] = d.x; fv[2] = d.y; fu[3] = d.z; fv[3] = d.w;
+  } else {
+    const float4 a = *reinterpret_cast<const float4*>(su + r * kN + c0);
+    const float4 d = *reinterpret_cast<const float4*>(sv + r * kN + c0);
+    fu[0] = a.x; fu[1] = a.y; fu[2] = a.z; fu[3] = a.w; fv[0] = d.x; fv[1] = d.y; fv[2] = d.z; fv[3] = d.w;
+  }
+}
+
+// predictor of grid row i (navier_stokes2D.py:130-138) from the state rows i-1 (S), i (C), i+1 (N); cells on the domain edge
+// keep the state value (central_difference / laplace are zero there, :9-22)
+__device__ __forceinline__ void predictor_row(const NSScal<float>& S, int i, int lane, const float (&uc)[4], const float (&vc)[4],
+                                              const float (&us)[4], const float (&vs)[4], const float (&un_)[4], const float (&vn_)[4],
+                                              float (&uo)[4], float (&vo)[4]) {
+  const float ul = lane_left(uc[3]), ur = lane_right(uc[0]), vl = lane_left(vc[3]), vr = lane_right(vc[0]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float uw = (k == 0) ? ul : uc[k - 1], ue = (k == 3) ? ur : uc[k + 1];
+    const float vw = (k == 0) ? vl : vc[k - 1], ve = (k == 3) ? vr : vc[k + 1];
+    const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx), dudy = div_c(un_[k] - us[k], S.two_dy, S.inv_two_dy);
+    const float dvdx = div_c(ve - vw, S.two_dx, S.inv_two_dx), dvdy = div_c(vn_[k] - vs[k], S.two_dy, S.inv_two_dy);
+    const float lapu = div_c((((uw + us[k]) - 4.0f * uc[k]) + ue) + un_[k], S.dxdy, S.inv_dxdy);
+    const float lapv = div_c((((vw + vs[k]) - 4.0f * vc[k]) + ve) + vn_[k], S.dxdy, S.inv_dxdy);
+    const float a = uc[k] + S.dt * (((-uc[k]) * dudx - vc[k] * dudy) + S.nu * lapu);
+    const float d = vc[k] + S.dt * (((-uc[k]) * dvdx - vc[k] * dvdy) + S.nu * lapv);
+    const bool edge = (i <= 0) || (i >= kN - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
+    uo[k] = edge ? uc[k] : a;
+    vo[k] = edge ? vc[k] : d;
+  }
+}
+
+// apply_boundary (:76-90) restricted to grid row i, in registers.  `f` holds the row before the call (only its interior
+// cells matter), `nb` the row next to it on the inside of the wall -- read only when i is the lower / upper wall row.  Passes
+// in the reference's order: lower, upper (whole row), then left, right (one cell each, reading the cell the earlier pass set).
+__device__ __forceinline__ void bc_row(float (&f)[4], const float (&nb)[4], int i, int lane, int c0, const int (&bc)[4][2], int comp,
+                                       const float* act, int action_dim) {
+  // rows outside the grid pass through here on the pipelines' first / last iterations: keep the action index inside the array
+  auto aval = [&](int idx) -> float { return action_dim == 1 ? act[0] : act[idx < 0 ? 0 : (idx > kN - 1 ? kN - 1 : idx)]; };
+  if (i == 0 || i == kN - 1) {
+    const int c = bc[i == 0 ? PDEGYM_EDGE_LOWER : PDEGYM_EDGE_UPPER][comp];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f[k] = (c == PDEGYM_BC_NEUMANN) ? nb[k] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(c0 + k));
+  }
+  if (lane == 0) {
+    const int c = bc[PDEGYM_EDGE_LEFT][comp];
+    f[0] = (c == PDEGYM_BC_NEUMANN) ? f[1] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(i));
+  }
+  if (lane == 63) {
+    const int c = bc[PDEGYM_EDGE_RIGHT][comp];
+    f[3] = (c == PDEGYM_BC_NEUMANN) ? f[2] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(i));
+  }
+}
+
+// ---- one Jacobi sweep (state ST: 0 = UP, 1 = DOWN; see jacobi_sweep_bous), right-hand side partly in LDS -------------
+template <int ST>
+__device__ __forceinline__ void sweep256(float (&ph)[kPR + 1][4], const float (&rq)[kRR][4], const float4* rql, const EdgeFlags& E,
+                                         float* lds, int& xc, int tid, int ty) {
+  constexpr int PR = kPR, NJL = kRL / 2;
+  float hlast[4];
+  float buf[2][2][4];
+  auto ld = [&](int jl, int par) {
+    const float4 x = rql[(2 * jl) * kNT], y = rql[(2 * jl + 1) * kNT];
+    buf[par][0][0] = x.x; buf[par][0][1] = x.y; buf[par][0][2] = x.z; buf[par][0][3] = x.w;
+    buf[par][1][0] = y.x; buf[par][1][1] = y.y; buf[par][1][2] = y.z; buf[par][1][3] = y.w;
+  };
+  if constexpr (ST == 0) {
+    ld(0, 0);
+    asm volatile("" ::: "memory");
+    halo_tb<4, kNT, 64>(ph[bphys<PR>(0, 0)], ph[bphys<PR>(PR - 1, 0)], ph[PR], hlast, lds, xc, tid, ty);   // top halo -> free row PR
+#pragma unroll
+    for (int a = 0; a + 1 < PR; a += 2) {       // rows (a, a+1)
+      float (&da)[4] = ph[a == 0 ? PR : a - 1];
+      const bool inl = a >= kL0 && a < kL0 + kRL;
+      if (inl) {
+        const int jl = (a - kL0) / 2;
+        if (jl + 1 < NJL) ld(jl + 1, (jl + 1) & 1);
+        asm volatile("" ::: "memory");
+        if (a + 2 == PR) jacobi_pair_up(da, ph[a], ph[a + 1], hlast, buf[jl & 1][0], buf[jl & 1][1]);
+        else jacobi_pair_up(da, ph[a], ph[a + 1], ph[a + 2], buf[jl & 1][0], buf[jl & 1][1]);
+      } else {
+        if (a + 2 == PR) jacobi_pair_up(da, ph[a], ph[a + 1], hlast, rq[rq_reg(a)], rq[rq_reg(a + 1)]);
+        else jacobi_pair_up(da, ph[a], ph[a + 1], ph[a + 2], rq[rq_reg(a)], rq[rq_reg(a + 1)]);
+      }
+    }
+    jacobi_walls_state<PR, 1>(ph, E);
+  } else {
+    // state 1: logical row a in physical row a-1 (row 0 in PR); physical row PR-1 is free -> bottom halo
+    ld(NJL - 1, (NJL - 1) & 1);        // the DOWN sweep starts with the LDS rows: requested ahead of the exchange's barrier
+    asm volatile("" ::: "memory");
+    halo_tb<4, kNT, 64>(ph[bphys<PR>(0, 1)], ph[bphys<PR>(PR - 1, 1)], hlast, ph[PR - 1], lds, xc, tid, ty);
+#pragma unroll
+    for (int a = PR - 1; a >= 1; a -= 2) {      // rows (a, a-1): new row a -> physical row a, new row a-1 -> physical row a-1
+      const bool inl = (a - 1) >= kL0 && a < kL0 + kRL;
+      if (inl) {
+        const int jl = (a - 1 - kL0) / 2;
+        if (jl >= 1) ld(jl - 1, (jl - 1) & 1);
+        asm volatile("" ::: "memory");
+        if (a == 1) jacobi_pair_down(ph[a], ph[a - 1], ph[bphys<PR>(0, 1)], hlast, buf[jl & 1][1], buf[jl & 1][0]);
+        else jacobi_pair_down(ph[a], ph[a - 1], ph[bphys<PR>(a - 1, 1)], ph[bphys<PR>(a - 2, 1)], buf[jl & 1][1], buf[jl & 1][0]);
+      } else {
+        if (a == 1) jacobi_pair_down(ph[a], ph[a - 1], ph[bphys<PR>(0, 1)], hlast, rq[rq_reg(a)], rq[rq_reg(a - 1)]);
+        else jacobi_pair_down(ph[a], ph[a - 1], ph[bphys<PR>(a - 1, 1)], ph[bphys<PR>(a - 2, 1)], rq[rq_reg(a)], rq[rq_reg(a - 1)]);
+      }
+    }
+    jacobi_walls_state<PR, 0>(ph, E);
+  }
+}
+
+template <bool INTERLEAVED>
+__global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<float> S, NSPtrs<float> P, int B) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* lds = reinterpret_cast<float*>(smem_raw);
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c0 = 4 * lane, r0 = w * kPR;
+  const EdgeFlags E{w == 0, w == kWaves - 1, lane == 0, lane == 63};
+  const float* su = INTERLEAVED ? P.state_in + (size_t)b * kCells * 2 : P.u + (size_t)b * kCells;
+  const float* sv = INTERLEAVED ? nullptr : P.v + (size_t)b * kCells;
+  const float* act = P.action + (size_t)b * C.action_dim;
+  float4* rql = reinterpret_cast<float4*>(smem_raw + kHaloBytes) + tid;   // row j of this thread: rql[j * kNT]
+
+  float rq[kRR][4];
+
+  // ---- front: predictor -> apply_boundary(u*, v*) (:140) -> 0.25 dx dy rhs (:101-103, :108), a row pipeline ----
+  // iteration `it` works on grid row r = r0 - 1 + it:  P(r) = predictor of row r;  F(r-1) = row r-1 after the boundary rule
+  // (the lower wall row takes its inside neighbour P(1) = P(r), the upper one P(254) = P(r-2));  rq(r-2) from F_u(r-2),
+  // F_v(r-3), F_v(r-1).  The two rows outside the wave's block (r0-1, r0+32) are evaluated here too instead of being
+  // exchanged with the neighbouring waves (34/32 of the predictor work, no barrier).  The loop is rolled, so a finished row
+  // goes to the thread's LDS slots first (a register row cannot be picked by a run-time index); every kRL rows the slots are
+  // copied into the register rows by straight-line code, and the last kRL rows simply stay there.
+  {
+    float s0u[4], s0v[4], s1u[4], s1v[4], s2u[4], s2v[4];            // state rows r-1, r, r+1
+    float p1u[4], p1v[4], p2u[4], p2v[4];                            // P(r-1), P(r-2)
+    float f1u[4], f1v[4], f2v[4];                                    // F_u(r-2), F_v(r-2), F_v(r-3)
+    load_state_row<INTERLEAVED>(su, sv, r0 - 2, c0, s0u, s0v);
+    load_state_row<INTERLEAVED>(su, sv, r0 - 1, c0, s1u, s1v);
+    load_state_row<INTERLEAVED>(su, sv, r0, c0, s2u, s2v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p1u[k] = p1v[k] = p2u[k] = p2v[k] = f1u[k] = f1v[k] = f2v[k] = 0.f;
+    auto rows = [&](int it_lo, int it_hi, int slot0) {      // wave rows a = it - 3; row a goes to LDS slot a - slot0
+#pragma unroll 1
+      for (int it = it_lo; it < it_hi; ++it) {
+        const int r = r0 - 1 + it;
+        float nu_[4], nv_[4];
+        load_state_row<INTERLEAVED>(su, sv, r + 2, c0, nu_, nv_);     // next iteration's row r+1: in flight during this one
+        float pu[4], pv[4];
+        predictor_row(S, r, lane, s1u, s1v, s0u, s0v, s2u, s2v, pu, pv);
+        // boundary rule on row r-1
+        const int rr = r - 1;
+        float fu[4], fv[4], nbu[4], nbv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          fu[k] = p1u[k]; fv[k] = p1v[k];
+          nbu[k] = rr == 0 ? pu[k] : p2u[k];
+          nbv[k] = rr == 0 ? pv[k] : p2v[k];
+        }
+        bc_row(fu, nbu, rr, lane, c0, C.bc, 0, act, C.action_dim);
+        bc_row(fv, nbv, rr, lane, c0, C.bc, 1, act, C.action_dim);
+        // right-hand side of row r-2 = wave row a
+        const int a = it - 3;
+        if (a >= 0) {
+          const int i = r - 2;
+          const float ul = lane_left(f1u[3]), ur = lane_right(f1u[0]);
+          float q[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float uw = (k == 0) ? ul : f1u[k - 1], ue = (k == 3) ? ur : f1u[k + 1];
+            const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx);
+            const float dvdy = div_c(fv[k] - f2v[k], S.two_dy, S.inv_two_dy);
+            const float rh = S.rho_over_dt * (dudx + dvdy);
+            const bool edge = (i == 0) || (i == kN - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
+            q[k] = edge ? 0.0f : jacobi_rhs_term(S.dxdy, rh);
+          }
+          rql[(a - slot0) * kNT] = make_float4(q[0], q[1], q[2], q[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          f2v[k] = f1v[k]; f1v[k] = fv[k]; f1u[k] = fu[k];
+          p2u[k] = p1u[k]; p2v[k] = p1v[k]; p1u[k] = pu[k]; p1v[k] = pv[k];
+          s0u[k] = s1u[k]; s0v[k] = s1v[k]; s1u[k] = s2u[k]; s1v[k] = s2v[k]; s2u[k] = nu_[k]; s2v[k] = nv_[k];
+        }
+      }
+    };
+    constexpr int NCH = (kRR + kRL - 1) / kRL;          // chunks of register rows
+    int it0 = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int a_lo = c * kRL, a_hi = (c + 1) * kRL < kRR ? (c + 1) * kRL : kRR;
+      rows(it0, a_hi + 3, a_lo);
+      it0 = a_hi + 3;
+#pragma unroll
+      for (int a = a_lo; a < a_hi; ++a) {
+        const float4 x = rql[(a - a_lo) * kNT];
+        rq[a][0] = x.x; rq[a][1] = x.y; rq[a][2] = x.z; rq[a][3] = x.w;
+      }
+    }
+    rows(it0, kPR + 3, kRR);
+  }
+
+  // ---- K Jacobi sweeps (:104-114): p in registers, period-two row rotation ----
+  float ph[kPR + 1][4];
+  {
+    const float* p = P.p + (size_t)b * kCells + (size_t)r0 * kN + c0;
+#pragma unroll
+    for (int a = 0; a < kPR; ++a) {
+      const float4 x = *reinterpret_cast<const float4*>(p + a * kN);
+      ph[a][0] = x.x; ph[a][1] = x.y; ph[a][2] = x.z; ph[a][3] = x.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ph[kPR][k] = 0.f;
+  }
+  int xc = 0;
+  {
+    int it = 0;
+    for (; it + 2 <= C.iters; it += 2) {
+      sweep256<0>(ph, rq, rql, E, lds, xc, tid, w);
+      sweep256<1>(ph, rq, rql, E, lds, xc, tid, w);
+    }
+    if (it < C.iters) {   // odd sweep count: one more UP sweep, then rotate the rows back to the identity map
+      sweep256<0>(ph, rq, rql, E, lds, xc, tid, w);
+      float t[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] = ph[kPR][k];
+#pragma unroll
+      for (int a = kPR; a >= 1; --a)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ph[a][k] = ph[a - 1][k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ph[0][k] = t[k];
+    }
+  }
+  {
+    float* pd = (P.p_out ? P.p_out : P.p) + (size_t)b * kCells + (size_t)r0 * kN + c0;
+#pragma unroll
+    for (int a = 0; a < kPR; ++a) *reinterpret_cast<float4*>(pd + a * kN) = make_float4(ph[a][0], ph[a][1], ph[a][2], ph[a][3]);
+  }
+
+  // ---- back: corrector (:143-145), apply_boundary(u, v) (:146), observation (:147-154), reward (ns_reward.py:28) ----
+  // iteration `it` forms C(r), the corrected row r = r0 + it, from the re-evaluated predictor and p rows r-1, r, r+1, and
+  // finishes row r-1 (the lower wall row takes C(1) = C(r), the upper one C(254) = C(r-2)).
+  float acc = 0.f;
+  const int t_new = P.time_index[b] + 1;
+  const int tr = t_new < C.nt_ref ? t_new : C.nt_ref - 1;
+  {
+    float pt[4], pb[4];
+    halo_tb<4, kNT, 64>(ph[0], ph[kPR - 1], pt, pb, lds, xc, tid, w);
+    const float* uref = P.U_ref + (size_t)tr * kCells * 2;
+    float* obs = P.obs + (size_t)b * kCells * 2;
+    float s0u[4], s0v[4], s1u[4], s1v[4], s2u[4], s2v[4];
+    float c1u[4], c1v[4], c2u[4], c2v[4];                            // C(r-1), C(r-2)
+    float ps[4], pc[4];                                              // p rows r-1, r
+    // the wave's own pressure rows come back from where they were just stored (same thread, same addresses: L2 hits) so that
+    // no register row has to be picked by a run-time index
+    const float* pg = (P.p_out ? P.p_out : P.p) + (size_t)b * kCells + (size_t)r0 * kN + c0;
+    auto prow = [&](int a, float (&v)[4]) {
+      const float4 x = *reinterpret_cast<const float4*>(pg + (a < kPR - 1 ? a : kPR - 1) * kN);
+      v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    };
+    load_state_row<INTERLEAVED>(su, sv, r0 - 1, c0, s0u, s0v);
+    load_state_row<INTERLEAVED>(su, sv, r0, c0, s1u, s1v);
+    load_state_row<INTERLEAVED>(su, sv, r0 + 1, c0, s2u, s2v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      c1u[k] = c1v[k] = c2u[k] = c2v[k] = 0.f;
+      ps[k] = pt[k];
+    }
+    prow(0, pc);
+#pragma unroll 1
+    for (int it = 0; it <= kPR; ++it) {
+      const int r = r0 + it;
+      float nu_[4], nv_[4];
+      load_state_row<INTERLEAVED>(su, sv, r + 2, c0, nu_, nv_);
+      // reference frame of row r-1 (the row finished in this iteration)
+      float4 rf0 = make_float4(0.f, 0.f, 0.f, 0.f), rf1 = rf0;
+      if (it >= 1) {
+        const float4* rrow = reinterpret_cast<const float4*>(uref + ((r - 1) * kN + c0) * 2);
+        rf0 = rrow[0];
+        rf1 = rrow[1];
+      }
+      float cu[4], cv[4], pn[4];
+      prow(it + 1, pn);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pn[k] = (it + 1 < kPR) ? pn[k] : pb[k];
+      predictor_row(S, r, lane, s1u, s1v, s0u, s0v, s2u, s2v, cu, cv);
+      {
+        const float pl = lane_left(pc[3]), pr = lane_right(pc[0]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float pw = (k == 0) ? pl : pc[k - 1], pe = (k == 3) ? pr : pc[k + 1];
+          const float dpdx = div_c(pe - pw, S.two_dx, S.inv_two_dx);
+          const float dpdy = div_c(pn[k] - ps[k], S.two_dy, S.inv_two_dy);
+          const bool edge = (r <= 0) || (r >= kN - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
+          cu[k] = edge ? cu[k] : cu[k] - S.dt_over_rho * dpdx;
+          cv[k] = edge ? cv[k] : cv[k] - S.dt_over_rho * dpdy;
+        }
+      }
+      if (it >= 1) {
+        const int rr = r - 1;
+        float fu[4], fv[4], nbu[4], nbv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          fu[k] = c1u[k]; fv[k] = c1v[k];
+          nbu[k] = rr == 0 ? cu[k] : c2u[k];
+          nbv[k] = rr == 0 ? cv[k] : c2v[k];
+        }
+        bc_row(fu, nbu, rr, lane, c0, C.bc, 0, act, C.action_dim);
+        bc_row(fv, nbv, rr, lane, c0, C.bc, 1, act, C.action_dim);
+        float4* orow = reinterpret_cast<float4*>(obs + (rr * kN + c0) * 2);
+        orow[0] = make_float4(fu[0], fv[0], fu[1], fv[1]);
+        orow[1] = make_float4(fu[2], fv[2], fu[3], fv[3]);
+        const float d0 = fu[0] - rf0.x, d1 = fv[0] - rf0.y, d2 = fu[1] - rf0.z, d3 = fv[1] - rf0.w;
+        const float d4 = fu[2] - rf1.x, d5 = fv[2] - rf1.y, d6 = fu[3] - rf1.z, d7 = fv[3] - rf1.w;
+        acc += d0 * d0;
+        acc += d1 * d1;
+        acc += d2 * d2;
+        acc += d3 * d3;
+        acc += d4 * d4;
+        acc += d5 * d5;
+        acc += d6 * d6;
+        acc += d7 * d7;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        c2u[k] = c1u[k]; c2v[k] = c1v[k]; c1u[k] = cu[k]; c1v[k] = cv[k];
+        ps[k] = pc[k]; pc[k] = pn[k];
+        s0u[k] = s1u[k]; s0v[k] = s1v[k]; s1u[k] = s2u[k]; s1v[k] = s2v[k]; s2u[k] = nu_[k]; s2v[k] = nv_[k];
+      }
+    }
+  }
+  const float ss = block_sum<float>(acc, lds);     // the halo buffers are idle now (block_sum syncs first)
+  if (tid == 0) {
+    float asq = 0.f;
+    const float aref = P.action_ref[tr];
+    for (int k = 0; k < C.action_dim; ++k) {
+      const float d = act[k] - aref;
+      asq += d * d;
+    }
+    P.reward[b] = ((-0.5f * ss) / (float)kN) / (float)kN - S.gamma_half * asq;
+    P.time_index[b] = t_new;
+    P.terminated[b] = (t_new >= C.nt - 1) ? 1 : 0;      // navier_stokes2D.py:159-168
+  }
+}
+
+// separate-field state layout: the observation just written is copied out into u and v
+__global__ __launch_bounds__(256) void ns256_split_obs(const float* obs, float* u, float* v, size_t ncell4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per four cells
+  if (i >= ncell4) return;
+  const float4* q = reinterpret_cast<const float4*>(obs) + 2 * i;
+  const float4 a = q[0], d = q[1];
+  reinterpret_cast<float4*>(u)[i] = make_float4(a.x, a.z, d.x, d.z);
+  reinterpret_cast<float4*>(v)[i] = make_float4(a.y, a.w, d.y, d.w);
+}
+
+}  // namespace
+
+int launch_ns256_fused(const NSConst& C, const NSScal<float>& S, const NSPtrs<float>& P, int B, hipStream_t st) {
+  static signed char attr_i[pdegym::kMaxDevices] = {}, attr_s[pdegym::kMaxDevices] = {};
+  const bool inter = P.state_in != nullptr;
+  const bool ok = inter ? pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&ns256_fused_step<true>), kLdsBytes, attr_i)
+                        : pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&ns256_fused_step<false>), kLdsBytes, attr_s);
+  if (!ok) return pdegym::fail(-4, "cannot raise the dynamic LDS limit of ns256_fused_step");
+  if (inter) {
+    hipLaunchKernelGGL(ns256_fused_step<true>, dim3(B), dim3(kNT), kLdsBytes, st, C, S, P, B);
+  } else {
+    hipLaunchKernelGGL(ns256_fused_step<false>, dim3(B), dim3(kNT), kLdsBytes, st, C, S, P, B);
+    const size_t n4 = (size_t)B * kCells / 4;
+    hipLaunchKernelGGL(ns256_split_obs, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, P.obs, P.u, P.v, n4);
+  }
+  return pdegym::check_launch("ns2d_fused256_step");
+}
+
+}  // namespace ns
+}  // namespace pdegym
