@@ -23,6 +23,8 @@
 // pipeline it replaces moved 12 and its Jacobi pass ran at 3 waves per SIMD with one workgroup-wide burst of loads).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "pdegym.h"
 #include "pdegym_common.h"
 #include "pdegym_ns_common.h"
@@ -40,6 +42,10 @@ constexpr int kNT = 64 * kWaves;
 constexpr int kRL = PDEGYM_NS256_LDS_ROWS;        // right-hand-side rows per wave that live in LDS (even)
 constexpr int kRR = kPR - kRL;                    // rows in registers: the first kRR of the wave's block
 constexpr int kL0 = kRR;                          // first LDS row
+#ifndef PDEGYM_NS256_RING
+#define PDEGYM_NS256_RING 8
+#endif
+constexpr int kD = PDEGYM_NS256_RING;             // state rows in flight per lane in the front / back row pipelines (ring slots)
 constexpr int kHaloBytes = 2 * 2 * kNT * 16;      // two buffers x (top rows, bottom rows) x one float4 per thread
 constexpr int kLdsBytes = kHaloBytes + kRL * kNT * 16;
 static_assert(kRL % 2 == 0 && kRL >= 2 && kRL < kPR && kRR % 2 == 0, "LDS rows come in two-row blocks");
@@ -88,23 +94,50 @@ __device__ __forceinline__ void predictor_row(const NSScal<float>& S, int i, int
 // apply_boundary (:76-90) restricted to grid row i, in registers.  `f` holds the row before the call (only its interior
 // cells matter), `nb` the row next to it on the inside of the wall -- read only when i is the lower / upper wall row.  Passes
 // in the reference's order: lower, upper (whole row), then left, right (one cell each, reading the cell the earlier pass set).
-__device__ __forceinline__ void bc_row(float (&f)[4], const float (&nb)[4], int i, int lane, int c0, const int (&bc)[4][2], int comp,
-                                       const float* act, int action_dim) {
-  // rows outside the grid pass through here on the pipelines' first / last iterations: keep the action index inside the array
-  auto aval = [&](int idx) -> float { return action_dim == 1 ? act[0] : act[idx < 0 ? 0 : (idx > kN - 1 ? kN - 1 : idx)]; };
-  if (i == 0 || i == kN - 1) {
-    const int c = bc[i == 0 ? PDEGYM_EDGE_LOWER : PDEGYM_EDGE_UPPER][comp];
+// The left / right passes run for every row of the pipelines, so they are selects on lane masks formed once per launch
+// (BcSel) instead of branches on the boundary codes; the wall rows (two per instance) keep the branching form.
+struct BcSel {
+  bool ln[2], lw[2], rn[2], rw[2];   // per component: lane 0 takes its right neighbour (Neumann) / the wall value; lane 63 alike
+  bool ld[2], rd[2];                 // wall value is 0 (Dirichlet) rather than the action (Controllable); wave-uniform
+};
+__device__ __forceinline__ BcSel make_bc_sel(const int (&bc)[4][2], int lane) {
+  BcSel m;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) f[k] = (c == PDEGYM_BC_NEUMANN) ? nb[k] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(c0 + k));
+  for (int comp = 0; comp < 2; ++comp) {
+    const int cl = bc[PDEGYM_EDGE_LEFT][comp], cr = bc[PDEGYM_EDGE_RIGHT][comp];
+    m.ln[comp] = lane == 0 && cl == PDEGYM_BC_NEUMANN;
+    m.lw[comp] = lane == 0 && cl != PDEGYM_BC_NEUMANN;
+    m.rn[comp] = lane == 63 && cr == PDEGYM_BC_NEUMANN;
+    m.rw[comp] = lane == 63 && cr != PDEGYM_BC_NEUMANN;
+    m.ld[comp] = cl == PDEGYM_BC_DIRICHLET;
+    m.rd[comp] = cr == PDEGYM_BC_DIRICHLET;
   }
-  if (lane == 0) {
-    const int c = bc[PDEGYM_EDGE_LEFT][comp];
-    f[0] = (c == PDEGYM_BC_NEUMANN) ? f[1] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(i));
+  return m;
+}
+
+__device__ __forceinline__ void bc_row(float (&f)[4], const float (&nb)[4], int i, int c0, const int (&bc)[4][2], int comp,
+                                       const BcSel& m, const float* act, int action_dim, float a0) {
+  if (i == 0 || i == kN - 1) {        // wave-uniform, two rows per instance
+    const int c = bc[i == 0 ? PDEGYM_EDGE_LOWER : PDEGYM_EDGE_UPPER][comp];
+    if (c == PDEGYM_BC_NEUMANN) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) f[k] = nb[k];
+    } else if (c == PDEGYM_BC_DIRICHLET) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) f[k] = 0.0f;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) f[k] = action_dim == 1 ? a0 : act[c0 + k];
+    }
   }
-  if (lane == 63) {
-    const int c = bc[PDEGYM_EDGE_RIGHT][comp];
-    f[3] = (c == PDEGYM_BC_NEUMANN) ? f[2] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(i));
-  }
+  // rows outside the grid pass through here on the pipelines' first / last iterations: keep the action index inside the array
+  float ai = a0;
+  if (action_dim != 1) ai = act[i < 0 ? 0 : (i > kN - 1 ? kN - 1 : i)];
+  const float wl = m.ld[comp] ? 0.0f : ai, wr = m.rd[comp] ? 0.0f : ai;
+  f[0] = m.ln[comp] ? f[1] : f[0];
+  f[0] = m.lw[comp] ? wl : f[0];
+  f[3] = m.rn[comp] ? f[2] : f[3];
+  f[3] = m.rw[comp] ? wr : f[3];
 }
 
 // ---- one Jacobi sweep (state ST: 0 = UP, 1 = DOWN; see jacobi_sweep_bous), right-hand side partly in LDS -------------
@@ -114,7 +147,7 @@ __device__ __forceinline__ void sweep256(float (&ph)[kPR + 1][4], const float (&
   constexpr int PR = kPR, NJL = kRL / 2;
   float hlast[4];
   float buf[2][2][4];
-  auto ld = [&](int jl, int par) {
+  auto ld = [&](int jl, int par) __attribute__((always_inline)) {
     const float4 x = rql[(2 * jl) * kNT], y = rql[(2 * jl + 1) * kNT];
     buf[par][0][0] = x.x; buf[par][0][1] = x.y; buf[par][0][2] = x.z; buf[par][0][3] = x.w;
     buf[par][1][0] = y.x; buf[par][1][1] = y.y; buf[par][1][2] = y.z; buf[par][1][3] = y.w;
@@ -176,6 +209,8 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
   const float* sv = INTERLEAVED ? nullptr : P.v + (size_t)b * kCells;
   const float* act = P.action + (size_t)b * C.action_dim;
   float4* rql = reinterpret_cast<float4*>(smem_raw + kHaloBytes) + tid;   // row j of this thread: rql[j * kNT]
+  const BcSel bsel = make_bc_sel(C.bc, lane);
+  const float a0 = act[0];
 
   float rq[kRR][4];
 
@@ -183,76 +218,92 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
   // iteration `it` works on grid row r = r0 - 1 + it:  P(r) = predictor of row r;  F(r-1) = row r-1 after the boundary rule
   // (the lower wall row takes its inside neighbour P(1) = P(r), the upper one P(254) = P(r-2));  rq(r-2) from F_u(r-2),
   // F_v(r-3), F_v(r-1).  The two rows outside the wave's block (r0-1, r0+32) are evaluated here too instead of being
-  // exchanged with the neighbouring waves (34/32 of the predictor work, no barrier).  The loop is rolled, so a finished row
-  // goes to the thread's LDS slots first (a register row cannot be picked by a run-time index); every kRL rows the slots are
-  // copied into the register rows by straight-line code, and the last kRL rows simply stay there.
+  // exchanged with the neighbouring waves (34/32 of the predictor work, no barrier).
+  // State rows arrive through a ring of kD register rows with static slots (the loop is unrolled kD times): the slot that
+  // held row r-1 is refilled with row r-1+kD as soon as the predictor has read it, so kD-3 rows (10 loads per lane) are in
+  // flight while a row is processed -- with one row in flight the phase ran at the latency of an HBM access per row.
+  // A finished rq row goes to the thread's LDS slots first (a register row cannot be picked by a run-time index); after kRL
+  // rows the slots are copied into register rows by straight-line code, and the last kRL rows simply stay there.
   {
-    float s0u[4], s0v[4], s1u[4], s1v[4], s2u[4], s2v[4];            // state rows r-1, r, r+1
+    constexpr int D = kD;
+    float ru[D][4], rv[D][4];                                        // ring of state rows
     float p1u[4], p1v[4], p2u[4], p2v[4];                            // P(r-1), P(r-2)
     float f1u[4], f1v[4], f2v[4];                                    // F_u(r-2), F_v(r-2), F_v(r-3)
-    load_state_row<INTERLEAVED>(su, sv, r0 - 2, c0, s0u, s0v);
-    load_state_row<INTERLEAVED>(su, sv, r0 - 1, c0, s1u, s1v);
-    load_state_row<INTERLEAVED>(su, sv, r0, c0, s2u, s2v);
+    // slot of row S(r+1) at iteration `it` is (it - 3) mod D; S(r) and S(r-1) sit in the two slots before it
+#pragma unroll
+    for (int s = 0; s < D; ++s) load_state_row<INTERLEAVED>(su, sv, r0 - 2 + ((s + D - 3) % D), c0, ru[s], rv[s]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) p1u[k] = p1v[k] = p2u[k] = p2v[k] = f1u[k] = f1v[k] = f2v[k] = 0.f;
-    auto rows = [&](int it_lo, int it_hi, int slot0) {      // wave rows a = it - 3; row a goes to LDS slot a - slot0
+    auto row_iter = [&](int it, auto slot_c, int slot0) __attribute__((always_inline)) {   // wave row a = it - 3 goes to LDS slot a - slot0
+      constexpr int sl = decltype(slot_c)::value, sc = (sl + D - 1) % D, ss = (sl + D - 2) % D;
+      const int r = r0 - 1 + it;
+      float pu[4], pv[4];
+      predictor_row(S, r, lane, ru[sc], rv[sc], ru[ss], rv[ss], ru[sl], rv[sl], pu, pv);
+      load_state_row<INTERLEAVED>(su, sv, r - 1 + D, c0, ru[ss], rv[ss]);     // refill the slot row r-1 has left
+      // boundary rule on row r-1
+      const int rr = r - 1;
+      float fu[4], fv[4], nbu[4], nbv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        fu[k] = p1u[k]; fv[k] = p1v[k];
+        nbu[k] = rr == 0 ? pu[k] : p2u[k];
+        nbv[k] = rr == 0 ? pv[k] : p2v[k];
+      }
+      bc_row(fu, nbu, rr, c0, C.bc, 0, bsel, act, C.action_dim, a0);
+      bc_row(fv, nbv, rr, c0, C.bc, 1, bsel, act, C.action_dim, a0);
+      // right-hand side of row r-2 = wave row a
+      const int a = it - 3;
+      if (a >= 0) {
+        const int i = r - 2;
+        const float ul = lane_left(f1u[3]), ur = lane_right(f1u[0]);
+        float q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float uw = (k == 0) ? ul : f1u[k - 1], ue = (k == 3) ? ur : f1u[k + 1];
+          const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx);
+          const float dvdy = div_c(fv[k] - f2v[k], S.two_dy, S.inv_two_dy);
+          const float rh = S.rho_over_dt * (dudx + dvdy);
+          const bool edge = (i == 0) || (i == kN - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
+          q[k] = edge ? 0.0f : jacobi_rhs_term(S.dxdy, rh);
+        }
+        rql[(a - slot0) * kNT] = make_float4(q[0], q[1], q[2], q[3]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f2v[k] = f1v[k]; f1v[k] = fv[k]; f1u[k] = fu[k];
+        p2u[k] = p1u[k]; p2v[k] = p1v[k]; p1u[k] = pu[k]; p1v[k] = pv[k];
+      }
+    };
+    row_iter(0, std::integral_constant<int, (D - 3) % D>{}, 0);
+    row_iter(1, std::integral_constant<int, (D - 2) % D>{}, 0);
+    row_iter(2, std::integral_constant<int, (D - 1) % D>{}, 0);
+    auto rows = [&](int a_lo, int a_hi, int slot0) __attribute__((always_inline)) {        // a_hi - a_lo is a multiple of D
 #pragma unroll 1
-      for (int it = it_lo; it < it_hi; ++it) {
-        const int r = r0 - 1 + it;
-        float nu_[4], nv_[4];
-        load_state_row<INTERLEAVED>(su, sv, r + 2, c0, nu_, nv_);     // next iteration's row r+1: in flight during this one
-        float pu[4], pv[4];
-        predictor_row(S, r, lane, s1u, s1v, s0u, s0v, s2u, s2v, pu, pv);
-        // boundary rule on row r-1
-        const int rr = r - 1;
-        float fu[4], fv[4], nbu[4], nbv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          fu[k] = p1u[k]; fv[k] = p1v[k];
-          nbu[k] = rr == 0 ? pu[k] : p2u[k];
-          nbv[k] = rr == 0 ? pv[k] : p2v[k];
-        }
-        bc_row(fu, nbu, rr, lane, c0, C.bc, 0, act, C.action_dim);
-        bc_row(fv, nbv, rr, lane, c0, C.bc, 1, act, C.action_dim);
-        // right-hand side of row r-2 = wave row a
-        const int a = it - 3;
-        if (a >= 0) {
-          const int i = r - 2;
-          const float ul = lane_left(f1u[3]), ur = lane_right(f1u[0]);
-          float q[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float uw = (k == 0) ? ul : f1u[k - 1], ue = (k == 3) ? ur : f1u[k + 1];
-            const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx);
-            const float dvdy = div_c(fv[k] - f2v[k], S.two_dy, S.inv_two_dy);
-            const float rh = S.rho_over_dt * (dudx + dvdy);
-            const bool edge = (i == 0) || (i == kN - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
-            q[k] = edge ? 0.0f : jacobi_rhs_term(S.dxdy, rh);
-          }
-          rql[(a - slot0) * kNT] = make_float4(q[0], q[1], q[2], q[3]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          f2v[k] = f1v[k]; f1v[k] = fv[k]; f1u[k] = fu[k];
-          p2u[k] = p1u[k]; p2v[k] = p1v[k]; p1u[k] = pu[k]; p1v[k] = pv[k];
-          s0u[k] = s1u[k]; s0v[k] = s1v[k]; s1u[k] = s2u[k]; s1v[k] = s2v[k]; s2u[k] = nu_[k]; s2v[k] = nv_[k];
+      for (int it0 = a_lo + 3; it0 < a_hi + 3; it0 += D) {
+        row_iter(it0 + 0, std::integral_constant<int, 0>{}, slot0);
+        row_iter(it0 + 1, std::integral_constant<int, 1 % D>{}, slot0);
+        row_iter(it0 + 2, std::integral_constant<int, 2 % D>{}, slot0);
+        row_iter(it0 + 3, std::integral_constant<int, 3 % D>{}, slot0);
+        if constexpr (D == 8) {
+          row_iter(it0 + 4, std::integral_constant<int, 4 % D>{}, slot0);
+          row_iter(it0 + 5, std::integral_constant<int, 5 % D>{}, slot0);
+          row_iter(it0 + 6, std::integral_constant<int, 6 % D>{}, slot0);
+          row_iter(it0 + 7, std::integral_constant<int, 7 % D>{}, slot0);
         }
       }
     };
     constexpr int NCH = (kRR + kRL - 1) / kRL;          // chunks of register rows
-    int it0 = 0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int a_lo = c * kRL, a_hi = (c + 1) * kRL < kRR ? (c + 1) * kRL : kRR;
-      rows(it0, a_hi + 3, a_lo);
-      it0 = a_hi + 3;
+      rows(a_lo, a_hi, a_lo);
 #pragma unroll
       for (int a = a_lo; a < a_hi; ++a) {
         const float4 x = rql[(a - a_lo) * kNT];
         rq[a][0] = x.x; rq[a][1] = x.y; rq[a][2] = x.z; rq[a][3] = x.w;
       }
     }
-    rows(it0, kPR + 3, kRR);
+    rows(kRR, kPR, kRR);
   }
 
   // ---- K Jacobi sweeps (:104-114): p in registers, period-two row rotation ----
@@ -295,95 +346,115 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
 
   // ---- back: corrector (:143-145), apply_boundary(u, v) (:146), observation (:147-154), reward (ns_reward.py:28) ----
   // iteration `it` forms C(r), the corrected row r = r0 + it, from the re-evaluated predictor and p rows r-1, r, r+1, and
-  // finishes row r-1 (the lower wall row takes C(1) = C(r), the upper one C(254) = C(r-2)).
+  // finishes row r-1 (the lower wall row takes C(1) = C(r), the upper one C(254) = C(r-2)).  Rings with static slots as in
+  // the front: state rows (kD slots), pressure rows (kD slots; the wave's own rows come back from where they were just
+  // stored -- same thread, same addresses, L2 hits -- so that no register row has to be picked by a run-time index; the rows
+  // above / below the block come through the LDS exchange) and rows of the reference frame (4 slots).
   float acc = 0.f;
   const int t_new = P.time_index[b] + 1;
   const int tr = t_new < C.nt_ref ? t_new : C.nt_ref - 1;
   {
+    constexpr int D = kD;
+    static_assert(kPR % kD == 0 && (kD == 4 || kD == 8), "the back loop runs kPR iterations in blocks of kD");
     float pt[4], pb[4];
     halo_tb<4, kNT, 64>(ph[0], ph[kPR - 1], pt, pb, lds, xc, tid, w);
     const float* uref = P.U_ref + (size_t)tr * kCells * 2;
     float* obs = P.obs + (size_t)b * kCells * 2;
-    float s0u[4], s0v[4], s1u[4], s1v[4], s2u[4], s2v[4];
-    float c1u[4], c1v[4], c2u[4], c2v[4];                            // C(r-1), C(r-2)
-    float ps[4], pc[4];                                              // p rows r-1, r
-    // the wave's own pressure rows come back from where they were just stored (same thread, same addresses: L2 hits) so that
-    // no register row has to be picked by a run-time index
     const float* pg = (P.p_out ? P.p_out : P.p) + (size_t)b * kCells + (size_t)r0 * kN + c0;
-    auto prow = [&](int a, float (&v)[4]) {
-      const float4 x = *reinterpret_cast<const float4*>(pg + (a < kPR - 1 ? a : kPR - 1) * kN);
-      v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    constexpr int DP = 4, DF = 2;      // pressure rows and reference rows are L2 hits: one row ahead is enough
+    float ru[D][4], rv[D][4], rp[DP][4];
+    float4 rf[DF][2];
+    float c1u[4], c1v[4], c2u[4], c2v[4];                            // C(r-1), C(r-2)
+    auto prow = [&](int a, float (&v)[4]) __attribute__((always_inline)) {                          // p row r0 + a, -1 <= a
+      const int ac = a < 0 ? 0 : (a < kPR - 1 ? a : kPR - 1);
+      const float4 x = *reinterpret_cast<const float4*>(pg + ac * kN);
+      v[0] = a < 0 ? pt[0] : (a < kPR ? x.x : pb[0]);
+      v[1] = a < 0 ? pt[1] : (a < kPR ? x.y : pb[1]);
+      v[2] = a < 0 ? pt[2] : (a < kPR ? x.z : pb[2]);
+      v[3] = a < 0 ? pt[3] : (a < kPR ? x.w : pb[3]);
     };
-    load_state_row<INTERLEAVED>(su, sv, r0 - 1, c0, s0u, s0v);
-    load_state_row<INTERLEAVED>(su, sv, r0, c0, s1u, s1v);
-    load_state_row<INTERLEAVED>(su, sv, r0 + 1, c0, s2u, s2v);
+    auto urow = [&](int row, float4 (&q)[2]) __attribute__((always_inline)) {
+      const int rc = row < 0 ? 0 : (row > kN - 1 ? kN - 1 : row);
+      const float4* rrow = reinterpret_cast<const float4*>(uref + (rc * kN + c0) * 2);
+      q[0] = rrow[0];
+      q[1] = rrow[1];
+    };
+    // at iteration `it`: S(r-1), S(r), S(r+1) sit in slots it, it+1, it+2 (mod D), p(r-1), p(r), p(r+1) likewise (mod DP),
+    // Uref(r-1) in slot it mod DF
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      c1u[k] = c1v[k] = c2u[k] = c2v[k] = 0.f;
-      ps[k] = pt[k];
-    }
-    prow(0, pc);
-#pragma unroll 1
-    for (int it = 0; it <= kPR; ++it) {
-      const int r = r0 + it;
-      float nu_[4], nv_[4];
-      load_state_row<INTERLEAVED>(su, sv, r + 2, c0, nu_, nv_);
-      // reference frame of row r-1 (the row finished in this iteration)
-      float4 rf0 = make_float4(0.f, 0.f, 0.f, 0.f), rf1 = rf0;
-      if (it >= 1) {
-        const float4* rrow = reinterpret_cast<const float4*>(uref + ((r - 1) * kN + c0) * 2);
-        rf0 = rrow[0];
-        rf1 = rrow[1];
+    for (int s = 0; s < D; ++s) load_state_row<INTERLEAVED>(su, sv, r0 - 1 + s, c0, ru[s], rv[s]);
+#pragma unroll
+    for (int s = 0; s < DP; ++s) prow(s - 1, rp[s]);
+#pragma unroll
+    for (int s = 0; s < DF; ++s) urow(r0 - 1 + s, rf[s]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c1u[k] = c1v[k] = c2u[k] = c2v[k] = 0.f;
+    auto finish_row = [&](int rr, const float (&cu)[4], const float (&cv)[4], const float4 (&ref)[2]) __attribute__((always_inline)) {
+      float fu[4], fv[4], nbu[4], nbv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        fu[k] = c1u[k]; fv[k] = c1v[k];
+        nbu[k] = rr == 0 ? cu[k] : c2u[k];
+        nbv[k] = rr == 0 ? cv[k] : c2v[k];
       }
-      float cu[4], cv[4], pn[4];
-      prow(it + 1, pn);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) pn[k] = (it + 1 < kPR) ? pn[k] : pb[k];
-      predictor_row(S, r, lane, s1u, s1v, s0u, s0v, s2u, s2v, cu, cv);
+      bc_row(fu, nbu, rr, c0, C.bc, 0, bsel, act, C.action_dim, a0);
+      bc_row(fv, nbv, rr, c0, C.bc, 1, bsel, act, C.action_dim, a0);
+      float4* orow = reinterpret_cast<float4*>(obs + (rr * kN + c0) * 2);
+      orow[0] = make_float4(fu[0], fv[0], fu[1], fv[1]);
+      orow[1] = make_float4(fu[2], fv[2], fu[3], fv[3]);
+      const float d0 = fu[0] - ref[0].x, d1 = fv[0] - ref[0].y, d2 = fu[1] - ref[0].z, d3 = fv[1] - ref[0].w;
+      const float d4 = fu[2] - ref[1].x, d5 = fv[2] - ref[1].y, d6 = fu[3] - ref[1].z, d7 = fv[3] - ref[1].w;
+      acc += d0 * d0;
+      acc += d1 * d1;
+      acc += d2 * d2;
+      acc += d3 * d3;
+      acc += d4 * d4;
+      acc += d5 * d5;
+      acc += d6 * d6;
+      acc += d7 * d7;
+    };
+    auto row_iter = [&](int it, auto slot_c) __attribute__((always_inline)) {
+      constexpr int s0 = decltype(slot_c)::value, s1 = (s0 + 1) % D, s2 = (s0 + 2) % D, sf = s0 % DF;
+      constexpr int q0 = s0 % DP, q1 = (s0 + 1) % DP, q2 = (s0 + 2) % DP;
+      const int r = r0 + it;
+      float cu[4], cv[4];
+      predictor_row(S, r, lane, ru[s1], rv[s1], ru[s0], rv[s0], ru[s2], rv[s2], cu, cv);
       {
-        const float pl = lane_left(pc[3]), pr = lane_right(pc[0]);
+        const float pl = lane_left(rp[q1][3]), pr = lane_right(rp[q1][0]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float pw = (k == 0) ? pl : pc[k - 1], pe = (k == 3) ? pr : pc[k + 1];
+          const float pw = (k == 0) ? pl : rp[q1][k - 1], pe = (k == 3) ? pr : rp[q1][k + 1];
           const float dpdx = div_c(pe - pw, S.two_dx, S.inv_two_dx);
-          const float dpdy = div_c(pn[k] - ps[k], S.two_dy, S.inv_two_dy);
+          const float dpdy = div_c(rp[q2][k] - rp[q0][k], S.two_dy, S.inv_two_dy);
           const bool edge = (r <= 0) || (r >= kN - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
           cu[k] = edge ? cu[k] : cu[k] - S.dt_over_rho * dpdx;
           cv[k] = edge ? cv[k] : cv[k] - S.dt_over_rho * dpdy;
         }
       }
-      if (it >= 1) {
-        const int rr = r - 1;
-        float fu[4], fv[4], nbu[4], nbv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          fu[k] = c1u[k]; fv[k] = c1v[k];
-          nbu[k] = rr == 0 ? cu[k] : c2u[k];
-          nbv[k] = rr == 0 ? cv[k] : c2v[k];
-        }
-        bc_row(fu, nbu, rr, lane, c0, C.bc, 0, act, C.action_dim);
-        bc_row(fv, nbv, rr, lane, c0, C.bc, 1, act, C.action_dim);
-        float4* orow = reinterpret_cast<float4*>(obs + (rr * kN + c0) * 2);
-        orow[0] = make_float4(fu[0], fv[0], fu[1], fv[1]);
-        orow[1] = make_float4(fu[2], fv[2], fu[3], fv[3]);
-        const float d0 = fu[0] - rf0.x, d1 = fv[0] - rf0.y, d2 = fu[1] - rf0.z, d3 = fv[1] - rf0.w;
-        const float d4 = fu[2] - rf1.x, d5 = fv[2] - rf1.y, d6 = fu[3] - rf1.z, d7 = fv[3] - rf1.w;
-        acc += d0 * d0;
-        acc += d1 * d1;
-        acc += d2 * d2;
-        acc += d3 * d3;
-        acc += d4 * d4;
-        acc += d5 * d5;
-        acc += d6 * d6;
-        acc += d7 * d7;
-      }
+      load_state_row<INTERLEAVED>(su, sv, r - 1 + D, c0, ru[s0], rv[s0]);
+      prow(it - 1 + DP, rp[q0]);
+      if (it >= 1) finish_row(r - 1, cu, cv, rf[sf]);
+      urow(r - 1 + DF, rf[sf]);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         c2u[k] = c1u[k]; c2v[k] = c1v[k]; c1u[k] = cu[k]; c1v[k] = cv[k];
-        ps[k] = pc[k]; pc[k] = pn[k];
-        s0u[k] = s1u[k]; s0v[k] = s1v[k]; s1u[k] = s2u[k]; s1v[k] = s2v[k]; s2u[k] = nu_[k]; s2v[k] = nv_[k];
+      }
+    };
+#pragma unroll 1
+    for (int it0 = 0; it0 < kPR; it0 += D) {
+      row_iter(it0 + 0, std::integral_constant<int, 0>{});
+      row_iter(it0 + 1, std::integral_constant<int, 1 % D>{});
+      row_iter(it0 + 2, std::integral_constant<int, 2 % D>{});
+      row_iter(it0 + 3, std::integral_constant<int, 3 % D>{});
+      if constexpr (D == 8) {
+        row_iter(it0 + 4, std::integral_constant<int, 4 % D>{});
+        row_iter(it0 + 5, std::integral_constant<int, 5 % D>{});
+        row_iter(it0 + 6, std::integral_constant<int, 6 % D>{});
+        row_iter(it0 + 7, std::integral_constant<int, 7 % D>{});
       }
     }
+    // the block's last row: C(r0+31) is in c1; the wall rule of row 255 reads C(254) = c2
+    finish_row(r0 + kPR - 1, c1u, c1v, rf[kPR % DF]);
   }
   const float ss = block_sum<float>(acc, lds);     // the halo buffers are idle now (block_sum syncs first)
   if (tid == 0) {

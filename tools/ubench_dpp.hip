@@ -58,6 +58,14 @@ __device__ __forceinline__ float dpp_right(float v) {
   return r;
 }
 
+__device__ __forceinline__ float bperm(int addr, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+}
+template <int PAT>
+__device__ __forceinline__ float swz(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), PAT));
+}
+
 template <int MODE, int NT>
 __global__ __launch_bounds__(NT) void k(float* out, int iters) {
   constexpr int PR = 15;
@@ -67,7 +75,30 @@ __global__ __launch_bounds__(NT) void k(float* out, int iters) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) { ph[r][c] = threadIdx.x * 1e-3f + r + c; if (r < PR) rq[r][c] = 0.01f * (r + c); }
   for (int i = 0; i < iters; ++i) {
-    if constexpr (MODE == 4) {
+    if constexpr (MODE == 5 || MODE == 6) {
+      // neighbour-lane values through the LDS crossbar (ds_bpermute_b32 / ds_swizzle_b32), requested one group ahead
+      const int al = (((threadIdx.x & 63) + 63) & 63) * 4, ar = (((threadIdx.x & 63) + 1) & 63) * 4;
+      auto L = [&](float v) { return MODE == 5 ? bperm(al, v) : swz<0x8000 | (31 << 5) | 0>(v); };
+      auto R = [&](float v) { return MODE == 5 ? bperm(ar, v) : swz<0x8000 | (1 << 5) | 0>(v); };
+      float l0 = L(ph[0][3]), r0 = R(ph[0][0]);
+#pragma unroll
+      for (int a = 0; a < PR; ++a) {
+        float l1 = 0, r1 = 0;
+        if (a + 1 < PR) { l1 = L(ph[a + 1][3]); r1 = R(ph[a + 1][0]); }
+        asm volatile("" ::: "memory");
+        group_pre(ph[a == 0 ? PR : a - 1], ph[a], ph[a + 1 == PR ? PR : a + 1], rq[a], l0, r0);
+        l0 = l1; r0 = r1;
+      }
+      l0 = L(ph[PR - 2][3]); r0 = R(ph[PR - 2][0]);
+#pragma unroll
+      for (int a = PR - 1; a >= 0; --a) {
+        float l1 = 0, r1 = 0;
+        if (a >= 1) { const int c = (a - 1 == 0) ? PR : a - 2; l1 = L(ph[c][3]); r1 = R(ph[c][0]); }
+        asm volatile("" ::: "memory");
+        group_pre(ph[a], ph[a == 0 ? PR : a - 1], ph[a == 0 ? PR - 1 : (a == 1 ? PR : a - 2)], rq[a], l0, r0);
+        l0 = l1; r0 = r1;
+      }
+    } else if constexpr (MODE == 4) {
       float hl[PR], hr[PR];
 #pragma unroll
       for (int a = 0; a < PR; ++a) { hl[a] = dpp_left(ph[a][3]); hr[a] = dpp_right(ph[a][0]); }
@@ -113,6 +144,18 @@ void run(const char* name) {
 }
 
 int main() {
+  for (int rep = 0; rep < 1; ++rep) {
+    run<0, 512>("no lane crossing");
+    run<1, 512>("wave_shr/wave_shl");
+    run<5, 512>("ds_bpermute one group ahead");
+    run<6, 512>("ds_swizzle one group ahead");
+    run<5, 1024>("ds_bpermute one group ahead");
+    run<6, 1024>("ds_swizzle one group ahead");
+  }
+  run<0, 512>("no lane crossing");
+  run<1, 512>("wave_shr/wave_shl");
+  run<2, 512>("row_shr/row_shl");
+  run<3, 512>("quad_perm");
   run<0, 768>("no lane crossing");
   run<1, 768>("wave_shr/wave_shl");
   run<2, 768>("row_shr/row_shl");
