@@ -8,6 +8,15 @@
 
 #include "pdegym.h"
 
+#ifndef PDEGYM_NS_DPP_NOP
+#define PDEGYM_NS_DPP_NOP 1
+#endif
+#if PDEGYM_NS_DPP_NOP
+#define PDEGYM_DPP_NOP "s_nop 0\n\t"
+#else
+#define PDEGYM_DPP_NOP
+#endif
+
 namespace pdegym {
 namespace ns {
 
@@ -186,10 +195,12 @@ __device__ __forceinline__ void jacobi_row_into_south(float (&sv)[4], const floa
       "v_add_f32 %1, %4, %1\n\t"
       "v_add_f32 %2, %5, %2\n\t"
       "v_add_f32 %3, %6, %3\n\t"
+      PDEGYM_DPP_NOP
       "v_add_f32_dpp %0, %7, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32 %0, %0, %5\n\t"
       "v_add_f32 %1, %1, %6\n\t"
       "v_add_f32 %2, %2, %7\n\t"
+      PDEGYM_DPP_NOP
       "v_add_f32_dpp %3, %4, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32 %0, %0, %8\n\t"
       "v_add_f32 %1, %1, %9\n\t"
@@ -210,10 +221,12 @@ __device__ __forceinline__ void jacobi_row_into_north(float (&nv)[4], const floa
       "v_add_f32 %5, %8, %13\n\t"
       "v_add_f32 %6, %9, %14\n\t"
       "v_add_f32 %7, %10, %15\n\t"
+      PDEGYM_DPP_NOP
       "v_add_f32_dpp %4, %11, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32 %4, %4, %9\n\t"
       "v_add_f32 %5, %5, %10\n\t"
       "v_add_f32 %6, %6, %11\n\t"
+      PDEGYM_DPP_NOP
       "v_add_f32_dpp %7, %8, %7 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32 %0, %4, %0\n\t"
       "v_add_f32 %1, %5, %1\n\t"
@@ -228,6 +241,10 @@ __device__ __forceinline__ void jacobi_row_into_north(float (&nv)[4], const floa
         "v"(rq[2]), "v"(rq[3]), "s"(0.25f));
 }
 
+// An s_nop 0 goes ahead of every DPP add: without it a DPP operand costs the SIMD ~15 cycles in these blocks -- the two waves of a
+// SIMD stop overlapping, any density of DPP from 2 in 16 up runs at ~4.2 cycles per instruction instead of 2.3-2.5 -- with it
+// ~6 (tools/ubench_dpp5.hip: pair block 261 -> 207 cycles per SIMD at two waves, 451 -> 386 at four; 166 / 294 without any
+// lane crossing).
 // Two rows per block (8 independent dependency chains instead of 4: a wave issues only about every 8 cycles along ONE
 // chain of 4, so three or four waves per SIMD cannot fill it with single-row blocks -- tools/ubench_dpp.hip).
 // UP, rows a (A) and a+1 (B):  da = old row a-1 (South of A, becomes new row a), db = old row a (centre of A, South of B,
@@ -243,7 +260,9 @@ __device__ __forceinline__ void jacobi_pair_up(float (&da)[4], float (&db)[4], c
       "v_add_f32 %10, %13, %6\n\t"
       "v_add_f32 %3, %6, %3\n\t"
       "v_add_f32 %11, %14, %7\n\t"
+      PDEGYM_DPP_NOP
       "v_add_f32_dpp %0, %7, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      PDEGYM_DPP_NOP
       "v_add_f32_dpp %8, %15, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32 %0, %0, %5\n\t"                  // + E
       "v_add_f32 %8, %8, %13\n\t"
@@ -251,7 +270,9 @@ __device__ __forceinline__ void jacobi_pair_up(float (&da)[4], float (&db)[4], c
       "v_add_f32 %9, %9, %14\n\t"
       "v_add_f32 %2, %2, %7\n\t"
       "v_add_f32 %10, %10, %15\n\t"
+      PDEGYM_DPP_NOP
       "v_add_f32_dpp %3, %4, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      PDEGYM_DPP_NOP
       "v_add_f32_dpp %11, %12, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32 %0, %0, %12\n\t"                 // + N
       "v_add_f32 %8, %8, %16\n\t"
@@ -288,7 +309,9 @@ __device__ __forceinline__ void jacobi_pair_down(float (&da)[4], float (&db)[4],
       "v_add_f32 %14, %17, %22\n\t"
       "v_add_f32 %11, %6, %19\n\t"
       "v_add_f32 %15, %18, %23\n\t"
+      PDEGYM_DPP_NOP
       "v_add_f32_dpp %8, %7, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      PDEGYM_DPP_NOP
       "v_add_f32_dpp %12, %19, %20 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32 %8, %8, %5\n\t"                  // + E
       "v_add_f32 %12, %12, %17\n\t"
@@ -296,7 +319,9 @@ __device__ __forceinline__ void jacobi_pair_down(float (&da)[4], float (&db)[4],
       "v_add_f32 %13, %13, %18\n\t"
       "v_add_f32 %10, %10, %7\n\t"
       "v_add_f32 %14, %14, %19\n\t"
+      PDEGYM_DPP_NOP
       "v_add_f32_dpp %11, %4, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      PDEGYM_DPP_NOP
       "v_add_f32_dpp %15, %16, %15 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_add_f32 %0, %8, %0\n\t"                  // + N, in place on the North rows (A has read db for the last time)
       "v_add_f32 %4, %12, %4\n\t"
