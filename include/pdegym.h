@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PDEGYM_ABI_VERSION 11
+#define PDEGYM_ABI_VERSION 12
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
 #define PDEGYM_MAX_N1D 2048      /* nodes per 1D row kept in registers by the wave-per-instance kernels */
@@ -435,6 +435,19 @@ typedef struct pdegym_mlp_s {
 /* y[b, :] = net(x[b, :]) for b < B; x_stride / y_stride = ELEMENTS between consecutive rows (>= the row lengths). */
 int pdegym_mlp_forward(const pdegym_mlp* net, const void* x, int64_t x_stride, void* y, int64_t y_stride, int32_t B,
                        void* stream);
+
+/* ---- test-only: kernel dispatch overrides -------------------------------------------------------------------------
+ * Nothing on the product path calls this (the reference has no counterpart); the parity tests use it to run the SAME step
+ * through two kernel families and compare the results bit for bit, developer tools for A/B timings.  Process-wide; returns
+ * the previous value, or a negative error code for an unknown key. */
+enum {
+  PDEGYM_DEBUG_NS_GENERIC = 0,        /* != 0: every NavierStokes2D step takes ns_generic_step (workgroup per instance)     */
+  PDEGYM_DEBUG_NS_NO_COL = 1,         /* != 0: small grids skip the column-per-lane kernel                                   */
+  PDEGYM_DEBUG_NS_COL_MIN_BATCH = 2,  /* >= 0: smallest batch the column-per-lane kernel takes (-1: the built-in rule)       */
+  PDEGYM_DEBUG_NS_NO_LDS_JACOBI = 3,  /* != 0: ns_generic_step keeps the pressure in global memory during the sweeps         */
+  PDEGYM_DEBUG_COUNT = 4
+};
+int32_t pdegym_debug_set(int32_t key, int32_t value);
 
 #ifdef __cplusplus
 }

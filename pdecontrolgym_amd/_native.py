@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 RING = 128
 LOOKBACK = 100
 MAX_N1D = 8192
@@ -31,8 +31,10 @@ EXPORTS = [
     "pdegym_ns2d_solve_pressure_f32", "pdegym_ns2d_solve_pressure_f64", "pdegym_ns2d_reset_masked_f32",
     "pdegym_ns2d_reset_masked_f64", "pdegym_traffic_step", "pdegym_traffic_reset_masked",
     "pdegym_tumor_step", "pdegym_tumor_advance", "pdegym_tumor_reset_masked", "pdegym_mlp_forward",
-    "pdegym_transport_rollout", "pdegym_parabolic_rollout", "pdegym_traffic_rollout",
+    "pdegym_transport_rollout", "pdegym_parabolic_rollout", "pdegym_traffic_rollout", "pdegym_debug_set",
 ]
+# keys of pdegym_debug_set (test-only dispatch overrides, include/pdegym.h)
+DEBUG_NS_GENERIC, DEBUG_NS_NO_COL, DEBUG_NS_COL_MIN_BATCH, DEBUG_NS_NO_LDS_JACOBI = range(4)
 MLP_MAX_LAYERS, MLP_MAX_WIDTH, MLP_MAX_INPUT = 4, 256, 8192
 MLP_IDENTITY, MLP_TANH, MLP_RELU = 0, 1, 2
 
@@ -185,10 +187,35 @@ def load():
     lib.pdegym_tumor_reset_masked.restype = C.c_int
     lib.pdegym_mlp_forward.argtypes = [C.POINTER(Mlp), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     lib.pdegym_mlp_forward.restype = C.c_int
+    lib.pdegym_debug_set.argtypes = [C.c_int32, C.c_int32]
+    lib.pdegym_debug_set.restype = C.c_int32
     if lib.pdegym_abi_version() != ABI_VERSION:
         raise NativeError(f"ABI mismatch: library {lib.pdegym_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+class ns_dispatch:
+    """Test-only context manager around pdegym_debug_set: run NavierStokes2D steps through another kernel family
+    (generic=True: workgroup-per-instance kernel; no_col=True: no column-per-lane kernel; col_min_batch=n; no_lds_jacobi=True)."""
+
+    def __init__(self, generic=None, no_col=None, col_min_batch=None, no_lds_jacobi=None):
+        self.want = {DEBUG_NS_GENERIC: generic, DEBUG_NS_NO_COL: no_col, DEBUG_NS_COL_MIN_BATCH: col_min_batch,
+                     DEBUG_NS_NO_LDS_JACOBI: no_lds_jacobi}
+        self.old = {}
+
+    def __enter__(self):
+        lib = load()
+        for k, v in self.want.items():
+            if v is not None:
+                self.old[k] = lib.pdegym_debug_set(k, int(v))
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for k, v in self.old.items():
+            lib.pdegym_debug_set(k, v)
+        return False
 
 
 def check(rc: int, what: str):

@@ -19,17 +19,19 @@ SOURCES = ["pdegym_abi.hip", "pdegym_1d.hip", "pdegym_ns2d.hip", "pdegym_ns256.h
 # -ffp-contract=off: NumPy rounds after every operation; a fused multiply-add would break bit parity.
 # -fno-slp-vectorize: v_pk_*_f32 has the same per-element issue cost as the scalar forms on gfx950 (tools/ubench_valu.hip:
 # 5.1 vs 2.8 cycles per wave-instruction at 4 waves/SIMD) and packing adjacent stencil nodes costs shuffle moves.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
-         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+OPTS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC"]
+FLAGS = OPTS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
 def _fingerprint() -> str:
+    """Hash of what the library is built from: the sources, the public header and the compiler options -- no absolute paths
+    (the include directories are named by the files hashed above), so the stamp survives moving or copying the tree."""
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)) + ["../../include/pdegym.h"]:
         with open(os.path.join(CSRC, f), "rb") as fh:
-            h.update(f.encode())
+            h.update(os.path.basename(f).encode())
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(OPTS).encode())
     return h.hexdigest()
 
 

@@ -37,23 +37,13 @@ constexpr int kWavesPerBlock = 4;
 
 // lane i <- lane i-1 ; lane 0 <- `edge`      (DPP wave_shr:1, gfx9 wave-wide shift)
 __device__ __forceinline__ float from_left_lane(float v, float edge) {
-#ifdef PDEGYM_NO_DPP
-  const float r = __shfl_up(v, 1);
-  return (threadIdx.x & 63) == 0 ? edge : r;
-#else
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v),
                                                                0x138, 0xf, 0xf, false));
-#endif
 }
 // lane i <- lane i+1 ; lane 63 <- `edge`     (DPP wave_shl:1)
 __device__ __forceinline__ float from_right_lane(float v, float edge) {
-#ifdef PDEGYM_NO_DPP
-  const float r = __shfl_down(v, 1);
-  return (threadIdx.x & 63) == 63 ? edge : r;
-#else
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v),
                                                                0x130, 0xf, 0xf, false));
-#endif
 }
 
 // Wave-wide reductions on DPP (result in every lane).  __shfl_xor compiles to ds_bpermute_b32, an LDS round trip per step:

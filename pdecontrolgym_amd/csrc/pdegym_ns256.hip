@@ -213,6 +213,13 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
   const float a0 = act[0];
 
   float rq[kRR][4];
+#ifdef PDEGYM_NS256_TIMING      // developer build (tools/timing_probe_ns256.py): s_memtime at the phase boundaries of every wave
+  unsigned long long tm[6];
+  tm[0] = __builtin_amdgcn_s_memtime();
+#define NS256_STAMP(i, dep) tm[i] = __builtin_amdgcn_s_memtime() + (unsigned long long)((dep) != (dep))
+#else
+#define NS256_STAMP(i, dep)
+#endif
 
   // ---- front: predictor -> apply_boundary(u*, v*) (:140) -> 0.25 dx dy rhs (:101-103, :108), a row pipeline ----
   // iteration `it` works on grid row r = r0 - 1 + it:  P(r) = predictor of row r;  F(r-1) = row r-1 after the boundary rule
@@ -306,6 +313,7 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
     rows(kRR, kPR, kRR);
   }
 
+  NS256_STAMP(1, rq[0][0]);
   // ---- K Jacobi sweeps (:104-114): p in registers, period-two row rotation ----
   float ph[kPR + 1][4];
   {
@@ -318,6 +326,7 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
 #pragma unroll
     for (int k = 0; k < 4; ++k) ph[kPR][k] = 0.f;
   }
+  NS256_STAMP(2, ph[0][0]);
   int xc = 0;
   {
     int it = 0;
@@ -338,6 +347,7 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
       for (int k = 0; k < 4; ++k) ph[0][k] = t[k];
     }
   }
+  NS256_STAMP(3, ph[0][0]);
   {
     float* pd = (P.p_out ? P.p_out : P.p) + (size_t)b * kCells + (size_t)r0 * kN + c0;
 #pragma unroll
@@ -456,6 +466,15 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
     // the block's last row: C(r0+31) is in c1; the wall rule of row 255 reads C(254) = c2
     finish_row(r0 + kPR - 1, c1u, c1v, rf[kPR % DF]);
   }
+  NS256_STAMP(4, acc);
+#ifdef PDEGYM_NS256_TIMING
+  if (lane == 0) {
+    unsigned int* dbg = reinterpret_cast<unsigned int*>(P.scratch + (size_t)b * 4 * kCells) + w * 8;
+    for (int i = 0; i < 4; ++i) dbg[i] = (unsigned int)(tm[i + 1] - tm[i]);
+    dbg[4] = (unsigned int)tm[0];
+    dbg[5] = (unsigned int)tm[4];
+  }
+#endif
   const float ss = block_sum<float>(acc, lds);     // the halo buffers are idle now (block_sum syncs first)
   if (tid == 0) {
     float asq = 0.f;

@@ -28,6 +28,13 @@ namespace {
 
 using namespace pdegym::ns;
 
+// Dispatch overrides for tests and A/B runs (pdegym_debug_set, include/pdegym.h): the product never sets them.
+int g_debug[PDEGYM_DEBUG_COUNT] = {0, 0, -1, 0};
+inline bool pdegym_ns_no_col() { return g_debug[PDEGYM_DEBUG_NS_NO_COL] != 0; }               // small grids take ns_generic_step
+inline bool pdegym_force_generic() { return g_debug[PDEGYM_DEBUG_NS_GENERIC] != 0; }         // every grid takes ns_generic_step
+inline bool pdegym_no_lds_jacobi() { return g_debug[PDEGYM_DEBUG_NS_NO_LDS_JACOBI] != 0; }   // ns_generic_step sweeps in global memory
+
+
 
 // K Jacobi sweeps on one instance: src/dst ping-pong, result in `p`. One workgroup; caller syncs before.
 template <typename T>
@@ -363,27 +370,6 @@ __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, 
   }
   gen_back<T>(C, S, P, b, p, red);
 }
-
-// ---- split pipeline for grids whose p + rhs do not fit one CU (256x256 float32) --------------------------------
-// ns_front_kernel -> ns_slab_jacobi x ceil(K/H) -> ns_back_kernel ; each a separate launch, so no workgroup ever
-// waits for another one (the slab passes ping-pong p between the p field and scratch quarter 3).
-template <typename T>
-__global__ __launch_bounds__(1024) void ns_front_kernel(NSConst C, NSScal<T> S, NSPtrs<T> P, int B) {
-  const int b = blockIdx.x;
-  if (b >= B) return;
-  gen_front<T>(C, S, P, b);
-}
-
-template <typename T>
-__global__ __launch_bounds__(1024) void ns_back_kernel(NSConst C, NSScal<T> S, NSPtrs<T> P, int final_in_scratch, int B) {
-  __shared__ T red[16];
-  const int b = blockIdx.x;
-  if (b >= B) return;
-  const int ncell = C.nx * C.ny;
-  const T* pfin = final_in_scratch ? P.scratch + (size_t)b * 4 * ncell + 3 * (size_t)ncell : P.p + (size_t)b * ncell;
-  gen_back<T>(C, S, P, b, pfin, red);
-}
-
 
 // ================================================================================================
 // float32 register-tiled path: 512 threads per instance, thread (ty, tx) (16 x 32) owns the PR x PC patch at
@@ -892,348 +878,6 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
 }
 
 // ================================================================================================
-// Slab Jacobi pass for 256x256 float32 (BASELINE config 5): p + rhs of one instance (512 KB) exceed one CU's
-// registers, so an instance is cut into two slabs of 128 rows; each slab is swept by its own workgroup together with
-// H = 32 halo rows of the other slab (rows next to the cut go stale by one row per sweep, so after H sweeps the
-// slab's own rows are still exact).  A pass does up to H sweeps entirely in registers (patch PR x 4 per thread, a wave
-// = one full 256-wide row of patches -> left/right halos are DPP lane shifts, top/bottom halos cross waves through
-// LDS), then stores its own rows; passes ping-pong between two global copies of p, so no workgroup waits for another.
-// Redundant work: (128+32)/128 = 1.25x.  Same update expression as ns_generic<float>: bit-identical results.
-// ================================================================================================
-template <int PR, int H>
-__global__ __launch_bounds__(1024, 4) void ns_slab_jacobi(NSScal<float> S, const float* p_src, size_t src_stride, float* p_dst,
-                                                         size_t dst_stride, const float* us_base, const float* vs_base,
-                                                         size_t uv_stride, int nsweeps, int B) {
-  constexpr int n = 256, PC = 4, NT = 1024, RS = 64, OWN = 128;
-  static_assert(16 * PR == OWN + H, "16 thread rows must cover the slab plus its halo rows");
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* lds = reinterpret_cast<float*>(smem_raw);
-  const int b = blockIdx.x >> 1, slab = blockIdx.x & 1;
-  if (b >= B) return;
-  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-  const int c0 = tx * PC, lr0 = ty * PR;
-  const int g0 = (slab == 0 ? 0 : n - (OWN + H)) + lr0;          // global row of this thread's first patch row
-  const EdgeFlags E{slab == 0 && ty == 0, slab == 1 && ty == 15, tx == 0, tx == 63};
-  const float* ps = p_src + (size_t)b * src_stride;
-  float* pd = p_dst + (size_t)b * dst_stride;
-  const float* us = us_base + (size_t)b * uv_stride;
-  const float* vs = vs_base + (size_t)b * uv_stride;
-  float ph[PR + 1][PC], rq[PR][PC];
-  // 0.25*dx*dy*rhs with rhs = rho/dt (d/dx u* + d/dy v*) (navier_stokes2D.py:101-103) straight from u*, v*: the
-  // left/right u* neighbours are the neighbouring lanes (DPP), the v* rows above/below are two more row loads
-  {
-    auto vrow = [&](int g, float (&r)[PC]) {
-      const int gg = g < 0 ? 0 : (g > n - 1 ? n - 1 : g);     // clamped rows feed domain-edge cells only (rq = 0 there)
-      const float4 w = *reinterpret_cast<const float4*>(vs + gg * n + c0);
-      r[0] = w.x; r[1] = w.y; r[2] = w.z; r[3] = w.w;
-    };
-    float vprev[PC], vcur[PC], vnext[PC];
-    vrow(g0 - 1, vprev);
-    vrow(g0, vcur);
-#pragma unroll
-    for (int a = 0; a < PR; ++a) {
-      const int g = g0 + a;
-      vrow(g + 1, vnext);
-      const float4 w = *reinterpret_cast<const float4*>(ps + g * n + c0);
-      ph[a][0] = w.x; ph[a][1] = w.y; ph[a][2] = w.z; ph[a][3] = w.w;
-      const float4 uu = *reinterpret_cast<const float4*>(us + g * n + c0);
-      const float ur[PC] = {uu.x, uu.y, uu.z, uu.w};
-      const float ul = lane_left(ur[PC - 1]), urr = lane_right(ur[0]);
-#pragma unroll
-      for (int k = 0; k < PC; ++k) {
-        const float uw = (k == 0) ? ul : ur[k - 1], ue = (k == PC - 1) ? urr : ur[k + 1];
-        const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx);
-        const float dvdy = div_c(vnext[k] - vprev[k], S.two_dy, S.inv_two_dy);
-        const float r = S.rho_over_dt * (dudx + dvdy);
-        const bool edge = (g == 0) || (g == n - 1) || (tx == 0 && k == 0) || (tx == 63 && k == PC - 1);
-        rq[a][k] = edge ? 0.0f : jacobi_rhs_term(S.dxdy, r);
-      }
-#pragma unroll
-      for (int k = 0; k < PC; ++k) { vprev[k] = vcur[k]; vcur[k] = vnext[k]; }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < PC; ++k) ph[PR][k] = 0.f;
-  int xc = 0, it = 0, rot = 0;
-  while (true) {
-    const int r = SweepChain<PR, PC, 0, NT, RS, 4>::run(ph, rq, E, lds, xc, tid, ty, it, nsweeps);
-    if (r >= 0) {
-      rot = r;
-      break;
-    }
-  }
-  float pf[PR][PC];
-  unrotate<PR, PC, 0>(ph, pf, rot);
-#pragma unroll
-  for (int a = 0; a < PR; ++a) {
-    const int g = g0 + a;
-    const bool own = slab == 0 ? (g < OWN) : (g >= n - OWN);       // wave-uniform
-    if (own) *reinterpret_cast<float4*>(pd + g * n + c0) = make_float4(pf[a][0], pf[a][1], pf[a][2], pf[a][3]);
-  }
-}
-
-// ---- row-wave kernels of the 256x256 split pipeline: one 64-lane wave per grid row (4 cells per lane, float4 I/O,
-// left/right neighbours by DPP), 16 rows per workgroup; only the first / last workgroup of an instance touch the lower /
-// upper wall, and they hold the row next to it themselves (exchanged through LDS).
-template <int NROW>
-__device__ __forceinline__ void bc_rows_256(float (&fu)[4], float (&fv)[4], int i, int lane, int w, const float* lds_u,
-                                            const float* lds_v, const int (&bc)[4][2], const float* act, int action_dim) {
-  constexpr int n = 256;
-  const int c0 = 4 * lane;
-  auto aval = [&](int idx) -> float { return action_dim == 1 ? act[0] : act[idx]; };
-#pragma unroll
-  for (int comp = 0; comp < 2; ++comp) {
-    float (&f)[4] = comp == 0 ? fu : fv;
-    const float* lds = comp == 0 ? lds_u : lds_v;
-    if (i == 0 || i == n - 1) {               // lower / upper pass over the whole row (navier_stokes2D.py:76-90)
-      const int c = bc[i == 0 ? PDEGYM_EDGE_LOWER : PDEGYM_EDGE_UPPER][comp];
-      const int wr = (i == 0) ? w + 1 : w - 1;  // the row next to the wall lives in the neighbouring wave of this workgroup
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        f[k] = (c == PDEGYM_BC_NEUMANN) ? lds[wr * n + c0 + k] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(c0 + k));
-    }
-    if (lane == 0) {                          // left pass
-      const int c = bc[PDEGYM_EDGE_LEFT][comp];
-      f[0] = (c == PDEGYM_BC_NEUMANN) ? f[1] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(i));
-    }
-    if (lane == 63) {                         // right pass
-      const int c = bc[PDEGYM_EDGE_RIGHT][comp];
-      f[3] = (c == PDEGYM_BC_NEUMANN) ? f[2] : ((c == PDEGYM_BC_DIRICHLET) ? 0.0f : aval(i));
-    }
-  }
-}
-
-template <bool INTERLEAVED>
-__global__ __launch_bounds__(1024) void ns256_front(NSConst C, NSScal<float> S, NSPtrs<float> P, int B) {
-  constexpr int n = 256, ncell = n * n;
-  __shared__ __attribute__((aligned(16))) float lds_u[16 * n], lds_v[16 * n];
-  const int b = blockIdx.x >> 4, rb = blockIdx.x & 15;
-  if (b >= B) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = rb * 16 + w, c0 = 4 * lane;
-  float* us = P.scratch + (size_t)b * 4 * ncell;
-  float* vs = us + ncell;
-  const float* act = P.action + (size_t)b * C.action_dim;
-  auto load_uv = [&](int row, float (&fu)[4], float (&fv)[4]) {
-    const int r = row < 0 ? 0 : (row > n - 1 ? n - 1 : row);
-    if constexpr (INTERLEAVED) {
-      const float4* q = reinterpret_cast<const float4*>(P.state_in + (size_t)b * ncell * 2 + (r * n + c0) * 2);
-      const float4 a = q[0], d = q[1];
-      fu[0] = a.x; fv[0] = a.y; fu[1] = a.z; fv[1] = a.w; fu[2] = d.x; fv[2] = d.y; fu[3] = d.z; fv[3] = d.w;
-    } else {
-      const float4 a = *reinterpret_cast<const float4*>(P.u + (size_t)b * ncell + r * n + c0);
-      const float4 d = *reinterpret_cast<const float4*>(P.v + (size_t)b * ncell + r * n + c0);
-      fu[0] = a.x; fu[1] = a.y; fu[2] = a.z; fu[3] = a.w; fv[0] = d.x; fv[1] = d.y; fv[2] = d.z; fv[3] = d.w;
-    }
-  };
-  float uc[4], vc[4], uu[4], vu[4], ud[4], vd[4];
-  load_uv(i, uc, vc);
-  load_uv(i - 1, uu, vu);
-  load_uv(i + 1, ud, vd);
-  const float ul = lane_left(uc[3]), ur = lane_right(uc[0]), vl = lane_left(vc[3]), vr = lane_right(vc[0]);
-  float un[4], vn[4];
-  // ---- predictor (navier_stokes2D.py:130-138) ----
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float uw = (k == 0) ? ul : uc[k - 1], ue = (k == 3) ? ur : uc[k + 1];
-    const float vw = (k == 0) ? vl : vc[k - 1], ve = (k == 3) ? vr : vc[k + 1];
-    const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx), dudy = div_c(ud[k] - uu[k], S.two_dy, S.inv_two_dy);
-    const float dvdx = div_c(ve - vw, S.two_dx, S.inv_two_dx), dvdy = div_c(vd[k] - vu[k], S.two_dy, S.inv_two_dy);
-    const float lapu = div_c((((uw + uu[k]) - 4.0f * uc[k]) + ue) + ud[k], S.dxdy, S.inv_dxdy);
-    const float lapv = div_c((((vw + vu[k]) - 4.0f * vc[k]) + ve) + vd[k], S.dxdy, S.inv_dxdy);
-    const float a = uc[k] + S.dt * (((-uc[k]) * dudx - vc[k] * dudy) + S.nu * lapu);
-    const float d = vc[k] + S.dt * (((-uc[k]) * dvdx - vc[k] * dvdy) + S.nu * lapv);
-    const bool edge = (i == 0) || (i == n - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
-    un[k] = edge ? uc[k] : a;
-    vn[k] = edge ? vc[k] : d;
-  }
-  // ---- apply_boundary(u*, v*) (:140) ----
-  *reinterpret_cast<float4*>(lds_u + w * n + c0) = make_float4(un[0], un[1], un[2], un[3]);
-  *reinterpret_cast<float4*>(lds_v + w * n + c0) = make_float4(vn[0], vn[1], vn[2], vn[3]);
-  __syncthreads();
-  bc_rows_256<16>(un, vn, i, lane, w, lds_u, lds_v, C.bc, act, C.action_dim);
-  *reinterpret_cast<float4*>(us + i * n + c0) = make_float4(un[0], un[1], un[2], un[3]);
-  *reinterpret_cast<float4*>(vs + i * n + c0) = make_float4(vn[0], vn[1], vn[2], vn[3]);
-}
-
-template <bool INTERLEAVED>
-__global__ __launch_bounds__(1024) void ns256_back(NSConst C, NSScal<float> S, NSPtrs<float> P, int final_in_scratch, int B) {
-  constexpr int n = 256, ncell = n * n;
-  __shared__ __attribute__((aligned(16))) float lds_u[16 * n], lds_v[16 * n];
-  __shared__ float red[16];
-  const int b = blockIdx.x >> 4, rb = blockIdx.x & 15;
-  if (b >= B) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = rb * 16 + w, c0 = 4 * lane;
-  float* sc = P.scratch + (size_t)b * 4 * ncell;
-  const float* us = sc;
-  const float* vs = sc + ncell;
-  const float* pfin = final_in_scratch ? sc + 3 * ncell : P.p + (size_t)b * ncell;
-  const float* act = P.action + (size_t)b * C.action_dim;
-  auto row4 = [&](const float* base, int row, float (&f)[4]) {
-    const int r = row < 0 ? 0 : (row > n - 1 ? n - 1 : row);
-    const float4 a = *reinterpret_cast<const float4*>(base + r * n + c0);
-    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
-  };
-  float pc[4], pu[4], pd[4], un[4], vn[4];
-  row4(pfin, i, pc);
-  row4(pfin, i - 1, pu);
-  row4(pfin, i + 1, pd);
-  row4(us, i, un);
-  row4(vs, i, vn);
-  if (final_in_scratch || P.p_out)
-    *reinterpret_cast<float4*>((P.p_out ? P.p_out : P.p) + (size_t)b * ncell + i * n + c0) = make_float4(pc[0], pc[1], pc[2], pc[3]);
-  const float pl = lane_left(pc[3]), pr = lane_right(pc[0]);
-  // ---- corrector (:143-145) ----
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float pw = (k == 0) ? pl : pc[k - 1], pe = (k == 3) ? pr : pc[k + 1];
-    const float dpdx = div_c(pe - pw, S.two_dx, S.inv_two_dx);
-    const float dpdy = div_c(pd[k] - pu[k], S.two_dy, S.inv_two_dy);
-    const bool edge = (i == 0) || (i == n - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
-    un[k] = edge ? un[k] : un[k] - S.dt_over_rho * dpdx;
-    vn[k] = edge ? vn[k] : vn[k] - S.dt_over_rho * dpdy;
-  }
-  // ---- apply_boundary(u, v) (:146) ----
-  *reinterpret_cast<float4*>(lds_u + w * n + c0) = make_float4(un[0], un[1], un[2], un[3]);
-  *reinterpret_cast<float4*>(lds_v + w * n + c0) = make_float4(vn[0], vn[1], vn[2], vn[3]);
-  __syncthreads();
-  bc_rows_256<16>(un, vn, i, lane, w, lds_u, lds_v, C.bc, act, C.action_dim);
-  if constexpr (!INTERLEAVED) {
-    *reinterpret_cast<float4*>(P.u + (size_t)b * ncell + i * n + c0) = make_float4(un[0], un[1], un[2], un[3]);
-    *reinterpret_cast<float4*>(P.v + (size_t)b * ncell + i * n + c0) = make_float4(vn[0], vn[1], vn[2], vn[3]);
-  }
-  // ---- observation (:147-154) and the reward's squared distance to the reference frame (ns_reward.py:28) ----
-  const int t = P.time_index[b] + 1;
-  const int tr = t < C.nt_ref ? t : C.nt_ref - 1;
-  const float4* rr = reinterpret_cast<const float4*>(P.U_ref + (size_t)tr * ncell * 2 + (i * n + c0) * 2);
-  float4* oo = reinterpret_cast<float4*>(P.obs + (size_t)b * ncell * 2 + (i * n + c0) * 2);
-  float acc = 0.f;
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const float4 r4 = rr[q];
-    const float a0 = un[2 * q], b0 = vn[2 * q], a1 = un[2 * q + 1], b1 = vn[2 * q + 1];
-    oo[q] = make_float4(a0, b0, a1, b1);
-    const float d0 = a0 - r4.x, d1 = b0 - r4.y, d2 = a1 - r4.z, d3 = b1 - r4.w;
-    acc += d0 * d0;
-    acc += d1 * d1;
-    acc += d2 * d2;
-    acc += d3 * d3;
-  }
-  const float ss = block_sum<float>(acc, red);
-  if (threadIdx.x == 0) sc[2 * ncell + rb] = ss;   // partial sum of this 16-row band (the rhs quarter is free here)
-}
-
-__global__ void ns256_finish(NSConst C, NSScal<float> S, NSPtrs<float> P, int B) {
-  constexpr int n = 256, ncell = n * n;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const float* part = P.scratch + (size_t)b * 4 * ncell + 2 * ncell;
-  float ss = 0.f;
-  for (int k = 0; k < 16; ++k) ss += part[k];          // fixed order: deterministic
-  const int t = P.time_index[b] + 1;
-  const int tr = t < C.nt_ref ? t : C.nt_ref - 1;
-  const float* act = P.action + (size_t)b * C.action_dim;
-  float asq = 0.f;
-  const float aref = P.action_ref[tr];
-  for (int k = 0; k < C.action_dim; ++k) {
-    const float d = act[k] - aref;
-    asq += d * d;
-  }
-  P.reward[b] = ((-0.5f * ss) / (float)n) / (float)n - S.gamma_half * asq;
-  P.time_index[b] = t;
-  P.terminated[b] = (t >= C.nt - 1) ? 1 : 0;
-}
-
-// ================================================================================================
-// 256x256 float32, interleaved state (the observation of the previous call IS the velocity state): second-generation
-// pipeline (round 2).  Three launches move 12 fields' worth of HBM traffic per env-step instead of 18.5 (+ register spills):
-//   ns256_rq_front   state -> 0.25 dx dy rhs (one field)                                  [u*, v* are never written]
-//   ns_slab_jacobi_rq<15, 12>   ALL K <= 52 sweeps in ONE pass: two slabs per instance of 128 own + 52 halo rows,
-//                               12 waves (3 per SIMD: the best barrier-per-sweep shape, tools/ubench_barrier.hip),
-//                               p and rq in registers (15 x 4 patch per lane), loads/stores of whole 1 KB rows
-//   ns256_back_pred  state + solved p -> observation (the predictor is re-evaluated per row: the corrector only needs
-//                               u*, v* of interior cells, which apply_boundary never touches)
-// Same expression trees as ns_generic_step<float>: bit-identical results (tested).
-// ================================================================================================
-// predictor of grid row i (navier_stokes2D.py:130-138) from the state rows i-1, i, i+1; edge cells keep the state value
-__device__ __forceinline__ void predictor_row_256(const NSScal<float>& S, int i, int lane, const float (&uc)[4], const float (&vc)[4],
-                                                  const float (&uu)[4], const float (&vu)[4], const float (&ud)[4], const float (&vd)[4],
-                                                  float (&un)[4], float (&vn)[4]) {
-  constexpr int n = 256;
-  const float ul = lane_left(uc[3]), ur = lane_right(uc[0]), vl = lane_left(vc[3]), vr = lane_right(vc[0]);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float uw = (k == 0) ? ul : uc[k - 1], ue = (k == 3) ? ur : uc[k + 1];
-    const float vw = (k == 0) ? vl : vc[k - 1], ve = (k == 3) ? vr : vc[k + 1];
-    const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx), dudy = div_c(ud[k] - uu[k], S.two_dy, S.inv_two_dy);
-    const float dvdx = div_c(ve - vw, S.two_dx, S.inv_two_dx), dvdy = div_c(vd[k] - vu[k], S.two_dy, S.inv_two_dy);
-    const float lapu = div_c((((uw + uu[k]) - 4.0f * uc[k]) + ue) + ud[k], S.dxdy, S.inv_dxdy);
-    const float lapv = div_c((((vw + vu[k]) - 4.0f * vc[k]) + ve) + vd[k], S.dxdy, S.inv_dxdy);
-    const float a = uc[k] + S.dt * (((-uc[k]) * dudx - vc[k] * dudy) + S.nu * lapu);
-    const float d = vc[k] + S.dt * (((-uc[k]) * dvdx - vc[k] * dvdy) + S.nu * lapv);
-    const bool edge = (i == 0) || (i == n - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
-    un[k] = edge ? uc[k] : a;
-    vn[k] = edge ? vc[k] : d;
-  }
-}
-
-__device__ __forceinline__ void load_state_row_256(const float* state, int row, int c0, float (&fu)[4], float (&fv)[4]) {
-  constexpr int n = 256;
-  const int r = row < 0 ? 0 : (row > n - 1 ? n - 1 : row);
-  const float4* q = reinterpret_cast<const float4*>(state + (r * n + c0) * 2);
-  const float4 a = q[0], d = q[1];
-  fu[0] = a.x; fv[0] = a.y; fu[1] = a.z; fv[1] = a.w; fu[2] = d.x; fv[2] = d.y; fu[3] = d.z; fv[3] = d.w;
-}
-
-// One wave per grid row; a workgroup of 16 waves covers rows b0-1 .. b0+14 and emits rq for the 14 rows b0 .. b0+13 (the
-// two outer rows only supply v* to their neighbours: 16/14 redundant predictor work instead of a u*, v* round trip).
-constexpr int kRqBand = 14;
-__global__ __launch_bounds__(1024) void ns256_rq_front(NSConst C, NSScal<float> S, NSPtrs<float> P, int B) {
-  constexpr int n = 256, ncell = n * n, nband = (n + kRqBand - 1) / kRqBand;
-  __shared__ __attribute__((aligned(16))) float lds_u[16 * n], lds_v[16 * n], lds_v2[16 * n];
-  const int b = blockIdx.x / nband, band = blockIdx.x - b * nband;
-  if (b >= B) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c0 = 4 * lane;
-  const int i = band * kRqBand - 1 + w;                          // grid row of this wave
-  const bool live = i >= 0 && i < n;                             // wave-uniform
-  const float* state = P.state_in + (size_t)b * ncell * 2;
-  const float* act = P.action + (size_t)b * C.action_dim;
-  float un[4] = {0.f, 0.f, 0.f, 0.f}, vn[4] = {0.f, 0.f, 0.f, 0.f};
-  if (live) {
-    float uc[4], vc[4], uu[4], vu[4], ud[4], vd[4];
-    load_state_row_256(state, i, c0, uc, vc);
-    load_state_row_256(state, i - 1, c0, uu, vu);
-    load_state_row_256(state, i + 1, c0, ud, vd);
-    predictor_row_256(S, i, lane, uc, vc, uu, vu, ud, vd, un, vn);
-  }
-  *reinterpret_cast<float4*>(lds_u + w * n + c0) = make_float4(un[0], un[1], un[2], un[3]);
-  *reinterpret_cast<float4*>(lds_v + w * n + c0) = make_float4(vn[0], vn[1], vn[2], vn[3]);
-  __syncthreads();
-  // apply_boundary(u*, v*) (:140): the wall rows read the row next to them, which is a neighbouring wave of this workgroup
-  // (row 0 sits at w >= 1 with row 1 at w+1; row 255 at w <= 14 with row 254 at w-1)
-  if (live) bc_rows_256<16>(un, vn, i, lane, w, lds_u, lds_v, C.bc, act, C.action_dim);
-  *reinterpret_cast<float4*>(lds_v2 + w * n + c0) = make_float4(vn[0], vn[1], vn[2], vn[3]);
-  __syncthreads();
-  if (!live || w == 0 || w == 15) return;
-  // 0.25 dx dy rhs, rhs = rho/dt (d/dx u* + d/dy v*) (:101-103); zero on the domain edge (never read by a sweep)
-  const float ul = lane_left(un[3]), ur = lane_right(un[0]);
-  const float4 va = *reinterpret_cast<const float4*>(lds_v2 + (w - 1) * n + c0);
-  const float4 vb = *reinterpret_cast<const float4*>(lds_v2 + (w + 1) * n + c0);
-  const float vup[4] = {va.x, va.y, va.z, va.w}, vdn[4] = {vb.x, vb.y, vb.z, vb.w};
-  float rq[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float uw = (k == 0) ? ul : un[k - 1], ue = (k == 3) ? ur : un[k + 1];
-    const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx);
-    const float dvdy = div_c(vdn[k] - vup[k], S.two_dy, S.inv_two_dy);
-    const float r = S.rho_over_dt * (dudx + dvdy);
-    const bool edge = (i == 0) || (i == n - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
-    rq[k] = edge ? 0.0f : jacobi_rhs_term(S.dxdy, r);
-  }
-  float* rqd = P.scratch + (size_t)b * 4 * ncell + 2 * (size_t)ncell;
-  *reinterpret_cast<float4*>(rqd + i * n + c0) = make_float4(rq[0], rq[1], rq[2], rq[3]);
-}
-
-// ================================================================================================
 // float64 register-tiled step for 128x128 (the reference's own precision, BASELINE config 4 at float64): 1024 threads per
 // instance, one WAVE per thread row: lane tx of wave ty owns the 8 x 2 patch at rows 8 ty .. 8 ty + 7, columns 2 tx, 2 tx + 1.
 //   * left/right neighbours are the neighbouring lanes (two v_mov_b32_dpp per double);
@@ -1593,139 +1237,6 @@ __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<do
   }
 }
 
-// NTR thread rows (= waves) of PR patch rows each: NTR * PR = 128 own rows + H halo rows of the other slab.
-template <int PR, int NTR>
-__global__ __launch_bounds__(64 * NTR, NTR / 4) void ns_slab_jacobi_rq(const float* p_src, size_t src_stride, float* p_dst,
-                                                                      size_t dst_stride, const float* rq_base, size_t rq_stride,
-                                                                      int nsweeps, int B, int stagger) {
-  constexpr int n = 256, PC = 4, NT = 64 * NTR, RS = 64, OWN = 128, ROWS = NTR * PR;
-  static_assert(ROWS > OWN && ROWS <= n, "a slab is its own half plus halo rows of the other half");
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* lds = reinterpret_cast<float*>(smem_raw);
-  const int b = blockIdx.x >> 1, slab = blockIdx.x & 1;
-  if (b >= B) return;
-  // One slab fills a CU, so the workgroups of the first generation would all load at once (256 x 360 KB in one burst at the
-  // HBM rate), sweep in step, and store at once; started in phases -- (stagger >> 8) + 1 of them inside each XCD, (stagger &
-  // 255) x ~1 us apart -- the later generations inherit the offsets and every CU's load / store phases meet an idle memory
-  // system instead (C5: 618 -> 600 us per 512 env-steps with 32 phases; profiles/r02_ab_c5_second_pass.txt).
-  if (stagger > 0 && blockIdx.x < 256) {
-    const int units = ((blockIdx.x >> 3) & (stagger >> 8)) * (stagger & 255);
-    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(32);
-  }
-  const int tid = threadIdx.x, tx = tid & 63;
-  const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: row offsets become scalar address arithmetic
-  const int c0 = tx * PC;
-  const int g0 = (slab == 0 ? 0 : n - ROWS) + ty * PR;           // global row of this thread's first patch row
-  const EdgeFlags E{slab == 0 && ty == 0, slab == 1 && ty == NTR - 1, tx == 0, tx == 63};
-  const float* ps = p_src + (size_t)b * src_stride + (size_t)g0 * n;
-  const float* rqs = rq_base + (size_t)b * rq_stride + (size_t)g0 * n;
-  float ph[PR + 1][PC], rq[PR][PC];
-#pragma unroll
-  for (int a = 0; a < PR; ++a) {
-    const float4 w = *reinterpret_cast<const float4*>(ps + a * n + c0);
-    const float4 q = *reinterpret_cast<const float4*>(rqs + a * n + c0);
-    ph[a][0] = w.x; ph[a][1] = w.y; ph[a][2] = w.z; ph[a][3] = w.w;
-    rq[a][0] = q.x; rq[a][1] = q.y; rq[a][2] = q.z; rq[a][3] = q.w;
-  }
-#pragma unroll
-  for (int k = 0; k < PC; ++k) ph[PR][k] = 0.f;
-  int xc = 0, it = 0;
-  for (; it + 2 <= nsweeps; it += 2) {
-    jacobi_sweep_bous<PR, 0, NT, RS>(ph, rq, E, lds, xc, tid, ty);
-    jacobi_sweep_bous<PR, 1, NT, RS>(ph, rq, E, lds, xc, tid, ty);
-  }
-  float* pd = p_dst + (size_t)b * dst_stride + (size_t)g0 * n;
-  const int own_lo = slab == 0 ? 0 : n - OWN, own_hi = slab == 0 ? OWN : n;
-  if (it < nsweeps) {      // odd sweep count: one more UP sweep, the rows are stored from state 1
-    jacobi_sweep_bous<PR, 0, NT, RS>(ph, rq, E, lds, xc, tid, ty);
-#pragma unroll
-    for (int a = 0; a < PR; ++a) {
-      const int g = g0 + a;
-      if (g >= own_lo && g < own_hi) {        // wave-uniform
-        const float (&row)[PC] = ph[bphys<PR>(a, 1)];
-        *reinterpret_cast<float4*>(pd + a * n + c0) = make_float4(row[0], row[1], row[2], row[3]);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int a = 0; a < PR; ++a) {
-      const int g = g0 + a;
-      if (g >= own_lo && g < own_hi) {
-        const float (&row)[PC] = ph[a];
-        *reinterpret_cast<float4*>(pd + a * n + c0) = make_float4(row[0], row[1], row[2], row[3]);
-      }
-    }
-  }
-}
-
-// corrector + apply_boundary + observation + reward partials, u*, v* re-evaluated from the state (interleaved mode only: the
-// state is the previous observation, a different buffer from the one written here)
-__global__ __launch_bounds__(1024) void ns256_back_pred(NSConst C, NSScal<float> S, NSPtrs<float> P, const float* pfin_base,
-                                                        size_t pfin_stride, float* p_copy_to, int B) {
-  constexpr int n = 256, ncell = n * n;
-  __shared__ __attribute__((aligned(16))) float lds_u[16 * n], lds_v[16 * n];
-  __shared__ float red[16];
-  const int b = blockIdx.x >> 4, rb = blockIdx.x & 15;
-  if (b >= B) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = rb * 16 + w, c0 = 4 * lane;
-  float* sc = P.scratch + (size_t)b * 4 * ncell;
-  const float* pfin = pfin_base + (size_t)b * pfin_stride;
-  const float* state = P.state_in + (size_t)b * ncell * 2;
-  const float* act = P.action + (size_t)b * C.action_dim;
-  auto row4 = [&](const float* base, int row, float (&f)[4]) {
-    const int r = row < 0 ? 0 : (row > n - 1 ? n - 1 : row);
-    const float4 a = *reinterpret_cast<const float4*>(base + r * n + c0);
-    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
-  };
-  float pc[4], pu[4], pd[4], un[4], vn[4];
-  row4(pfin, i, pc);
-  row4(pfin, i - 1, pu);
-  row4(pfin, i + 1, pd);
-  {
-    float uc[4], vc[4], uu[4], vu[4], ud[4], vd[4];
-    load_state_row_256(state, i, c0, uc, vc);
-    load_state_row_256(state, i - 1, c0, uu, vu);
-    load_state_row_256(state, i + 1, c0, ud, vd);
-    predictor_row_256(S, i, lane, uc, vc, uu, vu, ud, vd, un, vn);     // u*, v* of this row (edge cells: the state)
-  }
-  if (p_copy_to) *reinterpret_cast<float4*>(p_copy_to + (size_t)b * ncell + i * n + c0) = make_float4(pc[0], pc[1], pc[2], pc[3]);
-  const float pl = lane_left(pc[3]), pr = lane_right(pc[0]);
-  // ---- corrector (:143-145) ----
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float pw = (k == 0) ? pl : pc[k - 1], pe = (k == 3) ? pr : pc[k + 1];
-    const float dpdx = div_c(pe - pw, S.two_dx, S.inv_two_dx);
-    const float dpdy = div_c(pd[k] - pu[k], S.two_dy, S.inv_two_dy);
-    const bool edge = (i == 0) || (i == n - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
-    un[k] = edge ? un[k] : un[k] - S.dt_over_rho * dpdx;
-    vn[k] = edge ? vn[k] : vn[k] - S.dt_over_rho * dpdy;
-  }
-  // ---- apply_boundary(u, v) (:146): boundary cells are functions of the interior cells next to them only ----
-  *reinterpret_cast<float4*>(lds_u + w * n + c0) = make_float4(un[0], un[1], un[2], un[3]);
-  *reinterpret_cast<float4*>(lds_v + w * n + c0) = make_float4(vn[0], vn[1], vn[2], vn[3]);
-  __syncthreads();
-  bc_rows_256<16>(un, vn, i, lane, w, lds_u, lds_v, C.bc, act, C.action_dim);
-  // ---- observation (:147-154) and the reward's squared distance to the reference frame (ns_reward.py:28) ----
-  const int t = P.time_index[b] + 1;
-  const int tr = t < C.nt_ref ? t : C.nt_ref - 1;
-  const float4* rr = reinterpret_cast<const float4*>(P.U_ref + (size_t)tr * ncell * 2 + (i * n + c0) * 2);
-  float4* oo = reinterpret_cast<float4*>(P.obs + (size_t)b * ncell * 2 + (i * n + c0) * 2);
-  float acc = 0.f;
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const float4 r4 = rr[q];
-    const float a0 = un[2 * q], b0 = vn[2 * q], a1 = un[2 * q + 1], b1 = vn[2 * q + 1];
-    oo[q] = make_float4(a0, b0, a1, b1);
-    const float d0 = a0 - r4.x, d1 = b0 - r4.y, d2 = a1 - r4.z, d3 = b1 - r4.w;
-    acc += d0 * d0;
-    acc += d1 * d1;
-    acc += d2 * d2;
-    acc += d3 * d3;
-  }
-  const float ss = block_sum<float>(acc, red);
-  if (threadIdx.x == 0) sc[2 * ncell + rb] = ss;   // partial sum of this 16-row band (rq is dead by now)
-}
-
 // ================================================================================================
 // Small grids (the reference's shipped example: 21 x 21, K = 2000 sweeps, float64 -- examples/NavierStokes/NS2Dppo.py):
 // one LANE per grid column, the column's ny cells in registers, floor(64 / nx) instances side by side in one wave.
@@ -1947,13 +1458,13 @@ __global__ __launch_bounds__(64, (sizeof(T) == 8 || NY > 21 ? 2 : 3)) void ns_co
 // The column kernel is instantiated for the grid height of the reference's shipped example (21 rows) and a few neighbours
 // (8, 11, 16, 26, 31, 32); any width up to 64.  One wave works through all K sweeps of its (up to three) instances alone: in
 // float64 a lone instance finishes sooner on the workgroup-per-instance kernel (seven waves per instance; 0.77 vs 0.98 ms per
-// env-step at 21 x 21, K = 2000), so batches below PDEGYM_NS_COL_MIN_BATCH (default: 1024 for float64, 1 for float32, where
+// env-step at 21 x 21, K = 2000), so batches below a minimum (PDEGYM_DEBUG_NS_COL_MIN_BATCH overrides it; default: 1024 for float64, 1 for float32, where
 // the two kernels are equal at B = 1) stay there.
 template <typename T>
 bool launch_ns_col(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int B, hipStream_t st) {
   if (C.nx < 3 || C.nx > 64) return false;
-  const char* e = std::getenv("PDEGYM_NS_COL_MIN_BATCH");
-  const int min_batch = e ? std::atoi(e) : (sizeof(T) == 8 ? 1024 : 1);
+  const int dbg = g_debug[PDEGYM_DEBUG_NS_COL_MIN_BATCH];
+  const int min_batch = dbg >= 0 ? dbg : (sizeof(T) == 8 ? 1024 : 1);
   if (B < min_batch) return false;
   const int G = 64 / C.nx;
   const dim3 grid((B + G - 1) / G), block(64);
@@ -2094,23 +1605,6 @@ int fill(const pdegym_params_ns2d* prm, NSConst& C, NSScal<T>& S) {
   return 0;
 }
 
-// PDEGYM_NS_GENERIC=1 in the environment routes float32 steps through ns_generic (A/B testing of the tiled path)
-// Phased start of the 256 x 256 Jacobi pass (ns_slab_jacobi_rq): (phases - 1) << 8 | microseconds between phases.  Default: 32
-// phases, 1 us apart, when the pass runs more than one generation of workgroups; PDEGYM_NS256_STAGGER overrides (0 = off).
-inline int pdegym_ns256_stagger(int workgroups) {
-  if (const char* e = getenv("PDEGYM_NS256_STAGGER")) return atoi(e);
-  return workgroups > 256 ? ((31 << 8) | 1) : 0;
-}
-
-inline bool pdegym_ns_no_col() {          // PDEGYM_NS_NO_COL=1: small grids take ns_generic_step (A/B and tests)
-  const char* e = std::getenv("PDEGYM_NS_NO_COL");
-  return e && e[0] == '1';
-}
-inline bool pdegym_force_generic() {
-  const char* e = getenv("PDEGYM_NS_GENERIC");
-  return e && e[0] == '1';
-}
-
 // LDS-resident Jacobi: every thread owns at most kLdsCPT cells
 // LDS-resident Jacobi: every thread owns at most kLdsCPT cells.  A lone wave issues an instruction only every ~6.5 cycles,
 // so when the batch leaves CUs idle anyway (B <= 512: at most two workgroups per CU) one thread per cell (up to 512) cuts the
@@ -2126,18 +1620,6 @@ inline int lds_block_threads(int ncell, int B) {
   if (ncell <= 2048) return 512;
   return 1024;
 }
-
-// PDEGYM_NS256_OLD=1: the round-1 256x256 pipeline (u*, v* round trip, two 32-sweep passes) for A/B runs
-inline bool pdegym_ns256_old_pipeline() {
-  const char* e = getenv("PDEGYM_NS256_OLD");
-  return e && e[0] == '1';
-}
-
-inline bool pdegym_no_lds_jacobi() {
-  const char* e = getenv("PDEGYM_NS_NO_LDS_JACOBI");
-  return e && e[0] == '1';
-}
-
 
 // 1: two LDS copies (<= kLdsCells cells); 2: one LDS copy (larger grids that still fit the 160 KB of a CU); 0: global memory
 template <typename T>
@@ -2242,62 +1724,8 @@ int ns_step_launch(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, i
     }
   }
   if constexpr (sizeof(T) == 4) {
-    // 256x256 float32 (BASELINE config 5): front kernel -> slab Jacobi passes -> back kernel
-    if (!pdegym_force_generic() && C.nx == 256 && C.ny == 256) {
-      const size_t ncell = (size_t)C.nx * C.ny;
-      hipStream_t st = (hipStream_t)stream;
-      const bool inter = buf->state_in != nullptr;
-      float* bufs[2] = {P.p, P.scratch + 3 * ncell};
-      const size_t strides[2] = {ncell, 4 * ncell};
-      int cur = 0;
-      if (!pdegym_ns256_old_pipeline() && !getenv("PDEGYM_NS256_GEN2")) return launch_ns256_fused(C, S, P, B, st);
-      if (inter && !pdegym_ns256_old_pipeline()) {
-        // second-generation pipeline: rq from the state, all sweeps of a pass in registers (up to 52 per pass), the back
-        // kernel re-evaluates the predictor
-        constexpr int nband = (256 + kRqBand - 1) / kRqBand;
-        constexpr int kPR = 15, kNTR = 12, kH = kNTR * kPR - 128;         // 12 waves x 15 rows = 128 own + 52 halo rows
-        hipLaunchKernelGGL(ns256_rq_front, dim3(nband * B), dim3(1024), 0, st, C, S, P, B);
-        const int npass = C.iters > 0 ? (C.iters + kH - 1) / kH : 0;
-        // pass i reads src and writes dst; the last pass lands in p_out when the caller ping-pongs pressure tensors, otherwise
-        // passes alternate p <-> scratch quarter 3 and the back kernel copies the result home if it ended in the scratch
-        const float* src = P.p;
-        size_t src_stride = ncell;
-        int left = C.iters;
-        for (int i = 0; i < npass; ++i, left -= kH) {
-          const int nsw = left < kH ? left : kH;
-          float* dst;
-          size_t dst_stride;
-          const bool to_scratch = P.p_out ? ((npass - 1 - i) & 1) : !(i & 1);
-          if (to_scratch) { dst = P.scratch + 3 * ncell; dst_stride = 4 * ncell; }
-          else { dst = P.p_out ? P.p_out : P.p; dst_stride = ncell; }
-          hipLaunchKernelGGL((ns_slab_jacobi_rq<kPR, kNTR>), dim3(2 * B), dim3(64 * kNTR), 2 * 2 * (64 * kNTR) * 16, st, src, src_stride, dst,
-                             dst_stride, P.scratch + 2 * ncell, 4 * ncell, nsw, B, pdegym_ns256_stagger(2 * B));
-          src = dst;
-          src_stride = dst_stride;
-        }
-        float* home = P.p_out ? P.p_out : P.p;
-        hipLaunchKernelGGL(ns256_back_pred, dim3(16 * B), dim3(1024), 0, st, C, S, P, src, src_stride, src == home ? (float*)nullptr : home, B);
-        hipLaunchKernelGGL(ns256_finish, dim3((B + 255) / 256), dim3(256), 0, st, C, S, P, B);
-        return pdegym::check_launch("ns2d_slab_step");
-      }
-      constexpr int kH = 32, kPR = 10;
-      if (inter)
-        hipLaunchKernelGGL(ns256_front<true>, dim3(16 * B), dim3(1024), 0, st, C, S, P, B);
-      else
-        hipLaunchKernelGGL(ns256_front<false>, dim3(16 * B), dim3(1024), 0, st, C, S, P, B);
-      for (int left = C.iters; left > 0; left -= kH) {
-        const int nsw = left < kH ? left : kH;
-        hipLaunchKernelGGL((ns_slab_jacobi<kPR, kH>), dim3(2 * B), dim3(1024), 2 * 2 * 1024 * 16, st, S, bufs[cur], strides[cur],
-                           bufs[cur ^ 1], strides[cur ^ 1], P.scratch, P.scratch + ncell, 4 * ncell, nsw, B);
-        cur ^= 1;
-      }
-      if (inter)
-        hipLaunchKernelGGL(ns256_back<true>, dim3(16 * B), dim3(1024), 0, st, C, S, P, cur, B);
-      else
-        hipLaunchKernelGGL(ns256_back<false>, dim3(16 * B), dim3(1024), 0, st, C, S, P, cur, B);
-      hipLaunchKernelGGL(ns256_finish, dim3((B + 255) / 256), dim3(256), 0, st, C, S, P, B);
-      return pdegym::check_launch("ns2d_slab_step");
-    }
+    // 256x256 float32 (BASELINE config 5): the whole env-step in one launch, one workgroup per instance (pdegym_ns256.hip)
+    if (!pdegym_force_generic() && C.nx == 256 && C.ny == 256) return launch_ns256_fused(C, S, P, B, (hipStream_t)stream);
   }
   const int ncell = C.nx * C.ny;
   const int mode = lds_jacobi_mode<T>(ncell);
@@ -2363,6 +1791,13 @@ int ns_reset(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, const v
 }  // namespace
 
 extern "C" {
+
+int32_t pdegym_debug_set(int32_t key, int32_t value) {
+  if (key < 0 || key >= PDEGYM_DEBUG_COUNT) return pdegym::fail(-2, "unknown debug key");
+  const int32_t old = g_debug[key];
+  g_debug[key] = value;
+  return old;
+}
 
 int pdegym_ns2d_step_f32(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int32_t B, void* stream) {
   return ns_step<float>(prm, buf, B, stream);

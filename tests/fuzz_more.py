@@ -14,6 +14,12 @@ from oracle import pde_oracle as po  # noqa: E402
 BCS = ["Neumann", "Dirchilet", "Controllable"]
 
 
+def _dbg(key, value):
+    """Test-only kernel dispatch override (pdegym_debug_set, include/pdegym.h); takes ints or the "0"/"1" strings looped over."""
+    from pdecontrolgym_amd import _native as N
+    N.load().pdegym_debug_set(getattr(N, key), int(value))
+
+
 def bits_equal(a, b):
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
     ui = np.uint64 if a.dtype == np.float64 else np.uint32
@@ -56,7 +62,7 @@ def ns_case(rng, idx):
     # grids of 8 / 11 / 16 / 21 / 26 / 31 / 32 rows and up to 64 columns: half of the cases on the column-per-lane kernel (which float64
     # batches this small would not reach by themselves), half on the workgroup kernel -- the switch is read at every launch
     col = rng.random() < 0.5
-    os.environ["PDEGYM_NS_COL_MIN_BATCH"] = "0" if col else "1000000"
+    _dbg("DEBUG_NS_COL_MIN_BATCH", "0" if col else "1000000")
     desc += f" col={col}"
     orc = po.NavierStokesOracle(**kw)
     env = NSBatch2D(num_envs=B, device="cuda", dtype=torch.float64, interleaved_state=inter, action_dim=adim, **kw)
@@ -70,12 +76,12 @@ def ns_case(rng, idx):
         assert bits_equal(env.p.cpu().numpy(), orc.p), desc + f" step {i}: p"
         assert np.allclose(r.cpu().numpy(), r_ref, rtol=1e-12, atol=1e-300), desc + f" step {i}: reward {r.cpu().numpy()} {r_ref}"
         assert np.array_equal(te.cpu().numpy().astype(bool), te_ref), desc + f" step {i}: terminate"
-    os.environ.pop("PDEGYM_NS_COL_MIN_BATCH", None)
+    _dbg("DEBUG_NS_COL_MIN_BATCH", -1)
     # float32: tiled kernel == generic kernel for the sizes the tiled path exists for
     if n == m and n in (64, 128):
         outs = []
         for force in ("0", "1"):
-            os.environ["PDEGYM_NS_GENERIC"] = force
+            _dbg("DEBUG_NS_GENERIC", force)
             e32 = NSBatch2D(num_envs=B, device="cuda", dtype=torch.float32, interleaved_state=inter, action_dim=adim, **kw)
             e32.reset(u0, v0, p0)
             acts = np.random.default_rng(idx).uniform(2, 4, (2, B, adim))
@@ -84,7 +90,7 @@ def ns_case(rng, idx):
                 obs, r, te = e32.step(a)
                 res.append((obs.cpu().numpy().copy(), e32.p.cpu().numpy().copy()))
             outs.append(res)
-        os.environ["PDEGYM_NS_GENERIC"] = "0"
+        _dbg("DEBUG_NS_GENERIC", "0")
         for (o1, p1), (o2, p2) in zip(*outs):
             assert bits_equal(o1, o2) and bits_equal(p1, p2), desc + " f32 tile != generic"
     return desc

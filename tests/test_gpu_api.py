@@ -15,9 +15,10 @@ torch = pytest.importorskip("torch")
 
 
 def test_loaded_backend_is_the_hip_library():
+    from pdecontrolgym_amd import _native as N
     from pdecontrolgym_amd.backend import default_backend
     b = default_backend()
-    assert b.name == "hip-gfx950" and b.lib.pdegym_abi_version() == 11
+    assert b.name == "hip-gfx950" and b.lib.pdegym_abi_version() == N.ABI_VERSION
 
 
 @pytest.mark.parametrize("name", sorted(KAT_PUBLISHED))

@@ -15,6 +15,12 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+def _dbg(key, value):
+    """Test-only kernel dispatch override (pdegym_debug_set, include/pdegym.h); takes ints or the "0"/"1" strings looped over."""
+    from pdecontrolgym_amd import _native as N
+    N.load().pdegym_debug_set(getattr(N, key), int(value))
+
+
 def _mk(kw, B, dtype):
     from pdecontrolgym_amd.batch2d import NSBatch2D
     return NSBatch2D(num_envs=B, device="cuda", dtype=dtype, **kw)
@@ -264,10 +270,10 @@ def test_ns_f32_tiled_kernel_equals_generic_kernel_bitwise(n):
     """The register-tiled float32 kernel and the generic float32 kernel evaluate the same expression tree:
     fields, pressure and observations must agree bit for bit over several steps (reward: summation order)."""
     import os
-    kw, u0, v0, p0, acts = _random_case(n, 5, 50 if n != 256 else 37, 900 + n, BC_MIX)    # 256: 32 + 5 sweeps, odd pass count
+    kw, u0, v0, p0, acts = _random_case(n, 5, 50 if n != 256 else 37, 900 + n, BC_MIX)    # 256: an odd sweep count (the row rotation ends off the identity map)
     outs = []
     for force in ("0", "1"):
-        os.environ["PDEGYM_NS_GENERIC"] = force
+        _dbg("DEBUG_NS_GENERIC", force)
         try:
             env = _mk(kw, 5, torch.float32)
             env.reset(u0, v0, p0)
@@ -277,7 +283,7 @@ def test_ns_f32_tiled_kernel_equals_generic_kernel_bitwise(n):
                 res.append((obs.cpu().numpy().copy(), env.p.cpu().numpy().copy(), r.cpu().numpy().copy()))
             outs.append(res)
         finally:
-            os.environ["PDEGYM_NS_GENERIC"] = "0"
+            _dbg("DEBUG_NS_GENERIC", "0")
     for (o1, p1, r1), (o2, p2, r2) in zip(*outs):
         np.testing.assert_array_equal(o1, o2)
         np.testing.assert_array_equal(p1, p2)
@@ -297,7 +303,7 @@ def test_ns_f64_tiled_kernel_equals_generic_kernel_and_oracle_bitwise(K, interle
     kw = dict(kw, action_dim=adim)
     outs = []
     for force in ("0", "1"):
-        os.environ["PDEGYM_NS_GENERIC"] = force
+        _dbg("DEBUG_NS_GENERIC", force)
         try:
             env = NSBatch2D(num_envs=B, device="cuda", dtype=torch.float64, interleaved_state=interleaved, **kw)
             env.reset(u0, v0, p0)
@@ -307,7 +313,7 @@ def test_ns_f64_tiled_kernel_equals_generic_kernel_and_oracle_bitwise(K, interle
                 res.append((obs.cpu().numpy().copy(), env.p.cpu().numpy().copy(), r.cpu().numpy().copy(), env.u.cpu().numpy().copy()))
             outs.append(res)
         finally:
-            os.environ["PDEGYM_NS_GENERIC"] = "0"
+            _dbg("DEBUG_NS_GENERIC", "0")
     orc = po.NavierStokesOracle(**{k: v for k, v in kw.items() if k != "action_dim"})
     orc.reset(u0, v0, p0)
     for a, (o1, p1, r1, u1), (o2, p2, r2, u2) in zip(acts, *outs):
@@ -334,8 +340,8 @@ def test_ns_lds_resident_jacobi_equals_global_memory_jacobi_bitwise(n, dtype, K)
     kw, u0, v0, p0, acts = _random_case(n, 3, K, 77 + n + K, BC_MIX)
     outs = []
     for no_lds in ("0", "1"):
-        os.environ["PDEGYM_NS_NO_LDS_JACOBI"] = no_lds
-        os.environ["PDEGYM_NS_GENERIC"] = "1"
+        _dbg("DEBUG_NS_NO_LDS_JACOBI", no_lds)
+        _dbg("DEBUG_NS_GENERIC", "1")
         try:
             env = _mk(kw, 3, td)
             env.reset(u0, v0, p0)
@@ -346,8 +352,8 @@ def test_ns_lds_resident_jacobi_equals_global_memory_jacobi_bitwise(n, dtype, K)
             res.append((env.solve_pressure(u0, v0, p0).cpu().numpy().copy(),))
             outs.append(res)
         finally:
-            os.environ["PDEGYM_NS_NO_LDS_JACOBI"] = "0"
-            os.environ["PDEGYM_NS_GENERIC"] = "0"
+            _dbg("DEBUG_NS_NO_LDS_JACOBI", "0")
+            _dbg("DEBUG_NS_GENERIC", "0")
     for a, b in zip(*outs):
         for x, y in zip(a, b):
             if x.ndim == 1:      # rewards: the block reduction order follows the workgroup size, which differs between the paths
@@ -356,7 +362,7 @@ def test_ns_lds_resident_jacobi_equals_global_memory_jacobi_bitwise(n, dtype, K)
                 np.testing.assert_array_equal(x, y)
 
 
-@pytest.mark.parametrize("n,dtype", [(128, "float32"), (40, "float32"), (21, "float64")])
+@pytest.mark.parametrize("n,dtype", [(128, "float32"), (40, "float32"), (21, "float64"), (256, "float32")])
 def test_ns_interleaved_state_equals_separate_fields(n, dtype):
     """interleaved_state=True (state lives in the double-buffered obs tensors) == separate u, v fields, bitwise."""
     from pdecontrolgym_amd.batch2d import NSBatch2D
@@ -477,8 +483,8 @@ def test_ns_column_kernel_equals_workgroup_kernel_bitwise(dtype, nx, B, K, inter
     kw, u0, v0, p0, acts = _rect_case(21, nx, B, K, 900 + nx + K, BC_MIX, adim)
     outs = []
     for col in (True, False):
-        os.environ["PDEGYM_NS_COL_MIN_BATCH"] = "0"
-        os.environ["PDEGYM_NS_NO_COL"] = "0" if col else "1"
+        _dbg("DEBUG_NS_COL_MIN_BATCH", "0")
+        _dbg("DEBUG_NS_NO_COL", "0" if col else "1")
         try:
             env = NSBatch2D(num_envs=B, device="cuda", dtype=td, interleaved_state=interleaved, **kw)
             env.reset(u0, v0, p0)
@@ -489,8 +495,8 @@ def test_ns_column_kernel_equals_workgroup_kernel_bitwise(dtype, nx, B, K, inter
                             env.time_index.cpu().numpy().copy(), te.cpu().numpy().copy(), r.cpu().numpy().copy()))
             outs.append(res)
         finally:
-            os.environ.pop("PDEGYM_NS_COL_MIN_BATCH", None)
-            os.environ["PDEGYM_NS_NO_COL"] = "0"
+            _dbg("DEBUG_NS_COL_MIN_BATCH", -1)
+            _dbg("DEBUG_NS_NO_COL", "0")
     for a, b in zip(*outs):
         for x, y in zip(a[:-1], b[:-1]):
             np.testing.assert_array_equal(x, y)
@@ -508,8 +514,8 @@ def test_ns_column_kernel_other_heights_bitwise(dtype, ny, nx, B, K):
     kw, u0, v0, p0, acts = _rect_case(ny, nx, B, K, 700 + ny + nx, BC_MIX, 1)
     outs = []
     for col in (True, False):
-        os.environ["PDEGYM_NS_COL_MIN_BATCH"] = "0"
-        os.environ["PDEGYM_NS_NO_COL"] = "0" if col else "1"
+        _dbg("DEBUG_NS_COL_MIN_BATCH", "0")
+        _dbg("DEBUG_NS_NO_COL", "0" if col else "1")
         try:
             env = NSBatch2D(num_envs=B, device="cuda", dtype=td, **kw)
             env.reset(u0, v0, p0)
@@ -519,8 +525,8 @@ def test_ns_column_kernel_other_heights_bitwise(dtype, ny, nx, B, K):
                 res.append((obs.cpu().numpy().copy(), env.p.cpu().numpy().copy(), r.cpu().numpy().copy()))
             outs.append(res)
         finally:
-            os.environ.pop("PDEGYM_NS_COL_MIN_BATCH", None)
-            os.environ["PDEGYM_NS_NO_COL"] = "0"
+            _dbg("DEBUG_NS_COL_MIN_BATCH", -1)
+            _dbg("DEBUG_NS_NO_COL", "0")
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a[0], b[0])
         np.testing.assert_array_equal(a[1], b[1])
@@ -532,7 +538,7 @@ def test_ns_column_kernel_reproduces_target_npz_and_oracle(golden_ns):
     bit (B = 5: two waves, the second with one live lane group), and a random mixed-boundary case against the oracle."""
     import os
     from oracle import pde_oracle as po
-    os.environ["PDEGYM_NS_COL_MIN_BATCH"] = "0"
+    _dbg("DEBUG_NS_COL_MIN_BATCH", "0")
     try:
         g = golden_ns["N1"]
         B = 5
@@ -562,7 +568,7 @@ def test_ns_column_kernel_reproduces_target_npz_and_oracle(golden_ns):
             np.testing.assert_array_equal(env.p.cpu().numpy(), orc.p)
             np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-12)
     finally:
-        os.environ.pop("PDEGYM_NS_COL_MIN_BATCH", None)
+        _dbg("DEBUG_NS_COL_MIN_BATCH", -1)
 
 
 def test_ns_column_kernel_default_dispatch_large_batch():
@@ -574,8 +580,8 @@ def test_ns_column_kernel_default_dispatch_large_batch():
     kw, u0, v0, p0, acts = _rect_case(21, 21, B, 5, 4321, BC_MIX, 1)
     outs = []
     for no_col in ("0", "1"):
-        os.environ.pop("PDEGYM_NS_COL_MIN_BATCH", None)
-        os.environ["PDEGYM_NS_NO_COL"] = no_col
+        _dbg("DEBUG_NS_COL_MIN_BATCH", -1)
+        _dbg("DEBUG_NS_NO_COL", no_col)
         try:
             env = NSBatch2D(num_envs=B, device="cuda", dtype=torch.float64, **kw)
             env.reset(u0, v0, p0)
@@ -585,7 +591,7 @@ def test_ns_column_kernel_default_dispatch_large_batch():
                 res.append((obs.cpu().numpy().copy(), env.p.cpu().numpy().copy(), r.cpu().numpy().copy()))
             outs.append(res)
         finally:
-            os.environ["PDEGYM_NS_NO_COL"] = "0"
+            _dbg("DEBUG_NS_NO_COL", "0")
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a[0], b[0])
         np.testing.assert_array_equal(a[1], b[1])

@@ -16,8 +16,14 @@ BC = {"upper": ["Controllable", "Dirchilet"], "lower": ["Dirchilet", "Dirchilet"
       "right": ["Dirchilet", "Dirchilet"]}
 
 
+def _dbg(key, value):
+    """Test-only kernel dispatch override (pdegym_debug_set, include/pdegym.h); takes ints or the "0"/"1" strings looped over."""
+    from pdecontrolgym_amd import _native as N
+    N.load().pdegym_debug_set(getattr(N, key), int(value))
+
+
 def run(B, no_col, steps=20, n=21, K=2000, dtype=torch.float64):
-    os.environ["PDEGYM_NS_NO_COL"] = "1" if no_col else "0"
+    _dbg("DEBUG_NS_NO_COL", "1" if no_col else "0")
     nt = 200
     env = NSBatch2D(T=0.2, dt=1e-3, X=1, dx=1 / (n - 1), Y=1, dy=1 / (n - 1), boundary_condition=BC, U_ref=np.zeros((nt, n, n, 2)),
                     action_ref=2 * np.ones(nt), gamma=0.1, maximum_pressure_iteration=K, num_envs=B, device="cuda", dtype=dtype)

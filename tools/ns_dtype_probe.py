@@ -14,8 +14,14 @@ BC = {"upper": ["Controllable", "Dirchilet"], "lower": ["Dirchilet", "Dirchilet"
       "right": ["Dirchilet", "Dirchilet"]}
 
 
+def _dbg(key, value):
+    """Test-only kernel dispatch override (pdegym_debug_set, include/pdegym.h); takes ints or the "0"/"1" strings looped over."""
+    from pdecontrolgym_amd import _native as N
+    N.load().pdegym_debug_set(getattr(N, key), int(value))
+
+
 def run(n, K, B, dt_, no_lds):
-    os.environ["PDEGYM_NS_NO_LDS_JACOBI"] = "1" if no_lds else "0"
+    _dbg("DEBUG_NS_NO_LDS_JACOBI", "1" if no_lds else "0")
     dx = 1 / (n - 1)
     dt = 0.2 * 0.5 * dx * dx / 0.1
     nt = 200
@@ -38,7 +44,7 @@ if __name__ == "__main__":
     for n, K, B in ((21, 50, 512), (32, 50, 512), (45, 50, 512), (64, 50, 512), (64, 50, 64), (100, 50, 512), (128, 50, 512)):
         for dt_ in (torch.float64, torch.float32):
             if dt_ == torch.float32 and n in (64, 128):
-                os.environ["PDEGYM_NS_GENERIC"] = "1"
+                _dbg("DEBUG_NS_GENERIC", "1")
             a, b = run(n, K, B, dt_, False), run(n, K, B, dt_, True)
-            os.environ["PDEGYM_NS_GENERIC"] = "0"
+            _dbg("DEBUG_NS_GENERIC", "0")
             print(f"n={n} K={K} B={B} {str(dt_)[6:]} (generic kernel): LDS-path {a*1e3:.3f} ms | global-path {b*1e3:.3f} ms per step")
