@@ -53,6 +53,7 @@ class DeviceRollout:
         self.one_launch = fits if one_launch is None else bool(one_launch)
         self.use_graph = bool(use_graph) and dev.type == "cuda"
         self._graph = None
+        self._state_buf = None     # observation tensor the captured graph leaves the end state in (see _rebind_state)
 
     def _body(self):
         import torch
@@ -85,6 +86,21 @@ class DeviceRollout:
                 core.t[k] = v
             if getattr(core, "state_in_obs", False):
                 core.t["u"] = core.t["obs"]
+
+    def _rebind_state(self, core):
+        """The captured graph has the ADDRESS of the engine's observation tensor baked in (it copies slot T there, and where the
+        observation is the state that copy is the state hand-over).  The engines double-buffer their observations, so a plain
+        step() / reset between two run() calls leaves ``core.t["obs"]`` naming the other buffer: after a replay the engine is
+        pointed back at the buffer the graph wrote, otherwise the next step would restart from the pre-rollout state."""
+        buf = self._state_buf
+        if buf is None or core.t.get("obs") is buf:
+            return
+        for i, o in enumerate(getattr(core, "_obs", ())):
+            if o is buf:
+                core._flip = i
+        core.t["obs"] = buf
+        if getattr(core, "state_in_obs", False):
+            core.t["u"] = buf
 
     def _steps(self, core, torch):
         if self._ns or getattr(core, "state_in_obs", False):
@@ -141,6 +157,7 @@ class DeviceRollout:
             snapshot = {k: core.t[k].clone() for k in keys}
             extra = {k: getattr(self.venv, k).clone() for k in ("_consecutive", "treatment_calls", "soft_constraint_violations")
                      if torch.is_tensor(getattr(self.venv, k, None))}
+            self._state_buf = core.t["obs"] if "obs" in core.t else None
             with torch.cuda.stream(side):
                 self._body()                               # warm-up on the side stream (allocator, lazy init)
                 for k, v in snapshot.items():
@@ -158,4 +175,5 @@ class DeviceRollout:
             for k, v in extra.items():
                 getattr(self.venv, k).copy_(v)
         self._graph.replay()
+        self._rebind_state(core)
         return self

@@ -278,7 +278,9 @@ class PDEBatch1D:
 
         ``policy`` (a ``FusedMLP`` with layers of at most 64 units and one output, see ``policy_fits_rollout``): evaluated
         inside the launch on ``obs[t]``; ``actions[t]`` then RECEIVES the command (after ``noise[t]`` [T, B] float32 and the
-        clamp), as ``policy.forward_into(obs[t], actions[t], clamp, noise[t])`` would have written it."""
+        clamp).  The in-kernel network sums each neuron in one fmaf chain, ``policy.forward_into`` in MFMA group order: the
+        commands agree to float32 rounding (rtol ~2e-5), NOT bit for bit, and trajectories drift apart accordingly -- only the
+        environment arithmetic is bit-identical to step calls (given the same commands)."""
         if not self.can_rollout():
             raise ValueError("rollout needs full-state sensing without history, Dirichlet actuation and float32 operands")
         self.params.action_kind = N.ACTION_F32

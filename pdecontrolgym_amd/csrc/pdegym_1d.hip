@@ -145,7 +145,7 @@ struct Row {
 // sub-step, i.e. parabolic Neumann control).
 // M64: float64 beta and/or float64 / Python-float control (pdegym_params1d.beta_f64 / action_kind): the select form with the
 // reference's mixed-precision expressions (see step1d_wide_kernel for the same arithmetic on LDS-resident rows).
-template <int EPL, bool PARABOLIC, bool NEUMANN, bool FAST, bool HIST, bool BURGERS = false, bool M64 = false>
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool FAST, bool HIST, bool BURGERS = false, bool M64 = false, bool ROLL = false>
 __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EPL], const pdegym_params1d& P, int nsub,
                                              float a, float* ring, float* hist, int lane, const double* b64 = nullptr, double a64 = 0.0) {
   static_assert(!(FAST && (NEUMANN || HIST)), "fast mode is the Dirichlet, history-free path");
@@ -210,11 +210,27 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
       for (int e = 0; e < EPL; ++e) {
         // pm - 2p: 2p is exact, so fma(-2, p, pm) == pm + (-2p).  The first slot takes the product form so that the
         // lane shift folds into the add (v_add_f32_dpp); VOP3 fma cannot carry a DPP operand.
-        if (e == 0 && !GENERAL_EDGE) t2[e] = xl + (-2.0f * R.x[e]);
+        // ROLL (the T-steps-per-launch kernels, whose waves drift apart) with EPL > 1: the two DPP operands are written out with
+        // an s_nop 0 ahead of each (the wave yields its issue slot before the DPP operation: open-loop rollout 368 -> 350 us per
+        // 25 env-steps; in the lock-step per-env-step launch the same form is 2 % slower, so it stays on the compiler's).  Each
+        // statement opens with a plain VALU instruction of its own, so that together with the s_nop two wait states separate
+        // the DPP read from whatever the compiler scheduled in front (VALU write -> DPP read hazard).
+        if (ROLL && EPL > 1 && e == 0 && !GENERAL_EDGE) {
+          asm volatile("v_add_f32 %0, %2, %2\n\ts_nop 0\n\tv_sub_f32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                       : "=&v"(t2[0]) : "v"(R.x[EPL - 1]), "v"(R.x[0]));
+        } else if (ROLL && EPL > 1 && e == EPL - 1 && !GENERAL_EDGE) {
+          t2[e] = 0.f;     // formed inside the statement below
+        } else if (e == 0 && !GENERAL_EDGE) t2[e] = xl + (-2.0f * R.x[e]);
         else t2[e] = __builtin_fmaf(-2.0f, R.x[e], (e == 0) ? xl : R.x[e - 1]);
       }
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) t3[e] = t2[e] + ((e == EPL - 1) ? xr : R.x[e + 1]);
+      for (int e = 0; e < EPL; ++e) {
+        if (ROLL && EPL > 1 && e == EPL - 1 && !GENERAL_EDGE)
+          asm volatile("v_fma_f32 %0, -2.0, %2, %3\n\ts_nop 0\n\tv_add_f32_dpp %0, %1, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                       : "=&v"(t3[e]) : "v"(R.x[0]), "v"(R.x[e]), "v"(R.x[e > 0 ? e - 1 : 0]));
+        else
+          t3[e] = t2[e] + ((e == EPL - 1) ? xr : R.x[e + 1]);
+      }
 #pragma unroll
       for (int e = 0; e < EPL; ++e) t7[e] = c[e] * R.x[e];
 #pragma unroll
@@ -396,7 +412,7 @@ __device__ __forceinline__ void load_row(Row<EPL>& R, float (&beta)[EPL], const 
 }
 
 // One env-step of one instance by one wave: the body of step1d_kernel, and of every iteration of rollout1d_kernel.
-template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false, bool M64 = false>
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false, bool M64 = false, bool ROLL = false>
 __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdegym_bufs1d& Bf, const int B, const int inst,
                                             const int lane, const float* command = nullptr) {
   constexpr int J0 = PARABOLIC ? 1 : 0;
@@ -479,7 +495,7 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
     }
     norm_now = 0.f;
     if (!exact) {
-      run_substeps<EPL, PARABOLIC, false, true, false, BURGERS>(R, beta, P, nsub, a, ring, nullptr, lane);
+      run_substeps<EPL, PARABOLIC, false, true, false, BURGERS, false, ROLL>(R, beta, P, nsub, a, ring, nullptr, lane);
       norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
       // inf/NaN somewhere (or a squared overflow): 0*inf may have leaked into a frozen slot -> redo exactly
       exact = !(fabsf(norm_now) <= 3.4028234663852886e38f);
@@ -665,7 +681,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void rollout1d_kernel(pdegym
     S.reward = Ro.rewards + (size_t)t * B;
     S.terminated = Ro.terminated + (size_t)t * B;
     S.truncated = Ro.truncated + (size_t)t * B;
-    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false>(P, S, B, inst, lane);
+    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false, true>(P, S, B, inst, lane);
     // lane 0's stores (node 0 of a parabolic row, time index, |u| sum, norm ring) are read by the whole wave in the next
     // iteration: make them visible first
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1071,7 +1087,7 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy
     S.reward = Ro.rewards + (size_t)t * B;
     S.terminated = Ro.terminated + (size_t)t * B;
     S.truncated = Ro.truncated + (size_t)t * B;
-    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false>(P, S, B, inst, lane, &a);
+    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false, true>(P, S, B, inst, lane, &a);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }

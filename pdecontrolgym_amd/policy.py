@@ -67,8 +67,9 @@ class FusedMLP:
     def from_sb3(cls, policy, clamp=None, backend=None):
         """The deterministic actor of a Stable-Baselines3 policy as a ``FusedMLP`` (duck-typed, SB3 itself is not imported):
         ``ActorCriticPolicy`` (PPO / A2C ``MlpPolicy``): ``mlp_extractor.policy_net`` followed by ``action_net`` -- the mean of
-        the Gaussian, which SB3 clips to the action box (pass ``clamp``); ``SACPolicy`` / ``TD3Policy``: ``actor.latent_pi`` +
-        ``actor.mu`` with the tanh squashing of ``actor.forward(deterministic=True)``.  The wrapper shares the parameters
+        the Gaussian, which SB3 clips to the action box (pass ``clamp``); ``SACPolicy``: ``actor.latent_pi`` + ``actor.mu`` with
+        the tanh squashing of ``actor.forward(deterministic=True)``; ``TD3Policy``: ``actor.mu`` alone (a Sequential that already
+        ends in Tanh -- its actor has no ``latent_pi``).  The wrapper shares the parameters
         with ``policy`` (no copy), so ``model.learn()`` steps are picked up by ``refresh()``.  Observations must already be
         flat vectors (``FlattenExtractor``), which is what ``MlpPolicy`` uses on these environments."""
         import torch
@@ -76,11 +77,12 @@ class FusedMLP:
             mods = list(policy.mlp_extractor.policy_net) + [policy.action_net]
         elif hasattr(policy, "actor") and hasattr(policy.actor, "mu"):
             head = policy.actor.mu
-            mods = list(policy.actor.latent_pi) + (list(head) if isinstance(head, torch.nn.Sequential) else [head])
+            lat = getattr(policy.actor, "latent_pi", None)
+            mods = (list(lat) if lat is not None else []) + (list(head) if isinstance(head, torch.nn.Sequential) else [head])
             if not isinstance(mods[-1], torch.nn.Tanh):
                 mods.append(torch.nn.Tanh())          # SAC squashes the mean; TD3's mu already ends in Tanh
         else:
-            raise ValueError("expected an SB3 ActorCriticPolicy (mlp_extractor + action_net) or SAC/TD3 policy (actor.latent_pi + actor.mu)")
+            raise ValueError("expected an SB3 ActorCriticPolicy (mlp_extractor + action_net) or SAC/TD3 policy (actor.mu, with actor.latent_pi in front for SAC)")
         return cls(torch.nn.Sequential(*mods), clamp=clamp, backend=backend)
 
     def refresh(self, force: bool = False):

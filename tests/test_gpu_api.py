@@ -187,6 +187,40 @@ def test_device_rollout_graph_equals_eager_on_gpu():
     assert outs[0][3][13].all() and not outs[0][3][12].any()      # every instance terminates at step 14 and restarts
 
 
+@pytest.mark.parametrize("one_launch", [False, True])
+def test_device_rollout_replay_after_plain_steps_keeps_the_state(one_launch):
+    """A plain step between two replays flips the engine's double-buffered observation (= state) tensors; the captured graph
+    still writes its end state into the buffer it was captured with, so the engine has to be pointed back at it.  run(), step,
+    run(), step must equal the eager path bit for bit (round-2 advisor finding: the second run used to hand a stale state on)."""
+    import pde_control_gym
+    from pde_control_gym import DeviceRollout, FusedMLP
+    from pde_control_gym.src import TunedReward1D
+    B, T = 48, 6
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Linear(100, 32), torch.nn.Tanh(), torch.nn.Linear(32, 1)).cuda()
+    outs = []
+    for graph in (False, True):
+        p = _transport_params(T=0.0400, dt=1e-4, control_sample_rate=30e-4, reward_class=TunedReward1D(400, -1e3, 3e2))
+        rng = np.random.default_rng(7)
+        p["reset_init_condition_func"] = lambda nx: np.ones(nx) * rng.uniform(1, 3)
+        venv = pde_control_gym.make_vec("PDEControlGym-TransportPDE1D", num_envs=B, **p)
+        venv.reset_tensor()
+        venv.enable_fused_auto_reset()
+        pol = FusedMLP(net) if one_launch else net
+        ro = DeviceRollout(venv, pol, T, use_graph=graph, one_launch=one_launch)
+        res = []
+        a = torch.full((B,), 0.25, device="cuda")
+        for rep in range(3):
+            ro.run()
+            res += [ro.obs.cpu().numpy().copy(), ro.rewards.cpu().numpy().copy()]
+            for k in range(1 + rep):               # an odd and an even number of plain steps between replays
+                o, r, te, tr = venv.step_tensor(a)
+                res += [o.cpu().numpy().copy(), r.cpu().numpy().copy()]
+        outs.append(res)
+    for x, y in zip(*outs):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_quickstart_example_runs():
     import subprocess
     import sys

@@ -371,5 +371,11 @@ def test_from_sb3_duck_typed_policies():
     sac = types.SimpleNamespace(actor=types.SimpleNamespace(latent_pi=lat, mu=torch.nn.Linear(16, 2)))
     g = FusedMLP.from_sb3(sac, backend=FakeBackend())
     np.testing.assert_allclose(g(x).numpy(), torch.tanh(sac.actor.mu(lat(x))).detach().numpy(), rtol=1e-5, atol=1e-6)
+    # TD3: the actor is ONE Sequential `mu` ending in Tanh, no latent_pi
+    mu = torch.nn.Sequential(torch.nn.Linear(9, 16), torch.nn.ReLU(), torch.nn.Linear(16, 1), torch.nn.Tanh())
+    td3 = types.SimpleNamespace(actor=types.SimpleNamespace(mu=mu))
+    h = FusedMLP.from_sb3(td3, backend=FakeBackend())
+    np.testing.assert_allclose(h(x).numpy(), mu(x).detach().numpy(), rtol=1e-5, atol=1e-6)
+    assert len(h.layers) == 2
     with pytest.raises(ValueError):
         FusedMLP.from_sb3(types.SimpleNamespace())
