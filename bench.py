@@ -593,6 +593,39 @@ def run_workload(wl, steps, warmup, world, graph=False, repeats=REPEATS):
             "all_regions_s": maxes}
 
 
+def vecenv_host_rate(device, B=4096, steps=60, warmup=8):
+    """The SB3-facing path at the C2 shape: ``PDEVecEnv.step(numpy actions)`` -> NumPy observations / rewards / dones / infos,
+    host round trip included (what ``PPO("MlpPolicy", venv).learn()`` drives; reference caller
+    examples/transportPDE/transport1Dppo.py:77-90).  PCIe-inclusive, so it is reported beside the headline, never as it."""
+    import numpy as np
+    import pde_control_gym
+    from pde_control_gym.src import TunedReward1D
+    nx, S = Parabolic1D.nx, Parabolic1D.S
+    dx = 1.0 / nx
+    dt = 0.25 * dx * dx
+    beta = (50 * np.cos(8 * np.arccos(np.linspace(0, 1, nx + 1)))).astype(np.float32)
+    rng = np.random.default_rng(0)
+    p = {"T": 1000 * S * dt, "dt": dt, "X": 1, "dx": dx, "reward_class": TunedReward1D(1000 * S, -1e3, 3e2), "normalize": True,
+         "sensing_loc": "full", "control_type": "Dirchilet", "sensing_type": None, "sensing_noise_func": None,
+         "limit_pde_state_size": True, "max_state_value": 1e10, "max_control_value": 20, "control_sample_rate": S * dt,
+         "batched_reset_func": lambda idx, nx_: (rng.uniform(1, 10, (len(idx), 1)).astype(np.float32) * np.ones((1, nx_ + 1), np.float32),
+                                                 np.tile(beta, (len(idx), 1)))}
+    venv = pde_control_gym.make_vec("PDEControlGym-ReactionDiffusionPDE1D", num_envs=B, device=str(device), **p)
+    venv.reset()
+    venv.enable_fused_auto_reset()
+    acts = np.random.default_rng(1).uniform(-1, 1, (warmup + steps, B, 1)).astype(np.float32)
+    for k in range(warmup):
+        venv.step(acts[k])
+    t0 = time.perf_counter()
+    for k in range(steps):
+        obs, rew, dones, infos = venv.step(acts[warmup + k])
+    el = (time.perf_counter() - t0) / steps
+    return {"value": B / el, "unit": "env-steps/s", "us_per_step": el * 1e6, "batch": B,
+            "host_bytes_per_step": int(obs.nbytes + rew.nbytes + dones.nbytes + acts[0].nbytes),
+            "note": "PDEVecEnv.step: numpy actions in, numpy observations / rewards / dones / infos out through rotating pinned "
+                    "staging buffers, one stream synchronisation per step; PCIe-inclusive (never the headline value)"}
+
+
 def roofline_block(wl, key, step_ms, default_config):
     """The resource that binds the step and how close the step is to it.  Two candidates, both reported:
       * VALU issue: SQ_INSTS_VALU of one step (profiled) x 2 cycles / (1024 SIMDs x step time x 2.4 GHz);
@@ -722,6 +755,10 @@ def main():
                 del w2
             except Exception as ex:  # keep the headline line alive
                 also[name] = {"error": repr(ex)}
+        try:
+            also["vecenv_host"] = vecenv_host_rate(device)
+        except Exception as ex:
+            also["vecenv_host"] = {"error": repr(ex)}
         out["also"] = also
     if rank == 0:
         print(json.dumps(out))

@@ -51,6 +51,15 @@ class DeviceRollout:
             raise ValueError("one_launch=True needs a transport / reaction-diffusion engine with full-state sensing or a traffic "
                              "engine of <= 64 nodes, and a FusedMLP of <= 64-unit layers")
         self.one_launch = fits if one_launch is None else bool(one_launch)
+        # device-side sensing noise (PDEVecEnv(sensing_noise_tensor_func=...)): the policy reads obs_seen[t] = f(obs[t]) while
+        # obs[t] -- the plant state with full-state sensing -- stays clean; the call is part of the captured graph (torch's
+        # random generators are graph-safe: every replay draws new numbers).  The one-launch kernel has no such hook.
+        self._noise_f = getattr(venv, "sensing_noise_tensor_func", None)
+        self.obs_seen = torch.zeros_like(self.obs) if self._noise_f is not None else None
+        if self._noise_f is not None:
+            if one_launch:
+                raise ValueError("one_launch=True cannot apply sensing_noise_tensor_func (the policy runs inside the step kernel)")
+            self.one_launch = False
         self.use_graph = bool(use_graph) and dev.type == "cuda"
         self._graph = None
         self._state_buf = None     # observation tensor the captured graph leaves the end state in (see _rebind_state)
@@ -108,13 +117,17 @@ class DeviceRollout:
             # warm-up run leaves in its end state)
             core.t["obs"] = self.obs[0]
         fused = hasattr(self.policy, "forward_into") and self.obs.dtype in (torch.float32, torch.float64)
+        seen = self.obs if self.obs_seen is None else self.obs_seen
         for t in range(self.T):
             nz = self.action_noise[t] if self.action_noise is not None else None
+            if self.obs_seen is not None:
+                with torch.no_grad():
+                    self.obs_seen[t].copy_(self._noise_f(self.obs[t]))
             if fused:       # pdecontrolgym_amd.FusedMLP: forward pass (+ noise) + action clamp in one launch, written into slot t
-                self.policy.forward_into(self.obs[t], self.actions[t], clamp=(self.lo, self.hi), noise=nz)
+                self.policy.forward_into(seen[t], self.actions[t], clamp=(self.lo, self.hi), noise=nz)
             else:
                 with torch.no_grad():
-                    a = self.policy(self.obs[t]).reshape(self.actions[t].shape)
+                    a = self.policy(seen[t]).reshape(self.actions[t].shape)
                     if nz is not None:
                         a = a + nz.to(a.dtype)
                     a = a.clamp(self.lo, self.hi)
@@ -132,6 +145,9 @@ class DeviceRollout:
                 self.rewards[t].copy_(r)
                 self.terminated[t].copy_(te)
                 self.truncated[t].copy_(tr)
+        if self.obs_seen is not None:
+            with torch.no_grad():
+                self.obs_seen[self.T].copy_(self._noise_f(self.obs[self.T]))
 
     def run(self, first_obs=None):
         """Roll T steps from ``first_obs`` (default: the environment's current observation). Returns self."""

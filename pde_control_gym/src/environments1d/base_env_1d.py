@@ -25,10 +25,10 @@ class HistoryView:
     callbacks (``uVec[t]``, ``uVec[t - 100]``, ``uVec[:, -1]`` ... are fetched on demand)."""
 
     def __init__(self, hist_tensor):
-        self._h = hist_tensor          # [nt, n] device tensor
+        self._h = hist_tensor          # [nt, n] (1D environments) or [nt, ny, nx, 2] (Navier-Stokes) device tensor
         self.shape = tuple(hist_tensor.shape)
-        self.dtype = np.dtype(np.float32)
-        self.ndim = 2
+        self.dtype = np.dtype(str(hist_tensor.dtype).replace("torch.", "")) if hasattr(hist_tensor, "device") else np.dtype(hist_tensor.dtype)
+        self.ndim = len(self.shape)
 
     def __len__(self):
         return self.shape[0]

@@ -86,7 +86,15 @@ class TrafficPDE1D(PDEEnv1D):
         obs, rew, done, trunc = self._core.step(a[None, : self._core.action_dim])
         self._done_flag, self._trunc_flag = bool(done[0]), bool(trunc[0])
         o = self._load_state(obs)
-        return o, float(rew[0]), self._done_flag, self._trunc_flag, self.info
+        reward = float(rew[0])
+        from pde_control_gym.src.rewards import TrafficARZReward
+        if type(self.reward_class) is not TrafficARZReward:
+            # a user reward class (docs/source/utils/customrewards.rst): called as the reference does (:228); outside
+            # 'outlet-train' the episode also ends when THIS reward exceeds -0.00023 (:233)
+            reward = self.reward_class.reward(self.vs, self.rs, self.v, self.r)
+            if self.simulation_type != "outlet-train":
+                self._done_flag = bool(self.time_index == 0 or reward > -0.00023)    # terminate() rewinds the clock when it fires
+        return o, reward, self._done_flag, self._trunc_flag, self.info
 
     def reset(self, seed=None, options=None):
         if self.simulation_type == "outlet-train":               # stochastic reset (:249-253)

@@ -61,6 +61,11 @@ class PDEVecEnv:
         from pdecontrolgym_amd.batch1d import PDEBatch1D
         from pde_control_gym.src.environments1d.base_env_1d import reward_spec_for
         self.sensing_noise_func = kw.get("sensing_noise_func", None)
+        # device-side twin of the hook (hyperbolic.py:160-164 applies it to what sensing_update returns): a callable on TORCH
+        # tensors, [B, obs_dim] -> [B, obs_dim], evaluated on the device -- out of place, the returned tensor is what the
+        # policy sees while the plant state (which the observation tensor IS with full-state sensing) stays clean -- by
+        # step_tensor / reset_tensor and, captured into the graph, by DeviceRollout.  NumPy callbacks keep the host path.
+        self.sensing_noise_tensor_func = kw.get("sensing_noise_tensor_func", None)
         self._beta_dtype = kw.get("beta_dtype", None)
         self.reset_init_condition_func = kw.get("reset_init_condition_func")
         self.reset_recirculation_func = kw.get("reset_recirculation_func")
@@ -87,20 +92,30 @@ class PDEVecEnv:
         import torch
         from pdecontrolgym_amd.batch2d import NSBatch2D
         from pde_control_gym.src.rewards import NSReward
-        if type(self.reward_class) is not NSReward:
-            raise NotImplementedError("PDEVecEnv(NavierStokes2D) evaluates NSReward inside the step kernel")
+        # Any other BaseReward subclass (docs/source/utils/customrewards.rst: the extension point is environment-agnostic)
+        # takes the slow compatibility path: the trajectories U[nt, ny, nx, 2] are recorded on the device and after every step
+        # the user's reward(U, time_index, U_ref, action, action_ref) (navier_stokes2D.py:151) is called once per instance on
+        # the host with a lazy view of that instance's trajectory.
+        self._host_reward = type(self.reward_class) is not NSReward
         self.reset_init_condition_func = kw.get("reset_init_condition_func")
         tdtype = dtype or torch.float32
         if isinstance(tdtype, str):
             tdtype = {"float32": torch.float32, "float64": torch.float64}[tdtype]
         self.core = NSBatch2D(kw["T"], kw["dt"], kw["X"], kw["dx"], kw["Y"], kw["dy"], kw["boundary_condition"],
                               kw["U_ref"], kw["action_ref"], action_dim=kw.get("action_dim", 1),
-                              gamma=self.reward_class.gamma, viscosity=kw.get("viscosity", 0.1),
+                              gamma=getattr(self.reward_class, "gamma", 0.0), viscosity=kw.get("viscosity", 0.1),
                               density=kw.get("density", 1.0),
                               maximum_pressure_iteration=int(kw.get("maximum_pressure_iteration", 2000)),
                               stable_factor=kw.get("stable_factor", 0.5), num_envs=self.num_envs, device=self.device,
                               dtype=tdtype, backend=backend)
         self.nx, self.ny, self.nt = self.core.nx, self.core.ny, self.core.nt
+        if self._host_reward:
+            nbytes = self.num_envs * self.nt * self.ny * self.nx * 2 * (8 if tdtype == torch.float64 else 4)
+            if nbytes > (64 << 30):
+                raise MemoryError(f"a host reward callback on NavierStokes2D records every trajectory on the device: "
+                                  f"{nbytes / 2**30:.0f} GiB for {self.num_envs} instances; lower num_envs")
+            self._ns_hist = torch.zeros(self.num_envs, self.nt, self.ny, self.nx, 2, dtype=tdtype, device=self.device)
+            self._U_ref_np, self._a_ref_np = np.asarray(kw["U_ref"]), np.asarray(kw["action_ref"])
         self.X, self.Y = np.meshgrid(np.linspace(0, kw["X"], self.nx), np.linspace(0, kw["Y"], self.ny))
         self.observation_space = spaces.Box(np.full((self.nx, self.ny, 2), -np.inf, dtype="float32"),
                                             np.full((self.nx, self.ny, 2), np.inf, dtype="float32"))
@@ -110,8 +125,8 @@ class PDEVecEnv:
         import random
         from pdecontrolgym_amd.batch_traffic import TrafficBatch
         from pde_control_gym.src.rewards import TrafficARZReward
-        if type(self.reward_class) is not TrafficARZReward:
-            raise NotImplementedError("PDEVecEnv(TrafficPDE1D) evaluates TrafficARZReward inside the step kernel")
+        # any other BaseReward subclass: reward(v_desired, r_desired, v, r) (traffic_arz_env.py:228) per instance on the host
+        self._host_reward = type(self.reward_class) is not TrafficARZReward
         sim = kw.get("simulation_type", "inlet")
         self.core = TrafficBatch(kw["T"], kw["dt"], kw["X"], kw["dx"], sim, kw.get("v_max", 40), kw.get("ro_max", 0.16),
                                  kw.get("tau", 60), kw.get("limit_pde_state_size", False), kw.get("control_freq", 1),
@@ -179,9 +194,17 @@ class PDEVecEnv:
             return self.core.reset(self._draw_rs(self.num_envs))
         if self.kind == "ns2d":
             u, v, p = self._sample_ns(idx)
-            return self.core.reset(u, v, p)
+            obs = self.core.reset(u, v, p)
+            if self._host_reward:
+                self._ns_hist.zero_()
+                self._ns_hist[:, 0] = obs
+            return obs
         init, beta = self._sample_1d(idx)
-        return self.core.reset(init, beta)
+        return self._noise_t(self.core.reset(init, beta))
+
+    def _noise_t(self, obs):
+        f = getattr(self, "sensing_noise_tensor_func", None)
+        return obs if f is None else f(obs)
 
     def enable_fused_auto_reset(self, init_pool=None, beta_pool=None, pool_episodes: int = 4):
         """Finished instances restart inside the step kernel (no host sync).  The reference calls BOTH reset
@@ -189,6 +212,8 @@ class PDEVecEnv:
         ``pool_episodes * num_envs`` rows (initial condition AND beta), and the k-th restart of instance b takes row
         (b + k*num_envs) mod rows.  Call ``refresh_pool()`` (any time between steps) to draw fresh rows; pass explicit
         ``init_pool`` / ``beta_pool`` tensors [P >= num_envs, n] to control them (``beta_pool=False`` keeps beta fixed)."""
+        if getattr(self, "_host_reward", False):
+            raise NotImplementedError("a host reward callback needs the finished trajectory: use the plain auto-reset of step()")
         if self.kind == "ns2d":
             return self._enable_fused_auto_reset_ns(init_pool, min(int(pool_episodes), 2) if init_pool is None else 1)
         if self.kind == "traffic":       # pool of steady-state densities (redrawn per episode in 'outlet-train', :247-252)
@@ -196,8 +221,6 @@ class PDEVecEnv:
             self.core.enable_auto_reset(self._draw_rs(rows) if init_pool is None else init_pool)
             self._fused_reset = True
             return
-        if getattr(self, "_host_reward", False):
-            raise NotImplementedError("a host reward callback needs the finished trajectory: use the plain auto-reset of step()")
         if init_pool is None:
             init_pool, drawn_beta = self._sample_1d(np.arange(self.num_envs * max(1, int(pool_episodes))))
             if beta_pool is None:
@@ -247,11 +270,51 @@ class PDEVecEnv:
         import torch
         if self.kind == "ns2d":
             obs, r, te = self.core.step(actions)
+            if self._host_reward:
+                r = self._host_rewards_ns(obs, actions)
             return obs, r, te, torch.zeros_like(te)
         out = self.core.step(actions)       # 1D envs and traffic: (obs, reward, terminated|done, truncated)
         if getattr(self, "_host_reward", False):
-            return (out[0], self._host_rewards(out[2], out[3]), out[2], out[3])
+            if self.kind == "traffic":
+                return self._host_rewards_traffic(out)
+            return (self._noise_t(out[0]), self._host_rewards(out[2], out[3]), out[2], out[3])
+        if getattr(self, "sensing_noise_tensor_func", None) is not None:
+            return (self._noise_t(out[0]),) + tuple(out[1:])
         return out
+
+    def _host_rewards_ns(self, obs, actions):
+        """NavierStokes2D with a user reward class: the step's observation joins the recorded trajectory, then one
+        reward(U, time_index, U_ref, action, action_ref) call per instance (navier_stokes2D.py:147-151)."""
+        import torch
+        from pde_control_gym.src.environments1d.base_env_1d import HistoryView
+        ti_t = self.core.time_index
+        self._ns_hist[torch.arange(self.num_envs, device=self.device), ti_t.long()] = obs
+        ti = ti_t.cpu().numpy()
+        a = torch.as_tensor(actions).detach().cpu().numpy().reshape(self.num_envs, -1)
+        vals = np.zeros(self.num_envs, dtype=np.float64)
+        for b in range(self.num_envs):
+            vals[b] = self.reward_class.reward(HistoryView(self._ns_hist[b]), int(ti[b]), self._U_ref_np, a[b], self._a_ref_np)
+        return torch.as_tensor(vals, dtype=self.core.dtype, device=self.device)
+
+    def _host_rewards_traffic(self, out):
+        """TrafficPDE1D with a user reward class: reward(v_desired, r_desired, v, r) per instance (traffic_arz_env.py:226-233);
+        outside 'outlet-train' an episode also ends when the reward exceeds -0.00023 -- with the USER's reward, as there."""
+        import torch
+        obs, _, done_t, trunc_t = out
+        c = self.core
+        r = c.t["r"].cpu().numpy()
+        y = c.t["y"].cpu().numpy()
+        rs = c.t["rs"].cpu().numpy()
+        v = y / r + c.vm * (1 - r / c.rm)
+        vs = c.vm * (1 - rs / c.rm)
+        M = c.M
+        vals = np.array([self.reward_class.reward(float(vs[b]), float(rs[b]), v[b].reshape(M, 1), r[b].reshape(M, 1))
+                         for b in range(self.num_envs)], dtype=np.float64)
+        rew = torch.as_tensor(vals, dtype=torch.float64, device=self.device)
+        if not self._traffic_train:
+            timed_out = c.t["time"] == 0           # terminate() fired: it rewinds the clock (traffic_arz_env.py:109-111)
+            done_t = (timed_out | (rew > -0.00023)).to(torch.uint8)
+        return obs, rew, done_t, trunc_t
 
     def _host_rewards(self, te_t, tr_t):
         """Slow path for user reward classes: one reward() call per instance on a lazy view of its device-resident history."""
@@ -281,22 +344,44 @@ class PDEVecEnv:
     def step_async(self, actions):
         self._actions = actions
 
+    # How many consecutive results stay valid: the NumPy arrays a step returns are VIEWS of pinned staging buffers that are
+    # reused ``host_buffers`` steps later (SB3 reads the observation of step k once more right after step k+1 returned -- its
+    # ``_last_obs`` -- and never again, so two would do; three leaves a step of slack).  Callers that keep results longer copy them.
+    host_buffers = 3
+
     def _to_host(self, tensors):
-        """Device tensors -> fresh NumPy arrays through pinned staging buffers: the copies are queued back to back and the
-        stream is synchronised ONCE (``t.cpu()`` per tensor goes through pageable memory and synchronises every time)."""
+        """Device tensors -> NumPy views of pinned staging buffers: the copies are queued back to back and the stream is
+        synchronised ONCE (``t.cpu()`` per tensor goes through pageable memory and synchronises every time); no host-side copy
+        afterwards -- the buffers rotate instead (``host_buffers``)."""
         import torch
         if self.device.type != "cuda":
             return [t.numpy().copy() for t in tensors]
         pins = self.__dict__.setdefault("_pins", {})
+        turn = self.__dict__.get("_pin_turn", 0)
+        self._pin_turn = (turn + 1) % max(2, int(self.host_buffers))
         out = []
         for i, t in enumerate(tensors):
-            key = (i, tuple(t.shape), t.dtype)
+            key = (turn, i, tuple(t.shape), t.dtype)
             if key not in pins:
-                pins[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-            pins[key].copy_(t, non_blocking=True)
-            out.append(pins[key])
+                pin = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                pins[key] = (pin, pin.numpy())
+            pins[key][0].copy_(t, non_blocking=True)
+            out.append(pins[key][1])
         torch.cuda.current_stream(self.device).synchronize()
-        return [p.numpy().copy() for p in out]
+        return out
+
+    def _fresh_infos(self):
+        """One dict per environment, as SB3 expects -- but the B empty dicts are made once and handed out again every step;
+        only the entries of instances that finished (filled in below) are replaced by new dicts on the next call.  Consumers
+        that annotate an info dict copy it first (SB3's VecMonitor does)."""
+        infos = self.__dict__.get("_infos")
+        if infos is None:
+            infos = self._infos = [{} for _ in range(self.num_envs)]
+            self._infos_dirty = ()
+        for i in self._infos_dirty:
+            infos[i] = {}
+        self._infos_dirty = ()
+        return infos
 
     def step_wait(self):
         import torch
@@ -319,16 +404,18 @@ class PDEVecEnv:
         obs, rew, te, tr = self._to_host([obs_t, r_t, te_t, tr_t])
         if self.kind != "traffic":
             obs = obs.astype(np.float32, copy=False)
-        rew, te, tr = rew.astype(np.float32), te.astype(bool), tr.astype(bool)
+        rew, te, tr = rew.astype(np.float32, copy=False), te.view(np.bool_), tr.view(np.bool_)
         dones = te | tr
-        infos = [{} for _ in range(self.num_envs)]
+        infos = self._fresh_infos()
         if dones.any():
             idx = np.nonzero(dones)[0]
+            self._infos_dirty = idx
             final = self.core.t.get("final_obs") if self._fused_reset else None
-            final_np = self._obs_np(final) if final is not None else None
-            for i in idx:
-                infos[i]["terminal_observation"] = (final_np[i] if final_np is not None else obs[i]).copy()
-                infos[i]["TimeLimit.truncated"] = bool(tr[i] and not te[i])
+            # only the finished instances' terminal observations cross to the host
+            final_np = self._obs_np(final[torch.as_tensor(idx, device=self.device)]) if final is not None else None
+            for k, i in enumerate(idx):
+                infos[i] = {"terminal_observation": (final_np[k] if final_np is not None else obs[i]).copy(),
+                            "TimeLimit.truncated": bool(tr[i] and not te[i])}
             if not self._fused_reset:
                 mask = torch.as_tensor(dones.astype(np.uint8), device=self.device)
                 if self.kind == "traffic":
@@ -340,6 +427,10 @@ class PDEVecEnv:
                     u, v, p = self._sample_ns(idx)
                     shp = (self.ny, self.nx)
                     new = self.core.reset(self._scatter(u, idx, shp), self._scatter(v, idx, shp), self._scatter(p, idx, shp), mask=mask)
+                    if self._host_reward:
+                        it = torch.as_tensor(idx, device=self.device)
+                        self._ns_hist[it] = 0
+                        self._ns_hist[it, 0] = new[it]
                 else:
                     init, beta = self._sample_1d(idx)
                     if self.core.t["beta"].dim() == 2:

@@ -221,6 +221,53 @@ def test_device_rollout_replay_after_plain_steps_keeps_the_state(one_launch):
         np.testing.assert_array_equal(x, y)
 
 
+def test_device_sensing_noise_in_the_rollout_graph():
+    """sensing_noise_tensor_func (the device-side twin of hyperbolic.py:160-164's hook): the policy sees f(obs) while the plant
+    state stays clean.  A deterministic f: graph == eager bit for bit, obs_seen == f(obs), the trajectory is that of a policy
+    composed with f on an environment without the hook.  A random f inside the graph: every replay draws new noise."""
+    import pde_control_gym
+    from pde_control_gym import DeviceRollout
+    from pde_control_gym.src import TunedReward1D
+    B, T = 32, 8
+    torch.manual_seed(2)
+    pol = torch.nn.Sequential(torch.nn.Linear(100, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1), torch.nn.Tanh()).cuda()
+    f = lambda o: o * 1.03125 + 0.25
+
+    def venv(noise):
+        p = _transport_params(T=0.0400, dt=1e-4, control_sample_rate=30e-4, reward_class=TunedReward1D(400, -1e3, 3e2))
+        rng = np.random.default_rng(9)
+        p["reset_init_condition_func"] = lambda nx: np.ones(nx) * rng.uniform(1, 3)
+        v = pde_control_gym.make_vec("PDEControlGym-TransportPDE1D", num_envs=B, sensing_noise_tensor_func=noise, **p)
+        v.reset_tensor()
+        v.enable_fused_auto_reset()
+        return v
+
+    outs = []
+    for graph in (False, True):
+        ro = DeviceRollout(venv(f), pol, T, use_graph=graph).run()
+        torch.cuda.synchronize()
+        assert not ro.one_launch
+        torch.testing.assert_close(ro.obs_seen, f(ro.obs), rtol=0, atol=0)
+        outs.append([x.cpu().numpy().copy() for x in (ro.obs, ro.actions, ro.rewards)])
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    ref = DeviceRollout(venv(None), lambda o: pol(f(o)), T, use_graph=False).run()
+    np.testing.assert_array_equal(ref.obs.cpu().numpy(), outs[0][0])
+    np.testing.assert_array_equal(ref.actions.cpu().numpy(), outs[0][1])
+    # the step_tensor face returns the noisy observation, the state stays clean
+    v = venv(f)
+    clean = v.core.t["obs"].clone()
+    o, *_ = v.step_tensor(torch.zeros(B, device="cuda"))
+    torch.testing.assert_close(o, f(v.core.t["obs"]), rtol=0, atol=0)
+    assert not torch.equal(v.core.t["obs"], clean)
+    # random noise captured in the graph
+    ro = DeviceRollout(venv(lambda o: o + 0.01 * torch.randn_like(o)), pol, T, use_graph=True).run()
+    n1 = (ro.obs_seen - ro.obs).clone()
+    ro.run()
+    n2 = ro.obs_seen - ro.obs
+    assert torch.isfinite(n1).all() and n1.abs().max() > 0 and not torch.equal(n1, n2)
+
+
 def test_quickstart_example_runs():
     import subprocess
     import sys

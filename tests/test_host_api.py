@@ -257,6 +257,59 @@ def test_vecenv_accepts_custom_reward_classes(golden_transport, bk):
         venv.enable_fused_auto_reset()
 
 
+@pytest.mark.parametrize("bk", BACKENDS)
+def test_vecenv_custom_reward_navier_stokes(golden_ns, bk):
+    """The reference's extension point is environment-agnostic (docs/source/utils/customrewards.rst:8-9, base_reward.py:13-32):
+    a user BaseReward subclass on the batched NavierStokes2D face is called as navier_stokes2D.py:151 calls it, per instance,
+    on a lazy view of the device-resident trajectory.  A re-implementation of NSReward must reproduce the in-kernel reward, a
+    reward that looks one frame back must equal the same class on single environments."""
+    import pde_control_gym
+    from pde_control_gym.src import BaseReward, NavierStokes2D, NSReward
+    g = golden_ns["N1"]
+
+    class Again(BaseReward):          # NSReward restated: must agree with the kernel's epilogue
+        def reward(self, uVec=None, time_index=None, U_ref=None, action=None, action_ref=None):
+            d = np.asarray(uVec[time_index]) - U_ref[time_index]
+            return -0.5 * np.linalg.norm(d) ** 2 / uVec.shape[1] / uVec.shape[2] - 0.05 * np.linalg.norm(action - action_ref[time_index]) ** 2
+
+    class Back(BaseReward):           # needs an earlier frame: the trajectory view, not only the current observation
+        def reward(self, uVec=None, time_index=None, U_ref=None, action=None, action_ref=None):
+            return float(np.abs(np.asarray(uVec[time_index]) - np.asarray(uVec[time_index - 1])).sum() + 0.25 * float(np.sum(action)))
+
+    B = 3
+    scale = [1.0, 0.5, -0.75]
+    Uref = np.full((200, 21, 21, 2), 0.1)
+
+    def params(rc, k=None):
+        it = iter(range(B))
+        return {"T": 0.2, "dt": 1e-3, "X": 1, "dx": 0.05, "Y": 1, "dy": 0.05, "action_dim": 1, "reward_class": rc, "normalize": False,
+                "reset_init_condition_func": (lambda X: (g.u0 * scale[next(it)], g.v0.copy(), np.zeros_like(X))) if k is None
+                else (lambda X: (g.u0 * scale[k], g.v0.copy(), np.zeros_like(X))),
+                "boundary_condition": NS_BC, "U_ref": Uref, "action_ref": 2.0 * np.ones(1000), "maximum_pressure_iteration": 30}
+
+    acts = [np.array([[3.5], [2.5], [3.0]]), np.array([[2.2], [3.9], [2.0]]), np.array([[3.1], [3.1], [2.6]])]
+    venv_k = pde_control_gym.make_vec("PDEControlGym-NavierStokes2D", num_envs=B, dtype="float64", **_bk(bk), **params(NSReward(0.1)))
+    venv_a = pde_control_gym.make_vec("PDEControlGym-NavierStokes2D", num_envs=B, dtype="float64", **_bk(bk), **params(Again()))
+    venv_b = pde_control_gym.make_vec("PDEControlGym-NavierStokes2D", num_envs=B, dtype="float64", **_bk(bk), **params(Back()))
+    singles = [NavierStokes2D(**_bk(bk), **params(Back(), k)) for k in range(B)]
+    for v in (venv_k, venv_a, venv_b):
+        v.reset()
+    for e in singles:
+        e.reset()
+    for a in acts:
+        ok, rk, *_ = venv_k.step(a)
+        oa, ra, *_ = venv_a.step(a)
+        ob, rb, *_ = venv_b.step(a)
+        np.testing.assert_array_equal(ok, oa)
+        np.testing.assert_allclose(ra, rk, rtol=1e-6)          # (the SB3 face hands rewards out in float32)
+        for k in range(B):
+            o1, r1, *_ = singles[k].step(a[k])
+            np.testing.assert_array_equal(ob[k], o1.astype(np.float32))
+            np.testing.assert_allclose(rb[k], r1, rtol=1e-6)
+    with pytest.raises(NotImplementedError):
+        venv_b.enable_fused_auto_reset()
+
+
 def test_parabolic_single_env_public_api(golden_parabolic):
     from pde_control_gym.src import ReactionDiffusionPDE1D, TunedReward1D
     g = golden_parabolic["P2_s100"]

@@ -122,6 +122,59 @@ def test_traffic_vecenv_on_test_double():
     assert venv.observation_space.shape == (102,) and venv.action_space.shape == (1,)
 
 
+@pytest.mark.parametrize("hip", [pytest.param(False, id="cpu-double"), pytest.param(True, id="hip", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("sim", ["outlet", "outlet-train"])
+def test_traffic_custom_reward_on_both_faces(sim, hip):
+    """A user BaseReward subclass on TrafficPDE1D (docs/source/utils/customrewards.rst; called as traffic_arz_env.py:228 calls
+    it): restating TrafficARZReward must reproduce the in-kernel reward AND the done rule that hangs on it (:233), on the single
+    environment and on the batched face; a different reward changes the rewards only."""
+    import pde_control_gym
+    from pde_control_gym.src import BaseReward, TrafficARZReward, TrafficPDE1D
+    bk = dict(device="cuda") if hip else dict(device="cpu", backend=FakeBackend())
+
+    class Again(BaseReward):
+        def reward(self, v_desired, r_desired, v, r):
+            assert v.shape == (51, 1) and r.shape == (51, 1)
+            return -(np.linalg.norm(v - v_desired) / v_desired + np.linalg.norm(r - r_desired) / r_desired)
+
+    class Other(BaseReward):
+        def reward(self, v_desired, r_desired, v, r):
+            return -float(np.abs(r - r_desired).max()) - 1.0
+
+    kw = dict(simulation_type=sim, limit_pde_state_size=True, control_freq=2, **BASE)
+    B = 4
+    envs = {}
+    for name, rc in (("kernel", TrafficARZReward()), ("again", Again()), ("other", Other())):
+        random.seed(3)
+        envs[name] = pde_control_gym.make_vec("PDEControlGym-TrafficPDE1D", num_envs=B, reward_class=rc, **bk, **kw)
+        random.seed(4)
+        envs[name].reset()
+    random.seed(3)
+    single = TrafficPDE1D(reward_class=Again(), **bk, **kw)
+    random.seed(3)
+    single_k = TrafficPDE1D(reward_class=TrafficARZReward(), **bk, **kw)
+    single.reset()
+    single_k.reset()
+    qs = envs["kernel"].core.t["qs_clip"].cpu().numpy()
+    for i in range(4):
+        a = qs[:, None] * (0.9 + 0.05 * i)
+        ok, rk, dk, _ = envs["kernel"].step(a)
+        oa, ra, da, _ = envs["again"].step(a)
+        oo, ro, do, _ = envs["other"].step(a)
+        np.testing.assert_array_equal(ok, oa)
+        np.testing.assert_array_equal(ok, oo)
+        np.testing.assert_allclose(ra, rk, rtol=1e-6)
+        np.testing.assert_array_equal(da, dk)
+        assert (ro <= -1.0).all()
+        if sim != "outlet-train":
+            assert not do.any()                # the other reward never exceeds -0.00023, and time is far from T
+        s1 = single.step(np.array([single.qs * (0.9 + 0.05 * i)]))
+        s2 = single_k.step(np.array([single_k.qs * (0.9 + 0.05 * i)]))
+        np.testing.assert_array_equal(s1[0], s2[0])
+        np.testing.assert_allclose(s1[1], s2[1], rtol=1e-12)
+        assert s1[2] == s2[2] and s1[3] == s2[3]
+
+
 @pytest.mark.gpu
 def test_traffic_device_rollout_with_fused_policy():
     """DeviceRollout on TrafficPDE1D with FusedMLP reading the float64 observation (102 entries) and writing the float64
