@@ -31,6 +31,7 @@ def _on_device_of(key):
             with torch.cuda.device(dev):
                 return fn(self, *args, **kw)
         wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+        wrapped.device_guard_key = key          # (tests/test_host_api.py checks that every C-ABI entry point carries the guard)
         return wrapped
     return deco
 

@@ -531,12 +531,46 @@ def gen_tumor(src):
     np.savez_compressed(os.path.join(OUT, "tumor.npz"), **store)
 
 
+FILES = {"transport": "transport.npz", "parabolic": "parabolic.npz", "kat": "kat.npz", "mixed": "mixed.npz", "ns": "ns2d.npz",
+         "traffic": "traffic.npz", "tumor": "tumor.npz"}
+
+
+def check(which):
+    """Regenerate into a scratch directory and compare with the committed fixtures: same keys, same dtypes, same shapes, same
+    BITS.  Returns the list of differences (empty = the committed files are exactly what the generator writes today)."""
+    import tempfile
+    global OUT
+    committed = OUT
+    diffs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        OUT = tmp
+        try:
+            src = import_reference()
+            for w in which:
+                GEN[w](src)
+                a, b = np.load(os.path.join(committed, FILES[w]), allow_pickle=False), np.load(os.path.join(tmp, FILES[w]), allow_pickle=False)
+                for k in sorted(set(a.files) | set(b.files)):
+                    if k not in a.files or k not in b.files:
+                        diffs.append(f"{FILES[w]}: key {k} only in the {'generator output' if k in b.files else 'committed file'}")
+                    elif a[k].dtype != b[k].dtype or a[k].shape != b[k].shape or a[k].tobytes() != b[k].tobytes():
+                        diffs.append(f"{FILES[w]}: {k} differs")
+        finally:
+            OUT = committed
+    return diffs
+
+
 if __name__ == "__main__":
+    GEN = {"transport": gen_transport, "parabolic": gen_parabolic, "kat": gen_kat, "mixed": gen_mixed, "ns": gen_ns,
+           "traffic": gen_traffic, "tumor": gen_tumor}
+    if "--check" in sys.argv[1:]:
+        d = check([w for w in sys.argv[1:] if w != "--check"] or list(GEN))
+        print("\n".join(d) if d else "fixtures == generator output")
+        sys.exit(1 if d else 0)
     src = import_reference()
     which = sys.argv[1:] or ["transport", "parabolic", "kat", "mixed", "ns", "traffic", "tumor"]
     store_meta = dict(numpy=np.__version__)
     for w in which:
-        {"transport": gen_transport, "parabolic": gen_parabolic, "kat": gen_kat, "mixed": gen_mixed, "ns": gen_ns, "traffic": gen_traffic, "tumor": gen_tumor}[w](src)
+        GEN[w](src)
         print("wrote", w)
     with open(os.path.join(OUT, "VERSIONS.txt"), "w") as f:
         f.write(f"numpy {np.__version__}\nreference snapshot 2026-01-09 (lukebhan/PDEControlGym)\n")

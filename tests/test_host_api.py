@@ -310,6 +310,62 @@ def test_vecenv_custom_reward_navier_stokes(golden_ns, bk):
         venv_b.enable_fused_auto_reset()
 
 
+def test_every_c_abi_call_runs_with_its_tensors_device_current(monkeypatch):
+    """One process may drive several GPUs (one engine per device): every backend method that reaches the C ABI switches to the
+    device of its tensors first (backend._on_device_of).  The guard cannot run for real on a one-GPU box (the -m gpu test needs
+    two devices), so it is unit-tested here: entered with the tensors' device, for the dict form and the tensor form, not at
+    all for CPU tensors -- and no public backend method lacks it.  (The multi-device path itself is hardware-unverified.)"""
+    import torch
+    from pdecontrolgym_amd import backend as bk_mod
+    entered = []
+
+    class Guard:
+        def __init__(self, dev):
+            entered.append(dev)
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    monkeypatch.setattr(torch.cuda, "device", Guard)
+
+    class Stub:                        # stands in for a tensor on cuda:1 in the dict form
+        device = torch.device("cuda", 1)
+
+    class B:
+        @bk_mod._on_device_of("obs")
+        def by_dict(self, P, T, n):
+            return ("ran", n)
+
+        @bk_mod._on_device_of("u")
+        def by_tensor(self, rows, out):
+            return "ran"
+
+    assert B().by_dict(None, {"obs": Stub()}, 3) == ("ran", 3) and entered == [torch.device("cuda", 1)]
+    entered.clear()
+    assert B().by_dict(None, {"obs": torch.zeros(1)}, 3) == ("ran", 3) and entered == []        # CPU tensors: no device switch
+    assert B().by_tensor(torch.zeros(2), torch.zeros(2)) == "ran" and entered == []
+    public = [n for n, f in vars(bk_mod.HipBackend).items() if callable(f) and not n.startswith("_") and n not in ("bind",)]
+    assert len(public) >= 14
+    for n in public:
+        assert hasattr(getattr(bk_mod.HipBackend, n), "device_guard_key"), f"HipBackend.{n} reaches the C ABI without the device guard"
+
+
+def test_golden_fixtures_are_exactly_what_the_generator_writes():
+    """'Pinned' stays literally true: tests/golden/make_golden.py --check re-runs the reference (build container only) and
+    compares every key of every committed .npz with what it would write today, bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isdir(os.environ.get("PDEGYM_REFERENCE", "/root/reference")):
+        pytest.skip("the reference checkout is not on this machine (GPU box): fixtures cannot be regenerated here")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "make_golden.py"), "--check"], cwd=root,
+                       env=dict(os.environ, PYTHONPATH=root), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 def test_parabolic_single_env_public_api(golden_parabolic):
     from pde_control_gym.src import ReactionDiffusionPDE1D, TunedReward1D
     g = golden_parabolic["P2_s100"]
