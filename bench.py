@@ -301,7 +301,7 @@ def cpu_port_rate(workload_key, seconds, seed=0):
         what = f"{S} sub-steps each"
     else:
         from bench_ns2d import NavierStokesC4, NavierStokesC5
-        W = NavierStokesC5 if workload_key == "ns2d_c5" else NavierStokesC4
+        W = NavierStokesC5 if workload_key in ("ns2d_c5", "ns2d_c5_f64") else NavierStokesC4
         nn, K, nt = W.n, W.K, 1000
         dx = 1.0 / (nn - 1)
         dt = 0.2 * 0.5 * dx * dx / 0.1
@@ -492,7 +492,8 @@ class BrainTumor:
                 "substeps_per_env_step": 1, "reward": "BrainTumorReward", "parallelism": "independent instances, no collective"}
 
 
-from bench_ns2d import NavierStokesC4, NavierStokesC4B4096, NavierStokesC4F64, NavierStokesC5, NavierStokesExample  # noqa: E402
+from bench_ns2d import (NavierStokesC4, NavierStokesC4B4096, NavierStokesC4B4096F64, NavierStokesC4F64, NavierStokesC5,  # noqa: E402
+                        NavierStokesC5F64, NavierStokesExample)
 WORKLOADS["parabolic_c2_policy_loop"] = ParabolicPolicyLoop
 WORKLOADS["parabolic_c2_rollout"] = ParabolicRollout
 WORKLOADS["parabolic_c2_open_loop_rollout"] = ParabolicOpenLoopRollout
@@ -500,6 +501,8 @@ WORKLOADS["ns2d_c4"] = NavierStokesC4
 WORKLOADS["ns2d_c4_f64"] = NavierStokesC4F64
 WORKLOADS["ns2d_c4_b4096"] = NavierStokesC4B4096
 WORKLOADS["ns2d_c5"] = NavierStokesC5
+WORKLOADS["ns2d_c5_f64"] = NavierStokesC5F64
+WORKLOADS["ns2d_c4_f64_b4096"] = NavierStokesC4B4096F64
 WORKLOADS["ns2d_example"] = NavierStokesExample
 WORKLOADS["traffic_arz"] = TrafficARZ
 WORKLOADS["traffic_arz_rollout"] = TrafficARZRollout
@@ -745,7 +748,7 @@ def main():
                 continue
             try:
                 w2 = cls(device, 99)
-                n2 = max(40, args.steps // 2) if name not in ("ns2d_c4_b4096", "ns2d_c5", "ns2d_example") else 20
+                n2 = max(40, args.steps // 2) if name not in ("ns2d_c4_b4096", "ns2d_c5", "ns2d_example", "ns2d_c5_f64", "ns2d_c4_f64_b4096") else 20
                 r2 = run_workload(w2, n2, max(5, args.warmup // 2), 1, graph=use_graph, repeats=3)
                 rf = roofline_block(w2, name, r2["step_ms_events"], True)
                 also[name] = {"value": w2.units_per_step() * n2 / r2["seconds"], "unit": "env-steps/s", "ms_per_step": r2["seconds"] / n2 * 1e3,

@@ -80,6 +80,18 @@ class NavierStokesC4B4096(NavierStokesC4):
     B = 4096
 
 
+class NavierStokesC4B4096F64(NavierStokesC4B4096):
+    """The metric string's "NS2D 128x128, batch 4096" at the reference's own precision (float64 end to end)."""
+    name = "NavierStokes2D 128x128 K=50 B=4096 fp64 (BASELINE metric string at the reference's precision)"
+    dtype = "f64"
+
+
+class NavierStokesC5F64(NavierStokesC5):
+    """BASELINE configs[4] per-GPU shard at the reference's own precision (float64 end to end, bit-exact against NumPy)."""
+    name = "NavierStokes2D 256x256 K=50 B=512/GPU fp64 (BASELINE configs[4] shard at the reference's precision)"
+    dtype = "f64"
+
+
 class NavierStokesExample(NavierStokesC4):
     """The reference's own shipped NavierStokes2D configuration (examples/NavierStokes/NS2Dppo.py:36-50: 21 x 21 grid, 2000 Jacobi
     sweeps per env-step, float64) at a batch that fills the chip: one lane per grid column, three instances per wave."""

@@ -327,6 +327,36 @@ def test_ns_f64_tiled_kernel_equals_generic_kernel_and_oracle_bitwise(K, interle
         np.testing.assert_allclose(r1, r2, rtol=1e-12)
 
 
+@pytest.mark.parametrize("K,interleaved,adim", [(50, True, 1), (17, True, 256), (18, False, 1), (1, True, 1), (0, False, 1), (35, True, 1)])
+def test_ns_f64_256_slab_passes_equal_generic_kernel_bitwise(K, interleaved, adim):
+    """256 x 256 float64 (BASELINE config 5 at the reference's precision): the pressure solve runs as passes of <= 17 sweeps
+    over three overlapping slabs per instance (pdegym_ns256_f64.hip).  Fields, pressure and observations must equal the
+    workgroup-per-instance kernel bit for bit: one pass, exactly 17, 17 + 1 (an odd second pass), three passes, none; both
+    state layouts, scalar and per-node boundary actions."""
+    from pdecontrolgym_amd.batch2d import NSBatch2D
+    B = 2
+    kw, u0, v0, p0, acts = _random_case(256, B, K, 5000 + K, BC_MIX, adim)
+    kw = dict(kw, action_dim=adim)
+    outs = []
+    for force in ("0", "1"):
+        _dbg("DEBUG_NS_GENERIC", force)
+        try:
+            env = NSBatch2D(num_envs=B, device="cuda", dtype=torch.float64, interleaved_state=interleaved, **kw)
+            env.reset(u0, v0, p0)
+            res = []
+            for a in acts[:2]:
+                obs, r, te = env.step(a)
+                res.append((obs.cpu().numpy().copy(), env.p.cpu().numpy().copy(), env.u.cpu().numpy().copy(), r.cpu().numpy().copy()))
+            outs.append(res)
+        finally:
+            _dbg("DEBUG_NS_GENERIC", "0")
+    for (o1, p1, u1, r1), (o2, p2, u2, r2) in zip(*outs):
+        np.testing.assert_array_equal(o1, o2)
+        np.testing.assert_array_equal(p1, p2)
+        np.testing.assert_array_equal(u1, u2)
+        np.testing.assert_allclose(r1, r2, rtol=1e-12)
+
+
 @pytest.mark.parametrize("n,dtype,K", [(21, "float64", 200), (21, "float64", 7), (33, "float32", 50), (64, "float64", 31),
                                        (64, "float32", 50), (5, "float64", 12),
                                        # one LDS copy (grids of 4097..16384 cells): float64 128x128 is 128 KB
