@@ -28,10 +28,13 @@
 #include "pdegym.h"
 #include "pdegym_common.h"
 #include "pdegym_ns_common.h"
+#include "pdegym_ns256_rows.h"
 
 namespace pdegym {
 namespace ns {
 namespace {
+
+using namespace rows256;
 
 constexpr int kN = 256, kCells = kN * kN;
 constexpr int kWaves = 8, kPR = kN / kWaves;      // 32 grid rows per wave, 4 columns per lane
@@ -52,93 +55,6 @@ static_assert(kRL % 2 == 0 && kRL >= 2 && kRL < kPR && kRR % 2 == 0, "LDS rows c
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget of one CU");
 
 __device__ __forceinline__ constexpr int rq_reg(int a) { return a; }
-
-// ---- state rows ---------------------------------------------------------------------------------------------------
-// (u, v) of columns 4 lane .. 4 lane + 3 of grid row `row` (clamped: rows outside the grid only feed values nobody reads)
-template <bool INTERLEAVED>
-__device__ __forceinline__ void load_state_row(const float* su, const float* sv, int row, int c0, float (&fu)[4], float (&fv)[4]) {
-  const int r = row < 0 ? 0 : (row > kN - 1 ? kN - 1 : row);
-  if constexpr (INTERLEAVED) {
-    const float4* q = reinterpret_cast<const float4*>(su + (r * kN + c0) * 2);
-    const float4 a = q[0], d = q[1];
-    fu[0] = a.x; fv[0] = a.y; fu[1] = a.z; fv[1] = a.w; fu[2] = d.x; fv[2] = d.y; fu[3] = d.z; fv[3] = d.w;
-  } else {
-    const float4 a = *reinterpret_cast<const float4*>(su + r * kN + c0);
-    const float4 d = *reinterpret_cast<const float4*>(sv + r * kN + c0);
-    fu[0] = a.x; fu[1] = a.y; fu[2] = a.z; fu[3] = a.w; fv[0] = d.x; fv[1] = d.y; fv[2] = d.z; fv[3] = d.w;
-  }
-}
-
-// predictor of grid row i (navier_stokes2D.py:130-138) from the state rows i-1 (S), i (C), i+1 (N); cells on the domain edge
-// keep the state value (central_difference / laplace are zero there, :9-22)
-__device__ __forceinline__ void predictor_row(const NSScal<float>& S, int i, int lane, const float (&uc)[4], const float (&vc)[4],
-                                              const float (&us)[4], const float (&vs)[4], const float (&un_)[4], const float (&vn_)[4],
-                                              float (&uo)[4], float (&vo)[4]) {
-  const float ul = lane_left(uc[3]), ur = lane_right(uc[0]), vl = lane_left(vc[3]), vr = lane_right(vc[0]);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float uw = (k == 0) ? ul : uc[k - 1], ue = (k == 3) ? ur : uc[k + 1];
-    const float vw = (k == 0) ? vl : vc[k - 1], ve = (k == 3) ? vr : vc[k + 1];
-    const float dudx = div_c(ue - uw, S.two_dx, S.inv_two_dx), dudy = div_c(un_[k] - us[k], S.two_dy, S.inv_two_dy);
-    const float dvdx = div_c(ve - vw, S.two_dx, S.inv_two_dx), dvdy = div_c(vn_[k] - vs[k], S.two_dy, S.inv_two_dy);
-    const float lapu = div_c((((uw + us[k]) - 4.0f * uc[k]) + ue) + un_[k], S.dxdy, S.inv_dxdy);
-    const float lapv = div_c((((vw + vs[k]) - 4.0f * vc[k]) + ve) + vn_[k], S.dxdy, S.inv_dxdy);
-    const float a = uc[k] + S.dt * (((-uc[k]) * dudx - vc[k] * dudy) + S.nu * lapu);
-    const float d = vc[k] + S.dt * (((-uc[k]) * dvdx - vc[k] * dvdy) + S.nu * lapv);
-    const bool edge = (i <= 0) || (i >= kN - 1) || (lane == 0 && k == 0) || (lane == 63 && k == 3);
-    uo[k] = edge ? uc[k] : a;
-    vo[k] = edge ? vc[k] : d;
-  }
-}
-
-// apply_boundary (:76-90) restricted to grid row i, in registers.  `f` holds the row before the call (only its interior
-// cells matter), `nb` the row next to it on the inside of the wall -- read only when i is the lower / upper wall row.  Passes
-// in the reference's order: lower, upper (whole row), then left, right (one cell each, reading the cell the earlier pass set).
-// The left / right passes run for every row of the pipelines, so they are selects on lane masks formed once per launch
-// (BcSel) instead of branches on the boundary codes; the wall rows (two per instance) keep the branching form.
-struct BcSel {
-  bool ln[2], lw[2], rn[2], rw[2];   // per component: lane 0 takes its right neighbour (Neumann) / the wall value; lane 63 alike
-  bool ld[2], rd[2];                 // wall value is 0 (Dirichlet) rather than the action (Controllable); wave-uniform
-};
-__device__ __forceinline__ BcSel make_bc_sel(const int (&bc)[4][2], int lane) {
-  BcSel m;
-#pragma unroll
-  for (int comp = 0; comp < 2; ++comp) {
-    const int cl = bc[PDEGYM_EDGE_LEFT][comp], cr = bc[PDEGYM_EDGE_RIGHT][comp];
-    m.ln[comp] = lane == 0 && cl == PDEGYM_BC_NEUMANN;
-    m.lw[comp] = lane == 0 && cl != PDEGYM_BC_NEUMANN;
-    m.rn[comp] = lane == 63 && cr == PDEGYM_BC_NEUMANN;
-    m.rw[comp] = lane == 63 && cr != PDEGYM_BC_NEUMANN;
-    m.ld[comp] = cl == PDEGYM_BC_DIRICHLET;
-    m.rd[comp] = cr == PDEGYM_BC_DIRICHLET;
-  }
-  return m;
-}
-
-__device__ __forceinline__ void bc_row(float (&f)[4], const float (&nb)[4], int i, int c0, const int (&bc)[4][2], int comp,
-                                       const BcSel& m, const float* act, int action_dim, float a0) {
-  if (i == 0 || i == kN - 1) {        // wave-uniform, two rows per instance
-    const int c = bc[i == 0 ? PDEGYM_EDGE_LOWER : PDEGYM_EDGE_UPPER][comp];
-    if (c == PDEGYM_BC_NEUMANN) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) f[k] = nb[k];
-    } else if (c == PDEGYM_BC_DIRICHLET) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) f[k] = 0.0f;
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) f[k] = action_dim == 1 ? a0 : act[c0 + k];
-    }
-  }
-  // rows outside the grid pass through here on the pipelines' first / last iterations: keep the action index inside the array
-  float ai = a0;
-  if (action_dim != 1) ai = act[i < 0 ? 0 : (i > kN - 1 ? kN - 1 : i)];
-  const float wl = m.ld[comp] ? 0.0f : ai, wr = m.rd[comp] ? 0.0f : ai;
-  f[0] = m.ln[comp] ? f[1] : f[0];
-  f[0] = m.lw[comp] ? wl : f[0];
-  f[3] = m.rn[comp] ? f[2] : f[3];
-  f[3] = m.rw[comp] ? wr : f[3];
-}
 
 // ---- one Jacobi sweep (state ST: 0 = UP, 1 = DOWN; see jacobi_sweep_bous), right-hand side partly in LDS -------------
 template <int ST>
@@ -238,7 +154,7 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
     float f1u[4], f1v[4], f2v[4];                                    // F_u(r-2), F_v(r-2), F_v(r-3)
     // slot of row S(r+1) at iteration `it` is (it - 3) mod D; S(r) and S(r-1) sit in the two slots before it
 #pragma unroll
-    for (int s = 0; s < D; ++s) load_state_row<INTERLEAVED>(su, sv, r0 - 2 + ((s + D - 3) % D), c0, ru[s], rv[s]);
+    for (int s = 0; s < D; ++s) load_state_row<INTERLEAVED, float>(su, sv, r0 - 2 + ((s + D - 3) % D), c0, ru[s], rv[s]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) p1u[k] = p1v[k] = p2u[k] = p2v[k] = f1u[k] = f1v[k] = f2v[k] = 0.f;
     auto row_iter = [&](int it, auto slot_c, int slot0) __attribute__((always_inline)) {   // wave row a = it - 3 goes to LDS slot a - slot0
@@ -246,7 +162,7 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
       const int r = r0 - 1 + it;
       float pu[4], pv[4];
       predictor_row(S, r, lane, ru[sc], rv[sc], ru[ss], rv[ss], ru[sl], rv[sl], pu, pv);
-      load_state_row<INTERLEAVED>(su, sv, r - 1 + D, c0, ru[ss], rv[ss]);     // refill the slot row r-1 has left
+      load_state_row<INTERLEAVED, float>(su, sv, r - 1 + D, c0, ru[ss], rv[ss]);     // refill the slot row r-1 has left
       // boundary rule on row r-1
       const int rr = r - 1;
       float fu[4], fv[4], nbu[4], nbv[4];
@@ -392,7 +308,7 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
     // at iteration `it`: S(r-1), S(r), S(r+1) sit in slots it, it+1, it+2 (mod D), p(r-1), p(r), p(r+1) likewise (mod DP),
     // Uref(r-1) in slot it mod DF
 #pragma unroll
-    for (int s = 0; s < D; ++s) load_state_row<INTERLEAVED>(su, sv, r0 - 1 + s, c0, ru[s], rv[s]);
+    for (int s = 0; s < D; ++s) load_state_row<INTERLEAVED, float>(su, sv, r0 - 1 + s, c0, ru[s], rv[s]);
 #pragma unroll
     for (int s = 0; s < DP; ++s) prow(s - 1, rp[s]);
 #pragma unroll
@@ -441,7 +357,7 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
           cv[k] = edge ? cv[k] : cv[k] - S.dt_over_rho * dpdy;
         }
       }
-      load_state_row<INTERLEAVED>(su, sv, r - 1 + D, c0, ru[s0], rv[s0]);
+      load_state_row<INTERLEAVED, float>(su, sv, r - 1 + D, c0, ru[s0], rv[s0]);
       prow(it - 1 + DP, rp[q0]);
       if (it >= 1) finish_row(r - 1, cu, cv, rf[sf]);
       urow(r - 1 + DF, rf[sf]);

@@ -371,25 +371,6 @@ __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, 
   gen_back<T>(C, S, P, b, p, red);
 }
 
-// ---- the phases around the pressure solve as launches of their own (256 x 256 float64: the solve is the slab passes of
-// pdegym_ns256_f64.hip) -------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(1024) void ns_front_kernel(NSConst C, NSScal<T> S, NSPtrs<T> P, int B) {
-  const int b = blockIdx.x;
-  if (b >= B) return;
-  gen_front<T>(C, S, P, b);
-}
-
-template <typename T>
-__global__ __launch_bounds__(1024) void ns_back_kernel(NSConst C, NSScal<T> S, NSPtrs<T> P, int final_in_scratch, int B) {
-  __shared__ T red[16];
-  const int b = blockIdx.x;
-  if (b >= B) return;
-  const int ncell = C.nx * C.ny;
-  const T* pfin = final_in_scratch ? P.scratch + (size_t)b * 4 * ncell + 3 * (size_t)ncell : P.p + (size_t)b * ncell;
-  gen_back<T>(C, S, P, b, pfin, red);
-}
-
 // ================================================================================================
 // float32 register-tiled path: 512 threads per instance, thread (ty, tx) (16 x 32) owns the PR x PC patch at
 // (ty*PR, tx*PC) in VGPRs:  (PR,PC) = (8,4) -> 128x128,  (4,2) -> 64x64.
@@ -1743,24 +1724,8 @@ int ns_step_launch(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, i
     }
   }
   if constexpr (sizeof(T) == 8) {
-    // 256x256 float64 (BASELINE config 5 at the reference's precision): predictor launch -> ceil(K / 17) slab passes of the
-    // pressure solve, ping-ponging between p and scratch quarter 3 -> corrector launch (which copies p home if needed)
-    if (!pdegym_force_generic() && C.nx == 256 && C.ny == 256) {
-      const size_t ncell = (size_t)C.nx * C.ny;
-      hipStream_t st = (hipStream_t)stream;
-      hipLaunchKernelGGL(ns_front_kernel<double>, dim3(B), dim3(1024), 0, st, C, S, P, B);
-      double* bufs[2] = {P.p, P.scratch + 3 * ncell};
-      const size_t strides[2] = {ncell, 4 * ncell};
-      int cur = 0;
-      for (int left = C.iters; left > 0; left -= 17) {
-        if (int rc = launch_ns256_slab_f64(bufs[cur], strides[cur], bufs[cur ^ 1], strides[cur ^ 1], P.scratch + 2 * ncell, 4 * ncell,
-                                           S.dxdy, left < 17 ? left : 17, B, st))
-          return rc;
-        cur ^= 1;
-      }
-      hipLaunchKernelGGL(ns_back_kernel<double>, dim3(B), dim3(1024), 0, st, C, S, P, cur, B);
-      return pdegym::check_launch("ns2d_slab_step_f64");
-    }
+    // 256x256 float64 (BASELINE config 5 at the reference's precision): pdegym_ns256_f64.hip
+    if (!pdegym_force_generic() && C.nx == 256 && C.ny == 256) return launch_ns256_step_f64(C, S, P, B, (hipStream_t)stream);
   }
   if constexpr (sizeof(T) == 4) {
     // 256x256 float32 (BASELINE config 5): the whole env-step in one launch, one workgroup per instance (pdegym_ns256.hip)

@@ -402,10 +402,8 @@ __device__ __forceinline__ void jacobi_sweep_bous(float (&ph)[PR + 1][4], const 
 // pdegym_ns256.hip: the whole 256 x 256 float32 env-step in one launch (state_in or separate u, v; any sweep count)
 int launch_ns256_fused(const NSConst& C, const NSScal<float>& S, const NSPtrs<float>& P, int B, hipStream_t st);
 
-// pdegym_ns256_f64.hip: the float64 pressure solve on 256 x 256 as passes of at most 17 sweeps over three slabs per instance
-int ns256_f64_passes(int iters);
-int launch_ns256_slab_f64(const double* p_src, size_t src_stride, double* p_dst, size_t dst_stride, const double* rhs, size_t rhs_stride,
-                          double dxdy, int nsweeps, int B, hipStream_t st);
+// pdegym_ns256_f64.hip: the 256 x 256 float64 env-step (front launch, slab passes of the pressure solve, back launch, finish)
+int launch_ns256_step_f64(const NSConst& C, const NSScal<double>& S, const NSPtrs<double>& P, int B, hipStream_t st);
 
 }  // namespace ns
 }  // namespace pdegym

@@ -420,27 +420,29 @@ def test_ns_interleaved_state_equals_separate_fields(n, dtype):
             np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("n,B", [(256, 512), (128, 4096)])
-def test_ns_full_size_shards_properties_and_sampled_oracle(n, B):
-    """BASELINE config 5's per-GPU shard (256x256, 512 instances) and the metric string's NS2D 128x128 at batch 4096, float32,
-    K = 50, at FULL size: duplicated instances give identical fields (batch invariance), everything is finite, the lid row
-    carries the action, and sampled instances agree with the float64 oracle within the stated float32 tolerance."""
+@pytest.mark.parametrize("n,B,dtype", [(256, 512, "float32"), (128, 4096, "float32"), (256, 512, "float64"), (128, 4096, "float64")])
+def test_ns_full_size_shards_properties_and_sampled_oracle(n, B, dtype):
+    """BASELINE config 5's per-GPU shard (256x256, 512 instances) and the metric string's NS2D 128x128 at batch 4096, K = 50, at
+    FULL size, in float32 and at the reference's own precision: duplicated instances give identical fields (batch invariance),
+    everything is finite, the lid row carries the action, and sampled instances agree with the float64 oracle -- bit for bit in
+    float64, within the stated float32 tolerance otherwise."""
     from oracle import pde_oracle as po
+    td = getattr(torch, dtype)
     rng = np.random.default_rng(n + B)
     dx = 1.0 / (n - 1)
     dt = 0.2 * 0.5 * dx * dx / 0.1
     nt = 6
-    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=NS_BC, U_ref=np.zeros((nt, n, n, 2), dtype=np.float32),
+    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=NS_BC, U_ref=np.zeros((nt, n, n, 2), dtype=dtype),
               action_ref=2.0 * np.ones(nt), gamma=0.1, maximum_pressure_iteration=50)
-    env = _mk(kw, B, torch.float32)
+    env = _mk(kw, B, td)
     half = B // 2
-    c = torch.as_tensor(rng.uniform(-5, 5, (half, 3)), dtype=torch.float32)
+    c = torch.as_tensor(rng.uniform(-5, 5, (half, 3)), dtype=td)
     c = torch.cat([c, c])
-    ic = [(c[:, k].reshape(B, 1, 1) * torch.ones(1, n, n)).contiguous() for k in range(3)]
+    ic = [(c[:, k].reshape(B, 1, 1) * torch.ones(1, n, n, dtype=td)).contiguous() for k in range(3)]
     env.reset(*ic)
     acts = []
     for _ in range(2):
-        a = torch.as_tensor(rng.uniform(2, 4, half), dtype=torch.float32)
+        a = torch.as_tensor(rng.uniform(2, 4, half), dtype=td)
         a = torch.cat([a, a])
         acts.append(a)
         obs, r, te = env.step(a)
@@ -453,8 +455,13 @@ def test_ns_full_size_shards_properties_and_sampled_oracle(n, B):
     for a in acts:
         o_ref, r_ref, _, _ = orc.step(a[sel].double().numpy())
     o = obs[sel].cpu().double().numpy()
-    np.testing.assert_allclose(o, o_ref, rtol=1e-5, atol=1e-5 * np.abs(o_ref).max())
-    np.testing.assert_allclose(r[sel].cpu().numpy(), r_ref, rtol=1e-4)
+    if dtype == "float64":
+        np.testing.assert_array_equal(o, o_ref)
+        np.testing.assert_array_equal(env.p[sel].cpu().numpy(), orc.p)
+        np.testing.assert_allclose(r[sel].cpu().numpy(), r_ref, rtol=1e-12)
+    else:
+        np.testing.assert_allclose(o, o_ref, rtol=1e-5, atol=1e-5 * np.abs(o_ref).max())
+        np.testing.assert_allclose(r[sel].cpu().numpy(), r_ref, rtol=1e-4)
 
 
 def test_ns_c5_grid_256_parity():
