@@ -277,6 +277,11 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
   // stored -- same thread, same addresses, L2 hits -- so that no register row has to be picked by a run-time index; the rows
   // above / below the block come through the LDS exchange) and rows of the reference frame (4 slots).
   float acc = 0.f;
+  // the lane's column offset is formed again behind an opaque copy: left to itself the compiler computes every address of this
+  // phase before the front and carries it in scratch across the sweeps (whose registers are all spoken for)
+  int lane_b = lane;
+  asm volatile("" : "+v"(lane_b));
+  const int c0b = 4 * lane_b;
   const int t_new = P.time_index[b] + 1;
   const int tr = t_new < C.nt_ref ? t_new : C.nt_ref - 1;
   {
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
     halo_tb<4, kNT, 64>(ph[0], ph[kPR - 1], pt, pb, lds, xc, tid, w);
     const float* uref = P.U_ref + (size_t)tr * kCells * 2;
     float* obs = P.obs + (size_t)b * kCells * 2;
-    const float* pg = (P.p_out ? P.p_out : P.p) + (size_t)b * kCells + (size_t)r0 * kN + c0;
+    const float* pg = (P.p_out ? P.p_out : P.p) + (size_t)b * kCells + (size_t)r0 * kN + c0b;
     constexpr int DP = 4, DF = 2;      // pressure rows and reference rows are L2 hits: one row ahead is enough
     float ru[D][4], rv[D][4], rp[DP][4];
     float4 rf[DF][2];
@@ -301,14 +306,14 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
     };
     auto urow = [&](int row, float4 (&q)[2]) __attribute__((always_inline)) {
       const int rc = row < 0 ? 0 : (row > kN - 1 ? kN - 1 : row);
-      const float4* rrow = reinterpret_cast<const float4*>(uref + (rc * kN + c0) * 2);
+      const float4* rrow = reinterpret_cast<const float4*>(uref + (rc * kN + c0b) * 2);
       q[0] = rrow[0];
       q[1] = rrow[1];
     };
     // at iteration `it`: S(r-1), S(r), S(r+1) sit in slots it, it+1, it+2 (mod D), p(r-1), p(r), p(r+1) likewise (mod DP),
     // Uref(r-1) in slot it mod DF
 #pragma unroll
-    for (int s = 0; s < D; ++s) load_state_row<INTERLEAVED, float>(su, sv, r0 - 1 + s, c0, ru[s], rv[s]);
+    for (int s = 0; s < D; ++s) load_state_row<INTERLEAVED, float>(su, sv, r0 - 1 + s, c0b, ru[s], rv[s]);
 #pragma unroll
     for (int s = 0; s < DP; ++s) prow(s - 1, rp[s]);
 #pragma unroll
@@ -323,9 +328,9 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
         nbu[k] = rr == 0 ? cu[k] : c2u[k];
         nbv[k] = rr == 0 ? cv[k] : c2v[k];
       }
-      bc_row(fu, nbu, rr, c0, C.bc, 0, bsel, act, C.action_dim, a0);
-      bc_row(fv, nbv, rr, c0, C.bc, 1, bsel, act, C.action_dim, a0);
-      float4* orow = reinterpret_cast<float4*>(obs + (rr * kN + c0) * 2);
+      bc_row(fu, nbu, rr, c0b, C.bc, 0, bsel, act, C.action_dim, a0);
+      bc_row(fv, nbv, rr, c0b, C.bc, 1, bsel, act, C.action_dim, a0);
+      float4* orow = reinterpret_cast<float4*>(obs + (rr * kN + c0b) * 2);
       orow[0] = make_float4(fu[0], fv[0], fu[1], fv[1]);
       orow[1] = make_float4(fu[2], fv[2], fu[3], fv[3]);
       const float d0 = fu[0] - ref[0].x, d1 = fv[0] - ref[0].y, d2 = fu[1] - ref[0].z, d3 = fv[1] - ref[0].w;
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
           cv[k] = edge ? cv[k] : cv[k] - S.dt_over_rho * dpdy;
         }
       }
-      load_state_row<INTERLEAVED, float>(su, sv, r - 1 + D, c0, ru[s0], rv[s0]);
+      load_state_row<INTERLEAVED, float>(su, sv, r - 1 + D, c0b, ru[s0], rv[s0]);
       prow(it - 1 + DP, rp[q0]);
       if (it >= 1) finish_row(r - 1, cu, cv, rf[sf]);
       urow(r - 1 + DF, rf[sf]);

@@ -96,6 +96,71 @@ def ns_case(rng, idx):
     return desc
 
 
+def ns256_case(rng, idx):
+    """256 x 256 (BASELINE config 5): the float64 slab-pass pipeline against the oracle and the float32 fused launch against the
+    workgroup kernel, bit for bit -- random boundary sets, per-node actions, sweep counts around the pass boundaries (17, 34),
+    zero / constant / random fields (a zero field puts denormals and signed zeros through the sweeps)."""
+    from pdecontrolgym_amd.batch2d import NSBatch2D
+    n = 256
+    K = int(rng.choice([0, 1, 2, 3, 16, 17, 18, 33, 34, 35, 50, 51]))
+    B = int(rng.choice([1, 2, 3]))
+    adim = int(rng.choice([1, 1, n]))
+    bc = {e: [str(rng.choice(BCS)), str(rng.choice(BCS))] for e in ("upper", "lower", "left", "right")}
+    dx = 1.0 / (n - 1)
+    nu = float(rng.choice([0.1, 0.01, 1.0]))
+    dt = 0.2 * 0.5 * dx ** 2 / nu * float(rng.choice([1.0, 0.5]))
+    nt = 4
+    inter = bool(rng.random() < 0.6)
+    Xg, Yg = np.meshgrid(np.linspace(0, 1, n), np.linspace(0, 1, n))
+    style = rng.choice(["smooth", "const", "zero", "rand", "tiny"])
+    def field():
+        if style == "smooth":
+            return np.stack([np.sin(2 * np.pi * Xg * rng.uniform(0.5, 2)) * np.cos(np.pi * Yg) * rng.uniform(0.5, 2) + rng.uniform(-1, 1) for _ in range(B)])
+        if style == "const":
+            return np.stack([np.full((n, n), rng.uniform(-5, 5)) for _ in range(B)])
+        if style == "zero":
+            return np.zeros((B, n, n))
+        if style == "tiny":
+            return rng.uniform(-1, 1, (B, n, n)) * 1e-300
+        return rng.uniform(-1, 1, (B, n, n))
+    u0, v0, p0 = field(), field(), field()
+    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=bc, U_ref=rng.uniform(-1, 1, (nt, n, n, 2)),
+              action_ref=rng.uniform(1, 3, nt), gamma=float(rng.choice([0.1, 0.0, 2.0])), maximum_pressure_iteration=K, viscosity=nu,
+              density=float(rng.choice([1.0, 2.0])))
+    desc = f"#{idx} ns256 K={K} B={B} adim={adim} inter={inter} ic={style} bc={bc}"
+    orc = po.NavierStokesOracle(**kw)
+    env = NSBatch2D(num_envs=B, device="cuda", dtype=torch.float64, interleaved_state=inter, action_dim=adim, **kw)
+    orc.reset(u0, v0, p0)
+    env.reset(u0, v0, p0)
+    with np.errstate(all="ignore"):
+        for i in range(2):
+            a = rng.uniform(2, 4, (B, adim)) * float(rng.choice([1.0, 0.0, -1.0]))
+            o_ref, r_ref, te_ref, _ = orc.step(a)
+            obs, r, te = env.step(a)
+            assert bits_equal(obs.cpu().numpy(), o_ref), desc + f" step {i}: obs (float64)"
+            assert bits_equal(env.p.cpu().numpy(), orc.p), desc + f" step {i}: p (float64)"
+            assert bits_equal(env.u.cpu().numpy(), o_ref[..., 0]), desc + f" step {i}: u (float64)"
+            assert np.allclose(r.cpu().numpy(), r_ref, rtol=1e-12, atol=1e-300), desc + f" step {i}: reward"
+    outs = []
+    u32, v32, p32 = (x.astype(np.float32) if style != "tiny" else (x * 1e262).astype(np.float32) for x in (u0, v0, p0))
+    for force in ("0", "1"):
+        _dbg("DEBUG_NS_GENERIC", force)
+        try:
+            e32 = NSBatch2D(num_envs=B, device="cuda", dtype=torch.float32, interleaved_state=inter, action_dim=adim, **kw)
+            e32.reset(u32, v32, p32)
+            acts = np.random.default_rng(idx).uniform(2, 4, (2, B, adim))
+            res = []
+            for a in acts:
+                obs, r, te = e32.step(a)
+                res.append((obs.cpu().numpy().copy(), e32.p.cpu().numpy().copy(), e32.u.cpu().numpy().copy()))
+            outs.append(res)
+        finally:
+            _dbg("DEBUG_NS_GENERIC", "0")
+    for (o1, p1, u1), (o2, p2, u2) in zip(*outs):
+        assert bits_equal(o1, o2) and bits_equal(p1, p2) and bits_equal(u1, u2), desc + " float32 fused launch != workgroup kernel"
+    return desc
+
+
 def traffic_case(rng, idx):
     from pdecontrolgym_amd.batch_traffic import TrafficBatch
     sim = str(rng.choice(["inlet", "outlet", "both", "outlet-train"]))
@@ -191,8 +256,8 @@ def tumor_case(rng, idx):
 if __name__ == "__main__":
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    which = sys.argv[3].split(",") if len(sys.argv) > 3 else ["ns", "traffic", "tumor"]
-    fns = {"ns": ns_case, "traffic": traffic_case, "tumor": tumor_case}
+    which = sys.argv[3].split(",") if len(sys.argv) > 3 else ["ns", "ns256", "traffic", "tumor"]
+    fns = {"ns": ns_case, "ns256": ns256_case, "traffic": traffic_case, "tumor": tumor_case}
     rng = np.random.default_rng(seed)
     t0, k = time.time(), 0
     counts = {w: 0 for w in which}

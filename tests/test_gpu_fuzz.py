@@ -35,12 +35,12 @@ def test_negative_zero_boundary_command_is_kept():
         assert last[0] == 0x80000000 and last[1] == 0 and env.u[2, -1].item() == 0.5
 
 
-@pytest.mark.parametrize("which,count", [("ns", 60), ("traffic", 60), ("tumor", 40)])
+@pytest.mark.parametrize("which,count", [("ns", 60), ("ns256", 14), ("traffic", 60), ("tumor", 40)])
 def test_fuzz_other_kernels_against_oracle(which, count):
     """tests/fuzz_more.py: NS2D float64 bit-exact for random grids / BC combinations / sweep counts (and float32 tiled ==
     generic), traffic ARZ and brain-tumour (daily steps and the in-kernel growth run) for random parameter sets."""
     import fuzz_more
-    fn = {"ns": fuzz_more.ns_case, "traffic": fuzz_more.traffic_case, "tumor": fuzz_more.tumor_case}[which]
+    fn = {"ns": fuzz_more.ns_case, "ns256": fuzz_more.ns256_case, "traffic": fuzz_more.traffic_case, "tumor": fuzz_more.tumor_case}[which]
     rng = np.random.default_rng(17)
     done = 0
     for k in range(count):
