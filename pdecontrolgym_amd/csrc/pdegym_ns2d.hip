@@ -613,6 +613,9 @@ __device__ __forceinline__ void unrotate(const float (&ph)[PR + 1][PC], float (&
 }
 
 
+#ifndef PDEGYM_NS_F64_TILE_ROWS
+#define PDEGYM_NS_F64_TILE_ROWS 16
+#endif
 #ifndef PDEGYM_NS_BACK_ROWS
 #define PDEGYM_NS_BACK_ROWS 2
 #endif
@@ -901,10 +904,11 @@ __device__ __forceinline__ double dpp_shl_f64(double v) {       // lane i <- lan
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-// top/bottom halo rows of a 2-wide double patch through LDS (waves are thread rows: RS = 64)
+// top/bottom halo rows of a 2-wide double patch through LDS (waves are thread rows: RS = 64); NT threads per workgroup
+template <int NT>
 __device__ __forceinline__ void halo_tb_f64(const double (&top)[2], const double (&bot)[2], double (&ht)[2], double (&hb)[2], double* lds,
                                             int& xc, int tid, int ty) {
-  constexpr int NT = 1024, RS = 64;
+  constexpr int RS = 64;
   double2* base = reinterpret_cast<double2*>(lds) + (xc & 1) * (2 * NT);
   ++xc;
   double2* eT = base;
@@ -973,7 +977,7 @@ __device__ __forceinline__ void jacobi_sweep_f64(double (&ph)[PR + 1][2], const 
     dst[1] = 0.25 * (s1 - q[1]);
   };
   if constexpr (ST == 0) {
-    halo_tb_f64(ph[0], ph[PR - 1], ph[PR], hlast, lds, xc, tid, ty);            // top halo -> free row PR
+    halo_tb_f64<64 * (128 / PR)>(ph[0], ph[PR - 1], ph[PR], hlast, lds, xc, tid, ty);            // top halo -> free row PR
 #pragma unroll
     for (int a = 0; a < PR; ++a) {
       // new row a overwrites old row a-1 (its South neighbour, dead afterwards); dst may alias sv: all reads come first
@@ -985,7 +989,7 @@ __device__ __forceinline__ void jacobi_sweep_f64(double (&ph)[PR + 1][2], const 
     }
     jacobi_walls_f64<PR, 1>(ph, E);
   } else {
-    halo_tb_f64(ph[bphys<PR>(0, 1)], ph[bphys<PR>(PR - 1, 1)], hlast, ph[PR - 1], lds, xc, tid, ty);   // bottom halo -> free row PR-1
+    halo_tb_f64<64 * (128 / PR)>(ph[bphys<PR>(0, 1)], ph[bphys<PR>(PR - 1, 1)], hlast, ph[PR - 1], lds, xc, tid, ty);   // bottom halo -> free row PR-1
 #pragma unroll
     for (int a = PR - 1; a >= 0; --a) {
       double out[2];
@@ -998,11 +1002,24 @@ __device__ __forceinline__ void jacobi_sweep_f64(double (&ph)[PR + 1][2], const 
   }
 }
 
-constexpr int kF64HaloBytes = 2 * 2 * 1024 * 16;            // two buffers x (top, bottom) x one double2 per thread
-constexpr int kF64ParkRows = 5;                             // 5 x 16 KB next to the 64 KB of halo buffers: 144 of the CU's 160 KB
-template <bool INTERLEAVED>
-__global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<double> S, NSPtrs<double> P, int B) {
-  constexpr int n = 128, ncell = n * n, PR = 8;
+// Two shapes.  PR = 8: 16 waves of 8 rows, 128 registers per lane, five u* rows wait in LDS, the others and v* in the caller's
+// scratch (round 2).  PR = 16 (round 3): 8 waves of 16 rows, 256 registers per lane -- float64 issues at a quarter of the
+// float32 rate, two waves per SIMD keep the pipe as busy as four -- and nothing is parked in memory: ALL u* rows wait in LDS
+// (128 KB next to 32 KB of halo buffers), ALL v* rows in registers: HBM traffic 753 -> ~430 MB per 512 env-steps.
+template <int PR>
+struct F64Tile {
+  static constexpr int NW = 128 / PR, NT = 64 * NW;
+  static constexpr int HALO_BYTES = 2 * 2 * NT * 16;            // two buffers x (top, bottom) x one double2 per thread
+  static constexpr int PARK_ROWS = PR == 16 ? 16 : 5;           // u* rows in LDS (16 bytes per thread and row)
+  static constexpr bool V_IN_REGS = PR == 16;
+  static constexpr int LDS_BYTES = HALO_BYTES + PARK_ROWS * NT * 16;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget of one CU");
+};
+template <bool INTERLEAVED, int PR>
+__global__ __launch_bounds__(64 * (128 / PR), PR == 16 ? 2 : 4) void ns_tile_step_f64(NSConst C, NSScal<double> S, NSPtrs<double> P, int B) {
+  using Cfg = F64Tile<PR>;
+  constexpr int kF64HaloBytes = Cfg::HALO_BYTES, kF64ParkRows = Cfg::PARK_ROWS, NT = Cfg::NT;
+  constexpr int n = 128, ncell = n * n;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* lds = reinterpret_cast<double*>(smem_raw);
   const int b = blockIdx.x;
@@ -1010,7 +1027,7 @@ __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<do
   const int tid = threadIdx.x, tx = tid & 63;
   const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = ty * PR, c0 = tx * 2;
-  const EdgeFlags E{ty == 0, ty == 15, tx == 0, tx == 63};
+  const EdgeFlags E{ty == 0, ty == Cfg::NW - 1, tx == 0, tx == 63};
   double* u = INTERLEAVED ? nullptr : P.u + (size_t)b * ncell;
   double* v = INTERLEAVED ? nullptr : P.v + (size_t)b * ncell;
   const double* p = P.p + (size_t)b * ncell;
@@ -1023,6 +1040,8 @@ __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<do
   auto edge_cell = [&](int a, int k) { return (a == 0 && E.top) || (a == PR - 1 && E.bot) || (k == 0 && E.lef) || (k == 1 && E.rig); };
 
   double rq[PR][2];     // dx dy rhs, kept for all sweeps
+  double keep_v[Cfg::V_IN_REGS ? PR : 1][2];    // PR = 16: v* waits here for the corrector phase
+  (void)keep_v;
   {
     auto load_row = [&](int grow, double (&ru)[2], double (&rv)[2]) {
       if constexpr (INTERLEAVED) {
@@ -1076,9 +1095,14 @@ __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<do
           fin[i][0] = t0;
           fin[i][1] = t1;
         }
-        if (i < kF64ParkRows) park[i * 1024 + tid] = make_double2(fin_u[i][0], fin_u[i][1]);
+        if (i < kF64ParkRows) park[i * NT + tid] = make_double2(fin_u[i][0], fin_u[i][1]);
         else *reinterpret_cast<double2*>(us + (r0 + i) * n + c0) = make_double2(fin_u[i][0], fin_u[i][1]);
-        *reinterpret_cast<double2*>(vs + (r0 + i) * n + c0) = make_double2(fin_v[i][0], fin_v[i][1]);
+        if constexpr (Cfg::V_IN_REGS) {
+          keep_v[i][0] = fin_v[i][0];
+          keep_v[i][1] = fin_v[i][1];
+        } else {
+          *reinterpret_cast<double2*>(vs + (r0 + i) * n + c0) = make_double2(fin_v[i][0], fin_v[i][1]);
+        }
       };
       auto rhs_row = [&](int i, const double (&vbelow)[2], const double (&vabove)[2]) {
         const double ul = dpp_shr_f64(fin_u[i][1]), ur = dpp_shl_f64(fin_u[i][0]);
@@ -1127,7 +1151,7 @@ __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<do
       finalise(PR - 1);
       rhs_row(PR - 2, fin_v[PR - 3], fin_v[PR - 1]);
       double vt[2], vb[2];
-      halo_tb_f64(fin_v[0], fin_v[PR - 1], vt, vb, lds, xc, tid, ty);
+      halo_tb_f64<NT>(fin_v[0], fin_v[PR - 1], vt, vb, lds, xc, tid, ty);
       rhs_row(0, vt, fin_v[1]);
       rhs_row(PR - 1, fin_v[PR - 2], vb);
     }
@@ -1169,7 +1193,7 @@ __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<do
     // loads are issued: see ns_tile_step -- the whole-patch form spilled 268 bytes per lane
     constexpr int HR = 2, NBLK = PR / HR;
     double pt[2], pb[2];
-    halo_tb_f64(pf[0], pf[PR - 1], pt, pb, lds, xc, tid, ty);
+    halo_tb_f64<NT>(pf[0], pf[PR - 1], pt, pb, lds, xc, tid, ty);
     const double* uref = P.U_ref + (size_t)tr * ncell * 2;
     double* obs = P.obs + (size_t)b * ncell * 2;
 #pragma unroll
@@ -1179,10 +1203,16 @@ __global__ __launch_bounds__(1024, 4) void ns_tile_step_f64(NSConst C, NSScal<do
 #pragma unroll
       for (int la = 0; la < HR; ++la) {
         const double2 wu = (a0 + la < kF64ParkRows)
-                               ? reinterpret_cast<const double2*>(smem_raw + kF64HaloBytes)[(a0 + la) * 1024 + tid]
+                               ? reinterpret_cast<const double2*>(smem_raw + kF64HaloBytes)[(a0 + la) * NT + tid]
                                : *reinterpret_cast<const double2*>(us + (r0 + a0 + la) * n + c0);   // written by this same thread above
-        const double2 wv = *reinterpret_cast<const double2*>(vs + (r0 + a0 + la) * n + c0);
-        uf[la][0] = wu.x; uf[la][1] = wu.y; vf[la][0] = wv.x; vf[la][1] = wv.y;
+        uf[la][0] = wu.x; uf[la][1] = wu.y;
+        if constexpr (Cfg::V_IN_REGS) {
+          vf[la][0] = keep_v[a0 + la][0];
+          vf[la][1] = keep_v[a0 + la][1];
+        } else {
+          const double2 wv = *reinterpret_cast<const double2*>(vs + (r0 + a0 + la) * n + c0);
+          vf[la][0] = wv.x; vf[la][1] = wv.y;
+        }
       }
 #pragma unroll
       for (int la = 0; la < HR; ++la) {
@@ -1709,16 +1739,17 @@ int ns_step_launch(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, i
   if constexpr (sizeof(T) == 8) {
     // register-tiled float64 path for 128x128 (BASELINE config 4 at the reference's own precision)
     if (!pdegym_force_generic() && C.nx == 128 && C.ny == 128) {
-      constexpr int lds_bytes = kF64HaloBytes + kF64ParkRows * 1024 * 16;
+      constexpr int kPRf64 = PDEGYM_NS_F64_TILE_ROWS;
+      constexpr int lds_bytes = F64Tile<kPRf64>::LDS_BYTES, nt = F64Tile<kPRf64>::NT;
       static signed char attr_a[pdegym::kMaxDevices] = {}, attr_b[pdegym::kMaxDevices] = {};
       if (buf->state_in) {
-        if (!pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&ns_tile_step_f64<true>), lds_bytes, attr_a))
+        if (!pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&ns_tile_step_f64<true, kPRf64>), lds_bytes, attr_a))
           return pdegym::fail(-4, "cannot raise the dynamic LDS limit");
-        hipLaunchKernelGGL(ns_tile_step_f64<true>, dim3(B), dim3(1024), lds_bytes, (hipStream_t)stream, C, S, P, B);
+        hipLaunchKernelGGL((ns_tile_step_f64<true, kPRf64>), dim3(B), dim3(nt), lds_bytes, (hipStream_t)stream, C, S, P, B);
       } else {
-        if (!pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&ns_tile_step_f64<false>), lds_bytes, attr_b))
+        if (!pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&ns_tile_step_f64<false, kPRf64>), lds_bytes, attr_b))
           return pdegym::fail(-4, "cannot raise the dynamic LDS limit");
-        hipLaunchKernelGGL(ns_tile_step_f64<false>, dim3(B), dim3(1024), lds_bytes, (hipStream_t)stream, C, S, P, B);
+        hipLaunchKernelGGL((ns_tile_step_f64<false, kPRf64>), dim3(B), dim3(nt), lds_bytes, (hipStream_t)stream, C, S, P, B);
       }
       return pdegym::check_launch("ns2d_tile_step_f64");
     }
