@@ -35,7 +35,7 @@ class PDEVecEnv:
     render_mode = None
 
     def __init__(self, env_id: str, num_envs: int, device="cuda", backend=None, batched_reset_func=None,
-                 dtype=None, **kw):
+                 dtype=None, copy_outputs: bool = False, **kw):
         import torch
         if env_id not in _KINDS:
             raise KeyError(f"No registered env with id: {env_id}")
@@ -46,6 +46,9 @@ class PDEVecEnv:
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
         self.batched_reset_func = batched_reset_func
+        # copy_outputs=True: step() / reset() hand out fresh NumPy arrays (+ ~40 us per step at 4096 x 257 float32) instead of
+        # views of the rotating pinned staging buffers -- for callers that keep results for more than two further steps
+        self.copy_outputs = bool(copy_outputs)
         self.reward_class = kw["reward_class"]
         self._actions = None
         self._fused_reset = False
@@ -368,7 +371,7 @@ class PDEVecEnv:
             pins[key][0].copy_(t, non_blocking=True)
             out.append(pins[key][1])
         torch.cuda.current_stream(self.device).synchronize()
-        return out
+        return [o.copy() for o in out] if self.copy_outputs else out
 
     def _fresh_infos(self):
         """One dict per environment, as SB3 expects -- but the B empty dicts are made once and handed out again every step;

@@ -310,6 +310,31 @@ def test_vecenv_custom_reward_navier_stokes(golden_ns, bk):
         venv_b.enable_fused_auto_reset()
 
 
+def test_device_sensing_noise_hook_on_the_cpu_double():
+    """sensing_noise_tensor_func on the torch-native face and in the eager DeviceRollout: the policy sees f(obs), the state stays
+    clean, the trajectory is that of the policy composed with f (the graph-captured form runs under -m gpu)."""
+    import torch
+    import pde_control_gym
+    from pde_control_gym import DeviceRollout
+    f = lambda o: o * 1.5 - 0.125
+    pol = lambda o: torch.tanh(o.mean(dim=1))
+
+    def venv(noise):
+        v = pde_control_gym.make_vec("PDEControlGym-TransportPDE1D", num_envs=3, device="cpu", backend=FakeBackend(),
+                                     sensing_noise_tensor_func=noise, **_transport_params(reset_init_condition_func=lambda nx: np.ones(nx) * 2.0))
+        v.reset_tensor()
+        return v
+
+    a = DeviceRollout(venv(f), pol, 4, use_graph=False).run()
+    b = DeviceRollout(venv(None), lambda o: pol(f(o)), 4, use_graph=False).run()
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.actions, b.actions) and torch.equal(a.obs_seen, f(a.obs)) and b.obs_seen is None
+    v = venv(f)
+    o, *_ = v.step_tensor(torch.zeros(3))
+    assert torch.equal(o, f(v.core.t["obs"]))
+    with pytest.raises(ValueError):
+        DeviceRollout(venv(f), pol, 4, use_graph=False, one_launch=True)
+
+
 def test_every_c_abi_call_runs_with_its_tensors_device_current(monkeypatch):
     """One process may drive several GPUs (one engine per device): every backend method that reaches the C ABI switches to the
     device of its tensors first (backend._on_device_of).  The guard cannot run for real on a one-GPU box (the -m gpu test needs
