@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PDEGYM_ABI_VERSION 12
+#define PDEGYM_ABI_VERSION 13
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
 #define PDEGYM_MAX_N1D 2048      /* nodes per 1D row kept in registers by the wave-per-instance kernels */
@@ -71,6 +71,11 @@ enum {
   PDEGYM_REWARD_NORM_L2 = 3,
   PDEGYM_REWARD_NORM_LINF = 4
 };
+/* NormReward horizon (rewards/norm_reward.py:52-59); "t-horizon" stays on the host path */
+enum {
+  PDEGYM_HORIZON_TEMPORAL = 0,     /* -||u[t]||                                                                */
+  PDEGYM_HORIZON_DIFFERENTIAL = 1  /* +||u[t] - u[t-1]|| over fine-time rows (t > 0), evaluated by pdegym_step1d_* */
+};
 
 /* Scalars of one 1D environment family (same for every instance of the batch). */
 typedef struct pdegym_params1d {
@@ -99,7 +104,7 @@ typedef struct pdegym_params1d {
                                sums they enter are evaluated in double and rounded once when the row is stored
                                (hyperbolic.py:146-155, parabolic.py:143-144)                                              */
   int32_t action_kind;      /* PDEGYM_ACTION_*                                                                            */
-  int32_t reserved_;        /* keeps sizeof a multiple of 8 */
+  int32_t reward_horizon;   /* PDEGYM_HORIZON_* (NormReward kinds only; pdegym_step1d, not the rollout entry points)      */
   double dt64, dx64;        /* the Python doubles themselves (used where they meet a float64 operand)                     */
   double max_control64;
 } pdegym_params1d;

@@ -71,10 +71,11 @@ def reward_spec_for(reward_class):
     if type(reward_class) is TunedReward1D:
         return RewardSpec(N.REWARD_TUNED1D, int(reward_class.nt), float(reward_class.truncate_penalty),
                           float(reward_class.terminate_reward))
-    if type(reward_class) is NormReward and reward_class.horizon == "temporal":
+    if type(reward_class) is NormReward and reward_class.horizon in ("temporal", "differential"):
         kind = {"1": N.REWARD_NORM_L1, "2": N.REWARD_NORM_L2, "inf": N.REWARD_NORM_LINF}[reward_class.norm]
+        horizon = N.HORIZON_DIFFERENTIAL if reward_class.horizon == "differential" else N.HORIZON_TEMPORAL
         return RewardSpec(kind, int(reward_class.nt), float(reward_class.truncate_penalty),
-                          float(reward_class.terminate_reward))
+                          float(reward_class.terminate_reward), horizon)
     return None
 
 

@@ -5,7 +5,7 @@ The reference class (rewards/norm_reward.py:19-73) cannot run: its first call co
 documented intent (reference docs/source/utils/preimplementedrewards.rst:10-14): PARITY UNPINNED.
 
   horizon="temporal"      -||u_t||                      (evaluated inside the step kernel)
-  horizon="differential"  ||u_t - u_{t-1}||  (t > 0)    (host path over the trajectory view)
+  horizon="differential"  ||u_t - u_{t-1}||  (t > 0)    (evaluated inside the step kernel: PDEGYM_HORIZON_DIFFERENTIAL)
   horizon="t-horizon"     -mean of the last k norms     (host path)
 """
 import numpy as np

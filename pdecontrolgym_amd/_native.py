@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 RING = 128
 LOOKBACK = 100
 MAX_N1D = 8192
@@ -22,6 +22,7 @@ FLUX_LINEAR, FLUX_BURGERS = 0, 1
 ACTION_F32, ACTION_F64, ACTION_WEAK = 0, 1, 2
 SENSE_FULL, SENSE_LAST, SENSE_LAST_DERIV, SENSE_FIRST_DERIV, SENSE_FIRST = range(5)
 REWARD_NONE, REWARD_TUNED1D, REWARD_NORM_L1, REWARD_NORM_L2, REWARD_NORM_LINF = range(5)
+HORIZON_TEMPORAL, HORIZON_DIFFERENTIAL = 0, 1      # NormReward horizon evaluated by the step kernels
 BC = {"Neumann": 0, "Dirchilet": 1, "Controllable": 2}
 EDGES = ("lower", "upper", "left", "right")
 
@@ -45,7 +46,7 @@ class Params1D(C.Structure):
                 ("reward_kind", C.c_int32), ("reward_nt", C.c_int32), ("dt", C.c_float), ("dx", C.c_float),
                 ("F", C.c_float), ("max_control", C.c_float), ("max_state", C.c_float),
                 ("truncate_penalty", C.c_float), ("terminate_reward", C.c_float), ("rdx", C.c_double),
-                ("flux", C.c_int32), ("beta_f64", C.c_int32), ("action_kind", C.c_int32), ("reserved_", C.c_int32),
+                ("flux", C.c_int32), ("beta_f64", C.c_int32), ("action_kind", C.c_int32), ("reward_horizon", C.c_int32),
                 ("dt64", C.c_double), ("dx64", C.c_double), ("max_control64", C.c_double)]
 
 

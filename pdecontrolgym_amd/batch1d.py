@@ -29,6 +29,7 @@ class RewardSpec:
     nt: int = 0
     truncate_penalty: float = -1e-4
     terminate_reward: float = 1e2
+    horizon: int = N.HORIZON_TEMPORAL      # NormReward kinds: HORIZON_DIFFERENTIAL = +||u[t] - u[t-1]|| (step kernels only)
 
 
 _BAD_SENSING_LOC = "Invalid sensing_loc parameter. Please use 'full', 'collocated', or 'opposite'. See documentation for details."
@@ -95,6 +96,7 @@ class PDEBatch1D:
         P.limit_state = 1 if limit_pde_state_size else 0
         P.reward_kind = self.reward_spec.kind
         P.reward_nt = int(self.reward_spec.nt)
+        P.reward_horizon = int(self.reward_spec.horizon) if self.reward_spec.kind >= N.REWARD_NORM_L1 else N.HORIZON_TEMPORAL
         P.dt, P.dx = dt, dx                       # ctypes c_float rounds the Python double to float32
         P.F = dt / (dx ** 2)                      # parabolic.py:138, computed in double then cast
         P.rdx = 1.0 / float(C.c_float(dx).value)  # reciprocal of the float32 dx, in double (see pdegym.h)
@@ -255,8 +257,9 @@ class PDEBatch1D:
 
     def can_rollout(self) -> bool:
         """True when ``rollout`` applies: the observation is the row (full-state sensing, no history), Dirichlet actuation,
-        float32 operands, register-resident rows."""
+        float32 operands, register-resident rows, and a reward the rollout kernels evaluate (not the "differential" horizon)."""
         return bool(self.state_in_obs and self.params.control_type != N.CONTROL["Neumann"] and not self.params.beta_f64
+                    and self.params.reward_horizon == N.HORIZON_TEMPORAL
                     and self.n <= N.MAX_N1D_REG and hasattr(self.backend, "rollout1d"))
 
     def policy_fits_rollout(self, policy) -> bool:

@@ -81,6 +81,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float wave_max(float v) {      // callers pass magnitudes: 0 is the identity
   return wave_reduce(v, 0.0f, [](float a, float b) { return fmaxf(a, b); });
 }
+// max of two magnitudes (sign bit clear) that propagates NaN like np.max: non-negative floats order as their bit patterns,
+// and every NaN pattern lies above +inf.  The Linf reward norms use it (np.linalg.norm(row, ord=inf) of a row holding NaN is NaN).
+__device__ __forceinline__ float mag_max(float a, float b) {
+  const unsigned int ua = __float_as_uint(a), ub = __float_as_uint(b);
+  return __uint_as_float(ua > ub ? ua : ub);
+}
+__device__ __forceinline__ float wave_mag_max(float v) {
+  return wave_reduce(v, 0.0f, [](float a, float b) { return mag_max(a, b); });
+}
 
 // value of slot s when lane l holds slots [l*EPL, l*EPL+EPL)
 template <int EPL>
@@ -147,7 +156,9 @@ struct Row {
 // reference's mixed-precision expressions (see step1d_wide_kernel for the same arithmetic on LDS-resident rows).
 template <int EPL, bool PARABOLIC, bool NEUMANN, bool FAST, bool HIST, bool BURGERS = false, bool M64 = false, bool ROLL = false>
 __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EPL], const pdegym_params1d& P, int nsub,
-                                             float a, float* ring, float* hist, int lane, const double* b64 = nullptr, double a64 = 0.0) {
+                                             float a, float* ring, float* hist, int lane, const double* b64 = nullptr, double a64 = 0.0,
+                                             float* xprev = nullptr, float* blprev = nullptr) {
+  // xprev/blprev (select form only): the row BEFORE the last sub-step, for NormReward's "differential" horizon
   static_assert(!(FAST && (NEUMANN || HIST)), "fast mode is the Dirichlet, history-free path");
   static_assert(!(FAST && M64), "the mixed-precision mode uses the select form");
   constexpr int J0 = PARABOLIC ? 1 : 0;
@@ -380,16 +391,23 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
     }
   } else {
     for (int s = 0; s < nsub; ++s) {
+      if (xprev && s == nsub - 1) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) xprev[e] = R.x[e];
+        *blprev = R.bl;
+      }
       pde_substep(std::true_type{}, std::false_type{});
       ++R.t;
       R.k = (R.k + 1 == S) ? 0 : R.k + 1;
       if constexpr (NEUMANN) R.bsum += (double)fabsf(bval);
       if constexpr (HIST) {
-        float* hrow = hist + (size_t)R.t * n;
-        if (PARABOLIC && lane == 0) hrow[0] = 0.0f;
+        if (hist) {     // HIST without a buffer: the select-form kernel taken for the "differential" reward
+          float* hrow = hist + (size_t)R.t * n;
+          if (PARABOLIC && lane == 0) hrow[0] = 0.0f;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e)
-          if (s0 + e < ns) hrow[J0 + s0 + e] = R.x[e];
+          for (int e = 0; e < EPL; ++e)
+            if (s0 + e < ns) hrow[J0 + s0 + e] = R.x[e];
+        }
       }
       record_norm(s + 1);
     }
@@ -471,6 +489,12 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
 #ifdef PDEGYM_TIMING
   const unsigned long long tm1 = __builtin_amdgcn_s_memtime() + (unsigned long long)(R.x[0] != R.x[0]);
 #endif
+  // NormReward "differential" (norm_reward.py:55-59): ||u[t] - u[t-1]|| over FINE rows, so the row before the last sub-step is
+  // kept.  Only the select-form instantiations evaluate it (launch_epl routes the request there; rollouts refuse it).
+  const bool differential = !kFast && P.reward_horizon == PDEGYM_HORIZON_DIFFERENTIAL && P.reward_kind >= PDEGYM_REWARD_NORM_L1;
+  float xprev[kFast ? 1 : EPL], blprev = 0.f;
+#pragma unroll
+  for (int e = 0; e < (kFast ? 1 : EPL); ++e) xprev[e] = 0.f;
   float norm_now;
   if constexpr (kFast) {
     // The fast loop freezes the controlled boundary slot with zero coefficients: x + 0*t keeps every x except -0.0
@@ -512,7 +536,8 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
       norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
     }
   } else {
-    run_substeps<EPL, PARABOLIC, NEUMANN, false, HIST, BURGERS, M64>(R, beta, P, nsub, a, ring, hist, lane, b64, a64);
+    run_substeps<EPL, PARABOLIC, NEUMANN, false, HIST, BURGERS, M64>(R, beta, P, nsub, a, ring, hist, lane, b64, a64,
+                                                                     differential ? xprev : nullptr, &blprev);
     norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
   }
   const int t = R.t;
@@ -529,16 +554,34 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
   const bool truncate = P.limit_state && (norm_now >= P.max_state);     // hyperbolic.py:182-194
   // NormReward variants need wave-wide reductions: do them before the single-lane tail
   float nr_alt = norm_now;
-  if (P.reward_kind == PDEGYM_REWARD_NORM_L1) {
+  bool nr_diff = false;
+  if constexpr (!kFast) {
+    if (differential && t > 0 && nsub > 0) {    // the row minus the one before it; the sign flips (norm_reward.py:56-58)
+      nr_diff = true;
+      const float d0 = fabsf(R.bl - blprev);      // node 0 is wave-uniform: joined after the reduction
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const float d = (s0 + e < ns) ? fabsf(R.x[e] - xprev[e]) : 0.f;
+        if (P.reward_kind == PDEGYM_REWARD_NORM_L1) acc += d;
+        else if (P.reward_kind == PDEGYM_REWARD_NORM_L2) acc += d * d;
+        else acc = mag_max(acc, d);
+      }
+      if (P.reward_kind == PDEGYM_REWARD_NORM_L1) nr_alt = wave_sum(acc) + d0;
+      else if (P.reward_kind == PDEGYM_REWARD_NORM_L2) nr_alt = sqrtf(wave_sum(acc) + d0 * d0);
+      else nr_alt = mag_max(wave_mag_max(acc), d0);
+    }
+  }
+  if (!nr_diff && P.reward_kind == PDEGYM_REWARD_NORM_L1) {
     float s1 = 0.f;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) s1 += (s0 + e < ns) ? fabsf(R.x[e]) : 0.f;
     nr_alt = wave_sum(s1) + fabsf(R.bl);
-  } else if (P.reward_kind == PDEGYM_REWARD_NORM_LINF) {
+  } else if (!nr_diff && P.reward_kind == PDEGYM_REWARD_NORM_LINF) {
     float m = fabsf(R.bl);
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) m = fmaxf(m, (s0 + e < ns) ? fabsf(R.x[e]) : 0.f);
-    nr_alt = wave_max(m);
+    for (int e = 0; e < EPL; ++e) m = mag_max(m, (s0 + e < ns) ? fabsf(R.x[e]) : 0.f);
+    nr_alt = wave_mag_max(m);
   }
   // look-back norm: fetched before the loop, captured inside it, the final row itself (nsub == 100 ends on it only
   // when LOOKBACK == 0, never), or 0 for an unwritten row
@@ -557,7 +600,8 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
     } else if (P.reward_kind >= PDEGYM_REWARD_NORM_L1) {
       // documented intent of norm_reward.py:48-54 ("temporal" horizon)
       reward = terminate ? P.terminate_reward
-                         : (truncate ? (float)((double)P.truncate_penalty * (double)(P.reward_nt - t)) : -nr_alt);
+                         : (truncate ? (float)((double)P.truncate_penalty * (double)(P.reward_nt - t))
+                                     : (nr_diff ? nr_alt : -nr_alt));
     }
   }
 
@@ -820,14 +864,26 @@ __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, p
   const bool terminate = t >= P.nt - 1;
   const bool truncate = P.limit_state && (norm_now >= P.max_state);
   float nr_alt = norm_now;
-  if (P.reward_kind == PDEGYM_REWARD_NORM_L1) {
+  // "differential" horizon (norm_reward.py:55-59): after the last swap nxt still holds the row before the last sub-step
+  const bool nr_diff = P.reward_horizon == PDEGYM_HORIZON_DIFFERENTIAL && P.reward_kind >= PDEGYM_REWARD_NORM_L1 && nsub > 0;
+  if (nr_diff) {
+    float acc = 0.f;
+    for (int j = lane; j < n; j += kWave) {
+      const float d = fabsf(cur[j] - nxt[j]);
+      if (P.reward_kind == PDEGYM_REWARD_NORM_L1) acc += d;
+      else if (P.reward_kind == PDEGYM_REWARD_NORM_L2) acc += d * d;
+      else acc = mag_max(acc, d);
+    }
+    nr_alt = P.reward_kind == PDEGYM_REWARD_NORM_LINF ? wave_mag_max(acc)
+                                                      : (P.reward_kind == PDEGYM_REWARD_NORM_L2 ? sqrtf(wave_sum(acc)) : wave_sum(acc));
+  } else if (P.reward_kind == PDEGYM_REWARD_NORM_L1) {
     float s1 = 0.f;
     for (int j = lane; j < n; j += kWave) s1 += fabsf(cur[j]);
     nr_alt = wave_sum(s1);
   } else if (P.reward_kind == PDEGYM_REWARD_NORM_LINF) {
     float m = 0.f;
-    for (int j = lane; j < n; j += kWave) m = fmaxf(m, fabsf(cur[j]));
-    nr_alt = wave_max(m);
+    for (int j = lane; j < n; j += kWave) m = mag_max(m, fabsf(cur[j]));
+    nr_alt = wave_mag_max(m);
   }
   const float norm_back = from_ring ? norm_back_pre : ((back_row >= 0) ? ((back_row == t) ? norm_now : back_norm) : 0.f);
   float reward = 0.f;
@@ -836,7 +892,8 @@ __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, p
     else if (truncate) reward = (float)((double)P.truncate_penalty * (double)(P.reward_nt - t));
     else reward = norm_back - norm_now;
   } else if (P.reward_kind >= PDEGYM_REWARD_NORM_L1) {
-    reward = terminate ? P.terminate_reward : (truncate ? (float)((double)P.truncate_penalty * (double)(P.reward_nt - t)) : -nr_alt);
+    reward = terminate ? P.terminate_reward
+                       : (truncate ? (float)((double)P.truncate_penalty * (double)(P.reward_nt - t)) : (nr_diff ? nr_alt : -nr_alt));
   }
   const bool auto_reset = (Bf.reset_init != nullptr) && (terminate || truncate);
   auto emit_obs = [&](float* obs_base, const float* row) {
@@ -978,7 +1035,9 @@ __global__ void selftest_quotient_kernel(const float* a, float dx, double rdx, u
 template <int EPL, bool PARABOLIC, bool BURGERS = false>
 int launch_epl(const pdegym_params1d& P, const pdegym_bufs1d& Bf, int B, hipStream_t st) {
   const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-  const bool neu = P.control_type == PDEGYM_CONTROL_NEUMANN, hist = Bf.history != nullptr;
+  // the select-form (HIST) instantiation also serves NormReward's "differential" horizon: it keeps the row before the last sub-step
+  const bool differential = P.reward_horizon == PDEGYM_HORIZON_DIFFERENTIAL && P.reward_kind >= PDEGYM_REWARD_NORM_L1;
+  const bool neu = P.control_type == PDEGYM_CONTROL_NEUMANN, hist = Bf.history != nullptr || differential;
   // (a dummy dynamic-LDS request that capped resident workgroups per CU was A/B-tested and removed: profiles/r02_ab_lds_balance.txt)
   constexpr int lds = 0;
   if (neu && hist)
@@ -1010,11 +1069,14 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
   if (P.reward_kind != PDEGYM_REWARD_NONE && !buf->reward) return pdegym::fail(-3, "null reward buffer");
   hipStream_t st = (hipStream_t)stream;
   if (P.action_kind < PDEGYM_ACTION_F32 || P.action_kind > PDEGYM_ACTION_WEAK) return pdegym::fail(-2, "bad action_kind");
+  if (P.reward_horizon != PDEGYM_HORIZON_TEMPORAL && P.reward_horizon != PDEGYM_HORIZON_DIFFERENTIAL)
+    return pdegym::fail(-2, "bad reward_horizon");
   if (P.beta_f64 || P.action_kind != PDEGYM_ACTION_F32) {   // the reference's float64-operand arithmetic (parity mode)
     const int slots = P.n - (PARABOLIC ? 1 : 0), epl64 = (slots + kWave - 1) / kWave;
     if (!BURGERS && epl64 <= 8) {      // rows of up to 512 nodes stay in registers in this mode too
       const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-      const bool neu = P.control_type == PDEGYM_CONTROL_NEUMANN, hist = buf->history != nullptr;
+      const bool neu = P.control_type == PDEGYM_CONTROL_NEUMANN,
+                 hist = buf->history != nullptr || (P.reward_horizon == PDEGYM_HORIZON_DIFFERENTIAL && P.reward_kind >= PDEGYM_REWARD_NORM_L1);
       auto go = [&](auto epl_tag) {
         constexpr int E = decltype(epl_tag)::value;
         if (neu && hist) hipLaunchKernelGGL((step1d_kernel<E, PARABOLIC, true, true, false, true>), grid, block, 0, st, P, *buf, B);
@@ -1104,6 +1166,7 @@ int launch_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const p
   if (P.control_type == PDEGYM_CONTROL_NEUMANN) return pdegym::fail(-2, "rollout: Neumann actuation is not supported");
   if (P.beta_f64 || P.action_kind != PDEGYM_ACTION_F32) return pdegym::fail(-2, "rollout: float32 beta and actions only");
   if (buf->history) return pdegym::fail(-2, "rollout cannot record a history buffer");
+  if (P.reward_horizon != PDEGYM_HORIZON_TEMPORAL) return pdegym::fail(-2, "rollout: only the temporal reward horizon is evaluated in the rollout kernels");
   if (!buf->beta || !buf->time_index || !buf->bsum || !buf->ring || !buf->norm_now || !buf->norm_back)
     return pdegym::fail(-3, "null device buffer");
   if (!ro->obs || !ro->actions || !ro->terminated || !ro->truncated) return pdegym::fail(-3, "null rollout buffer");

@@ -26,7 +26,8 @@ class FakeBackend:
         if P.reward_kind == N.REWARD_TUNED1D:
             rw = po.TunedReward1DOracle(P.reward_nt, P.truncate_penalty, P.terminate_reward)
         elif P.reward_kind >= N.REWARD_NORM_L1:
-            rw = po.NormRewardOracle(P.reward_nt, {2: "1", 3: "2", 4: "inf"}[P.reward_kind], P.truncate_penalty, P.terminate_reward)
+            rw = po.NormRewardOracle(P.reward_nt, {2: "1", 3: "2", 4: "inf"}[P.reward_kind], P.truncate_penalty, P.terminate_reward,
+                                     "differential" if P.reward_horizon == N.HORIZON_DIFFERENTIAL else "temporal")
         else:
             rw = None
         cls = po.ParabolicOracle if c.kind == "parabolic" else (po.BurgersOracle if getattr(c, "flux", "linear") == "burgers" else po.TransportOracle)
@@ -45,6 +46,7 @@ class FakeBackend:
         orc.beta = self._beta(T, B)
         src = T["state_in"] if T.get("state_in") is not None else (T["u"] if T.get("u") is not None else T["obs"])
         orc.row = src.numpy().copy()                 # state_in: the previous observation is the state (include/pdegym.h)
+        orc.prev_row = orc.row.copy()
         orc.time_index = T["time_index"].numpy().astype(np.int64)
         orc.bsum = T["bsum"].numpy().copy()
         orc.ring = T["ring"].numpy().copy()

@@ -223,13 +223,16 @@ def test_burgers_extension_matches_own_restatement(nx, S, B, ctrl):
         np.testing.assert_array_equal(env.t["history"].cpu().numpy(), orc.hist)
 
 
+@pytest.mark.parametrize("horizon", ["temporal", "differential"])
 @pytest.mark.parametrize("norm", ["1", "2", "inf"])
 @pytest.mark.parametrize("kind,nx,beta64", [("parabolic", 256, False), ("transport", 100, False), ("transport", 2100, False),
                                             ("parabolic", 2500, False), ("parabolic", 200, True), ("transport", 64, True)])
-def test_norm_reward_epilogues_match_oracle(kind, nx, beta64, norm):
-    """PDEGYM_REWARD_NORM_L1 / L2 / LINF ("temporal" NormReward, parity unpinned: the reference class raises) through the
+def test_norm_reward_epilogues_match_oracle(kind, nx, beta64, norm, horizon):
+    """PDEGYM_REWARD_NORM_L1 / L2 / LINF (NormReward, parity unpinned: the reference class raises) through the
     register-resident kernel (n <= 2048), the wide LDS kernel (n > 2048) and the mixed-precision kernel (float64 beta) against
-    NormRewardOracle: -||u_t|| per step, the truncation penalty and the terminal reward.  rtol 1e-6 (reduction order)."""
+    NormRewardOracle: -||u_t|| ("temporal") or +||u_t - u_{t-1}|| over fine-time rows ("differential", evaluated by the
+    select-form kernel, which keeps the row before its last sub-step) per step, the truncation penalty and the terminal
+    reward.  rtol 1e-6 (reduction order); the differential norm is a sum of rounded differences, so atol 1e-6 of the row scale."""
     from oracle import pde_oracle as po
     from pdecontrolgym_amd import _native as N
     from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
@@ -252,10 +255,12 @@ def test_norm_reward_epilogues_match_oracle(kind, nx, beta64, norm):
     kw["max_state_value"] = 0.5 * l2_0
     init[1:] *= np.float32(0.2 * l2_0 / np.max(np.linalg.norm(init[1:], axis=1)))
     orc = (po.ParabolicOracle if kind == "parabolic" else po.TransportOracle)(
-        reward=po.NormRewardOracle(rargs[0], norm, rargs[1], rargs[2]), keep_history=False, **_oracle_kwargs(kw))
-    env = PDEBatch1D(kind, reward=RewardSpec(code, *rargs), num_envs=B, device="cuda", **kw)
+        reward=po.NormRewardOracle(rargs[0], norm, rargs[1], rargs[2], horizon), keep_history=False, **_oracle_kwargs(kw))
+    hz = N.HORIZON_DIFFERENTIAL if horizon == "differential" else N.HORIZON_TEMPORAL
+    env = PDEBatch1D(kind, reward=RewardSpec(code, *rargs, hz), num_envs=B, device="cuda", **kw)
     orc.reset(init, beta)
     env.reset(torch.tensor(init), torch.tensor(beta))
+    assert env.can_rollout() == (horizon == "temporal" and not beta64 and n <= N.MAX_N1D_REG)
     saw_trunc = saw_term = False
     for i in range(nsteps):
         a = rng.uniform(-1, 1, B).astype(np.float32)
@@ -268,7 +273,8 @@ def test_norm_reward_epilogues_match_oracle(kind, nx, beta64, norm):
         np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-6, err_msg=f"step {i}")
         saw_trunc |= bool((tr_ref & ~te_ref).any())
         saw_term |= bool(te_ref.any())
-        assert (r_ref[~te_ref & ~tr_ref] < 0).all()
+        live = r_ref[~te_ref & ~tr_ref]
+        assert (live > 0).all() if horizon == "differential" else (live < 0).all()
     assert saw_trunc and saw_term
 
 

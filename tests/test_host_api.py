@@ -224,6 +224,46 @@ def test_custom_reward_class_gets_a_trajectory_view(golden_transport, bk):
 
 
 @pytest.mark.parametrize("bk", BACKENDS)
+@pytest.mark.parametrize("norm", ["1", "2", "inf"])
+def test_norm_reward_differential_is_evaluated_by_the_step_kernel(bk, norm):
+    """NormReward(horizon="differential") maps onto the in-kernel reward (reward_horizon of pdegym_params1d; no host callback,
+    no recorded trajectory on the batched face) and equals the host definition ||u[t] - u[t-1]|| over fine-time rows, evaluated
+    on the trajectory of a single environment that records it; "t-horizon" stays on the host path."""
+    import pde_control_gym
+    from pde_control_gym.src import NormReward, TransportPDE1D
+    from pde_control_gym.src.environments1d.base_env_1d import reward_spec_for
+    from pdecontrolgym_amd import _native as N
+    assert reward_spec_for(NormReward(10, norm, "differential")).horizon == N.HORIZON_DIFFERENTIAL
+    assert reward_spec_for(NormReward(10, norm, "temporal")).horizon == N.HORIZON_TEMPORAL
+    assert reward_spec_for(NormReward(10, norm, "t-horizon")) is None
+    B, T, dt = 3, 0.05, 1e-4
+    ics = [np.linspace(1.0, 2.0 + k, 100).astype(np.float32) for k in range(B)]
+    import itertools
+    it = itertools.cycle(ics)                 # the episode-end auto reset draws initial conditions again
+    rw = NormReward(int(round(T / dt)), norm, "differential", -2.0, 55.0)
+    p = _transport_params(T=T, dt=dt, control_sample_rate=0.01, reward_class=rw, reset_init_condition_func=lambda nx: next(it))
+    venv = pde_control_gym.make_vec("PDEControlGym-TransportPDE1D", num_envs=B, **_bk(bk), **p)
+    assert not venv._host_reward and venv.core.t["history"] is None and not venv.core.can_rollout()
+    venv.reset()
+    singles = []
+    for b in range(B):
+        e = TransportPDE1D(**_bk(bk), **_transport_params(T=T, dt=dt, control_sample_rate=0.01, reward_class=rw,
+                                                          reset_init_condition_func=lambda nx, b=b: ics[b]))
+        e.reset()
+        singles.append(e)
+    rng = np.random.default_rng(5)
+    for i in range(5):
+        a = rng.uniform(-1, 1, (B, 1)).astype(np.float32)
+        _, r, dones, _ = venv.step(a)
+        for b, e in enumerate(singles):
+            _, r1, te, tr, _ = e.step(a[b])
+            want = rw.reward(e.u, e.time_index, te, tr, a[b])
+            assert r1 == pytest.approx(want, rel=1e-5, abs=1e-6) and r[b] == pytest.approx(want, rel=1e-5, abs=1e-6)
+            assert (want == 55.0) == te and (te or want > 0)
+    assert dones.all()
+
+
+@pytest.mark.parametrize("bk", BACKENDS)
 def test_vecenv_accepts_custom_reward_classes(golden_transport, bk):
     """docs/source/utils/customrewards.rst on the batched face: a user BaseReward subclass is evaluated per instance on a
     lazy view of the device-resident trajectory (slow compatibility path); values equal those of single environments."""
