@@ -149,6 +149,19 @@ struct Row {
   float back_norm;  // its norm, captured in the loop (lane-uniform)
 };
 
+// State of one instance kept in registers ACROSS the env-steps of a rollout launch (rollout1d_kernel): the row, its plant
+// parameter, the time index, the running |u[-1]| sum and the wave maximum of |dt*beta| (constant between resets).
+template <int EPL>
+struct Carry {
+  float x[EPL];
+  float beta[EPL];
+  float bl;
+  float cm;       // wave_max |dt * beta[j]| (the fast-loop overflow pre-check)
+  float norm;     // ||row||_2 as the previous step (or the prologue) computed it: an upper bound of max |row[j]|
+  int t;
+  double bsum;
+};
+
 // S sub-steps of one instance.  FAST: boundary/padding slots are frozen by zero coefficients (no selects);
 // otherwise explicit selects (exact for non-finite states, and required when the boundary value changes every
 // sub-step, i.e. parabolic Neumann control).
@@ -430,11 +443,15 @@ __device__ __forceinline__ void load_row(Row<EPL>& R, float (&beta)[EPL], const 
 }
 
 // One env-step of one instance by one wave: the body of step1d_kernel, and of every iteration of rollout1d_kernel.
-template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false, bool M64 = false, bool ROLL = false>
+// CARRY (rollout1d_kernel): the state enters and leaves through *carry instead of memory -- no row / beta / time-index / sum
+// loads at the head of the step; the stores stay (observation slot t + 1, scalars), nothing waits for them.
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false, bool M64 = false, bool ROLL = false,
+          bool CARRY = false>
 __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdegym_bufs1d& Bf, const int B, const int inst,
-                                            const int lane, const float* command = nullptr) {
+                                            const int lane, const float* command = nullptr, Carry<EPL>* carry = nullptr) {
   constexpr int J0 = PARABOLIC ? 1 : 0;
   constexpr bool kFast = !NEUMANN && !HIST && !M64;
+  static_assert(!CARRY || kFast, "the carried state is the float32 Dirichlet rollout path");
 #ifdef PDEGYM_TIMING
   const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
   const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
@@ -454,15 +471,31 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
 
   Row<EPL> R;
   float beta[EPL];
-  load_row<EPL, PARABOLIC>(R, beta, urow_in, brow, n, lane);
+  if constexpr (CARRY) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      R.x[e] = carry->x[e];
+      beta[e] = carry->beta[e];
+    }
+    R.bl = carry->bl;
+  } else {
+    load_row<EPL, PARABOLIC>(R, beta, urow_in, brow, n, lane);
+  }
   double b64[M64 ? EPL : 1];
   if constexpr (M64) {
     const double* brow64 = static_cast<const double*>(Bf.beta) + (size_t)inst * Bf.beta_stride;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) b64[e] = (beta64 && s0 + e < ns) ? brow64[J0 + s0 + e] : 0.0;
   }
-  const int t_in = __builtin_amdgcn_readfirstlane(Bf.time_index[inst]);
-  const double bsum_in = Bf.bsum[inst];
+  int t_in;
+  double bsum_in;
+  if constexpr (CARRY) {
+    t_in = __builtin_amdgcn_readfirstlane(carry->t);     // wave-uniform by construction; keeps the loop counters scalar
+    bsum_in = carry->bsum;
+  } else {
+    t_in = __builtin_amdgcn_readfirstlane(Bf.time_index[inst]);
+    bsum_in = Bf.bsum[inst];
+  }
   const int S = P.substeps > 0 ? P.substeps : 1;
   int nsub = P.nt - 1 - t_in;  // hyperbolic.py:140: while i < sample_rate and time_index < nt-1
   nsub = nsub < P.substeps ? nsub : P.substeps;
@@ -507,13 +540,22 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
       // most g = 1 + max|dt*beta| (+ rounding); otherwise by 1 + 4|F| + max|dt*beta|.  If max|u| * g^nsub can reach 2^126 the
       // exact loop runs instead (wave-uniform; costs two wave reductions per launch).
       float mx = fmaxf(fabsf(R.bl), fabsf(normalize_ctrl(a, P.max_control, P.normalize))), cm = 0.f;
+      if constexpr (CARRY) {
+        // no reductions here: max|dt*beta| is carried, and max|u| <= ||u||_2, the norm the previous step ended with.  That norm
+        // is a float sum of squares: any |u[j]| >= 2^-60 has a normal square, so norm*(1 + 2^-10) bounds it; smaller rows are
+        // covered by the 2^-60 floor.  A non-finite norm (NaN would be dropped by fmaxf) takes the exact loop.
+        mx = fmaxf(fabsf(normalize_ctrl(a, P.max_control, P.normalize)), fmaxf(carry->norm * 1.0009765625f, 8.673617379884035e-19f));
+        cm = carry->cm;
+        exact = exact || !(carry->norm <= 3.4028234663852886e38f);
+      } else {
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) {
-        mx = fmaxf(mx, fabsf(R.x[e]));
-        cm = fmaxf(cm, fabsf(P.dt * beta[e]));
+        for (int e = 0; e < EPL; ++e) {
+          mx = fmaxf(mx, fabsf(R.x[e]));
+          cm = fmaxf(cm, fabsf(P.dt * beta[e]));
+        }
+        mx = wave_max(mx);
+        cm = wave_max(cm);
       }
-      mx = wave_max(mx);
-      cm = wave_max(cm);
       const float g = ((P.F >= 0.0f && P.F <= 0.5f) ? 1.0f : 1.0f + 4.0f * fabsf(P.F)) + cm + 9.5367431640625e-7f;
       exact = exact || !(__log2f(mx) + (float)nsub * __log2f(g) < 126.0f);   // NaN / inf anywhere -> exact
     }
@@ -524,7 +566,14 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
       // inf/NaN somewhere (or a squared overflow): 0*inf may have leaked into a frozen slot -> redo exactly
       exact = !(fabsf(norm_now) <= 3.4028234663852886e38f);
       if (exact) {
+        if constexpr (CARRY) {
+          // the carried input was overwritten: observation slot t holds the row (each lane re-reads the slots it stored),
+          // beta may have been redrawn by another lane's stores of an earlier auto-reset -> order them first
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         load_row<EPL, PARABOLIC>(R, beta, urow_in, brow, n, lane);
+        if constexpr (CARRY) R.bl = carry->bl;
         R.t = t_in;
         R.k = (t_in + PDEGYM_LOOKBACK) % S;
         R.bsum = bsum_in;
@@ -643,6 +692,11 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
       Bf.time_index[inst] = t;
       Bf.bsum[inst] = R.bsum;
     }
+    if constexpr (CARRY) {
+      carry->t = t;
+      carry->bsum = R.bsum;
+      carry->norm = norm_now;
+    }
   } else {
     // fused VecEnv auto-reset: keep the terminal observation, restart from the pool row (hyperbolic.py:214-227)
     if (Bf.final_obs) emit_obs(Bf.final_obs);
@@ -657,6 +711,15 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
         float* bdst = const_cast<float*>(brow);
         const float* bsrc = static_cast<const float*>(Bf.reset_beta) + (size_t)prow * n;
         for (int j = lane; j < n; j += kWave) bdst[j] = bsrc[j];
+        if constexpr (CARRY) {      // the carried copy follows the redraw
+          float cm = 0.f;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            carry->beta[e] = (s0 + e < ns) ? bsrc[J0 + s0 + e] : 0.f;
+            cm = fmaxf(cm, fabsf(P.dt * carry->beta[e]));
+          }
+          carry->cm = wave_max(cm);
+        }
       }
     }
     if (Bf.reset_count && lane == 0) Bf.reset_count[inst] += 1;
@@ -679,6 +742,16 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
       Bf.bsum[inst] = (double)fabsf(last);
       ring[0] = n0;
     }
+    if constexpr (CARRY) {
+      carry->t = 0;
+      carry->bsum = (double)fabsf(last);
+      carry->norm = n0;
+    }
+  }
+  if constexpr (CARRY) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) carry->x[e] = R.x[e];
+    carry->bl = R.bl;
   }
 #ifdef PDEGYM_TIMING
   if (lane == 0) {
@@ -703,11 +776,32 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_pa
   step1d_body<EPL, PARABOLIC, NEUMANN, HIST, BURGERS, M64>(P, Bf, B, inst, lane);
 }
 
-// T env-steps of one instance by one wave in ONE launch (pdegym_*_rollout): iteration t is exactly the step kernel's body with
-// the row read from observation slot t and written to slot t + 1, action / reward / flags taken from / written to row t of
-// the [T, B] rollout arrays -- so every value equals what T separate step calls produce, bit for bit.  What it removes is
-// the kernel boundary between env-steps: no dispatch gap, no L2 invalidate (the row a wave wrote is re-read from its own
-// CU's cache path), and the waves of a SIMD drift apart instead of finishing in two generations.
+// The state a rollout launch starts from, read ONCE: row (observation slot 0), beta, time index and |u[-1]| sum.
+template <int EPL, bool PARABOLIC>
+__device__ __forceinline__ void carry_load(Carry<EPL>& C, const pdegym_params1d& P, const pdegym_bufs1d& Bf, const float* row0, int inst,
+                                           int lane) {
+  constexpr int J0 = PARABOLIC ? 1 : 0;
+  const int ns = P.n - J0, s0 = lane * EPL;
+  Row<EPL> R0;
+  load_row<EPL, PARABOLIC>(R0, C.beta, row0 + (size_t)inst * P.n, static_cast<const float*>(Bf.beta) + (size_t)inst * Bf.beta_stride, P.n, lane);
+  float cm = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    C.x[e] = R0.x[e];
+    cm = fmaxf(cm, fabsf(P.dt * C.beta[e]));
+  }
+  C.bl = R0.bl;
+  C.cm = wave_max(cm);
+  C.norm = sqrtf(slots_sumsq<EPL>(C.x, s0, ns) + C.bl * C.bl);
+  C.t = __builtin_amdgcn_readfirstlane(Bf.time_index[inst]);
+  C.bsum = Bf.bsum[inst];
+}
+
+// T env-steps of one instance by one wave in ONE launch (pdegym_*_rollout): iteration t is the step kernel's body with the
+// row written to observation slot t + 1, action / reward / flags taken from / written to row t of the [T, B] rollout arrays
+// -- every value equals what T separate step calls produce, bit for bit.  What it removes is the kernel boundary between
+// env-steps: no dispatch gap, no load phase (the state stays in registers, Carry), and the waves of a SIMD drift apart
+// instead of finishing in two generations.
 template <int EPL, bool PARABOLIC, bool BURGERS>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void rollout1d_kernel(pdegym_params1d P, pdegym_bufs1d Bf, pdegym_rollout1d Ro,
                                                                          int B) {
@@ -715,6 +809,12 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void rollout1d_kernel(pdegym
   const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (inst >= B) return;  // wave-uniform
   const size_t slot = (size_t)B * P.n;
+  // The state stays in registers over the T env-steps (Carry); each step still stores its observation slot and scalars, but
+  // no step waits for memory at its head -- the next command is fetched one step ahead, and the norm ring is read and written
+  // by lane 0 alone (program order of one lane).
+  Carry<EPL> C;
+  carry_load<EPL, PARABOLIC>(C, P, Bf, Ro.obs, inst, lane);
+  float a_next = Ro.actions[inst];
   for (int t = 0; t < Ro.T; ++t) {
     pdegym_bufs1d S = Bf;
     S.u = nullptr;
@@ -725,11 +825,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void rollout1d_kernel(pdegym
     S.reward = Ro.rewards + (size_t)t * B;
     S.terminated = Ro.terminated + (size_t)t * B;
     S.truncated = Ro.truncated + (size_t)t * B;
-    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false, true>(P, S, B, inst, lane);
-    // lane 0's stores (node 0 of a parabolic row, time index, |u| sum, norm ring) are read by the whole wave in the next
-    // iteration: make them visible first
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const float a = a_next;
+    if (t + 1 < Ro.T) a_next = Ro.actions[(size_t)(t + 1) * B + inst];
+    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false, true, true>(P, S, B, inst, lane, &a, &C);
   }
 }
 
@@ -1130,10 +1228,17 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy
   float* const xw = pol_smem + St.end + wave * (xpad + 2 * pol::kMaxWidth);
   float* const hw = xw + xpad;
   const size_t slot = (size_t)B * n;
+  constexpr int J0 = PARABOLIC ? 1 : 0;
+  const int ns = n - J0, s0 = lane * EPL;
+  Carry<EPL> C;       // the state stays in registers over the T env-steps (see rollout1d_kernel)
+  carry_load<EPL, PARABOLIC>(C, P, Bf, Ro.obs, inst, lane);
+  for (int j = n + lane; j < xpad; j += kWave) xw[j] = 0.f;     // zero padding to a multiple of four: written once
   for (int t = 0; t < Ro.T; ++t) {
-    // observation of this instance (slot t) -> LDS, zero-padded to a multiple of four
-    const float* xrow = Ro.obs + (size_t)t * slot + (size_t)inst * n;
-    for (int j = lane; j < xpad; j += kWave) xw[j] = j < n ? xrow[j] : 0.f;
+    // observation of this instance -> LDS, straight from the carried row (slot t of Ro.obs holds the same values)
+    if (PARABOLIC && lane == 0) xw[0] = C.bl;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+      if (s0 + e < ns) xw[J0 + s0 + e] = C.x[e];
     pol::wave_lds_sync();
     float a = pol::lane_value(pol::eval(N, St, pol_smem, xw, hw, n, lane), 0);      // neuron 0 of the last layer
     if (N.noise) a += N.noise[((size_t)t * B + inst) * N.noise_stride];
@@ -1149,9 +1254,7 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy
     S.reward = Ro.rewards + (size_t)t * B;
     S.terminated = Ro.terminated + (size_t)t * B;
     S.truncated = Ro.truncated + (size_t)t * B;
-    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false, true>(P, S, B, inst, lane, &a);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false, true, true>(P, S, B, inst, lane, &a, &C);
   }
 }
 
