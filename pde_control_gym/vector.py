@@ -49,6 +49,9 @@ class PDEVecEnv:
         # copy_outputs=True: step() / reset() hand out fresh NumPy arrays (+ ~40 us per step at 4096 x 257 float32) instead of
         # views of the rotating pinned staging buffers -- for callers that keep results for more than two further steps
         self.copy_outputs = bool(copy_outputs)
+        # state_in_obs=False (1D) / interleaved_state=False (NavierStokes2D) in the parameters: the engine keeps the plant state in
+        # its own tensors and the observation is a separate output -- for torch callers that normalise or perturb the tensors
+        # returned by step_tensor() / reset_tensor() IN PLACE (by default those tensors ARE the state: read-only).
         self.reward_class = kw["reward_class"]
         self._actions = None
         self._fused_reset = False
@@ -84,7 +87,8 @@ class PDEVecEnv:
                                max_control_value=kw.get("max_control_value", 20),
                                limit_pde_state_size=kw.get("limit_pde_state_size", False),
                                max_state_value=kw.get("max_state_value", 1e10), reward=spec, num_envs=self.num_envs,
-                               device=self.device, backend=backend, flux=self._flux, record_history=self._host_reward)
+                               device=self.device, backend=backend, flux=self._flux, record_history=self._host_reward,
+                               state_in_obs=bool(kw.get("state_in_obs", True)))
         self.nx, self.nt = self.core.nx, self.core.nt
         msv = kw.get("max_state_value", 1e10)
         d = self.core.obs_dim
@@ -110,7 +114,7 @@ class PDEVecEnv:
                               density=kw.get("density", 1.0),
                               maximum_pressure_iteration=int(kw.get("maximum_pressure_iteration", 2000)),
                               stable_factor=kw.get("stable_factor", 0.5), num_envs=self.num_envs, device=self.device,
-                              dtype=tdtype, backend=backend)
+                              dtype=tdtype, backend=backend, interleaved_state=bool(kw.get("interleaved_state", True)))
         self.nx, self.ny, self.nt = self.core.nx, self.core.ny, self.core.nt
         if self._host_reward:
             nbytes = self.num_envs * self.nt * self.ny * self.nx * 2 * (8 if tdtype == torch.float64 else 4)

@@ -224,6 +224,31 @@ def test_custom_reward_class_gets_a_trajectory_view(golden_transport, bk):
 
 
 @pytest.mark.parametrize("bk", BACKENDS)
+def test_vecenv_with_a_separate_state_tolerates_in_place_edits_of_the_observation(bk):
+    """make_vec(..., state_in_obs=False): the observation tensor is an output only, so a caller that scales it in place does not
+    touch the plant -- trajectories equal those of the default engine (observation = state, read-only) step for step."""
+    import itertools
+    import torch
+    import pde_control_gym
+    B = 3
+    ics = [np.linspace(1.0, 2.0 + k, 100).astype(np.float32) for k in range(B)]
+    mk = lambda **extra: pde_control_gym.make_vec(  # noqa: E731
+        "PDEControlGym-TransportPDE1D", num_envs=B, **_bk(bk),
+        **_transport_params(T=0.05, dt=1e-4, control_sample_rate=0.01, reset_init_condition_func=(lambda it: lambda nx: next(it))(itertools.cycle(ics)), **extra))
+    ref, sep = mk(), mk(state_in_obs=False)
+    assert ref.core.state_in_obs and not sep.core.state_in_obs
+    o_ref, o_sep = ref.reset_tensor(), sep.reset_tensor()
+    assert torch.equal(o_ref, o_sep)
+    rng = np.random.default_rng(3)
+    for i in range(4):
+        a = torch.as_tensor(rng.uniform(-1, 1, (B, 1)).astype(np.float32), device=o_ref.device)
+        o_sep.mul_(0.0)                              # in-place post-processing of the previous observation
+        o_ref, r_ref, d_ref, _ = ref.step_tensor(a)
+        o_sep, r_sep, d_sep, _ = sep.step_tensor(a)
+        assert torch.equal(o_ref, o_sep) and torch.equal(r_ref, r_sep) and torch.equal(d_ref, d_sep)
+
+
+@pytest.mark.parametrize("bk", BACKENDS)
 @pytest.mark.parametrize("norm", ["1", "2", "inf"])
 def test_norm_reward_differential_is_evaluated_by_the_step_kernel(bk, norm):
     """NormReward(horizon="differential") maps onto the in-kernel reward (reward_horizon of pdegym_params1d; no host callback,
