@@ -751,7 +751,7 @@ def main():
             try:
                 w2 = cls(device, 99)
                 n2 = max(40, args.steps // 2) if name not in ("ns2d_c4_b4096", "ns2d_c5", "ns2d_example", "ns2d_c5_f64", "ns2d_c4_f64_b4096") else 20
-                r2 = run_workload(w2, n2, max(5, args.warmup // 2), 1, graph=use_graph, repeats=3)
+                r2 = run_workload(w2, n2, max(5, args.warmup // 2), 1, graph=use_graph, repeats=REPEATS)
                 rf = roofline_block(w2, name, r2["step_ms_events"], True)
                 also[name] = {"value": w2.units_per_step() * n2 / r2["seconds"], "unit": "env-steps/s", "ms_per_step": r2["seconds"] / n2 * 1e3,
                               "dtype": w2.dtype, "timed_regions_s": r2["all_regions_s"],
