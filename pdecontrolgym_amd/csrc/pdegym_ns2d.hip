@@ -379,8 +379,8 @@ __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, 
 //   * top/bottom patch halos: one PC-wide vector per thread through a double-buffered LDS area (32 KB), one
 //     barrier per exchange;
 //   * p and 0.25*dx*dy*rhs stay in registers for all K Jacobi sweeps on a ROTATING row map (no register copies);
-//     u*, v* are parked in caller scratch meanwhile (L2/MALL resident);
-//   * ~100 VGPRs -> 4 waves per SIMD, two instances per CU.
+//     u*, v* wait on chip meanwhile (v* and three u* rows in registers, five u* rows in LDS);
+//   * 128 VGPRs -> 4 waves per SIMD, two instances per CU.
 // Same expression tree as ns_generic<float> (the fma below is exact-equivalent), so both agree bit for bit.
 // ================================================================================================
 
@@ -633,8 +633,6 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
   float* u = INTERLEAVED ? nullptr : P.u + (size_t)b * ncell;
   float* v = INTERLEAVED ? nullptr : P.v + (size_t)b * ncell;
   float* p = P.p + (size_t)b * ncell;
-  float* us = P.scratch + (size_t)b * 4 * ncell;
-  float* vs = us + ncell;
   const float* act = P.action + (size_t)b * C.action_dim;
   const float* sin = INTERLEAVED ? P.state_in + (size_t)b * ncell * 2 : nullptr;
   int xc = 0;
@@ -647,6 +645,12 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
 #endif
 
   float rq[PR][PC];  // 0.25*dx*dy*rhs, kept for all sweeps
+  // u* and v* wait on chip for the corrector: v* and three u* rows in registers (next to rq and p they fill 112 of the 128
+  // registers during the sweeps), the other five u* rows in this thread's LDS slots -- nothing is parked in the caller's scratch
+  // (until the end of round 3 v* and three u* rows went there and back: 176 KB of HBM traffic per 128 x 128 env-step)
+  float vkeep[PR][PC];
+  constexpr int kUKeep = PR - TileCfg<PR, PC>::PARK_ROWS > 0 ? PR - TileCfg<PR, PC>::PARK_ROWS : 1;
+  float ukeep[kUKeep][PC];
   {
     float uf[PR][PC], vf[PR][PC];
     if constexpr (INTERLEAVED) {  // (u, v) interleaved: the previous call's observation IS the state
@@ -712,11 +716,18 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
       V* park = reinterpret_cast<V*>(smem_raw + TileCfg<PR, PC>::LDS_BYTES);
 #pragma unroll
       for (int a = 0; a < PR; ++a) {
-        if (a < TileCfg<PR, PC>::PARK_ROWS) park[a * 512 + tid] = pack_row<PC>(uf[a]);      // read back by this thread only
-        else *reinterpret_cast<V*>(us + ((r0 + a) * n + c0)) = pack_row<PC>(uf[a]);
+        if (a < TileCfg<PR, PC>::PARK_ROWS) {
+          park[a * 512 + tid] = pack_row<PC>(uf[a]);      // read back by this thread only
+        } else {
+#pragma unroll
+          for (int k = 0; k < PC; ++k) ukeep[a - TileCfg<PR, PC>::PARK_ROWS][k] = uf[a][k];
+        }
       }
     }
-    store_patch<PR, PC>(vf, vs, n, r0, c0);
+#pragma unroll
+    for (int a = 0; a < PR; ++a)
+#pragma unroll
+      for (int k = 0; k < PC; ++k) vkeep[a][k] = vf[a][k];
     // ---- rhs (:101-103), pre-multiplied by 0.25*dx*dy (:108) ----
     {
       float vt[PC], vb[PC], dummy_t[PC], dummy_b[PC];
@@ -811,9 +822,12 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
       for (int la = 0; la < HR; ++la) {     // written by this same thread above
         if (a0 + la < TileCfg<PR, PC>::PARK_ROWS)
           unpack_row<PC>(reinterpret_cast<const V*>(smem_raw + TileCfg<PR, PC>::LDS_BYTES)[(a0 + la) * 512 + tid], uf[la]);
-        else
-          unpack_row<PC>(*reinterpret_cast<const V*>(us + ((r0 + a0 + la) * n + c0)), uf[la]);
-        unpack_row<PC>(*reinterpret_cast<const V*>(vs + ((r0 + a0 + la) * n + c0)), vf[la]);
+        else {
+#pragma unroll
+          for (int k = 0; k < PC; ++k) uf[la][k] = ukeep[a0 + la - TileCfg<PR, PC>::PARK_ROWS][k];
+        }
+#pragma unroll
+        for (int k = 0; k < PC; ++k) vf[la][k] = vkeep[a0 + la][k];
       }
 #pragma unroll
       for (int la = 0; la < HR; ++la) {
@@ -874,7 +888,7 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
     P.terminated[b] = (t >= C.nt - 1) ? 1 : 0;
 #ifdef PDEGYM_TIMING
     tm[5] = __builtin_amdgcn_s_memtime();
-    unsigned int* dbg = reinterpret_cast<unsigned int*>(us + 2 * ncell);   // rhs quarter of the scratch is unused here
+    unsigned int* dbg = reinterpret_cast<unsigned int*>(P.scratch + (size_t)b * 4 * ncell + 2 * ncell);   // the scratch is unused here
     for (int i = 0; i < 5; ++i) dbg[i] = (unsigned int)(tm[i + 1] - tm[i]);
 #endif
   }

@@ -124,8 +124,8 @@ struct TileCfg {
   static constexpr int N = 32 * PC;                      // grid side (== 16 * PR)
   static constexpr int BUF = 2 * NT;                     // vectors per halo buffer (top edges, bottom edges)
   static constexpr int LDS_BYTES = 2 * BUF * PC * 4;     // two buffers
-  // rows of u* that wait in LDS (one PC-wide vector per thread and row) instead of the caller's scratch while the
-  // pressure solve runs: 128x128 -> 5 of 8 rows = 40 KB, so that two workgroups (2 x 72 KB) still share a CU's 160 KB
+  // rows of u* that wait in LDS (one PC-wide vector per thread and row) while the pressure solve runs -- the others and v* stay
+  // in registers: 128x128 -> 5 of 8 rows = 40 KB, so that two workgroups (2 x 72 KB) still share a CU's 160 KB
   static constexpr int PARK_ROWS = (PR == 8 && PC == 4) ? 5 : 0;
   static constexpr int PARK_BYTES = PARK_ROWS * NT * PC * 4;
   static_assert(16 * PR == 32 * PC, "square grids only");
