@@ -379,7 +379,7 @@ __global__ __launch_bounds__(1024) void ns_generic_step(NSConst C, NSScal<T> S, 
 //   * top/bottom patch halos: one PC-wide vector per thread through a double-buffered LDS area (32 KB), one
 //     barrier per exchange;
 //   * p and 0.25*dx*dy*rhs stay in registers for all K Jacobi sweeps on a ROTATING row map (no register copies);
-//     u*, v* wait on chip meanwhile (v* and three u* rows in registers, five u* rows in LDS);
+//     u*, v* wait on chip meanwhile (v* and two u* rows in registers, six u* rows in LDS);
 //   * 128 VGPRs -> 4 waves per SIMD, two instances per CU.
 // Same expression tree as ns_generic<float> (the fma below is exact-equivalent), so both agree bit for bit.
 // ================================================================================================
@@ -645,8 +645,8 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
 #endif
 
   float rq[PR][PC];  // 0.25*dx*dy*rhs, kept for all sweeps
-  // u* and v* wait on chip for the corrector: v* and three u* rows in registers (next to rq and p they fill 112 of the 128
-  // registers during the sweeps), the other five u* rows in this thread's LDS slots -- nothing is parked in the caller's scratch
+  // u* and v* wait on chip for the corrector: v* and two u* rows in registers (next to rq and p they fill 108 of the 128
+  // registers during the sweeps), the other six u* rows in this thread's LDS slots -- nothing is parked in the caller's scratch
   // (until the end of round 3 v* and three u* rows went there and back: 176 KB of HBM traffic per 128 x 128 env-step)
   float vkeep[PR][PC];
   constexpr int kUKeep = PR - TileCfg<PR, PC>::PARK_ROWS > 0 ? PR - TileCfg<PR, PC>::PARK_ROWS : 1;
@@ -1729,7 +1729,7 @@ int ns_step_launch(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, i
     // register-tiled float32 path for the square grids it is instantiated for (BASELINE config 4 is 128x128)
     if (!pdegym_force_generic() && C.nx == C.ny && (C.nx == 128 || C.nx == 64)) {
       constexpr int lds128 = TileCfg<8, 4>::LDS_BYTES + TileCfg<8, 4>::PARK_BYTES, lds64 = TileCfg<4, 2>::LDS_BYTES;
-      if (C.nx == 128) {   // 72 KB of dynamic LDS: above the 64 KB a kernel gets without asking
+      if (C.nx == 128) {   // 80 KB of dynamic LDS: above the 64 KB a kernel gets without asking
         static signed char attr_i[pdegym::kMaxDevices] = {}, attr_s[pdegym::kMaxDevices] = {};
         const bool ok = buf->state_in
             ? pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&ns_tile_step<8, 4, true>), lds128, attr_i)

@@ -118,6 +118,9 @@ __device__ __forceinline__ void unpack_row(const typename VecOf<PC>::type& v, fl
   }
 }
 
+#ifndef PDEGYM_NS_PARK_ROWS
+#define PDEGYM_NS_PARK_ROWS 6
+#endif
 template <int PR, int PC>
 struct TileCfg {
   static constexpr int NT = 512;
@@ -125,8 +128,9 @@ struct TileCfg {
   static constexpr int BUF = 2 * NT;                     // vectors per halo buffer (top edges, bottom edges)
   static constexpr int LDS_BYTES = 2 * BUF * PC * 4;     // two buffers
   // rows of u* that wait in LDS (one PC-wide vector per thread and row) while the pressure solve runs -- the others and v* stay
-  // in registers: 128x128 -> 5 of 8 rows = 40 KB, so that two workgroups (2 x 72 KB) still share a CU's 160 KB
-  static constexpr int PARK_ROWS = (PR == 8 && PC == 4) ? 5 : 0;
+  // in registers: 128x128 -> 6 of 8 rows = 48 KB, so that two workgroups (2 x 80 KB) share a CU's 160 KB exactly
+  // (5 rows: B = 4096 528 instead of 521 us; 4 rows: 533)
+  static constexpr int PARK_ROWS = (PR == 8 && PC == 4) ? PDEGYM_NS_PARK_ROWS : 0;
   static constexpr int PARK_BYTES = PARK_ROWS * NT * PC * 4;
   static_assert(16 * PR == 32 * PC, "square grids only");
 };
