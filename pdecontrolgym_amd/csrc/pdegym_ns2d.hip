@@ -705,6 +705,13 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
         }
 #pragma unroll
         for (int k = 0; k < PC; ++k) { pu[k] = cu[k]; pv[k] = cv[k]; }
+        // one row at a time: the new row is pinned here (an empty asm that "uses" it) -- left alone the compiler sinks every row's
+        // arithmetic towards its uses in the later phases while the lane shifts (convergent, cannot sink) stay put, so the shifted
+        // values of ALL rows are live at once and spill
+        if constexpr (PC == 4) {
+          asm volatile("" : "+v"(uf[a][0]), "+v"(uf[a][1]), "+v"(uf[a][2]), "+v"(uf[a][3]), "+v"(vf[a][0]), "+v"(vf[a][1]), "+v"(vf[a][2]),
+                       "+v"(vf[a][3]));
+        }
       }
     }
     PDEGYM_STAMP(1, uf[0][0]);
@@ -809,8 +816,15 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
     // freshly loaded rows to scratch memory and read them back (80 bytes per lane of extra HBM traffic each way).
     constexpr int HR = PDEGYM_NS_BACK_ROWS, NBLK = PR / HR;
     static_assert(PR % HR == 0, "row blocks must tile the patch");
+    // thread coordinates re-derived from an opaque copy: kept from the top of the kernel, the patch offsets and edge flags are
+    // live (spilled) across the predictor and the sweeps
+    int tid_c = threadIdx.x;
+    asm volatile("" : "+v"(tid_c));
+    const int tx_c = tid_c & 31, ty_c = tid_c >> 5;
+    const int r0c = ty_c * PR, c0c = tx_c * PC;
+    const EdgeFlags Ec{ty_c == 0, ty_c == 15, tx_c == 0, tx_c == 31};
     float pt[PC], pb[PC];
-    halo_tb<PC>(pf[0], pf[PR - 1], pt, pb, lds, xc, tid, ty);
+    halo_tb<PC>(pf[0], pf[PR - 1], pt, pb, lds, xc, tid_c, ty_c);
     const float* uref = P.U_ref + (size_t)tr * ncell * 2;
     float* obs = P.obs + (size_t)b * ncell * 2;
 #pragma unroll
@@ -821,7 +835,7 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
 #pragma unroll
       for (int la = 0; la < HR; ++la) {     // written by this same thread above
         if (a0 + la < TileCfg<PR, PC>::PARK_ROWS)
-          unpack_row<PC>(reinterpret_cast<const V*>(smem_raw + TileCfg<PR, PC>::LDS_BYTES)[(a0 + la) * 512 + tid], uf[la]);
+          unpack_row<PC>(reinterpret_cast<const V*>(smem_raw + TileCfg<PR, PC>::LDS_BYTES)[(a0 + la) * 512 + tid_c], uf[la]);
         else {
 #pragma unroll
           for (int k = 0; k < PC; ++k) uf[la][k] = ukeep[a0 + la - TileCfg<PR, PC>::PARK_ROWS][k];
@@ -839,20 +853,20 @@ __global__ __launch_bounds__(512, 4) void ns_tile_step(NSConst C, NSScal<float> 
           const float ps = (a == 0) ? pt[k] : pf[a - 1][k], pn = (a == PR - 1) ? pb[k] : pf[a + 1][k];
           const float dpdx = div_c(pe - pw, S.two_dx, S.inv_two_dx);
           const float dpdy = div_c(pn - ps, S.two_dy, S.inv_two_dy);
-          const bool edge = on_domain_edge<PR, PC>(E, a, k);
+          const bool edge = on_domain_edge<PR, PC>(Ec, a, k);
           uf[la][k] = edge ? uf[la][k] : uf[la][k] - S.dt_over_rho * dpdx;
           vf[la][k] = edge ? vf[la][k] : vf[la][k] - S.dt_over_rho * dpdy;
         }
       }
-      apply_bc_rows<HR, PC>(uf, E, C.bc, 0, act, C.action_dim, r0 + a0, c0, h == 0, h == NBLK - 1);
-      apply_bc_rows<HR, PC>(vf, E, C.bc, 1, act, C.action_dim, r0 + a0, c0, h == 0, h == NBLK - 1);
+      apply_bc_rows<HR, PC>(uf, Ec, C.bc, 0, act, C.action_dim, r0c + a0, c0c, h == 0, h == NBLK - 1);
+      apply_bc_rows<HR, PC>(vf, Ec, C.bc, 1, act, C.action_dim, r0c + a0, c0c, h == 0, h == NBLK - 1);
 #pragma unroll
       for (int la = 0; la < HR; ++la) {
         if constexpr (!INTERLEAVED) {
-          *reinterpret_cast<V*>(u + ((r0 + a0 + la) * n + c0)) = pack_row<PC>(uf[la]);
-          *reinterpret_cast<V*>(v + ((r0 + a0 + la) * n + c0)) = pack_row<PC>(vf[la]);
+          *reinterpret_cast<V*>(u + ((r0c + a0 + la) * n + c0c)) = pack_row<PC>(uf[la]);
+          *reinterpret_cast<V*>(v + ((r0c + a0 + la) * n + c0c)) = pack_row<PC>(vf[la]);
         }
-        const int o = ((r0 + a0 + la) * n + c0) * 2;
+        const int o = ((r0c + a0 + la) * n + c0c) * 2;
         const float4* rrow = reinterpret_cast<const float4*>(uref + o);
         float4* orow = reinterpret_cast<float4*>(obs + o);
 #pragma unroll
