@@ -408,7 +408,15 @@ class PDEVecEnv:
         if self.kind not in ("ns2d", "traffic"):
             a = a.reshape(self.num_envs)
         obs_t, r_t, te_t, tr_t = self.step_tensor(a)
-        obs, rew, te, tr = self._to_host([obs_t, r_t, te_t, tr_t])
+        pack = getattr(self.core, "host_pack", None)
+        if (pack is not None and r_t.data_ptr() == pack.data_ptr() and te_t.data_ptr() == pack.data_ptr() + 4 * self.num_envs
+                and tr_t.data_ptr() == pack.data_ptr() + 5 * self.num_envs):
+            # reward | terminated | truncated are one allocation of the 1D engine: one copy instead of three
+            obs, pk = self._to_host([obs_t, pack])
+            nb = self.num_envs
+            rew, te, tr = pk[:4 * nb].view(np.float32), pk[4 * nb:5 * nb], pk[5 * nb:6 * nb]
+        else:
+            obs, rew, te, tr = self._to_host([obs_t, r_t, te_t, tr_t])
         if self.kind != "traffic":
             obs = obs.astype(np.float32, copy=False)
         rew, te, tr = rew.astype(np.float32, copy=False), te.view(np.bool_), tr.view(np.bool_)

@@ -111,6 +111,9 @@ class PDEBatch1D:
 
         B, n, dev = self.num_envs, self.n, self.device
         f32 = torch.float32
+        # reward, terminated and truncated share one allocation (4B + B + B bytes): a host-facing caller fetches the three with
+        # ONE device-to-host copy (pde_control_gym.PDEVecEnv.step_wait) instead of three latency-bound ones
+        self.host_pack = torch.zeros(6 * B, dtype=torch.uint8, device=dev)
         self.t = {
             "u": torch.zeros(B, n, dtype=f32, device=dev),
             "beta": torch.zeros(B, n, dtype=f32, device=dev),
@@ -119,11 +122,11 @@ class PDEBatch1D:
             "bsum": torch.zeros(B, dtype=torch.float64, device=dev),
             "ring": torch.zeros(B, N.RING, dtype=f32, device=dev),
             "obs": None,
-            "reward": torch.zeros(B, dtype=f32, device=dev),
+            "reward": self.host_pack[:4 * B].view(f32),
             "norm_now": torch.zeros(B, dtype=f32, device=dev),
             "norm_back": torch.zeros(B, dtype=f32, device=dev),
-            "terminated": torch.zeros(B, dtype=torch.uint8, device=dev),
-            "truncated": torch.zeros(B, dtype=torch.uint8, device=dev),
+            "terminated": self.host_pack[4 * B:5 * B],
+            "truncated": self.host_pack[5 * B:],
             "history": torch.zeros(B, self.nt, n, dtype=f32, device=dev) if record_history else None,
             "reset_init": None,
             "final_obs": None,
