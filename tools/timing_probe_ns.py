@@ -13,7 +13,7 @@ for _ in range(10):
     wl.step()
 torch.cuda.synchronize()
 sc = wl.env.t["scratch"].cpu().numpy().view(np.uint32)[:, 2].reshape(wl.B, -1)[:, :5].astype(np.int64)
-names = ["load+predictor", "bc+store us,vs+rhs", "jacobi", "store p + corrector + obs/reward", "block reduce + tail"]
+names = ["load+predictor", "bc + park u*, v* on chip + rhs", "jacobi", "store p + corrector + obs/reward", "block reduce + tail"]
 for i, nm in enumerate(names):
     print(f"K={K} {nm:36s} med {np.median(sc[:, i]):9.0f}  min {sc[:, i].min():9d}  max {sc[:, i].max():9d} ticks")
 print("total med", np.median(sc.sum(1)))
