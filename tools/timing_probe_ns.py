@@ -1,12 +1,13 @@
-"""Developer probe: per-phase s_memtime ticks of ns_tile_step (library built with -DPDEGYM_TIMING)."""
+"""Developer probe: per-phase s_memtime ticks of ns_tile_step.  Needs a library built with -DPDEGYM_TIMING:
+    bash tools/build_variant.sh timing -DPDEGYM_TIMING && python tools/timing_probe_ns.py pdecontrolgym_amd/lib/ab/libtiming.so"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pdecontrolgym_amd import _native as N
-N.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tim", "libpdegym_hip_timing.so")
+N.LIB_PATH = os.path.abspath(sys.argv[1])
 import torch
 import bench
-K = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 wl = bench.WORKLOADS["ns2d_c4"](torch.device("cuda", 0), 1, S=K)
 wl.prepare(20)
 for _ in range(10):
