@@ -398,15 +398,17 @@ class PDEVecEnv:
             key = ("act", a_np.shape, a_np.dtype.str)
             if key not in pins:
                 tdt = getattr(torch, a_np.dtype.name)          # float32 / float64 / int64 ...
-                pins[key] = (torch.empty(a_np.shape, dtype=tdt, pin_memory=True), torch.empty(a_np.shape, dtype=tdt, device=self.device))
-            pin, dev_a = pins[key]
-            pin.numpy()[...] = a_np
+                pin = torch.empty(a_np.shape, dtype=tdt, pin_memory=True)
+                dev_a = torch.empty(a_np.shape, dtype=tdt, device=self.device)
+                flat = dev_a.reshape(self.num_envs) if (self.kind not in ("ns2d", "traffic") and dev_a.numel() == self.num_envs) else dev_a
+                pins[key] = (pin, dev_a, pin.numpy(), flat)
+            pin, dev_a, pin_np, a = pins[key]
+            pin_np[...] = a_np
             dev_a.copy_(pin, non_blocking=True)
-            a = dev_a
         else:
             a = torch.as_tensor(a_np, device=self.device)
-        if self.kind not in ("ns2d", "traffic"):
-            a = a.reshape(self.num_envs)
+            if self.kind not in ("ns2d", "traffic"):
+                a = a.reshape(self.num_envs)
         obs_t, r_t, te_t, tr_t = self.step_tensor(a)
         pack = getattr(self.core, "host_pack", None)
         if (pack is not None and r_t.data_ptr() == pack.data_ptr() and te_t.data_ptr() == pack.data_ptr() + 4 * self.num_envs

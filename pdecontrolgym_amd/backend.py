@@ -26,8 +26,8 @@ def _on_device_of(key):
                 if torch.is_tensor(a):
                     dev = a.device
                     break
-            if dev is None or dev.type != "cuda":
-                return fn(self, *args, **kw)
+            if dev is None or dev.type != "cuda" or dev.index == torch.cuda.current_device():
+                return fn(self, *args, **kw)          # already current (the common case): no device switch, no context manager
             with torch.cuda.device(dev):
                 return fn(self, *args, **kw)
         wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__

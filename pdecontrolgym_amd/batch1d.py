@@ -236,7 +236,10 @@ class PDEBatch1D:
         if action_kind is None:
             action_kind = N.ACTION_F64 if action.dtype == torch.float64 else N.ACTION_F32
         adt = torch.float32 if action_kind == N.ACTION_F32 else torch.float64
-        a = action.to(device=self.device, dtype=adt).reshape(self.num_envs).contiguous()
+        if action.dtype == adt and action.device == self.device and action.dim() == 1 and action.shape[0] == self.num_envs and action.is_contiguous():
+            a = action                      # already what the kernel reads (the VecEnv face's staging tensor): no torch dispatch
+        else:
+            a = action.to(device=self.device, dtype=adt).reshape(self.num_envs).contiguous()
         self.t["action"] = a
         self.params.action_kind = action_kind
         prev = self.t["obs"]

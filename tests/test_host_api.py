@@ -420,9 +420,13 @@ def test_every_c_abi_call_runs_with_its_tensors_device_current(monkeypatch):
             return False
 
     monkeypatch.setattr(torch.cuda, "device", Guard)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
 
     class Stub:                        # stands in for a tensor on cuda:1 in the dict form
         device = torch.device("cuda", 1)
+
+    class StubCurrent:                 # ... and for one on the device that is current already: no switch, no context manager
+        device = torch.device("cuda", 0)
 
     class B:
         @bk_mod._on_device_of("obs")
@@ -435,6 +439,7 @@ def test_every_c_abi_call_runs_with_its_tensors_device_current(monkeypatch):
 
     assert B().by_dict(None, {"obs": Stub()}, 3) == ("ran", 3) and entered == [torch.device("cuda", 1)]
     entered.clear()
+    assert B().by_dict(None, {"obs": StubCurrent()}, 4) == ("ran", 4) and entered == []
     assert B().by_dict(None, {"obs": torch.zeros(1)}, 3) == ("ran", 3) and entered == []        # CPU tensors: no device switch
     assert B().by_tensor(torch.zeros(2), torch.zeros(2)) == "ran" and entered == []
     public = [n for n, f in vars(bk_mod.HipBackend).items() if callable(f) and not n.startswith("_") and n not in ("bind",)]
