@@ -2,8 +2,9 @@
 
 Two faces on the same device-resident state:
 
-* the Stable-Baselines3 ``VecEnv`` duck type (``num_envs``, ``reset()``, ``step_async``/``step_wait``,
-  ``get_attr``/``set_attr``/``env_method``/``env_is_wrapped``/``seed``/``close``): NumPy in, NumPy out, automatic
+* a Stable-Baselines3 ``VecEnv`` -- a real subclass of ``stable_baselines3.common.vec_env.VecEnv`` whenever SB3 is importable
+  (its ``_wrap_env`` gates on ``isinstance``), of a stand-in with the same contract otherwise (``reset()``,
+  ``step_async``/``step_wait``, ``get_attr``/``set_attr``/``env_method``/``env_is_wrapped``/``seed``/``set_options``/``close``): NumPy in, NumPy out, automatic
   reset of finished instances with ``infos[i]["terminal_observation"]`` -- so ``PPO("MlpPolicy", vec_env)`` can
   replace the reference's ``DummyVecEnv(n=1)`` (examples/transportPDE/transport1Dppo.py:77-90);
 * a torch-native face (``reset_tensor``/``step_tensor``) that never leaves the device: one kernel launch per
@@ -17,7 +18,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from pde_control_gym._compat import spaces
+from pde_control_gym._compat import VecEnv, spaces
 
 _KINDS = {
     "PDEControlGym-TransportPDE1D": "transport", "transport": "transport", "TransportPDE1D": "transport",
@@ -30,12 +31,56 @@ _RESET_ERR = ("Please pass both an initial condition and a recirculation functio
               "See documentation for more details")
 
 
-class PDEVecEnv:
+class BatchedVecEnv(VecEnv):
+    """The part of the Stable-Baselines3 ``VecEnv`` interface that does not depend on the environment family.  ``VecEnv`` is
+    ``stable_baselines3.common.vec_env.VecEnv`` itself when SB3 is importable (``BaseAlgorithm._wrap_env`` lets exactly
+    its instances through un-wrapped), otherwise a stand-in with the same constructor contract (pde_control_gym/_compat.py).
+
+    There are no per-instance Python environment objects behind a batch: ``get_attr`` / ``set_attr`` / ``env_method`` act on the
+    batched environment and answer once per requested index, ``env_is_wrapped`` is False everywhere."""
     metadata = {"render_modes": []}
     render_mode = None
 
+    def _finish_vec_env_init(self):
+        """Runs the base-class constructor (``reset_infos``, ``_seeds``, ``_options``, the common ``render_mode``) once the
+        subclass knows ``num_envs`` and its spaces."""
+        VecEnv.__init__(self, self.num_envs, self.observation_space, self.action_space)
+
+    def _consume_reset_arguments(self):
+        """``VecEnv.seed()`` / ``set_options()`` park their arguments for the next ``reset()``.  The reference's ``reset(seed,
+        options)`` ignores both (hyperbolic.py:196-227: the user's callbacks draw the initial condition), so they are dropped."""
+        self.reset_infos = [{} for _ in range(self.num_envs)]
+        self._reset_seeds()
+        self._reset_options()
+
+    def step_async(self, actions):
+        self._actions = actions
+
+    def close(self):
+        pass
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False for _ in self._get_indices(indices)]
+
+    def get_attr(self, attr_name, indices=None):
+        return [getattr(self, attr_name) for _ in self._get_indices(indices)]
+
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        return [getattr(self, method_name)(*method_args, **method_kwargs) for _ in self._get_indices(indices)]
+
+    def get_images(self):
+        return []
+
+    def render(self, mode=None):
+        return None
+
+
+class PDEVecEnv(BatchedVecEnv):
     def __init__(self, env_id: str, num_envs: int, device="cuda", backend=None, batched_reset_func=None,
-                 dtype=None, copy_outputs: bool = False, **kw):
+                 dtype=None, copy_outputs: bool = True, **kw):
         import torch
         if env_id not in _KINDS:
             raise KeyError(f"No registered env with id: {env_id}")
@@ -46,8 +91,10 @@ class PDEVecEnv:
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
         self.batched_reset_func = batched_reset_func
-        # copy_outputs=True: step() / reset() hand out fresh NumPy arrays (+ ~40 us per step at 4096 x 257 float32) instead of
-        # views of the rotating pinned staging buffers -- for callers that keep results for more than two further steps
+        # copy_outputs=True (default): step() hands out fresh NumPy arrays that stay valid, as the reference's do for an episode.
+        # copy_outputs=False: the OBSERVATION array is a view of a rotating pinned staging buffer (reused ``host_buffers`` steps
+        # later; saves ~40 us per step at 4096 x 257 float32) -- for SB3-style loops, which copy what they keep into their own
+        # rollout buffer.  Rewards and flags (a few KB) are always fresh arrays.
         self.copy_outputs = bool(copy_outputs)
         # state_in_obs=False (1D) / interleaved_state=False (NavierStokes2D) in the parameters: the engine keeps the plant state in
         # its own tensors and the observation is a separate output -- for torch callers that normalise or perturb the tensors
@@ -61,6 +108,7 @@ class PDEVecEnv:
             self._init_traffic(kw, backend)
         else:
             self._init_1d(kw, backend)
+        self._finish_vec_env_init()
 
     # ---- construction ------------------------------------------------------------------------------
     def _init_1d(self, kw, backend):
@@ -346,20 +394,20 @@ class PDEVecEnv:
         return o if self.kind == "traffic" else o.astype(np.float32, copy=False)   # the traffic env observes in float64
 
     def reset(self):
-        return self._noise(self._obs_np(self.reset_tensor()))
+        obs = self._noise(self._obs_np(self.reset_tensor()))
+        self._consume_reset_arguments()
+        return obs
 
-    def step_async(self, actions):
-        self._actions = actions
-
-    # How many consecutive results stay valid: the NumPy arrays a step returns are VIEWS of pinned staging buffers that are
-    # reused ``host_buffers`` steps later (SB3 reads the observation of step k once more right after step k+1 returned -- its
-    # ``_last_obs`` -- and never again, so two would do; three leaves a step of slack).  Callers that keep results longer copy them.
+    # With copy_outputs=False: how many consecutive observation arrays stay valid -- they are VIEWS of pinned staging buffers that
+    # are reused ``host_buffers`` steps later (SB3 reads the observation of step k once more right after step k+1 returned -- its
+    # ``_last_obs`` -- and never again, so two would do; three leaves a step of slack).
     host_buffers = 3
 
     def _to_host(self, tensors):
-        """Device tensors -> NumPy views of pinned staging buffers: the copies are queued back to back and the stream is
-        synchronised ONCE (``t.cpu()`` per tensor goes through pageable memory and synchronises every time); no host-side copy
-        afterwards -- the buffers rotate instead (``host_buffers``)."""
+        """Device tensors -> NumPy arrays through pinned staging buffers: the copies are queued back to back and the stream is
+        synchronised ONCE (``t.cpu()`` per tensor goes through pageable memory and synchronises every time).  The first tensor
+        (the observation) is returned as a view of its staging buffer when ``copy_outputs`` is off (the buffers rotate,
+        ``host_buffers``); everything else is copied out."""
         import torch
         if self.device.type != "cuda":
             return [t.numpy().copy() for t in tensors]
@@ -375,7 +423,7 @@ class PDEVecEnv:
             pins[key][0].copy_(t, non_blocking=True)
             out.append(pins[key][1])
         torch.cuda.current_stream(self.device).synchronize()
-        return [o.copy() for o in out] if self.copy_outputs else out
+        return [o.copy() if (i > 0 or self.copy_outputs) else o for i, o in enumerate(out)]
 
     def _fresh_infos(self):
         """One dict per environment, as SB3 expects -- but the B empty dicts are made once and handed out again every step;
@@ -424,12 +472,19 @@ class PDEVecEnv:
         rew, te, tr = rew.astype(np.float32, copy=False), te.view(np.bool_), tr.view(np.bool_)
         dones = te | tr
         infos = self._fresh_infos()
+        # The sensing-noise hooks see every observation the caller gets, as in the reference: what step() returns
+        # (hyperbolic.py:160-164) -- hence also the terminal observation -- and what reset() returns (:224), hence the first
+        # observation of an auto-reset instance.  Finished instances go through the hook as a [k, obs_dim] batch of their own.
+        obs = self._noise(obs)
         if dones.any():
+            if not obs.flags.writeable:
+                obs = obs.copy()
             idx = np.nonzero(dones)[0]
             self._infos_dirty = idx
             final = self.core.t.get("final_obs") if self._fused_reset else None
             # only the finished instances' terminal observations cross to the host
-            final_np = self._obs_np(final[torch.as_tensor(idx, device=self.device)]) if final is not None else None
+            final_np = (self._noise(self._obs_np(self._noise_t(final[torch.as_tensor(idx, device=self.device)])))
+                        if final is not None else None)
             for k, i in enumerate(idx):
                 infos[i] = {"terminal_observation": (final_np[k] if final_np is not None else obs[i]).copy(),
                             "TimeLimit.truncated": bool(tr[i] and not te[i])}
@@ -453,45 +508,10 @@ class PDEVecEnv:
                     if self.core.t["beta"].dim() == 2:
                         self.core.t["beta"][torch.as_tensor(idx, device=self.device)] = torch.as_tensor(beta).to(
                             device=self.device, dtype=self.core.t["beta"].dtype)
-                    new = self.core.reset(self._scatter(init, idx, (self.core.n,)), mask=mask)
+                    new = self._noise_t(self.core.reset(self._scatter(init, idx, (self.core.n,)), mask=mask))
                 if self.kind != "traffic":
-                    obs[idx] = self._obs_np(new)[idx]
-        return self._noise(obs), rew, dones, infos
-
-    def step(self, actions):
-        self.step_async(actions)
-        return self.step_wait()
-
-    def close(self):
-        pass
-
-    def seed(self, seed=None):
-        return [seed] * self.num_envs
-
-    def env_is_wrapped(self, wrapper_class, indices=None):
-        return [False] * len(self._indices(indices))
-
-    def _indices(self, indices):
-        if indices is None:
-            return list(range(self.num_envs))
-        if isinstance(indices, int):
-            return [indices]
-        return list(indices)
-
-    def get_attr(self, attr_name, indices=None):
-        return [getattr(self, attr_name) for _ in self._indices(indices)]
-
-    def set_attr(self, attr_name, value, indices=None):
-        setattr(self, attr_name, value)
-
-    def env_method(self, method_name, *args, indices=None, **kwargs):
-        return [getattr(self, method_name)(*args, **kwargs) for _ in self._indices(indices)]
-
-    def get_images(self):
-        return []
-
-    def render(self, mode=None):
-        return None
+                    obs[idx] = self._noise(self._obs_np(new)[idx])
+        return obs, rew, dones, infos
 
     @property
     def unwrapped(self):

@@ -6,33 +6,45 @@
     obs, infos = venv.reset(seed=None, options=None)
     obs, rewards, terminations, truncations, infos = venv.step(actions)
 
-with same-step auto-reset: a finished sub-environment already returns the first observation of its next episode, and
-``infos["final_observation"][i]`` holds the observation the episode ended on (``infos["_final_observation"]`` is the boolean
-mask) -- the layout of gymnasium 0.29's ``SyncVectorEnv``.  Nothing is computed here; it only re-shapes what the SB3 face
-returns, so the two conventions cannot drift apart.
+with same-step auto-reset: a finished sub-environment already returns the first observation of its next episode, and the
+observation its episode ended on is in ``infos["final_obs"][i]`` (mask ``infos["_final_obs"]``; gymnasium >= 1.0's
+``AutoresetMode.SAME_STEP`` layout, with the matching ``final_info``) as well as ``infos["final_observation"][i]`` (gymnasium
+0.29's ``SyncVectorEnv`` layout).  Nothing is computed here; it only re-shapes what the SB3 face returns, so the two
+conventions cannot drift apart.
+
+The class IS a ``gymnasium.vector.VectorEnv`` whenever gymnasium is importable (wrappers and trainers test with ``isinstance``);
+``observation_space`` / ``action_space`` are the batched spaces, ``single_*`` the per-environment ones, as that class documents.
 """
 from __future__ import annotations
 
 import numpy as np
 
+from pde_control_gym._compat import AUTORESET_SAME_STEP, VectorEnv, batch_space
 
-class GymnasiumVectorAdapter:
-    metadata = {"autoreset_mode": "same_step"}
+
+class GymnasiumVectorAdapter(VectorEnv):
+    metadata = {"autoreset_mode": AUTORESET_SAME_STEP, "render_modes": []}
 
     def __init__(self, venv):
+        try:                        # gymnasium >= 1.0 (and the stand-in): no constructor arguments, attributes set below
+            VectorEnv.__init__(self)
+        except TypeError:           # gymnasium 0.2x: VectorEnv(num_envs, observation_space, action_space) batches the spaces itself
+            VectorEnv.__init__(self, venv.num_envs, venv.observation_space, venv.action_space)
         self.venv = venv
         self.num_envs = venv.num_envs
         self.single_observation_space = venv.observation_space
         self.single_action_space = venv.action_space
-        self.observation_space = venv.observation_space
-        self.action_space = venv.action_space
+        self.observation_space = batch_space(venv.observation_space, self.num_envs)
+        self.action_space = batch_space(venv.action_space, self.num_envs)
+        self.render_mode = None
         self.closed = False
 
     @property
     def unwrapped(self):
-        return self.venv
+        return self
 
     def reset(self, *, seed=None, options=None):
+        # the reference's reset(seed, options) ignores both (hyperbolic.py:196-227)
         return self.venv.reset(), {}
 
     def step(self, actions):
@@ -49,8 +61,18 @@ class GymnasiumVectorAdapter:
                 final[i] = infos[i]["terminal_observation"]
                 mask[i] = True
             out["final_observation"], out["_final_observation"] = final, mask
+            out["final_obs"], out["_final_obs"] = final, mask
+            finfo = np.empty(self.num_envs, dtype=object)
+            for i in np.nonzero(mask)[0]:
+                finfo[i] = {}
+            out["final_info"], out["_final_info"] = finfo, mask
         return obs, rew, term, trunc, out
 
-    def close(self):
-        self.closed = True
+    def close_extras(self, **kwargs):
         self.venv.close()
+
+    def close(self, **kwargs):
+        if self.closed:
+            return
+        self.close_extras(**kwargs)
+        self.closed = True

@@ -12,11 +12,10 @@ from __future__ import annotations
 import numpy as np
 
 from pde_control_gym._compat import spaces
+from pde_control_gym.vector import BatchedVecEnv
 
 
-class TumorVecEnv:
-    metadata = {"render_modes": []}
-    render_mode = None
+class TumorVecEnv(BatchedVecEnv):
 
     def __init__(self, num_envs: int, weekends: bool = False, device="cuda", backend=None, t_benchmark=None, **kw):
         import torch
@@ -43,6 +42,7 @@ class TumorVecEnv:
             self.t_benchmark = t_benchmark
             c.set_benchmark(t_benchmark)
         self._actions = None
+        self._finish_vec_env_init()
 
     # ---- TherapyWrapper.benchmark / reset -------------------------------------------------------------------------
     def benchmark(self):
@@ -70,7 +70,9 @@ class TumorVecEnv:
         return c.t["u"]
 
     def reset(self, seed=None, options=None):
-        return self.reset_tensor().cpu().numpy().copy()
+        obs = self.reset_tensor().cpu().numpy().copy()
+        self._consume_reset_arguments()
+        return obs
 
     # ---- TherapyWrapper.step for every patient ------------------------------------------------------------------------
     def step_tensor(self, actions):
@@ -114,9 +116,6 @@ class TumorVecEnv:
         return obs, rewards, term, trunc
 
     # ---- SB3 VecEnv face ------------------------------------------------------------------------------------------------
-    def step_async(self, actions):
-        self._actions = actions
-
     def step_wait(self):
         obs, rew, term, trunc = self.step_tensor(np.asarray(self._actions, dtype=np.float64).reshape(self.num_envs))
         done = (term | trunc).cpu().numpy()
@@ -128,10 +127,3 @@ class TumorVecEnv:
                 infos[i]["terminal_observation"] = tob[i].copy()
                 infos[i]["TimeLimit.truncated"] = bool(tr[i] and not term[i])
         return obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), done, infos
-
-    def step(self, actions):
-        self.step_async(actions)
-        return self.step_wait()
-
-    def close(self):
-        pass
