@@ -81,9 +81,12 @@ class DeviceRollout:
             core.t["p_out"] = None
         try:
             self._steps(core, torch)
-            if self._ns or getattr(core, "state_in_obs", False):
-                # the observation IS the state (Navier-Stokes; the 1D engines with full-state sensing): leave it in the engine's
-                # own buffer, not in slot T
+            if self._direct:
+                # The engine's own observation buffer must end up holding slot T for EVERY engine that wrote its observations
+                # straight into the rollout buffers: the next run() (and any reader of the engine's current observation) starts
+                # from it.  Where the observation IS the state (Navier-Stokes; the 1D engines with full-state sensing) this copy
+                # is also the state hand-over; engines with a separate state (state_in_obs=False, scalar sensing, history
+                # recording) advanced ``u`` in place and only their observation would otherwise be stale (advisor finding r3).
                 own["obs"].copy_(self.obs[self.T])
         finally:
             if pingpong:

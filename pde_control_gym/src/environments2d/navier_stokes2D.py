@@ -143,9 +143,12 @@ class NavierStokes2D(PDEEnv2D):
         obs, rew, te = self._core.step(a[None])
         self.time_index += 1
         o = obs[0].cpu().numpy()
-        if self.time_index < self.nt:
-            self.U[self.time_index] = o
-            o = self.U[self.time_index]
+        if self.time_index >= self.nt:
+            # navier_stokes2D.py:147-148 stores U[time_index] after the increment: the nt-th step of an episode (one past the
+            # terminal one) fails there with NumPy's IndexError, the flow fields already advanced -- same here
+            raise IndexError(f"index {self.time_index} is out of bounds for axis 0 with size {self.nt}")
+        self.U[self.time_index] = o
+        o = self.U[self.time_index]
         terminate = self.terminate()
         if self._fused_reward:
             reward = float(rew.cpu().numpy()[0])

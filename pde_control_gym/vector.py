@@ -77,8 +77,29 @@ class BatchedVecEnv(VecEnv):
     def render(self, mode=None):
         return None
 
+    # ---- checkpoint / resume (pdecontrolgym_amd/checkpoint.py) --------------------------------------------------------
+    _checkpoint_attrs = ()         # device tensors kept by the face itself, next to the engine's
+
+    def state_dict(self):
+        """Device state of the whole batch as (cloned) torch tensors -- ``torch.save``-able.  Restored by ``load_state_dict`` on
+        an environment built from the same parameters; the user's reset callbacks and their random generators are the
+        caller's to checkpoint."""
+        import torch
+        face = {k: getattr(self, k).detach().clone() for k in self._checkpoint_attrs if torch.is_tensor(getattr(self, k, None))}
+        return {"core": self.core.state_dict(), "face": face, "fused_reset": bool(getattr(self, "_fused_reset", False))}
+
+    def load_state_dict(self, sd):
+        self.core.load_state_dict(sd["core"])
+        for k, v in sd["face"].items():
+            getattr(self, k).copy_(v)
+        if hasattr(self, "_fused_reset"):
+            self._fused_reset = bool(sd["fused_reset"])
+        self._actions = None
+
 
 class PDEVecEnv(BatchedVecEnv):
+    _checkpoint_attrs = ("_ns_hist",)
+
     def __init__(self, env_id: str, num_envs: int, device="cuda", backend=None, batched_reset_func=None,
                  dtype=None, copy_outputs: bool = True, **kw):
         import torch

@@ -16,6 +16,7 @@ from pde_control_gym.vector import BatchedVecEnv
 
 
 class TumorVecEnv(BatchedVecEnv):
+    _checkpoint_attrs = ("_consecutive", "treatment_calls", "soft_constraint_violations")
 
     def __init__(self, num_envs: int, weekends: bool = False, device="cuda", backend=None, t_benchmark=None, **kw):
         import torch

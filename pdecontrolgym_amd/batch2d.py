@@ -13,6 +13,7 @@ mode asked for by BASELINE.json (tolerance stated in tests/test_gpu_ns2d.py).
 from __future__ import annotations
 
 from . import _native as N
+from .checkpoint import EngineCheckpoint
 
 
 def _bc_codes(boundary_condition: dict):
@@ -30,7 +31,7 @@ def _bc_codes(boundary_condition: dict):
     return codes
 
 
-class NSBatch2D:
+class NSBatch2D(EngineCheckpoint):
     def __init__(self, T: float, dt: float, X: float, dx: float, Y: float, dy: float, boundary_condition: dict,
                  U_ref, action_ref, action_dim: int = 1, gamma: float = 0.1, viscosity: float = 0.1,
                  density: float = 1.0, maximum_pressure_iteration: int = 2000, stable_factor: float = 0.5,
@@ -185,6 +186,11 @@ class NSBatch2D:
         scratch = torch.empty(M, 2, self.ny, self.nx, dtype=self.dtype, device=self.device)
         self.backend.ns2d_solve_pressure(self.params, u, v, p_prev, out, scratch, M)
         return out
+
+    # ---- checkpoint / resume (pdecontrolgym_amd/checkpoint.py) ---------------------------------------------
+    def _checkpoint_meta(self):
+        return {"engine": "NSBatch2D", "num_envs": self.num_envs, "nx": self.nx, "ny": self.ny, "nt": self.nt,
+                "dtype": str(self.dtype), "interleaved_state": self.interleaved_state}
 
     # ---- roofline bookkeeping ---------------------------------------------
     def algorithmic_bytes_per_env_step(self) -> int:

@@ -9,9 +9,10 @@ from __future__ import annotations
 import numpy as np
 
 from . import _native as N
+from .checkpoint import EngineCheckpoint
 
 
-class TrafficBatch:
+class TrafficBatch(EngineCheckpoint):
     def __init__(self, T: float, dt: float, X: float, dx: float, simulation_type: str = "inlet", v_max: float = 40,
                  ro_max: float = 0.16, tau: float = 60, limit_pde_state_size: bool = False, control_freq: int = 1,
                  num_envs: int = 1, device="cuda", backend=None):

@@ -9,9 +9,10 @@ from __future__ import annotations
 import numpy as np
 
 from . import _native as N
+from .checkpoint import EngineCheckpoint
 
 
-class TumorBatch:
+class TumorBatch(EngineCheckpoint):
     MARGIN = 25     # mm added to the T2 radius for the treated region (brain_tumor_env.py:257)
 
     def __init__(self, T: float, dt: float, X: float, dx: float, total_dosage: float,

@@ -21,7 +21,10 @@ import warnings
 import numpy as np
 
 REF = os.environ.get("PDEGYM_REFERENCE", "/root/reference")
-OUT = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:          # `python tests/golden/make_golden.py` from anywhere: tests.cases must be importable
+    sys.path.insert(0, ROOT)
 warnings.filterwarnings("ignore", category=DeprecationWarning)
 
 
@@ -121,7 +124,7 @@ def pack(prefix, d, store):
         store[f"{prefix}/{k}"] = v
 
 
-def gen_transport(src):
+def gen_transport(src, out=HERE):
     store = {}
     rng = np.random.default_rng(1234)
     # F-H1: BASELINE config 1 (nx=100, T=1, dt=1e-4, S=1000)
@@ -169,10 +172,10 @@ def gen_transport(src):
     kw = dict(base, T=0.0090, dt=1e-4, control_sample_rate=15e-4)      # nt=91, S=15: t-100 -> rows 6,21,36,...
     acts = rng.uniform(-1, 1, 6).astype(np.float32)
     pack("R_tiny", run_1d(src, "TransportPDE1D", kw, np.ones(nx) * 2.0, beta, acts, (90, -1e3, 3e2)), store)
-    np.savez_compressed(os.path.join(OUT, "transport.npz"), **store)
+    np.savez_compressed(os.path.join(out, "transport.npz"), **store)
 
 
-def gen_parabolic(src):
+def gen_parabolic(src, out=HERE):
     store = {}
     rng = np.random.default_rng(4321)
     base = dict(T=1, dt=1e-5, X=1, dx=5e-3, normalize=False, sensing_loc="full", control_type="Dirchilet",
@@ -206,10 +209,10 @@ def gen_parabolic(src):
         kw = dict(base, T=600 * dt, dt=dt, dx=dx, control_sample_rate=50 * dt, control_type=ct, sensing_loc=sl, sensing_type=st)
         acts = rng.uniform(-1, 1, 5).astype(np.float32)
         pack(f"P3_{name}", run_1d(src, "ReactionDiffusionPDE1D", kw, init, beta, acts, (600, -1e3, 3e2)), store)
-    np.savez_compressed(os.path.join(OUT, "parabolic.npz"), **store)
+    np.savez_compressed(os.path.join(out, "parabolic.npz"), **store)
 
 
-def gen_kat(src):
+def gen_kat(src, out=HERE):
     """Published known answers (backstepping episodes, notebook stored outputs)."""
     store = {}
     # transport: examples/transportPDE/transport1Dbackstepping.py:22-36,48-99
@@ -290,14 +293,13 @@ def gen_kat(src):
         pack(f"P_u{u0}", dict(total=np.float64(total), sum_l2=np.float64(l2), actions=np.array(acts, dtype=np.float64),
                               rewards=np.array(rews, dtype=np.float64), kernel_row=krow, beta=beta, last_obs=np.array(obs)), store)
         print("KAT parabolic", u0, total, l2)
-    np.savez_compressed(os.path.join(OUT, "kat.npz"), **store)
+    np.savez_compressed(os.path.join(out, "kat.npz"), **store)
 
 
-def gen_mixed(src):
+def gen_mixed(src, out=HERE):
     """float64 plant parameter and/or float64 / Python-scalar control inputs: NumPy then evaluates parts of the update in
     double and rounds once when the row is stored (hyperbolic.py:146-155, parabolic.py:143-150).  Case table: tests/cases.py
     MIXED_CASES (kwargs) -- here only the data."""
-    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
     from tests.cases import MIXED_CASES
     store = {}
     rng = np.random.default_rng(8642)
@@ -324,14 +326,14 @@ def gen_mixed(src):
         with np.errstate(all="ignore"):
             pack(name, run_1d(src, cls, kw, init, beta, acts, (nt1, -1e-4, 1e2) if name.startswith("Q_quick") else (nt1, -1e3, 3e2),
                               action_as=action_as), store)
-    np.savez_compressed(os.path.join(OUT, "mixed.npz"), **store)
+    np.savez_compressed(os.path.join(out, "mixed.npz"), **store)
 
 
 NS_BC = {"upper": ["Controllable", "Dirchilet"], "lower": ["Dirchilet", "Dirchilet"],
          "left": ["Dirchilet", "Dirchilet"], "right": ["Dirchilet", "Dirchilet"]}
 
 
-def gen_ns(src):
+def gen_ns(src, out=HERE):
     store = {}
     # F-N1: the reference's own golden trajectory examples/NavierStokes/target.npz (NS2Dppo.py:21-50)
     tgt = np.load(os.path.join(REF, "examples/NavierStokes/target.npz"))
@@ -416,10 +418,10 @@ def gen_ns(src):
         rews.append(r)
     pack("N3", dict(ic=np.array([cu, cv, cp]), actions=acts, sums=np.array(sums), pts=pts, samples=np.stack(samples),
                     rewards=np.array(rews), dx=np.float64(dx), dt=np.float64(dt), nt=np.int64(nt)), store)
-    np.savez_compressed(os.path.join(OUT, "ns2d.npz"), **store)
+    np.savez_compressed(os.path.join(out, "ns2d.npz"), **store)
 
 
-def gen_traffic(src):
+def gen_traffic(src, out=HERE):
     """TrafficPDE1D (environments1d/traffic_arz_env.py) with TrafficARZReward: the shipped notebook configuration
     (examples/TrafficPDE1D/*.ipynb cell 3: T=240, dt=0.25, dx=10, X=500, tau=60, v_max=40, ro_max=0.16)."""
     import contextlib
@@ -456,7 +458,7 @@ def gen_traffic(src):
         pack(name, dict(obs=obs, reward=np.array(rew), done=np.array(done), trunc=np.array(trunc), time=np.array(tim),
                         actions=acts, rs=np.float64(env.rs), qs_clip=np.float64(qs_clip), control_freq=np.int64(cf),
                         limit=np.bool_(limit), sim=np.array(sim)), store)
-    np.savez_compressed(os.path.join(OUT, "traffic.npz"), **store)
+    np.savez_compressed(os.path.join(out, "traffic.npz"), **store)
 
 
 def tumor_ic(X, nx):
@@ -470,7 +472,7 @@ TUMOR_KW = dict(X=200, dt=1, dx=1, normalize=True, dosage_termination_threshold=
                 t1_detection_radius=15, t1_death_radius=35, total_dosage=61.2, verbose=False)
 
 
-def gen_tumor(src):
+def gen_tumor(src, out=HERE):
     """BrainTumor1D + BrainTumorReward + TherapyWrapper (environments1d/brain_tumor_env.py, rewards/brain_tumor_reward.py)
     on the shipped notebook configuration (examples/BrainTumor1D: T=600, X=200, dt=dx=1, total_dosage=61.2)."""
     import importlib
@@ -528,40 +530,37 @@ def gen_tumor(src):
                                        -1 if env.cDeathDay is None else env.cDeathDay]),
                         calls=np.int64(w.treatment_calls), violations=np.int64(w.soft_constraint_violations),
                         dosage=env.dosage_vs_time.copy(), t1_idx=env.t1_radius_idx_vs_time.copy()), store)
-    np.savez_compressed(os.path.join(OUT, "tumor.npz"), **store)
+    np.savez_compressed(os.path.join(out, "tumor.npz"), **store)
 
 
 FILES = {"transport": "transport.npz", "parabolic": "parabolic.npz", "kat": "kat.npz", "mixed": "mixed.npz", "ns": "ns2d.npz",
          "traffic": "traffic.npz", "tumor": "tumor.npz"}
 
 
-def check(which):
+GEN = {"transport": gen_transport, "parabolic": gen_parabolic, "kat": gen_kat, "mixed": gen_mixed, "ns": gen_ns,
+       "traffic": gen_traffic, "tumor": gen_tumor}
+
+
+def check(which=None):
     """Regenerate into a scratch directory and compare with the committed fixtures: same keys, same dtypes, same shapes, same
     BITS.  Returns the list of differences (empty = the committed files are exactly what the generator writes today)."""
     import tempfile
-    global OUT
-    committed = OUT
+    committed = HERE
     diffs = []
     with tempfile.TemporaryDirectory() as tmp:
-        OUT = tmp
-        try:
-            src = import_reference()
-            for w in which:
-                GEN[w](src)
-                a, b = np.load(os.path.join(committed, FILES[w]), allow_pickle=False), np.load(os.path.join(tmp, FILES[w]), allow_pickle=False)
-                for k in sorted(set(a.files) | set(b.files)):
-                    if k not in a.files or k not in b.files:
-                        diffs.append(f"{FILES[w]}: key {k} only in the {'generator output' if k in b.files else 'committed file'}")
-                    elif a[k].dtype != b[k].dtype or a[k].shape != b[k].shape or a[k].tobytes() != b[k].tobytes():
-                        diffs.append(f"{FILES[w]}: {k} differs")
-        finally:
-            OUT = committed
+        src = import_reference()
+        for w in (which or list(GEN)):
+            GEN[w](src, tmp)
+            a, b = np.load(os.path.join(committed, FILES[w]), allow_pickle=False), np.load(os.path.join(tmp, FILES[w]), allow_pickle=False)
+            for k in sorted(set(a.files) | set(b.files)):
+                if k not in a.files or k not in b.files:
+                    diffs.append(f"{FILES[w]}: key {k} only in the {'generator output' if k in b.files else 'committed file'}")
+                elif a[k].dtype != b[k].dtype or a[k].shape != b[k].shape or a[k].tobytes() != b[k].tobytes():
+                    diffs.append(f"{FILES[w]}: {k} differs")
     return diffs
 
 
 if __name__ == "__main__":
-    GEN = {"transport": gen_transport, "parabolic": gen_parabolic, "kat": gen_kat, "mixed": gen_mixed, "ns": gen_ns,
-           "traffic": gen_traffic, "tumor": gen_tumor}
     if "--check" in sys.argv[1:]:
         d = check([w for w in sys.argv[1:] if w != "--check"] or list(GEN))
         print("\n".join(d) if d else "fixtures == generator output")
@@ -572,5 +571,5 @@ if __name__ == "__main__":
     for w in which:
         GEN[w](src)
         print("wrote", w)
-    with open(os.path.join(OUT, "VERSIONS.txt"), "w") as f:
+    with open(os.path.join(out, "VERSIONS.txt"), "w") as f:
         f.write(f"numpy {np.__version__}\nreference snapshot 2026-01-09 (lukebhan/PDEControlGym)\n")

@@ -1,0 +1,164 @@
+"""Checkpoint / resume of the batched environments: step, save, step n, load, step n
+must reproduce the same n results bit for bit -- in the same object, in a freshly built one, and through ``torch.save``."""
+import io
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from tests.cases import NS_BC
+from tests.fake_backend import FakeBackend
+
+BACKENDS = [pytest.param("double", id="cpu-double"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+def _bk(kind):
+    return dict(device="cpu", backend=FakeBackend()) if kind == "double" else dict(device="cuda")
+
+
+def _through_disk(sd):
+    f = io.BytesIO()
+    torch.save(sd, f)
+    f.seek(0)
+    return torch.load(f, weights_only=False)
+
+
+def _roundtrip(make, actions, n_before=3, n_after=6, prepare=None):
+    """make() -> a reset venv; actions(k) -> NumPy actions of step k."""
+    def run(v, k0, n):
+        out = []
+        for k in range(k0, k0 + n):
+            o, r, d, infos = v.step(actions(k))
+            out.append((o.copy(), r.copy(), d.copy(), [sorted(i) for i in infos],
+                        [i["terminal_observation"].copy() for i in infos if "terminal_observation" in i]))
+        return out
+
+    def same(a, b):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x[0], y[0])
+            np.testing.assert_array_equal(x[1], y[1])
+            np.testing.assert_array_equal(x[2], y[2])
+            assert x[3] == y[3] and len(x[4]) == len(y[4])
+            for p, q in zip(x[4], y[4]):
+                np.testing.assert_array_equal(p, q)
+    v = make()
+    run(v, 0, n_before)
+    sd = v.state_dict()
+    want = run(v, n_before, n_after)
+    assert any(w[2].any() for w in want), "the stretch after the checkpoint should contain episode ends"
+    v.load_state_dict(sd)                               # same object, rewound
+    same(run(v, n_before, n_after), want)
+    fresh = make()                                      # a new process would build it from the same parameters ...
+    if prepare is not None:
+        prepare(fresh)
+    fresh.load_state_dict(_through_disk(sd))            # ... and load what torch.save wrote
+    same(run(fresh, n_before, n_after), want)
+    with pytest.raises(ValueError):
+        bad = dict(sd, core=dict(sd["core"], meta=dict(sd["core"]["meta"], num_envs=sd["core"]["meta"]["num_envs"] + 1)))
+        fresh.load_state_dict(bad)
+
+
+@pytest.mark.parametrize("bk", BACKENDS)
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("kind", ["transport", "parabolic_scalar_f64beta"])
+def test_checkpoint_1d(bk, fused, kind):
+    import pde_control_gym
+    from pde_control_gym.src import TunedReward1D
+    B = 6
+    if kind == "transport":
+        nx, dt, S, nt = 100, 1e-4, 30, 150                  # episodes of 5 env-steps
+        p = {"T": nt * dt, "dt": dt, "X": 1, "dx": 1e-2, "control_sample_rate": S * dt, "sensing_loc": "full", "control_type": "Dirchilet",
+             "sensing_type": None, "normalize": True}
+        env_id, n = "PDEControlGym-TransportPDE1D", nx
+        beta = lambda i: (5 * np.cos((7 + 0.1 * i) * np.arccos(np.linspace(0, 1, n)))).astype(np.float32)    # noqa: E731
+    else:                                                   # separate state, scalar sensing, float64 beta (mixed-precision kernel)
+        nx = 64
+        dx = 1.0 / nx
+        dt, S, nt = 0.25 * dx * dx, 10, 50
+        p = {"T": nt * dt, "dt": dt, "X": 1, "dx": dx, "control_sample_rate": S * dt, "sensing_loc": "collocated", "control_type": "Neumann",
+             "sensing_type": None, "normalize": False}
+        env_id, n = "PDEControlGym-ReactionDiffusionPDE1D", nx + 1
+        beta = lambda i: 3.0 + 0.1 * i + np.cos(np.linspace(0, 3, n))                                          # noqa: E731
+
+    def make():
+        draws = iter(range(10 ** 6))
+
+        def batched(idx, nx_):
+            ks = [next(draws) for _ in idx]
+            return (np.stack([np.linspace(1, 2 + 0.25 * (k % 7), n) for k in ks]).astype(np.float32), np.stack([beta(k % 5) for k in ks]))
+        v = pde_control_gym.make_vec(env_id, num_envs=B, reward_class=TunedReward1D(nt - 1, -1e3, 3e2), limit_pde_state_size=True,
+                                     max_state_value=1e10, max_control_value=3, batched_reset_func=batched, **_bk(bk), **p)
+        v.reset()
+        if fused:
+            v.enable_fused_auto_reset(pool_episodes=3)
+        return v
+    rng = np.random.default_rng(2)
+    acts = rng.uniform(-1, 1, (16, B, 1)).astype(np.float32)
+    if fused:
+        _roundtrip(make, lambda k: acts[k])
+    else:                                                   # host-driven resets draw from the callback: only the rewind in place is
+        v = make()                                          # reproducible without checkpointing the caller's generator too
+        v.step(acts[0])
+        sd = v.state_dict()
+        want = []
+        for k in range(1, 4):                               # 5-step episodes: no episode end inside steps 1..3
+            o, r, d, _ = v.step(acts[k])
+            assert not d.any()
+            want.append((o.copy(), r.copy()))
+        v.load_state_dict(_through_disk(sd))
+        for k, (o, r) in zip(range(1, 4), want):
+            o2, r2, _, _ = v.step(acts[k])
+            np.testing.assert_array_equal(o2, o)
+            np.testing.assert_array_equal(r2, r)
+
+
+@pytest.mark.parametrize("bk", BACKENDS)
+def test_checkpoint_navier_stokes(bk):
+    import pde_control_gym
+    from pde_control_gym.src import NSReward
+    n, nt, K, B = 21, 5, 7, 3
+    rng = np.random.default_rng(4)
+    dx = 1.0 / (n - 1)
+    dt = 0.2 * 0.5 * dx * dx / 0.1
+    pools = tuple(rng.uniform(-1, 1, (3 * B, n, n)) for _ in range(3))
+    p = {"T": nt * dt, "dt": dt, "X": 1, "dx": dx, "Y": 1, "dy": dx, "action_dim": 1, "reward_class": NSReward(0.1), "normalize": False,
+         "boundary_condition": NS_BC, "U_ref": rng.uniform(-1, 1, (nt, n, n, 2)), "action_ref": 2.0 * np.ones(nt),
+         "maximum_pressure_iteration": K, "dtype": "float64", "reset_init_condition_func": lambda X: tuple(q[0] for q in pools)}
+
+    def make():
+        v = pde_control_gym.make_vec("PDEControlGym-NavierStokes2D", num_envs=B, **_bk(bk), **p)
+        v.core.reset(*[q[:B] for q in pools])
+        v.enable_fused_auto_reset(pools)
+        return v
+    acts = rng.uniform(2, 4, (16, B, 1))
+    _roundtrip(make, lambda k: acts[k], n_before=2, n_after=7)
+
+
+@pytest.mark.parametrize("bk", BACKENDS)
+def test_checkpoint_traffic_and_tumor(bk):
+    import pde_control_gym
+    from pde_control_gym.src import BrainTumorReward, TrafficARZReward
+    from tests.test_traffic import BASE
+    from tests.test_tumor import KW, tumor_ic
+    B = 4
+
+    def make_traffic():
+        random.seed(3)
+        v = pde_control_gym.make_vec("PDEControlGym-TrafficPDE1D", num_envs=B, reward_class=TrafficARZReward(), simulation_type="outlet-train",
+                                     limit_pde_state_size=True, control_freq=2, **_bk(bk), **dict(BASE, T=0.5))
+        v.reset()
+        v.enable_fused_auto_reset(init_pool=np.array([0.115, 0.12, 0.125, 0.12, 0.125, 0.115, 0.12, 0.115]))
+        return v
+    qs = make_traffic().core.t["qs_clip"].cpu().numpy()
+    rng = np.random.default_rng(1)
+    acts = qs[None, :, None] * rng.uniform(0.9, 1.1, (16, B, 1))
+    _roundtrip(make_traffic, lambda k: acts[k], n_before=2, n_after=8)
+
+    def make_tumor():
+        v = pde_control_gym.make_vec("PDEControlGym-BrainTumor1D", num_envs=B, weekends=True, T=600, reward_class=BrainTumorReward(),
+                                     reset_init_condition_func=tumor_ic, t_benchmark=300.0, **_bk(bk), **KW)
+        v.reset()
+        return v
+    doses = rng.uniform(0.15, 0.3, (16, B))
+    _roundtrip(make_tumor, lambda k: doses[k], n_before=2, n_after=9)

@@ -432,13 +432,22 @@ def test_ns_full_size_shards_properties_and_sampled_oracle(n, B, dtype):
     dx = 1.0 / (n - 1)
     dt = 0.2 * 0.5 * dx * dx / 0.1
     nt = 6
-    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=NS_BC, U_ref=np.zeros((nt, n, n, 2), dtype=dtype),
+    # smooth random fields (constants excite only the lid) and a non-zero reference trajectory for the reward
+    g1 = torch.linspace(0, 1, n, dtype=torch.float64)
+    Yg, Xg = torch.meshgrid(g1, g1, indexing="ij")
+    Uref = np.stack([np.stack([np.sin(np.pi * (Xg.numpy() + 0.1 * t)) * np.cos(np.pi * Yg.numpy()),
+                               0.5 * np.cos(2 * np.pi * Xg.numpy()) * np.sin(np.pi * (Yg.numpy() - 0.05 * t))], -1) for t in range(nt)])
+    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=NS_BC, U_ref=Uref.astype(dtype),
               action_ref=2.0 * np.ones(nt), gamma=0.1, maximum_pressure_iteration=50)
     env = _mk(kw, B, td)
     half = B // 2
-    c = torch.as_tensor(rng.uniform(-5, 5, (half, 3)), dtype=td)
-    c = torch.cat([c, c])
-    ic = [(c[:, k].reshape(B, 1, 1) * torch.ones(1, n, n, dtype=td)).contiguous() for k in range(3)]
+    c = torch.as_tensor(rng.uniform(-1, 1, (half, 8)), dtype=torch.float64).reshape(half, 8, 1, 1)
+    fx, fy = 0.5 + 1.5 * c[:, 6].abs(), 0.5 + 1.5 * c[:, 7].abs()
+    fields = (3 * c[:, 0] * torch.sin(2 * np.pi * fx * Xg) * torch.cos(np.pi * Yg) + 2 * c[:, 1],
+              3 * c[:, 2] * torch.cos(np.pi * Xg) * torch.sin(2 * np.pi * fy * Yg) + 2 * c[:, 3],
+              c[:, 4] * torch.cos(np.pi * Xg) * torch.cos(np.pi * fy * Yg) + c[:, 5])
+    ic = [torch.cat([f, f]).to(td).contiguous() for f in fields]
+    del fields
     env.reset(*ic)
     acts = []
     for _ in range(2):
@@ -450,7 +459,7 @@ def test_ns_full_size_shards_properties_and_sampled_oracle(n, B, dtype):
     assert torch.equal(obs[:half], obs[half:]) and torch.equal(env.p[:half], env.p[half:]) and torch.equal(r[:half], r[half:])
     assert torch.equal(obs[:, -1, 1:-1, 0].cpu(), acts[-1].reshape(B, 1).expand(B, n - 2))      # "upper" edge: u = action
     sel = [0, half // 3, half - 1]
-    orc = po.NavierStokesOracle(**dict(kw, U_ref=np.zeros((nt, n, n, 2))))
+    orc = po.NavierStokesOracle(**dict(kw, U_ref=Uref.astype(dtype).astype(np.float64)))
     orc.reset(*[x[sel].double().numpy() for x in ic])
     for a in acts:
         o_ref, r_ref, _, _ = orc.step(a[sel].double().numpy())

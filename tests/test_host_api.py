@@ -456,9 +456,24 @@ def test_golden_fixtures_are_exactly_what_the_generator_writes():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if not os.path.isdir(os.environ.get("PDEGYM_REFERENCE", "/root/reference")):
         pytest.skip("the reference checkout is not on this machine (GPU box): fixtures cannot be regenerated here")
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "make_golden.py"), "--check"], cwd=root,
-                       env=dict(os.environ, PYTHONPATH=root), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    # as its docstring documents it: no PYTHONPATH, any working directory (the script puts the repository root on sys.path itself)
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "make_golden.py"), "--check"], cwd=os.path.dirname(root),
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
+    # importable, with its generator table at module level (advisor finding r3): check() of one small file from this process
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_mod", os.path.join(root, "tests", "golden", "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "gymnasium" or k.startswith(("gymnasium.", "pde_control_gym"))}
+    try:
+        spec.loader.exec_module(mod)
+        assert set(mod.GEN) == set(mod.FILES)
+    finally:
+        for k in [k for k in sys.modules if k == "gymnasium" or k.startswith(("gymnasium.", "pde_control_gym"))]:
+            if k not in saved:
+                del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
 
 
 def test_parabolic_single_env_public_api(golden_parabolic):
@@ -737,3 +752,84 @@ def test_bench_docstring_names_every_workload():
     bench = importlib.import_module("bench")
     missing = [k for k in bench.WORKLOADS if k not in (bench.__doc__ or "") and k != "parabolic_c2"]
     assert not missing, missing
+
+
+@pytest.mark.parametrize("bk", BACKENDS)
+@pytest.mark.parametrize("variant", ["separate_state", "collocated", "opposite"])
+def test_device_rollout_consecutive_runs_start_from_the_last_observation(bk, variant):
+    """Engines whose observation is NOT the state (state_in_obs=False, scalar sensing): after run() the engine's current
+    observation must be slot T of the rollout, so that the next run() seeds obs[0] with it (advisor finding r3: it used to be the
+    pre-rollout observation while ``u`` had advanced).  Two runs of T steps equal one run of 2T steps."""
+    import torch
+    import pde_control_gym
+    from pde_control_gym import DeviceRollout
+    from pde_control_gym.src import TunedReward1D
+    B, T = 4, 3
+    extra = {"separate_state": dict(state_in_obs=False), "collocated": dict(sensing_loc="collocated", control_type="Neumann"),
+             "opposite": dict(sensing_loc="opposite", sensing_type="Dirchilet")}[variant]
+
+    def mk():
+        rng = np.random.default_rng(11)
+        p = _transport_params(T=0.2, dt=1e-4, control_sample_rate=20e-4, reward_class=TunedReward1D(2000, -1e3, 3e2))
+        p.update({k: v for k, v in extra.items() if k != "state_in_obs"})
+        p["reset_init_condition_func"] = lambda nx: np.linspace(1, 2, nx) * rng.uniform(1, 3)
+        v = pde_control_gym.make_vec("PDEControlGym-TransportPDE1D", num_envs=B, **_bk(bk), **{k: w for k, w in extra.items() if k == "state_in_obs"}, **p)
+        v.reset_tensor()
+        return v
+    d = 100 if variant == "separate_state" else 1
+    w = torch.linspace(-0.3, 0.4, d)
+    pol = lambda o: torch.tanh(o.float() @ w.to(o.device))          # noqa: E731
+    va, vb = mk(), mk()
+    assert not va.core.state_in_obs
+    graph = bk == "hip"
+    ro = DeviceRollout(va, pol, T, use_graph=graph)
+    first = ro.run().obs.cpu().numpy().copy()
+    np.testing.assert_array_equal(va.core.t["obs"].cpu().numpy(), first[T])
+    second = ro.run().obs.cpu().numpy().copy()
+    long = DeviceRollout(vb, pol, 2 * T, use_graph=graph).run().obs.cpu().numpy()
+    np.testing.assert_array_equal(second[0], first[T])
+    np.testing.assert_array_equal(np.concatenate([first, second[1:]]), long)
+
+
+@pytest.mark.parametrize("bk", BACKENDS)
+def test_truncation_reward_is_a_python_float_like_the_reference(golden_transport, bk):
+    """tuned_reward_1d.py:38-39: the truncation branch is ``truncate_penalty * (nt - time_index)`` on the constructor's Python
+    numbers -- the reference hands a Python float back (every other branch is NumPy arithmetic); so does the single environment
+    (it used to be a np.float32)."""
+    from pde_control_gym.src import TransportPDE1D, TunedReward1D
+    g = golden_transport["R_trunc"]
+    kw = dict(TRANSPORT_CASES["R_trunc"])
+    ra = g.reward_args                                  # (nt, truncate_penalty, terminate_reward) as the examples pass them: Python numbers
+    env = TransportPDE1D(reward_class=TunedReward1D(int(ra[0]), float(ra[1]), float(ra[2])), sensing_noise_func=lambda s: s,
+                         reset_init_condition_func=lambda nx: g.init, reset_recirculation_func=lambda nx: g.beta, **_bk(bk), **kw)
+    env.reset()
+    for k in range(2):
+        obs, r, te, tr, _ = env.step(np.float32(g.actions[k]))
+        assert tr == bool(g.truncate[k])
+        if tr:
+            assert type(r) is float and r == float(g.reward[k]) == -8.0e6
+        else:
+            assert isinstance(r, np.floating)
+            np.testing.assert_allclose(r, g.reward[k], rtol=1e-6)
+
+
+@pytest.mark.parametrize("bk", BACKENDS)
+def test_ns_step_past_the_last_frame_raises_index_error_like_the_reference(bk):
+    """navier_stokes2D.py:147-148 writes U[time_index] after the increment, so the nt-th step of an episode (one past the terminal
+    one) raises IndexError there; the drop-in used to keep going silently."""
+    from pde_control_gym.src import NavierStokes2D, NSReward
+    nt, n = 4, 11
+    dx = 0.1
+    dt = 0.2 * 0.5 * dx * dx / 0.1
+    p = {"T": nt * dt, "dt": dt, "X": 1, "dx": dx, "Y": 1, "dy": dx, "action_dim": 1, "reward_class": NSReward(0.1), "normalize": False,
+         "reset_init_condition_func": lambda X: (np.ones_like(X), np.zeros_like(X), np.zeros_like(X)), "boundary_condition": NS_BC,
+         "U_ref": np.zeros((nt, n, n, 2)), "action_ref": 2.0 * np.ones(nt), "maximum_pressure_iteration": 5}
+    env = NavierStokes2D(**_bk(bk), **p)
+    assert env.nt == nt
+    env.reset()
+    flags = [env.step(3.0)[2] for _ in range(nt - 1)]
+    assert flags == [False] * (nt - 2) + [True]
+    with pytest.raises(IndexError, match=f"index {nt} is out of bounds for axis 0 with size {nt}"):
+        env.step(3.0)
+    env.reset()                                        # and the environment is usable again after a reset
+    assert env.step(3.0)[2] is False
