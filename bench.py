@@ -245,6 +245,27 @@ class ParabolicOpenLoopRollout(Parabolic1D):
         return c
 
 
+class ParabolicS1(Parabolic1D):
+    """"S = 100 and also S = 1" -- the C2 environment with ONE PDE sub-step per env-step (control_sample_rate =
+    dt): 4 128 algorithmic bytes per env-step, the launch-bound regime (one launch per env-step costs more than its arithmetic)."""
+    name = "ReactionDiffusionPDE1D nx=256 B=4096 S=1 (SURVEY 8d: the launch-bound regime), one launch per env-step"
+    S = 1
+
+
+class ParabolicS1OpenLoopRollout(ParabolicOpenLoopRollout):
+    """S = 1 with the commands of 100 env-steps handed over at once: one launch per 100 env-steps (pdegym_parabolic_rollout)."""
+    S, CHUNK = 1, 100
+    name = "ReactionDiffusionPDE1D nx=256 B=4096 S=1, 100 env-steps per launch (pdegym_parabolic_rollout, commands given ahead)"
+
+
+class ParabolicS1Rollout(ParabolicRollout):
+    """S = 1 with the MLP controller inside the rollout kernel: policy + env-step + auto-reset, 100 env-steps per launch -- the
+    configuration SURVEY section 8f rank 1 says the whole-node figure is "actually won" in."""
+    S, CHUNK = 1, 100
+    name = ("ReactionDiffusionPDE1D nx=256 B=4096 S=1, 257-64-64-1 tanh MLP policy, 100 env-steps per launch "
+            "(pdegym_parabolic_rollout: policy + env-step + auto-reset inside one kernel)")
+
+
 class Transport1D(Parabolic1D):
     """BASELINE config 3 shape: TransportPDE1D nx=512, dt=0.5dx, S=100, B=16384/GPU (the reference has no
     Burgers env)."""
@@ -268,7 +289,7 @@ def cpu_port_rate(workload_key, seconds, seed=0):
     from oracle import pde_oracle as po
     rng = np.random.default_rng(seed)
     if workload_key.startswith("parabolic_c2"):      # the policy-in-the-loop variants: the CPU port times the environment alone
-        workload_key = "parabolic_c2"
+        workload_key = "parabolic_c2_s1" if workload_key.startswith("parabolic_c2_s1") else "parabolic_c2"
     if workload_key == "traffic_arz":
         env = po.TrafficOracle(240, 0.25, 500, 10, "outlet", 40, 0.16, 60, True, TrafficARZ.S)
         rs = [0.12]
@@ -285,8 +306,8 @@ def cpu_port_rate(workload_key, seconds, seed=0):
         reset = lambda: env.reset(ic, [363.0])
         done = lambda out: bool(out[2][0] or out[3][0])
         what = "float64, one simulated day each"
-    elif workload_key in ("parabolic_c2", "transport_c3", "burgers_c3"):
-        cls = {"parabolic_c2": Parabolic1D, "transport_c3": Transport1D, "burgers_c3": Burgers1D}[workload_key]
+    elif workload_key in ("parabolic_c2", "parabolic_c2_s1", "transport_c3", "burgers_c3"):
+        cls = {"parabolic_c2": Parabolic1D, "parabolic_c2_s1": ParabolicS1, "transport_c3": Transport1D, "burgers_c3": Burgers1D}[workload_key]
         nx, S = cls.nx, cls.S
         dx = 1.0 / nx
         dt = 0.25 * dx * dx if cls.kind == "parabolic" else 0.5 * dx
@@ -499,6 +520,9 @@ from bench_ns2d import (NavierStokesC4, NavierStokesC4B4096, NavierStokesC4B4096
 WORKLOADS["parabolic_c2_policy_loop"] = ParabolicPolicyLoop
 WORKLOADS["parabolic_c2_rollout"] = ParabolicRollout
 WORKLOADS["parabolic_c2_open_loop_rollout"] = ParabolicOpenLoopRollout
+WORKLOADS["parabolic_c2_s1"] = ParabolicS1
+WORKLOADS["parabolic_c2_s1_open_loop_rollout"] = ParabolicS1OpenLoopRollout
+WORKLOADS["parabolic_c2_s1_rollout"] = ParabolicS1Rollout
 WORKLOADS["ns2d_c4"] = NavierStokesC4
 WORKLOADS["ns2d_c4_f64"] = NavierStokesC4F64
 WORKLOADS["ns2d_c4_b4096"] = NavierStokesC4B4096
@@ -511,10 +535,35 @@ WORKLOADS["traffic_arz_rollout"] = TrafficARZRollout
 WORKLOADS["brain_tumor"] = BrainTumor
 
 
+# Which kernel sources each workload's launches are compiled from: the committed PMC counters of a workload are stamped with the
+# fingerprint of these files (build.sources_fingerprint) when they are collected, and roofline_block flags them as stale when the
+# tree has moved on ("roofline counters are not tied to the binary").
+_SRC_1D = ["pdegym_1d.hip", "pdegym_common.h", "pdegym_policy.h"]
+_SRC_NS = ["pdegym_ns2d.hip", "pdegym_ns_common.h", "pdegym_common.h"]
+KERNEL_SOURCES = {
+    "parabolic_c2": _SRC_1D, "transport_c3": _SRC_1D, "burgers_c3": _SRC_1D, "parabolic_c2_rollout": _SRC_1D,
+    "parabolic_c2_open_loop_rollout": _SRC_1D, "parabolic_c2_s1": _SRC_1D, "parabolic_c2_s1_open_loop_rollout": _SRC_1D,
+    "parabolic_c2_s1_rollout": _SRC_1D, "parabolic_c2_policy_loop": _SRC_1D + ["pdegym_mlp.hip"],
+    "ns2d_c4": _SRC_NS, "ns2d_c4_b4096": _SRC_NS, "ns2d_c4_f64": _SRC_NS, "ns2d_c4_f64_b4096": _SRC_NS, "ns2d_example": _SRC_NS,
+    "ns2d_c5": _SRC_NS + ["pdegym_ns256.hip", "pdegym_ns256_rows.h"],
+    "ns2d_c5_f64": _SRC_NS + ["pdegym_ns256_f64.hip", "pdegym_ns256_rows.h"],
+    "traffic_arz": ["pdegym_traffic.hip", "pdegym_common.h", "pdegym_policy.h"],
+    "traffic_arz_rollout": ["pdegym_traffic.hip", "pdegym_common.h", "pdegym_policy.h"],
+    "brain_tumor": ["pdegym_tumor.hip", "pdegym_common.h"],
+}
+
+
+def kernel_stamp(workload_key):
+    from pdecontrolgym_amd import build
+    files = [f for f in KERNEL_SOURCES.get(workload_key, []) if os.path.exists(os.path.join(build.CSRC, f))]
+    return build.sources_fingerprint(files) if files else None
+
+
 CLOCK_GHZ = 2.4          # MI355X peak shader clock (MI355X_MICROARCH.md); sustained clocks under VALU load are nearer 2.0
 N_SIMD = 256 * 4         # 256 CUs x 4 SIMDs
 VALU_PEAK_GINST = N_SIMD * CLOCK_GHZ / 2.0     # one wave64 VALU instruction per SIMD every 2 cycles -> 1228.8 G wave-inst/s
 REPEATS = 5              # median of 5 repeats of the K timed steps
+WARM_SECONDS = 0.05      # untimed graph replays before the first timed region
 
 
 def profiled_counters(workload_key):
@@ -571,7 +620,14 @@ def run_workload(wl, steps, warmup, world, graph=False, repeats=REPEATS):
                 for _ in range(steps):
                     wl.step()
         torch.cuda.current_stream().wait_stream(side)
-        g.replay()                          # untimed first replay (graph upload)
+        # untimed replays (graph upload, clocks, caches) until at least WARM_SECONDS have passed: short regions used to be
+        # timed while the box was still speeding up (five consecutive regions fell monotonically by 6-10 %)
+        t_warm = time.perf_counter()
+        while True:
+            g.replay()
+            torch.cuda.synchronize()
+            if time.perf_counter() - t_warm >= WARM_SECONDS:
+                break
         for _ in range(repeats):
             regions.append(_timed(g.replay, world))
     else:
@@ -661,6 +717,14 @@ def roofline_block(wl, key, step_ms, default_config):
     out["traffic"] = hbm["bytes_per_step"] if hbm else None
     if ctr and ctr.get("round"):
         src = f"round {ctr['round']}: " + (src or "")
+    if ctr:
+        # the counters were collected from kernels built from sources with this fingerprint; if the tree (or, on a GPU box, the
+        # shipped library's own stamp) has moved on since, the fractions below describe an OLDER kernel's instruction / byte counts
+        from pdecontrolgym_amd import build
+        now = kernel_stamp(key)
+        out["counters_kernel_stamp"] = ctr.get("kernel_stamp")
+        lib = build.library_stamp()
+        out["counters_stale"] = bool(ctr.get("kernel_stamp") != now or (lib != "" and lib != build._fingerprint()))
     out.update({"valu_issue": valu, "hbm": hbm, "step_ms": step_ms, "counters_source": src,
                 "kernels_per_step": (ctr or {}).get("kernels"),
                 "effective_streaming_GBps": alg / t / 1e9, "effective_streaming_frac_of_hbm_peak": alg / t / 1e9 / HBM_PEAK_GBPS,
@@ -755,7 +819,7 @@ def main():
                 rf = roofline_block(w2, name, r2["step_ms_events"], True)
                 also[name] = {"value": w2.units_per_step() * n2 / r2["seconds"], "unit": "env-steps/s", "ms_per_step": r2["seconds"] / n2 * 1e3,
                               "dtype": w2.dtype, "timed_regions_s": r2["all_regions_s"],
-                              "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "step_ms")},
+                              "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "step_ms", "counters_stale")},
                               "config": w2.config()}
                 del w2
             except Exception as ex:  # keep the headline line alive

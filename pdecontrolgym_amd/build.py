@@ -35,6 +35,27 @@ def _fingerprint() -> str:
     return h.hexdigest()
 
 
+def sources_fingerprint(files) -> str:
+    """Hash of a SUBSET of the kernel sources (+ the public header and the compiler options): what one workload's kernels are
+    compiled from.  bench.py stamps the committed PMC counters of a workload with it, so that a roofline fraction computed from
+    counters of an older kernel is flagged (``counters_stale``) instead of silently wrong."""
+    h = hashlib.sha256()
+    for f in sorted(files) + ["../../include/pdegym.h"]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(os.path.basename(f).encode())
+            h.update(fh.read())
+    h.update(" ".join(OPTS).encode())
+    return h.hexdigest()[:16]
+
+
+def library_stamp() -> str:
+    """Fingerprint the shipped library was built from (the stamp file next to it), or "" if there is none."""
+    try:
+        return open(os.path.join(LIBDIR, "libpdegym_hip.stamp")).read().strip()
+    except OSError:
+        return ""
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP translation unit for gfx950 and link libpdegym_hip.so. Returns its path."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

@@ -833,3 +833,25 @@ def test_ns_step_past_the_last_frame_raises_index_error_like_the_reference(bk):
         env.step(3.0)
     env.reset()                                        # and the environment is usable again after a reset
     assert env.step(3.0)[2] is False
+
+
+def test_roofline_counters_are_tied_to_the_kernel_sources(monkeypatch):
+    """profiles/counters_latest.json carries, per workload, the fingerprint of the kernel sources its PMC counters were collected
+    from; bench.py's roofline block says ``counters_stale`` when the tree has moved on.  The committed file must be
+    stamped, every workload of the table must have its sources listed, and a changed source flips the flag."""
+    import json
+    import bench
+
+    class W:
+        def algorithmic_bytes_per_step(self):
+            return 1
+
+        def compulsory_bytes_per_step(self):
+            return 1
+    d = json.load(open(os.path.join(ROOT, "profiles", "counters_latest.json")))
+    assert set(d["workloads"]) <= set(bench.KERNEL_SOURCES) and set(bench.WORKLOADS) == set(bench.KERNEL_SOURCES)
+    assert all(v.get("kernel_stamp") for v in d["workloads"].values())
+    r = bench.roofline_block(W(), "parabolic_c2", 0.02, True)
+    assert r["counters_stale"] == (r["counters_kernel_stamp"] != bench.kernel_stamp("parabolic_c2")) and 0.3 < r["frac"] < 0.7
+    monkeypatch.setattr(bench, "kernel_stamp", lambda k: "0" * 16)
+    assert bench.roofline_block(W(), "parabolic_c2", 0.02, True)["counters_stale"] is True
