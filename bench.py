@@ -671,20 +671,26 @@ def vecenv_host_rate(device, B=4096, steps=60, warmup=8):
          "limit_pde_state_size": True, "max_state_value": 1e10, "max_control_value": 20, "control_sample_rate": S * dt,
          "batched_reset_func": lambda idx, nx_: (rng.uniform(1, 10, (len(idx), 1)).astype(np.float32) * np.ones((1, nx_ + 1), np.float32),
                                                  np.tile(beta, (len(idx), 1)))}
-    venv = pde_control_gym.make_vec("PDEControlGym-ReactionDiffusionPDE1D", num_envs=B, device=str(device), **p)
-    venv.reset()
-    venv.enable_fused_auto_reset()
     acts = np.random.default_rng(1).uniform(-1, 1, (warmup + steps, B, 1)).astype(np.float32)
-    for k in range(warmup):
-        venv.step(acts[k])
-    t0 = time.perf_counter()
-    for k in range(steps):
-        obs, rew, dones, infos = venv.step(acts[warmup + k])
-    el = (time.perf_counter() - t0) / steps
+    res = {}
+    for copy_outputs in (True, False):
+        venv = pde_control_gym.make_vec("PDEControlGym-ReactionDiffusionPDE1D", num_envs=B, device=str(device), copy_outputs=copy_outputs, **p)
+        venv.reset()
+        venv.enable_fused_auto_reset()
+        for k in range(warmup):
+            venv.step(acts[k])
+        t0 = time.perf_counter()
+        for k in range(steps):
+            obs, rew, dones, infos = venv.step(acts[warmup + k])       # (results dropped every step, as SB3's loop does after copying)
+        res[copy_outputs] = (time.perf_counter() - t0) / steps
+    el = res[True]
     return {"value": B / el, "unit": "env-steps/s", "us_per_step": el * 1e6, "batch": B,
             "host_bytes_per_step": int(obs.nbytes + rew.nbytes + dones.nbytes + acts[0].nbytes),
-            "note": "PDEVecEnv.step: numpy actions in, numpy observations / rewards / dones / infos out through rotating pinned "
-                    "staging buffers, one stream synchronisation per step; PCIe-inclusive (never the headline value)"}
+            "zero_copy_observations": {"value": B / res[False], "us_per_step": res[False] * 1e6,
+                                       "note": "make_vec(..., copy_outputs=False): the observation array is a view of a rotating pinned "
+                                               "staging buffer (valid for two further steps -- what SB3's loop needs)"},
+            "note": "PDEVecEnv.step with its defaults: numpy actions in, numpy observations / rewards / dones / infos out (arrays the "
+                    "caller may keep), pinned staging buffers, one stream synchronisation per step; PCIe-inclusive (never the headline value)"}
 
 
 def roofline_block(wl, key, step_ms, default_config):
