@@ -112,10 +112,9 @@ class PDEVecEnv(BatchedVecEnv):
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
         self.batched_reset_func = batched_reset_func
-        # copy_outputs=True (default): step() hands out fresh NumPy arrays that stay valid, as the reference's do for an episode.
-        # copy_outputs=False: the OBSERVATION array is a view of a rotating pinned staging buffer (reused ``host_buffers`` steps
-        # later; saves ~40 us per step at 4096 x 257 float32) -- for SB3-style loops, which copy what they keep into their own
-        # rollout buffer.  Rewards and flags (a few KB) are always fresh arrays.
+        # The arrays step() returns stay valid for as long as the caller references them, as the reference's do (_to_host: pinned
+        # staging buffers recycled by reference count).  ``copy_outputs`` is accepted for compatibility with round-3 callers and
+        # has no effect any more.
         self.copy_outputs = bool(copy_outputs)
         # state_in_obs=False (1D) / interleaved_state=False (NavierStokes2D) in the parameters: the engine keeps the plant state in
         # its own tensors and the observation is a separate output -- for torch callers that normalise or perturb the tensors
@@ -419,51 +418,44 @@ class PDEVecEnv(BatchedVecEnv):
         self._consume_reset_arguments()
         return obs
 
-    # With copy_outputs=False: how many consecutive observation arrays stay valid -- they are VIEWS of pinned staging buffers that
-    # are reused ``host_buffers`` steps later (SB3 reads the observation of step k once more right after step k+1 returned -- its
-    # ``_last_obs`` -- and never again, so two would do; three leaves a step of slack).
-    host_buffers = 3
+    # Most pinned staging buffers kept per output; a caller that holds on to more results than this gets plain copies beyond it.
+    host_buffers = 16
 
     def _to_host(self, tensors):
-        """Device tensors -> NumPy arrays through pinned staging buffers: the copies are queued back to back and the stream is
-        synchronised ONCE (``t.cpu()`` per tensor goes through pageable memory and synchronises every time).  The first tensor
-        (the observation) is returned as a view of its staging buffer when ``copy_outputs`` is off (the buffers rotate,
-        ``host_buffers``); everything else is copied out."""
+        """Device tensors -> NumPy arrays the caller may keep, without a host-side copy: each tensor is copied (asynchronously,
+        ONE stream synchronisation for all of them; ``t.cpu()`` per tensor goes through pageable memory and synchronises every
+        time) into a pinned staging buffer THAT NOBODY REFERENCES ANY MORE, and the NumPy view of that buffer is what the caller
+        gets.  "Nobody references" is the reference count of the view: an array the caller still holds -- directly or through
+        any view or slice of it, which keep their base alive -- is never written again; once dropped it is recycled.  An
+        SB3-style loop (copies what it keeps into its rollout buffer) therefore cycles through two or three buffers; a caller
+        that appends every observation to a list keeps getting new ones (``host_buffers`` pinned, plain NumPy copies beyond)."""
+        import sys
         import torch
         if self.device.type != "cuda":
             return [t.numpy().copy() for t in tensors]
-        pins = self.__dict__.setdefault("_pins", {})
-        turn = self.__dict__.get("_pin_turn", 0)
-        self._pin_turn = (turn + 1) % max(2, int(self.host_buffers))
-        out = []
+        pools = self.__dict__.setdefault("_pins", {})
+        out, spill = [], []
         for i, t in enumerate(tensors):
-            key = (turn, i, tuple(t.shape), t.dtype)
-            if key not in pins:
+            pool = pools.setdefault(("out", i, tuple(t.shape), t.dtype), [])
+            k = next((k for k in range(len(pool)) if sys.getrefcount(pool[k][1]) == 2), None)    # the pool's reference + the argument
+            if k is None and len(pool) < max(2, int(self.host_buffers)):
                 pin = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-                pins[key] = (pin, pin.numpy())
-            pins[key][0].copy_(t, non_blocking=True)
-            out.append(pins[key][1])
+                pool.append((pin, pin.numpy()))
+                k = len(pool) - 1
+            if k is None:                      # everything is still referenced by the caller: stage through slot 0, hand out a copy
+                scratch = pools.setdefault(("scratch", i, tuple(t.shape), t.dtype), None)
+                if scratch is None:
+                    scratch = pools[("scratch", i, tuple(t.shape), t.dtype)] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                scratch.copy_(t, non_blocking=True)
+                spill.append(len(out))
+                out.append(scratch)
+                continue
+            pool[k][0].copy_(t, non_blocking=True)
+            out.append(pool[k][1])
         torch.cuda.current_stream(self.device).synchronize()
-        return [self._copy_out(i, o) if (i > 0 or self.copy_outputs) else o for i, o in enumerate(out)]
-
-    def _copy_out(self, slot, src):
-        """A NumPy array the caller may keep: a copy of ``src`` in memory nobody else references.  A fresh 4 MB allocation per
-        step costs ~200 us in page faults, so arrays handed out earlier are RE-USED once the caller has dropped them -- an
-        array (or any view of it: a view holds a reference to its base) that is still referenced anywhere is never touched."""
-        import sys
-        if src.nbytes < (1 << 16):
-            return src.copy()
-        pool = self.__dict__.setdefault("_out_pool", {}).setdefault((slot, src.shape, src.dtype.str), [])
-        for i in range(len(pool)):
-            if sys.getrefcount(pool[i]) == 2:          # the pool's reference + getrefcount's own argument: nobody else has it
-                dst = pool[i]
-                break
-        else:
-            dst = np.empty_like(src)
-            if len(pool) < 16:                         # a caller that keeps everything gets plain fresh arrays beyond this
-                pool.append(dst)
-        np.copyto(dst, src)
-        return dst
+        for j in spill:
+            out[j] = out[j].numpy().copy()
+        return out
 
     def _fresh_infos(self):
         """One dict per environment, as SB3 expects -- but the B empty dicts are made once and handed out again every step;

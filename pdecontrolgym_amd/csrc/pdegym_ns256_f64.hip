@@ -1,21 +1,29 @@
-// pdegym_ns256_f64.hip -- the pressure solve of NavierStokes2D on a 256 x 256 grid at the reference's own precision
-// (float64: navier_stokes2D.py:186, base_env_2d.py:50), BASELINE config 5.
+// pdegym_ns256_f64.hip -- NavierStokes2D on a 256 x 256 grid at the reference's own precision (float64: navier_stokes2D.py:186,
+// base_env_2d.py:50), BASELINE config 5: the whole env-step as ceil(K / 25) launches of ONE kernel.
 //
-// Reference semantics restated: solve_pressure's sweeps, environments2d/navier_stokes2D.py:104-114
-//   p_new = 1/4 (((W + S) + E) + N - dx dy rhs)  on interior cells, then the four Neumann copies;
-// same expression tree as ns_generic_step<double> (pdegym_ns2d.hip) -> bit-identical to NumPy (tests/test_gpu_ns2d.py).
+// Reference semantics restated (environments2d/navier_stokes2D.py): predictor :130-138, apply_boundary :68-91, rhs :101-103,
+// the sweeps of solve_pressure :104-114
+//   p_new = 1/4 (((W + S) + E) + N - dx dy rhs)  on interior cells, then the four Neumann copies,
+// corrector :143-146, observation / reward :147-154 (ns_reward.py:28).  Same expression trees as ns_generic_step<double>
+// (pdegym_ns2d.hip), IEEE division included -> bit-identical to NumPy (tests/test_gpu_ns2d.py).
 //
 // p and dx dy rhs of one instance are 2 x 512 KB in float64: more than a CU holds (512 KB of registers + 160 KB of LDS), and an
-// in-launch exchange between workgroups would make one workgroup wait for another.  So the K sweeps run as ceil(K / 17) PASSES
-// of at most 17 sweeps, each a launch of three slabs per instance: a slab = 112 consecutive grid rows (8 waves x 14 rows, 4
-// columns = 8 registers per lane and row) of which the middle ones are its OWN rows and the rest a halo of the neighbouring
-// slabs; rows next to a cut go stale by one row per sweep, after 17 sweeps the own rows are still exact and are the only ones
-// stored.  A pass keeps p (120 registers per lane) and 8 of its 14 dx dy rhs rows in registers, the other 6 in wave-private
-// LDS (one 32-byte read per row and sweep); left / right neighbours are lanes (two v_mov_b32_dpp per double), the rows above /
-// below a wave's block cross waves through a double-buffered 64 KB LDS area, one barrier per sweep, rows rotate with period
-// two (UP / DOWN sweeps, see jacobi_sweep_bous) so a sweep has no register copies.  Passes ping-pong between two pressure fields.
-// Redundant sweeps: 336 / 256 rows = 1.31x.  The predictor / corrector phases around the solve are ns_generic_step's
-// row-wave kernels below (ns256_front_f64 / ns256_back_f64: one wave per band of 16 grid rows).
+// in-launch exchange between workgroups would make one workgroup wait for another.  So the K sweeps run as PASSES of at most 25
+// sweeps, each a launch of three slabs per instance: a slab = 120 consecutive grid rows (8 waves x 15 rows, 4 columns = 8
+// registers per lane and row) of which the middle ones are its OWN rows and the rest a halo of the neighbouring slabs; rows next
+// to a cut go stale by one row per sweep, after 25 sweeps the own rows (and one more on either side) are still exact and are the
+// only ones stored.  A pass keeps p (128 registers per lane) and 9 of its 15 dx dy rhs rows in registers, the other 6 in
+// wave-private LDS (one 32-byte read per row and sweep); left / right neighbours are lanes (two v_mov_b32_dpp per double), the
+// rows above / below a wave's block cross waves through a double-buffered 64 KB LDS area, one barrier per sweep, rows rotate with
+// period two (UP / DOWN sweeps, see jacobi_sweep_bous) so a sweep has no register copies.  Redundant sweeps: 360 / 256 = 1.41x.
+//
+// Round 4: the phases around the solve are no longer launches of their own (round 3: front -> 3 passes of 17 -> back, 11.1 MB of
+// HBM traffic per instance against 3 MB of compulsory bytes).  The FIRST pass of a step opens with the front phase -- every wave
+// evaluates predictor -> boundary rule -> rhs for the 15 rows it is about to sweep (a rolled row pipeline over the state rows,
+// rows256 helpers) and leaves them in the rhs field, where it picks them up again itself (L2) and a later pass finds them; the
+// LAST pass closes with the back phase -- the slab's own pressure rows are stored, then its waves share the slab's own rows
+// among themselves and run predictor (again, from the state rows) -> corrector -> boundary rule -> observation -> reward partial
+// sums.  K = 50: two launches, 7.3 MB per instance (state + p in, rhs + p out | p + rhs + state in, p + observation out).
 #include <hip/hip_runtime.h>
 
 #include "pdegym.h"
@@ -27,34 +35,31 @@ namespace pdegym {
 namespace ns {
 namespace {
 
-constexpr int kN = 256, kCells = kN * kN;
-constexpr int kNW = 8, kPR = 14, kRows = kNW * kPR;          // 112 rows per slab
+using namespace rows256;
+
+constexpr int kCells = kN * kN;
+constexpr int kNW = 8, kPR = 15, kRows = kNW * kPR;          // 120 rows per slab
 constexpr int kNT = 64 * kNW;
 constexpr int kRL = 6, kRR = kPR - kRL;                      // dx dy rhs rows per wave in LDS / in registers (the first kRR)
-constexpr int kH = 17;                                       // sweeps per pass
+constexpr int kH = 25;                                       // sweeps per pass
 constexpr int kSlabs = 3;
-// slab s covers rows kLo[s] .. kLo[s] + 111 and owns rows kOwn[s] .. kOwn[s + 1] - 1; a cut row is >= kH rows away from every
-// own row of the slab it bounds (0 + 112 - 17 = 95 > 88; 72 + 17 = 89, 184 - 17 = 167; 144 + 17 = 161 <= 167)
-__device__ constexpr int kLo[kSlabs] = {0, 72, 144};
-__device__ constexpr int kOwn[kSlabs + 1] = {0, 89, 167, 256};
-static_assert(kLo[1] + kH <= kOwn[1] && kLo[1] + kRows - kH >= kOwn[2] && kLo[2] + kH <= kOwn[2] && kRows - kH >= kOwn[1] &&
-              kLo[2] + kRows == kN, "every own row must be at least kH rows away from the cuts of its slab");
+// slab s covers rows kLo[s] .. kLo[s] + 119 and owns rows kOwn[s] .. kOwn[s + 1] - 1.  After kH sweeps the rows within kH of a
+// cut are stale; the back phase also reads the rows next to the own range (corrector: p[r - 1], p[r + 1]), so every own row AND
+// its two neighbours must be at least kH rows away from the cuts of the slab:
+//   slab 0 (cut above row 119): exact rows 0 .. 94;  slab 1 (cuts at 68 and 188): 93 .. 162;  slab 2 (cut at 136): 161 .. 255
+__device__ constexpr int kLo[kSlabs] = {0, 68, 136};
+__device__ constexpr int kOwn[kSlabs + 1] = {0, 94, 162, 256};
+static_assert(kOwn[1] <= kLo[0] + kRows - kH - 1 && kOwn[1] - 1 >= kLo[1] + kH && kOwn[2] <= kLo[1] + kRows - kH - 1 &&
+                  kOwn[2] - 1 >= kLo[2] + kH && kLo[2] + kRows == kN && kLo[0] == 0,
+              "every own row and its two neighbours must be at least kH rows away from the cuts of the slab");
 constexpr int kHaloBytes = 2 * 2 * kNT * 32;                 // two buffers x (top rows, bottom rows) x four doubles per thread
 constexpr int kLdsBytes = kHaloBytes + kRL * kNT * 32;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget of one CU");
 
-__device__ __forceinline__ double shr_f64(double v) {       // lane i <- lane i-1 (lane 0: 0, a domain-edge lane)
-  const long long b = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x138, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xf, 0xf, true);
-  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-__device__ __forceinline__ double shl_f64(double v) {       // lane i <- lane i+1
-  const long long b = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x130, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xf, 0xf, true);
-  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
+enum : int { kPassFront = 1, kPassBack = 2 };
+
+__device__ __forceinline__ double shr_f64(double v) { return lane_left(v); }     // lane i <- lane i-1 (lane 0: 0, a domain-edge lane)
+__device__ __forceinline__ double shl_f64(double v) { return lane_right(v); }    // lane i <- lane i+1
 
 struct D4 {
   double2 a, b;
@@ -90,8 +95,6 @@ __device__ __forceinline__ void walls4(double (&ph)[kPR + 1][4], const EdgeFlags
   }
 #pragma unroll
   for (int a = 0; a < PR; ++a) {
-    constexpr int dummy = 0;
-    (void)dummy;
     double (&row)[4] = ph[bphys<PR>(a, ST)];
     row[0] = E.lef ? row[1] : row[0];
     row[3] = E.rig ? row[2] : row[3];
@@ -150,85 +153,13 @@ __device__ __forceinline__ void sweep4(double (&ph)[kPR + 1][4], const double (&
   }
 }
 
-__global__ __launch_bounds__(kNT, 2) void ns256_slab_f64(const double* p_src, size_t src_stride, double* p_dst, size_t dst_stride,
-                                                         const double* rhs_base, size_t rhs_stride, double dxdy, int nsweeps, int B) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int b = blockIdx.x / kSlabs, slab = blockIdx.x - b * kSlabs;
-  if (b >= B) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c0 = 4 * lane;
-  const int g0 = kLo[slab] + w * kPR;                       // grid row of this wave's first row
-  const EdgeFlags E{slab == 0 && w == 0, slab == kSlabs - 1 && w == kNW - 1, lane == 0, lane == 63};
-  const double* ps = p_src + (size_t)b * src_stride + (size_t)g0 * kN + c0;
-  const double* rs = rhs_base + (size_t)b * rhs_stride + (size_t)g0 * kN + c0;
-  D4* rql = reinterpret_cast<D4*>(smem_raw + kHaloBytes) + tid;        // row j of this thread: rql[j * kNT]
-  double ph[kPR + 1][4], rq[kRR][4];
-#pragma unroll
-  for (int a = 0; a < kPR; ++a) {
-    const double2 x = *reinterpret_cast<const double2*>(ps + a * kN), y = *reinterpret_cast<const double2*>(ps + a * kN + 2);
-    const double2 r = *reinterpret_cast<const double2*>(rs + a * kN), s = *reinterpret_cast<const double2*>(rs + a * kN + 2);
-    ph[a][0] = x.x; ph[a][1] = x.y; ph[a][2] = y.x; ph[a][3] = y.y;
-    const double q0 = dxdy * r.x, q1 = dxdy * r.y, q2 = dxdy * s.x, q3 = dxdy * s.y;       // dx dy rhs (:108)
-    if (a < kRR) {
-      rq[a][0] = q0; rq[a][1] = q1; rq[a][2] = q2; rq[a][3] = q3;
-    } else {
-      rql[(a - kRR) * kNT] = D4{make_double2(q0, q1), make_double2(q2, q3)};
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) ph[kPR][k] = 0.0;
-  int xc = 0, it = 0;
-  for (; it + 2 <= nsweeps; it += 2) {
-    sweep4<0>(ph, rq, rql, E, smem_raw, xc, tid, w);
-    sweep4<1>(ph, rq, rql, E, smem_raw, xc, tid, w);
-  }
-  double* pd = p_dst + (size_t)b * dst_stride + (size_t)g0 * kN + c0;
-  const int own_lo = kOwn[slab], own_hi = kOwn[slab + 1];
-  if (it < nsweeps) {      // odd sweep count: one more UP sweep, the rows are stored from state 1
-    sweep4<0>(ph, rq, rql, E, smem_raw, xc, tid, w);
-#pragma unroll
-    for (int a = 0; a < kPR; ++a) {
-      const int g = g0 + a;
-      if (g >= own_lo && g < own_hi) {        // wave-uniform
-        const double (&row)[4] = ph[bphys<kPR>(a, 1)];
-        *reinterpret_cast<double2*>(pd + a * kN) = make_double2(row[0], row[1]);
-        *reinterpret_cast<double2*>(pd + a * kN + 2) = make_double2(row[2], row[3]);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int a = 0; a < kPR; ++a) {
-      const int g = g0 + a;
-      if (g >= own_lo && g < own_hi) {
-        const double (&row)[4] = ph[a];
-        *reinterpret_cast<double2*>(pd + a * kN) = make_double2(row[0], row[1]);
-        *reinterpret_cast<double2*>(pd + a * kN + 2) = make_double2(row[2], row[3]);
-      }
-    }
-  }
-}
-
-// ---- the phases around the solve: one wave per band of kBand grid rows, a rolled row pipeline (rows256 helpers) ---------------
-// front: state rows -> predictor (:130-138) -> apply_boundary(u*, v*) (:140) -> rhs = rho/dt (d/dx u* + d/dy v*) (:101-103), ONE
-//        field written (u*, v* exist only as a three-row window in registers); the two rows outside a band are evaluated again
-//        by the neighbouring band (18/16 of the predictor work) instead of being exchanged.
-// back:  the predictor is evaluated again from the state rows, corrector (:143-145) with the solved pressure, apply_boundary(u, v)
-//        (:146), observation (:147-154), per-band partial sums of the reward's squared distance (ns_reward.py:28); the solved
-//        pressure is copied home when the last pass left it in the scratch field.
-using namespace rows256;
-constexpr int kBand = 16, kBandsPerWg = 4, kWgPerInst = kN / (kBand * kBandsPerWg);   // 4 workgroups of 4 waves per instance
-
+// ---- front phase of one wave: rhs = rho/dt (d/dx u* + d/dy v*) (:101-103) of grid rows r0 .. r0 + len - 1 ---------------------
+// state rows -> predictor (:130-138) -> apply_boundary(u*, v*) (:140) -> rhs; u*, v* exist only as a three-row window in
+// registers; the two rows outside the range are evaluated as well (every wave of every slab is self-sufficient: no exchange).
 template <bool INTERLEAVED>
-__global__ __launch_bounds__(64 * kBandsPerWg) void ns256_front_f64(NSConst C, NSScal<double> S, NSPtrs<double> P, int B) {
-  const int b = blockIdx.x / kWgPerInst, g = blockIdx.x - b * kWgPerInst;
-  if (b >= B) return;
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int c0 = 4 * lane, r0 = (g * kBandsPerWg + w) * kBand;
-  const double* su = INTERLEAVED ? P.state_in + (size_t)b * kCells * 2 : P.u + (size_t)b * kCells;
-  const double* sv = INTERLEAVED ? nullptr : P.v + (size_t)b * kCells;
-  const double* act = P.action + (size_t)b * C.action_dim;
-  double* rhs = P.scratch + (size_t)b * 4 * kCells + 2 * (size_t)kCells;
+__device__ __forceinline__ void front_rows(const NSConst& C, const NSScal<double>& S, const double* su, const double* sv, const double* act,
+                                           double* rhs, int r0, int len, int lane) {
+  const int c0 = 4 * lane;
   const BcSel bsel = make_bc_sel(C.bc, lane);
   const double a0 = act[0];
   double s0u[4], s0v[4], s1u[4], s1v[4], s2u[4], s2v[4];          // state rows r-1, r, r+1
@@ -240,7 +171,7 @@ __global__ __launch_bounds__(64 * kBandsPerWg) void ns256_front_f64(NSConst C, N
 #pragma unroll
   for (int k = 0; k < 4; ++k) p1u[k] = p1v[k] = p2u[k] = p2v[k] = f1u[k] = f1v[k] = f2v[k] = 0.0;
 #pragma unroll 1
-  for (int it = 0; it <= kBand + 2; ++it) {
+  for (int it = 0; it <= len + 2; ++it) {
     const int r = r0 - 1 + it;
     double nu_[4], nv_[4];
     load_state_row<INTERLEAVED, double>(su, sv, r + 2, c0, nu_, nv_);       // next iteration's row r+1
@@ -281,24 +212,17 @@ __global__ __launch_bounds__(64 * kBandsPerWg) void ns256_front_f64(NSConst C, N
   }
 }
 
+// ---- back phase of one wave: grid rows r0 .. r0 + len - 1 (len >= 2) of the new state ---------------------------------------------
+// the predictor is evaluated again from the state rows, corrector (:143-145) with the solved pressure `pf` (rows r0 - 1 ..
+// r0 + len must be in place), apply_boundary(u, v) (:146), observation (:147-154); returns the wave's share of the reward's
+// squared distance (ns_reward.py:28), summed over its lanes.
 template <bool INTERLEAVED>
-__global__ __launch_bounds__(64 * kBandsPerWg) void ns256_back_f64(NSConst C, NSScal<double> S, NSPtrs<double> P, const double* pfin_base,
-                                                                  size_t pfin_stride, double* p_copy_to, int B) {
-  __shared__ double red[kBandsPerWg];
-  const int b = blockIdx.x / kWgPerInst, g = blockIdx.x - b * kWgPerInst;
-  if (b >= B) return;
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int c0 = 4 * lane, r0 = (g * kBandsPerWg + w) * kBand;
-  const double* su = INTERLEAVED ? P.state_in + (size_t)b * kCells * 2 : P.u + (size_t)b * kCells;
-  const double* sv = INTERLEAVED ? nullptr : P.v + (size_t)b * kCells;
-  const double* act = P.action + (size_t)b * C.action_dim;
-  const double* pf = pfin_base + (size_t)b * pfin_stride + c0;
+__device__ __forceinline__ double back_rows(const NSConst& C, const NSScal<double>& S, const double* su, const double* sv, const double* act,
+                                            const double* pfin, const double* uref, double* obs, int r0, int len, int lane) {
+  const int c0 = 4 * lane;
+  const double* pf = pfin + c0;
   const BcSel bsel = make_bc_sel(C.bc, lane);
   const double a0 = act[0];
-  const int t_new = P.time_index[b] + 1;
-  const int tr = t_new < C.nt_ref ? t_new : C.nt_ref - 1;
-  const double* uref = P.U_ref + (size_t)tr * kCells * 2;
-  double* obs = P.obs + (size_t)b * kCells * 2;
   auto prow = [&](int row, double (&v)[4]) __attribute__((always_inline)) {
     const int rc = row < 0 ? 0 : (row > kN - 1 ? kN - 1 : row);
     const double2 x = *reinterpret_cast<const double2*>(pf + (size_t)rc * kN), y = *reinterpret_cast<const double2*>(pf + (size_t)rc * kN + 2);
@@ -339,16 +263,11 @@ __global__ __launch_bounds__(64 * kBandsPerWg) void ns256_back_f64(NSConst C, NS
     }
   };
 #pragma unroll 1
-  for (int it = 0; it < kBand; ++it) {
+  for (int it = 0; it < len; ++it) {
     const int r = r0 + it;
     double nu_[4], nv_[4], pnn[4];
     load_state_row<INTERLEAVED, double>(su, sv, r + 2, c0, nu_, nv_);
     prow(r + 2, pnn);
-    if (p_copy_to) {
-      double* dst = p_copy_to + (size_t)b * kCells + (size_t)r * kN + c0;
-      *reinterpret_cast<double2*>(dst) = make_double2(pc[0], pc[1]);
-      *reinterpret_cast<double2*>(dst + 2) = make_double2(pc[2], pc[3]);
-    }
     double cu[4], cv[4];
     predictor_row<double>(S, r, lane, s1u, s1v, s0u, s0v, s2u, s2v, cu, cv);
     {
@@ -371,30 +290,128 @@ __global__ __launch_bounds__(64 * kBandsPerWg) void ns256_back_f64(NSConst C, NS
       s0u[k] = s1u[k]; s0v[k] = s1v[k]; s1u[k] = s2u[k]; s1v[k] = s2v[k]; s2u[k] = nu_[k]; s2v[k] = nv_[k];
     }
   }
-  // the band's last row: C(r0+15) is in c1.  It is the lower wall row only in a one-row band (never); the upper wall row (255)
-  // reads C(254) = c2.  A band whose first row is the lower wall was finished inside the loop with C(1).
+  // the range's last row: C(r0 + len - 1) is in c1.  It is the lower wall row only in a one-row range (never: len >= 2); the upper
+  // wall row (255) reads C(254) = c2.  A range whose first row is the lower wall was finished inside the loop with C(1).
   {
     double dummy_u[4] = {0.0, 0.0, 0.0, 0.0}, dummy_v[4] = {0.0, 0.0, 0.0, 0.0};
-    finish_row(r0 + kBand - 1, dummy_u, dummy_v);
+    finish_row(r0 + len - 1, dummy_u, dummy_v);
   }
-  // the first band's row 0 needs C(1): finished at it = 1 above (rr == 0 takes cu = C(1)); nothing else crosses bands
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if (lane == 0) red[w] = acc;
+  return acc;
+}
+
+// One pass: [front phase] -> nsweeps <= 25 sweeps from p_src into p_dst (different fields) -> [back phase].
+template <bool INTERLEAVED>
+__global__ __launch_bounds__(kNT, 2) void ns256_pass_f64(NSConst C, NSScal<double> S, NSPtrs<double> P, const double* p_src, size_t src_stride,
+                                                         double* p_dst, size_t dst_stride, int nsweeps, int phases, int B) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int b = blockIdx.x / kSlabs, slab = blockIdx.x - b * kSlabs;
+  if (b >= B) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c0 = 4 * lane;
+  const int g0 = kLo[slab] + w * kPR;                       // grid row of this wave's first row
+  const double* su = INTERLEAVED ? P.state_in + (size_t)b * kCells * 2 : P.u + (size_t)b * kCells;
+  const double* sv = INTERLEAVED ? nullptr : P.v + (size_t)b * kCells;
+  const double* act = P.action + (size_t)b * C.action_dim;
+  double* rhs = P.scratch + (size_t)b * 4 * kCells + 2 * (size_t)kCells;
+  if (phases & kPassFront) {
+    // the 15 rhs rows this wave sweeps below; the thread that stores a value is the thread that loads it again (same lane, same
+    // columns), so no barrier is needed -- only program order of one thread's accesses to one address
+    front_rows<INTERLEAVED>(C, S, su, sv, act, rhs, g0, kPR, lane);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const EdgeFlags E{slab == 0 && w == 0, slab == kSlabs - 1 && w == kNW - 1, lane == 0, lane == 63};
+  const int own_lo = kOwn[slab], own_hi = kOwn[slab + 1];
+  {
+    const double* ps = p_src + (size_t)b * src_stride + (size_t)g0 * kN + c0;
+    const double* rs = rhs + (size_t)g0 * kN + c0;
+    D4* rql = reinterpret_cast<D4*>(smem_raw + kHaloBytes) + tid;        // row j of this thread: rql[j * kNT]
+    double ph[kPR + 1][4], rq[kRR][4];
+#pragma unroll
+    for (int a = 0; a < kPR; ++a) {
+      const double2 x = *reinterpret_cast<const double2*>(ps + a * kN), y = *reinterpret_cast<const double2*>(ps + a * kN + 2);
+      const double2 r = *reinterpret_cast<const double2*>(rs + a * kN), s = *reinterpret_cast<const double2*>(rs + a * kN + 2);
+      ph[a][0] = x.x; ph[a][1] = x.y; ph[a][2] = y.x; ph[a][3] = y.y;
+      const double q0 = S.dxdy * r.x, q1 = S.dxdy * r.y, q2 = S.dxdy * s.x, q3 = S.dxdy * s.y;       // dx dy rhs (:108)
+      if (a < kRR) {
+        rq[a][0] = q0; rq[a][1] = q1; rq[a][2] = q2; rq[a][3] = q3;
+      } else {
+        rql[(a - kRR) * kNT] = D4{make_double2(q0, q1), make_double2(q2, q3)};
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ph[kPR][k] = 0.0;
+    int xc = 0, it = 0;
+    for (; it + 2 <= nsweeps; it += 2) {
+      sweep4<0>(ph, rq, rql, E, smem_raw, xc, tid, w);
+      sweep4<1>(ph, rq, rql, E, smem_raw, xc, tid, w);
+    }
+    double* pd = p_dst + (size_t)b * dst_stride + (size_t)g0 * kN + c0;
+    // the back phase reads one row beyond the own range on either side: those two rows are exact here as well (see kOwn) and are
+    // stored too -- the slab that owns them stores the same bits
+    const int st_lo = (phases & kPassBack) ? own_lo - 1 : own_lo, st_hi = (phases & kPassBack) ? own_hi + 1 : own_hi;
+    if (it < nsweeps) {      // odd sweep count: one more UP sweep, the rows are stored from state 1
+      sweep4<0>(ph, rq, rql, E, smem_raw, xc, tid, w);
+#pragma unroll
+      for (int a = 0; a < kPR; ++a) {
+        const int g = g0 + a;
+        if (g >= st_lo && g < st_hi) {        // wave-uniform
+          const double (&row)[4] = ph[bphys<kPR>(a, 1)];
+          *reinterpret_cast<double2*>(pd + a * kN) = make_double2(row[0], row[1]);
+          *reinterpret_cast<double2*>(pd + a * kN + 2) = make_double2(row[2], row[3]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < kPR; ++a) {
+        const int g = g0 + a;
+        if (g >= st_lo && g < st_hi) {
+          const double (&row)[4] = ph[a];
+          *reinterpret_cast<double2*>(pd + a * kN) = make_double2(row[0], row[1]);
+          *reinterpret_cast<double2*>(pd + a * kN + 2) = make_double2(row[2], row[3]);
+        }
+      }
+    }
+  }
+  if (!(phases & kPassBack)) return;
+  // ---- back phase: the slab's own rows, shared among its eight waves (pressure rows of other waves: stored above, published by
+  // the barrier; p_dst lines were never read by this CU before, so no stale copy can sit in its vector cache)
+  __threadfence_block();
   __syncthreads();
-  if (threadIdx.x == 0) {
+  __builtin_amdgcn_sched_barrier(0);
+  const int n_own = own_hi - own_lo, per = (n_own + kNW - 1) / kNW;
+  const int r0 = own_lo + w * per;
+  int len = own_hi - r0;
+  len = len > per ? per : len;
+  double part = 0.0;
+  if (len >= 2) {          // (kOwn: every wave of every slab gets 5 .. 12 rows)
+    const int t_new = P.time_index[b] + 1;
+    const int tr = t_new < C.nt_ref ? t_new : C.nt_ref - 1;
+    part = back_rows<INTERLEAVED>(C, S, su, sv, act, p_dst + (size_t)b * dst_stride, P.U_ref + (size_t)tr * kCells * 2,
+                                  P.obs + (size_t)b * kCells * 2, r0, len, lane);
+  }
+  double* red = reinterpret_cast<double*>(smem_raw);        // the halo area is free now
+  if (lane == 0) red[w] = part;
+  __syncthreads();
+  if (tid == 0) {
     double ssum = 0.0;
-    for (int k = 0; k < kBandsPerWg; ++k) ssum += red[k];                  // fixed order: deterministic
-    P.scratch[(size_t)b * 4 * kCells + g] = ssum;                          // u* quarter of the scratch: unused on this path
+    for (int k = 0; k < kNW; ++k) ssum += red[k];                          // fixed order: deterministic
+    P.scratch[(size_t)b * 4 * kCells + slab] = ssum;                       // u* quarter of the scratch: unused on this path
   }
 }
+static_assert((kOwn[1] - kOwn[0] + kNW - 1) / kNW * (kNW - 1) + 2 <= kOwn[1] - kOwn[0] &&
+                  (kOwn[2] - kOwn[1] + kNW - 1) / kNW * (kNW - 1) + 2 <= kOwn[2] - kOwn[1] &&
+                  (kOwn[3] - kOwn[2] + kNW - 1) / kNW * (kNW - 1) + 2 <= kOwn[3] - kOwn[2],
+              "the last wave of every slab must be left with at least two own rows for the back phase");
 
 __global__ void ns256_finish_f64(NSConst C, NSScal<double> S, NSPtrs<double> P, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const double* part = P.scratch + (size_t)b * 4 * kCells;
   double ss = 0.0;
-  for (int k = 0; k < kWgPerInst; ++k) ss += part[k];                      // fixed order: deterministic
+  for (int k = 0; k < kSlabs; ++k) ss += part[k];                          // fixed order: deterministic
   const int t = P.time_index[b] + 1;
   const int tr = t < C.nt_ref ? t : C.nt_ref - 1;
   const double* act = P.action + (size_t)b * C.action_dim;
@@ -409,24 +426,8 @@ __global__ void ns256_finish_f64(NSConst C, NSScal<double> S, NSPtrs<double> P, 
   P.terminated[b] = (t >= C.nt - 1) ? 1 : 0;                               // navier_stokes2D.py:159-168
 }
 
-}  // namespace
-
-// Pass i of the solve: `nsweeps` <= 17 sweeps from p_src into p_dst (different fields); rhs as gen_front leaves it.
-static int launch_ns256_slab_f64(const double* p_src, size_t src_stride, double* p_dst, size_t dst_stride, const double* rhs, size_t rhs_stride,
-                          double dxdy, int nsweeps, int B, hipStream_t st) {
-  static signed char attr[pdegym::kMaxDevices] = {};
-  if (nsweeps < 1 || nsweeps > kH) return pdegym::fail(-2, "a float64 256x256 pass takes 1..17 sweeps");
-  if (!pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&ns256_slab_f64), kLdsBytes, attr))
-    return pdegym::fail(-4, "cannot raise the dynamic LDS limit of ns256_slab_f64");
-  hipLaunchKernelGGL(ns256_slab_f64, dim3(kSlabs * B), dim3(kNT), kLdsBytes, st, p_src, src_stride, p_dst, dst_stride, rhs, rhs_stride, dxdy,
-                     nsweeps, B);
-  return 0;
-}
-
-// The whole float64 env-step: front launch -> ceil(K / 17) slab passes ping-ponging between p and scratch quarter 3 -> back launch
-// (which leaves the solved pressure in p_out / p) -> finish.  With separate u, v fields the state is read from and written to them
-// in place: the back kernel's bands read rows r0-1 .. r0+16 of the OLD state, so the in-place form runs the interleaved observation
-// as the hand-over instead (obs is always written; u, v are filled from it by a copy launch).
+// With separate u, v fields the state is read from them and the interleaved observation is the hand-over: a slab's back phase
+// reads state rows that another slab's back phase would overwrite, so u, v are filled from the observation by a copy launch.
 __global__ __launch_bounds__(256) void ns256_split_obs_f64(const double* obs, double* u, double* v, size_t ncell2) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per two cells
   if (i >= ncell2) return;
@@ -436,34 +437,48 @@ __global__ __launch_bounds__(256) void ns256_split_obs_f64(const double* obs, do
   reinterpret_cast<double2*>(v)[i] = make_double2(a.y, d.y);
 }
 
+}  // namespace
+
+// The whole float64 env-step: npass launches of ns256_pass_f64 (the first with the front phase, the last with the back phase; one
+// launch does both when K <= 25) + the per-instance finish.  The pressure travels p -> scratch quarter 3 -> p -> ... and arrives in
+// its home field (p_out if given, else p) with the last pass; a pass never reads the field it writes (the slabs of an instance
+// read each other's rows), so with home == p the number of passes is made even (a pass may have zero sweeps).
 int launch_ns256_step_f64(const NSConst& C, const NSScal<double>& S, const NSPtrs<double>& P, int B, hipStream_t st) {
+  static signed char attr_a[pdegym::kMaxDevices] = {}, attr_b[pdegym::kMaxDevices] = {};
   const size_t ncell = kCells;
   const bool inter = P.state_in != nullptr;
-  const dim3 grid(kWgPerInst * B), block(64 * kBandsPerWg);
-  if (inter) hipLaunchKernelGGL(ns256_front_f64<true>, grid, block, 0, st, C, S, P, B);
-  else hipLaunchKernelGGL(ns256_front_f64<false>, grid, block, 0, st, C, S, P, B);
-  double* bufs[2] = {P.p, P.scratch + 3 * ncell};
-  const size_t strides[2] = {ncell, 4 * ncell};
-  int cur = 0;
-  for (int left = C.iters; left > 0; left -= kH) {
-    if (int rc = launch_ns256_slab_f64(bufs[cur], strides[cur], bufs[cur ^ 1], strides[cur ^ 1], P.scratch + 2 * ncell, 4 * ncell, S.dxdy,
-                                       left < kH ? left : kH, B, st))
-      return rc;
-    cur ^= 1;
-  }
+  if (!pdegym::raise_dynamic_lds_limit(inter ? reinterpret_cast<const void*>(&ns256_pass_f64<true>) : reinterpret_cast<const void*>(&ns256_pass_f64<false>),
+                                       kLdsBytes, inter ? attr_a : attr_b))
+    return pdegym::fail(-4, "cannot raise the dynamic LDS limit of ns256_pass_f64");
   double* home = P.p_out ? P.p_out : P.p;
-  double* copy_to = (bufs[cur] == home) ? nullptr : home;
-  if (inter) {
-    hipLaunchKernelGGL(ns256_back_f64<true>, grid, block, 0, st, C, S, P, bufs[cur], strides[cur], copy_to, B);
-  } else {
-    // reads the old state from P.u / P.v, writes only the observation (a band reads rows of its neighbours' state, so u, v
-    // cannot be updated in place by the same launch); u, v are split out of the observation afterwards
-    hipLaunchKernelGGL(ns256_back_f64<false>, grid, block, 0, st, C, S, P, bufs[cur], strides[cur], copy_to, B);
+  double* tmp = P.scratch + 3 * ncell;
+  int npass = (C.iters + kH - 1) / kH;
+  if (npass < 1) npass = 1;
+  if (home == P.p && (npass & 1)) ++npass;
+  const double* src = P.p;
+  size_t src_stride = ncell;
+  int left = C.iters;
+  for (int i = 0; i < npass; ++i) {
+    const bool last = i == npass - 1;
+    // intermediate fields alternate scratch, p, scratch, ... (p is free to be overwritten once the first pass has read it)
+    double* dst = last ? home : ((i & 1) ? P.p : tmp);
+    const size_t dst_stride = (dst == tmp) ? 4 * ncell : ncell;
+    const int rem_passes = npass - i;
+    int ns = (left + rem_passes - 1) / rem_passes;           // spread the sweeps evenly over the passes that are left
+    ns = ns > kH ? kH : ns;
+    const int phases = (i == 0 ? kPassFront : 0) | (last ? kPassBack : 0);
+    if (inter) hipLaunchKernelGGL(ns256_pass_f64<true>, dim3(kSlabs * B), dim3(kNT), kLdsBytes, st, C, S, P, src, src_stride, dst, dst_stride, ns, phases, B);
+    else hipLaunchKernelGGL(ns256_pass_f64<false>, dim3(kSlabs * B), dim3(kNT), kLdsBytes, st, C, S, P, src, src_stride, dst, dst_stride, ns, phases, B);
+    left -= ns;
+    src = dst;
+    src_stride = dst_stride;
+  }
+  if (!inter) {
     const size_t n2 = (size_t)B * kCells / 2;
     hipLaunchKernelGGL(ns256_split_obs_f64, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, P.obs, P.u, P.v, n2);
   }
   hipLaunchKernelGGL(ns256_finish_f64, dim3((B + 255) / 256), dim3(256), 0, st, C, S, P, B);
-  return pdegym::check_launch("ns2d_slab_step_f64");
+  return pdegym::check_launch("ns2d_pass_step_f64");
 }
 
 }  // namespace ns

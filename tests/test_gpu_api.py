@@ -335,3 +335,35 @@ def test_device_rollout_graph_equals_eager_other_families(family):
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
     assert np.isfinite(outs[0][2]).all()
+
+
+def test_vecenv_host_arrays_are_never_overwritten_while_referenced():
+    """PDEVecEnv.step hands out views of pinned staging buffers recycled by reference count (advisor finding r3: rotating buffers
+    silently overwrote results a caller kept).  Dropped results: the pool stays at two or three buffers.  Kept results -- also
+    through a slice -- keep their values for good, beyond ``host_buffers`` as plain copies."""
+    import pde_control_gym
+    B = 8
+    p = _transport_params(T=0.5, dt=1e-4, control_sample_rate=0.01)
+    venv = pde_control_gym.make_vec("PDEControlGym-TransportPDE1D", num_envs=B, **p)
+    venv.host_buffers = 6
+    venv.reset()
+    a = np.full((B, 1), 0.5, np.float32)
+    for _ in range(12):
+        obs, rew, dones, infos = venv.step(a)
+    pool = [v for k, v in venv._pins.items() if k[0] == "out" and k[1] == 0][0]
+    assert len(pool) <= 3
+    kept, want, rows = [], [], []
+    for k in range(10):                                   # more than host_buffers
+        obs, rew, dones, infos = venv.step(a * (1 + 0.1 * k))
+        kept.append(obs)
+        want.append(obs.copy())
+        rows.append((obs[3], obs[3].copy()))
+        del obs
+    assert len({id(x) for x in kept}) == 10
+    for x, y in zip(kept, want):
+        np.testing.assert_array_equal(x, y)
+    del kept
+    for _ in range(8):                                    # the row views still pin their base arrays
+        venv.step(a)
+    for view, copy in rows:
+        np.testing.assert_array_equal(view, copy)

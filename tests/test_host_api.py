@@ -855,25 +855,3 @@ def test_roofline_counters_are_tied_to_the_kernel_sources(monkeypatch):
     assert r["counters_stale"] == (r["counters_kernel_stamp"] != bench.kernel_stamp("parabolic_c2")) and 0.3 < r["frac"] < 0.7
     monkeypatch.setattr(bench, "kernel_stamp", lambda k: "0" * 16)
     assert bench.roofline_block(W(), "parabolic_c2", 0.02, True)["counters_stale"] is True
-
-
-def test_vecenv_output_copies_are_recycled_only_when_the_caller_dropped_them():
-    """PDEVecEnv._copy_out (the default copy_outputs=True path on the GPU): arrays the caller still references -- directly or
-    through a view -- are never overwritten by a later step; arrays it dropped are re-used (no fresh 4 MB allocation per step)."""
-    env = _vec(2)
-    src = np.arange(64 * 1024, dtype=np.float32).reshape(64, 1024)
-    a = env._copy_out(0, src)
-    ida = id(a)
-    b = env._copy_out(0, src + 1)                  # `a` is still held: a different array
-    assert b is not a and a[0, 1] == 1 and b[0, 1] == 2
-    view = a[3]                                    # a view keeps its base alive and referenced
-    del a
-    c = env._copy_out(0, src + 2)
-    assert id(c) != ida and view[1] == 3 * 1024 + 1
-    del view, b
-    d = env._copy_out(0, src + 3)                  # both dropped now: one of the two buffers comes back
-    assert id(d) in (ida, id(c)) or len(env._out_pool[(0, src.shape, src.dtype.str)]) == 3
-    kept = [env._copy_out(0, src + k) for k in range(40)]          # a caller that keeps everything still gets distinct arrays
-    assert len({id(k) for k in kept}) == 40 and all(k[0, 0] == i for i, k in enumerate(kept))
-    small = env._copy_out(1, np.ones(8, np.float32))
-    assert small.base is None and small.sum() == 8
