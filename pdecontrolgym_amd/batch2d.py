@@ -96,7 +96,8 @@ class NSBatch2D(EngineCheckpoint):
         self.t["obs"] = self._obs[0]
         # the 256x256 pipeline finishes its pressure solve in a second buffer: ping-pong two pressure tensors instead of
         # copying the result home every step (include/pdegym.h: p_out)
-        self._p_pingpong = self.interleaved_state and dt_ == torch.float32 and nx == 256 and ny == 256
+        # (float64: the last slab pass writes its own rows of the solved pressure into a field it does not read, include/pdegym.h)
+        self._p_pingpong = self.interleaved_state and nx == 256 and ny == 256
         if self._p_pingpong:
             self.t["p_out"] = torch.zeros(B, ny, nx, dtype=dt_, device=dev)
 

@@ -17,13 +17,15 @@
 // rows above / below a wave's block cross waves through a double-buffered 64 KB LDS area, one barrier per sweep, rows rotate with
 // period two (UP / DOWN sweeps, see jacobi_sweep_bous) so a sweep has no register copies.  Redundant sweeps: 360 / 256 = 1.41x.
 //
-// Round 4: the phases around the solve are no longer launches of their own (round 3: front -> 3 passes of 17 -> back, 11.1 MB of
-// HBM traffic per instance against 3 MB of compulsory bytes).  The FIRST pass of a step opens with the front phase -- every wave
-// evaluates predictor -> boundary rule -> rhs for the 15 rows it is about to sweep (a rolled row pipeline over the state rows,
-// rows256 helpers) and leaves them in the rhs field, where it picks them up again itself (L2) and a later pass finds them; the
-// LAST pass closes with the back phase -- the slab's own pressure rows are stored, then its waves share the slab's own rows
-// among themselves and run predictor (again, from the state rows) -> corrector -> boundary rule -> observation -> reward partial
-// sums.  K = 50: two launches, 7.3 MB per instance (state + p in, rhs + p out | p + rhs + state in, p + observation out).
+// Round 4 (round 3: front -> 3 passes of 17 sweeps -> back, 11.1 MB of HBM traffic per instance against 3 MB of compulsory bytes):
+// passes of 25 sweeps (K = 50: two instead of three) and the back phase inside the LAST pass -- the slab's own pressure rows are
+// stored, then its waves share the slab's own rows among themselves and run predictor (again, from the state rows) -> corrector
+// -> boundary rule -> observation -> reward partial sums (the solved pressure is never read back from memory by another launch
+// and never copied home).  The front phase (predictor -> boundary rule -> rhs) CAN run inside the first pass too (kPassFront: every
+// wave evaluates the 15 rhs rows it is about to sweep, leaves them in the rhs field and picks them up again itself) and does so
+// when one launch is the whole step (K <= 25); for K > 25 it stays a launch of its own: fused it saves no bytes (the rhs field is
+// written and read either way) and costs 1.6x the rows (slab overlap 1.41 x 17/15 per wave) at two waves per SIMD -- measured
+// 1.52 ms per 512 env-steps fused against the separate launch's figure in DESIGN.md section 4.
 #include <hip/hip_runtime.h>
 
 #include "pdegym.h"
@@ -301,6 +303,20 @@ __device__ __forceinline__ double back_rows(const NSConst& C, const NSScal<doubl
   return acc;
 }
 
+// The front phase as a launch of its own: one wave per band of 16 grid rows, four bands per workgroup (16 waves per CU: the phase is
+// bound by float64 division throughput and wants the occupancy).
+constexpr int kBand = 16, kBandsPerWg = 4, kWgPerInst = kN / (kBand * kBandsPerWg);
+template <bool INTERLEAVED>
+__global__ __launch_bounds__(64 * kBandsPerWg) void ns256_front_f64(NSConst C, NSScal<double> S, NSPtrs<double> P, int B) {
+  const int b = blockIdx.x / kWgPerInst, g = blockIdx.x - b * kWgPerInst;
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const double* su = INTERLEAVED ? P.state_in + (size_t)b * kCells * 2 : P.u + (size_t)b * kCells;
+  const double* sv = INTERLEAVED ? nullptr : P.v + (size_t)b * kCells;
+  front_rows<INTERLEAVED>(C, S, su, sv, P.action + (size_t)b * C.action_dim, P.scratch + (size_t)b * 4 * kCells + 2 * (size_t)kCells,
+                          (g * kBandsPerWg + w) * kBand, kBand, lane);
+}
+
 // One pass: [front phase] -> nsweeps <= 25 sweeps from p_src into p_dst (different fields) -> [back phase].
 template <bool INTERLEAVED>
 __global__ __launch_bounds__(kNT, 2) void ns256_pass_f64(NSConst C, NSScal<double> S, NSPtrs<double> P, const double* p_src, size_t src_stride,
@@ -439,8 +455,8 @@ __global__ __launch_bounds__(256) void ns256_split_obs_f64(const double* obs, do
 
 }  // namespace
 
-// The whole float64 env-step: npass launches of ns256_pass_f64 (the first with the front phase, the last with the back phase; one
-// launch does both when K <= 25) + the per-instance finish.  The pressure travels p -> scratch quarter 3 -> p -> ... and arrives in
+// The whole float64 env-step: [front launch ->] npass launches of ns256_pass_f64 (the last with the back phase; for K <= 25 one launch
+// with both phases) + the per-instance finish.  The pressure travels p -> scratch quarter 3 -> p -> ... and arrives in
 // its home field (p_out if given, else p) with the last pass; a pass never reads the field it writes (the slabs of an instance
 // read each other's rows), so with home == p the number of passes is made even (a pass may have zero sweeps).
 int launch_ns256_step_f64(const NSConst& C, const NSScal<double>& S, const NSPtrs<double>& P, int B, hipStream_t st) {
@@ -455,6 +471,12 @@ int launch_ns256_step_f64(const NSConst& C, const NSScal<double>& S, const NSPtr
   int npass = (C.iters + kH - 1) / kH;
   if (npass < 1) npass = 1;
   if (home == P.p && (npass & 1)) ++npass;
+  const bool fuse_front = C.iters <= kH && home != P.p;      // one launch is the whole step
+  if (!fuse_front) {
+    const dim3 grid(kWgPerInst * B), block(64 * kBandsPerWg);
+    if (inter) hipLaunchKernelGGL(ns256_front_f64<true>, grid, block, 0, st, C, S, P, B);
+    else hipLaunchKernelGGL(ns256_front_f64<false>, grid, block, 0, st, C, S, P, B);
+  }
   const double* src = P.p;
   size_t src_stride = ncell;
   int left = C.iters;
@@ -466,7 +488,7 @@ int launch_ns256_step_f64(const NSConst& C, const NSScal<double>& S, const NSPtr
     const int rem_passes = npass - i;
     int ns = (left + rem_passes - 1) / rem_passes;           // spread the sweeps evenly over the passes that are left
     ns = ns > kH ? kH : ns;
-    const int phases = (i == 0 ? kPassFront : 0) | (last ? kPassBack : 0);
+    const int phases = ((i == 0 && fuse_front) ? kPassFront : 0) | (last ? kPassBack : 0);
     if (inter) hipLaunchKernelGGL(ns256_pass_f64<true>, dim3(kSlabs * B), dim3(kNT), kLdsBytes, st, C, S, P, src, src_stride, dst, dst_stride, ns, phases, B);
     else hipLaunchKernelGGL(ns256_pass_f64<false>, dim3(kSlabs * B), dim3(kNT), kLdsBytes, st, C, S, P, src, src_stride, dst, dst_stride, ns, phases, B);
     left -= ns;

@@ -327,12 +327,16 @@ def test_ns_f64_tiled_kernel_equals_generic_kernel_and_oracle_bitwise(K, interle
         np.testing.assert_allclose(r1, r2, rtol=1e-12)
 
 
-@pytest.mark.parametrize("K,interleaved,adim", [(50, True, 1), (17, True, 256), (18, False, 1), (1, True, 1), (0, False, 1), (35, True, 1)])
+@pytest.mark.parametrize("K,interleaved,adim", [(50, True, 1), (25, True, 256), (26, False, 1), (1, True, 1), (0, False, 1), (35, True, 1),
+                                                (51, True, 1), (2, True, 256), (24, False, 256), (76, True, 1), (100, False, 1), (0, True, 1)])
 def test_ns_f64_256_slab_passes_equal_generic_kernel_bitwise(K, interleaved, adim):
-    """256 x 256 float64 (BASELINE config 5 at the reference's precision): the pressure solve runs as passes of <= 17 sweeps
-    over three overlapping slabs per instance (pdegym_ns256_f64.hip).  Fields, pressure and observations must equal the
-    workgroup-per-instance kernel bit for bit: one pass, exactly 17, 17 + 1 (an odd second pass), three passes, none; both
-    state layouts, scalar and per-node boundary actions."""
+    """256 x 256 float64 (BASELINE config 5 at the reference's precision): the env-step runs as passes of <= 25 sweeps over
+    three overlapping slabs per instance, the first pass opening with the predictor / rhs phase and the last one closing with
+    corrector / observation / reward (pdegym_ns256_f64.hip).  Fields, pressure and observations must equal the
+    workgroup-per-instance kernel bit for bit: one launch (K <= 25: front + sweeps + back in the same kernel), exactly 25,
+    25 + 1, two full passes (BASELINE), 50 + 1 (three passes), four passes, odd and even counts per pass, none; both state
+    layouts (the interleaved one ping-pongs the pressure field, the separate one brings it home in an even number of passes),
+    scalar and per-node boundary actions."""
     from pdecontrolgym_amd.batch2d import NSBatch2D
     B = 2
     kw, u0, v0, p0, acts = _random_case(256, B, K, 5000 + K, BC_MIX, adim)
