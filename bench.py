@@ -12,7 +12,9 @@ Default workload = BASELINE.json configs[1]: ReactionDiffusionPDE1D ("Parabolic1
 per GPU, fp32, S=100 sub-steps per env-step (SURVEY.md section 8d).  Other workloads (--workload NAME prints NAME's own line;
 the default run adds all of them under "also"): transport_c3, burgers_c3 (extension), parabolic_c2_policy_loop (C2 with its MLP
 controller evaluated on the device every step), parabolic_c2_rollout (the same loop as ONE kernel per 25 env-steps: here a
-"step" is one launch and `value` still counts env-steps), parabolic_c2_open_loop_rollout (25 env-steps per launch, commands given ahead), ns2d_c4, ns2d_c4_f64, ns2d_c4_b4096,
+"step" is one launch and `value` still counts env-steps), parabolic_c2_open_loop_rollout (25 env-steps per launch, commands given ahead),
+parabolic_c2_s1 / parabolic_c2_s1_open_loop_rollout / parabolic_c2_s1_rollout (SURVEY 8d "and also S = 1": one sub-step per env-step,
+per-step launch and 100 env-steps per launch without / with the policy inside), ns2d_c4, ns2d_c4_f64, ns2d_c4_b4096,
 ns2d_c4_f64_b4096, ns2d_c5, ns2d_c5_f64 (the _f64 lines: the same workloads at the reference's own precision), ns2d_example (the
 reference's shipped 21x21 K=2000 float64 configuration), traffic_arz, traffic_arz_rollout (25 env-steps per launch), brain_tumor;
 "also" additionally carries vecenv_host: the SB3-facing PDEVecEnv.step (NumPy in / out, PCIe-inclusive) at the C2 shape.

@@ -368,26 +368,28 @@ __global__ __launch_bounds__(kNT, 2) void ns256_pass_f64(NSConst C, NSScal<doubl
     // the back phase reads one row beyond the own range on either side: those two rows are exact here as well (see kOwn) and are
     // stored too -- the slab that owns them stores the same bits
     const int st_lo = (phases & kPassBack) ? own_lo - 1 : own_lo, st_hi = (phases & kPassBack) ? own_hi + 1 : own_hi;
-    if (it < nsweeps) {      // odd sweep count: one more UP sweep, the rows are stored from state 1
+    if (it < nsweeps) {      // odd sweep count: one more UP sweep, then the rows move back to their state-0 registers
       sweep4<0>(ph, rq, rql, E, smem_raw, xc, tid, w);
+      __builtin_amdgcn_sched_barrier(0);
+      double r0[4];
 #pragma unroll
-      for (int a = 0; a < kPR; ++a) {
-        const int g = g0 + a;
-        if (g >= st_lo && g < st_hi) {        // wave-uniform
-          const double (&row)[4] = ph[bphys<kPR>(a, 1)];
-          *reinterpret_cast<double2*>(pd + a * kN) = make_double2(row[0], row[1]);
-          *reinterpret_cast<double2*>(pd + a * kN + 2) = make_double2(row[2], row[3]);
-        }
+      for (int k = 0; k < 4; ++k) r0[k] = ph[bphys<kPR>(0, 1)][k];
+#pragma unroll
+      for (int a = kPR - 1; a >= 1; --a) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ph[a][k] = ph[bphys<kPR>(a, 1)][k];
       }
-    } else {
 #pragma unroll
-      for (int a = 0; a < kPR; ++a) {
-        const int g = g0 + a;
-        if (g >= st_lo && g < st_hi) {
-          const double (&row)[4] = ph[a];
-          *reinterpret_cast<double2*>(pd + a * kN) = make_double2(row[0], row[1]);
-          *reinterpret_cast<double2*>(pd + a * kN + 2) = make_double2(row[2], row[3]);
-        }
+      for (int k = 0; k < 4; ++k) ph[0][k] = r0[k];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int a = 0; a < kPR; ++a) {
+      const int g = g0 + a;
+      if (g >= st_lo && g < st_hi) {        // wave-uniform
+        const double (&row)[4] = ph[a];
+        *reinterpret_cast<double2*>(pd + a * kN) = make_double2(row[0], row[1]);
+        *reinterpret_cast<double2*>(pd + a * kN + 2) = make_double2(row[2], row[3]);
       }
     }
   }
