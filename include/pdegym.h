@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PDEGYM_ABI_VERSION 13
+#define PDEGYM_ABI_VERSION 14
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
 #define PDEGYM_MAX_N1D 2048      /* nodes per 1D row kept in registers by the wave-per-instance kernels */
@@ -158,8 +158,14 @@ int pdegym_parabolic_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, 
  * Step t reads the rows from obs slot t, the commands from actions row t, and writes obs slot t + 1, rewards / terminated /
  * truncated row t; everything else (beta, time_index, bsum, ring, norm_now, norm_back, the auto-reset pools, final_obs,
  * reset_count) comes from the pdegym_bufs1d of the call and behaves as in T consecutive pdegym_*_step calls with state_in --
- * the results are bit-identical to those calls.  bufs->u / state_in / obs / action / reward / terminated / truncated / history
- * are ignored.  Needs sensing == PDEGYM_SENSE_FULL, Dirichlet actuation, float32 beta and actions, n <= 2048. */
+ * the results are bit-identical to those calls.  bufs->state_in / obs / action / reward / terminated / truncated / history are
+ * ignored.  Every control / sensing combination of the reference's table (hyperbolic.py:66-124, parabolic.py:66-122):
+ *   - full-state sensing: the observation slots [T + 1, B, n] hold the state (slot t in, slot t + 1 out); bufs->u is ignored.
+ *     Dirichlet actuation keeps the row in registers across the T env-steps; Neumann actuation passes it through the slots;
+ *   - scalar sensing (PDEGYM_SENSE_LAST / _LAST_DERIV / _FIRST_DERIV / _FIRST): the state lives in bufs->u [B, n] (required,
+ *     advanced in place) and the observation slots are [T + 1, B, 1]: slot t + 1 receives the value sensed after step t
+ *     (slot 0 is only read by a policy).
+ * Needs float32 beta and actions, the temporal reward horizon, n <= 2048. */
 typedef struct pdegym_rollout1d {
   int32_t T;                /* env-steps per call                                                              */
   int32_t reserved_;
@@ -174,6 +180,12 @@ typedef struct pdegym_rollout1d {
    * (n <= 513).  noise, when given, is [T, B] (row t, instance b at noise[(t * B + b) * noise_stride]), added before the
    * clamp.  Same arithmetic as pdegym_mlp_forward except for the order of the additions inside a group of 16 inputs. */
   const struct pdegym_mlp_s* policy;
+  /* The sensing-noise hook (hyperbolic.py:160-164: the agent sees sensing_noise_func(observation)) for the policy inside the
+   * launch, as noise the caller drew ahead: the policy of step t reads obs[t] + obs_noise[t]; obs itself stays clean (with
+   * full-state sensing it is the plant state).  Both optional, both only with a policy:                                    */
+  const float* obs_noise;   /* [T, B, obs_dim] added to observation slot t on its way into the policy                  */
+  float* obs_seen;          /* [T, B, obs_dim] receives what the policy read (obs[t] + obs_noise[t]): the rollout's
+                               training input                                                                          */
 } pdegym_rollout1d;
 
 int pdegym_transport_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const pdegym_rollout1d* ro, int32_t B,

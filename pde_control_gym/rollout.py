@@ -17,7 +17,7 @@ class DeviceRollout:
     ``one_launch``: see the constructor (1D engines with full-state sensing + a small ``FusedMLP``: the rollout is ONE kernel)."""
 
     def __init__(self, venv, policy, n_steps: int, use_graph: bool = True, action_low: float = -1.0, action_high: float = 1.0,
-                 action_noise: bool = False, one_launch=None):
+                 action_noise: bool = False, one_launch=None, sensing_noise: bool = False):
         import torch
         kind = getattr(venv, "kind", "tumor")
         self.venv, self.policy, self.T = venv, policy, int(n_steps)
@@ -55,11 +55,23 @@ class DeviceRollout:
         # obs[t] -- the plant state with full-state sensing -- stays clean; the call is part of the captured graph (torch's
         # random generators are graph-safe: every replay draws new numbers).  The one-launch kernel has no such hook.
         self._noise_f = getattr(venv, "sensing_noise_tensor_func", None)
-        self.obs_seen = torch.zeros_like(self.obs) if self._noise_f is not None else None
+        # sensing_noise=True: the same hook as ADDITIVE noise the caller draws ahead (fill ``ro.sensing_noise`` [T + 1, B, ...] in
+        # place before each run(), e.g. ``ro.sensing_noise.normal_().mul_(sigma)``): obs_seen[t] = obs[t] + sensing_noise[t].
+        # This form also runs inside the one-launch rollout kernels (pdegym_rollout1d.obs_noise / obs_seen).
+        self.sensing_noise = None
+        if sensing_noise:
+            if self._noise_f is not None:
+                raise ValueError("sensing_noise=True and sensing_noise_tensor_func are two forms of the same hook: use one")
+            self.sensing_noise = torch.zeros_like(self.obs)
+            self._noise_f = None
+        self.obs_seen = torch.zeros_like(self.obs) if (self._noise_f is not None or sensing_noise) else None
         if self._noise_f is not None:
             if one_launch:
-                raise ValueError("one_launch=True cannot apply sensing_noise_tensor_func (the policy runs inside the step kernel)")
+                raise ValueError("one_launch=True cannot apply sensing_noise_tensor_func (the policy runs inside the step kernel); "
+                                 "sensing_noise=True (pre-drawn additive noise) can")
             self.one_launch = False
+        if self.sensing_noise is not None and self.one_launch and self._traffic:
+            self.one_launch = False          # (the traffic rollout kernel has no obs_noise input)
         self.use_graph = bool(use_graph) and dev.type == "cuda"
         self._graph = None
         self._state_buf = None     # observation tensor the captured graph leaves the end state in (see _rebind_state)
@@ -71,8 +83,13 @@ class DeviceRollout:
             acts, nz = self.actions, self.action_noise
             if self._traffic and acts.dim() == 2:       # the traffic kernel takes [T, B, action_dim]
                 acts, nz = acts.unsqueeze(2), (nz.unsqueeze(2) if nz is not None else None)
+            extra = {}
+            if self.sensing_noise is not None:
+                extra = dict(obs_noise=self.sensing_noise[:self.T], obs_seen=self.obs_seen[:self.T])
             core.rollout(self.obs, acts, self.rewards, self.terminated, self.truncated, policy=self.policy,
-                         clamp=(self.lo, self.hi), noise=nz)
+                         clamp=(self.lo, self.hi), noise=nz, **extra)
+            if self.sensing_noise is not None:
+                torch.add(self.obs[self.T], self.sensing_noise[self.T], out=self.obs_seen[self.T])
             return
         own = {k: core.t[k] for k in ("reward", "terminated", "truncated", "obs") if k in core.t} if self._direct else {}
         pingpong = self._ns and getattr(core, "_p_pingpong", False)
@@ -125,7 +142,7 @@ class DeviceRollout:
             nz = self.action_noise[t] if self.action_noise is not None else None
             if self.obs_seen is not None:
                 with torch.no_grad():
-                    self.obs_seen[t].copy_(self._noise_f(self.obs[t]))
+                    self._see(t, torch)
             if fused:       # pdecontrolgym_amd.FusedMLP: forward pass (+ noise) + action clamp in one launch, written into slot t
                 self.policy.forward_into(seen[t], self.actions[t], clamp=(self.lo, self.hi), noise=nz)
             else:
@@ -150,7 +167,14 @@ class DeviceRollout:
                 self.truncated[t].copy_(tr)
         if self.obs_seen is not None:
             with torch.no_grad():
-                self.obs_seen[self.T].copy_(self._noise_f(self.obs[self.T]))
+                self._see(self.T, torch)
+
+    def _see(self, t, torch):
+        """obs_seen[t]: what the policy reads of observation t (sensing_noise_tensor_func, or obs + the pre-drawn noise)."""
+        if self.sensing_noise is not None:
+            torch.add(self.obs[t], self.sensing_noise[t], out=self.obs_seen[t])
+        else:
+            self.obs_seen[t].copy_(self._noise_f(self.obs[t]))
 
     def run(self, first_obs=None):
         """Roll T steps from ``first_obs`` (default: the environment's current observation). Returns self."""

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 RING = 128
 LOOKBACK = 100
 MAX_N1D = 8192
@@ -62,7 +62,8 @@ class Bufs1D(C.Structure):
 
 class Rollout1D(C.Structure):
     _fields_ = [("T", C.c_int32), ("reserved_", C.c_int32), ("obs", C.c_void_p), ("actions", C.c_void_p),
-                ("rewards", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("policy", C.c_void_p)]
+                ("rewards", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("policy", C.c_void_p),
+                ("obs_noise", C.c_void_p), ("obs_seen", C.c_void_p)]
 
 
 class ParamsNS2D(C.Structure):

@@ -89,24 +89,34 @@ class HipBackend:
         N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["obs"].device)), f"pdegym_{kind}_step")
 
     @_on_device_of("obs")
-    def rollout1d(self, kind: str, P: N.Params1D, T: dict, obs, actions, rewards, terminated, truncated, B: int, policy=None):
-        """T env-steps in one launch (pdegym_*_rollout): ``obs`` [T+1, B, n] (slot 0 = input rows), ``actions`` / ``rewards`` /
-        ``terminated`` / ``truncated`` [T, B].  ``policy``: an ``N.Mlp`` descriptor evaluated inside the launch (``actions`` is
-        then an output; its ``noise``, if set, is [T, B])."""
+    def rollout1d(self, kind: str, P: N.Params1D, T: dict, obs, actions, rewards, terminated, truncated, B: int, policy=None,
+                  obs_noise=None, obs_seen=None):
+        """T env-steps in one launch (pdegym_*_rollout): ``obs`` [T+1, B, obs_dim] (slot 0 = input rows with full-state sensing;
+        with scalar sensing the state is ``T["u"]``, advanced in place), ``actions`` / ``rewards`` / ``terminated`` /
+        ``truncated`` [T, B].  ``policy``: an ``N.Mlp`` descriptor evaluated inside the launch (``actions`` is then an output;
+        its ``noise``, if set, is [T, B]); ``obs_noise`` / ``obs_seen`` [T, B, obs_dim]: the policy reads obs[t] + obs_noise[t],
+        which obs_seen[t] receives."""
         import torch
         fn = self.lib.pdegym_transport_rollout if kind == "transport" else self.lib.pdegym_parabolic_rollout
         steps = int(actions.shape[0])
-        if tuple(obs.shape) != (steps + 1, B, P.n) or not obs.is_contiguous():
-            raise N.NativeError(f"rollout obs must be a contiguous [{steps + 1}, {B}, {P.n}] tensor, got {tuple(obs.shape)}")
+        full = P.sensing == N.SENSE_FULL
+        od = P.n if full else 1
+        if tuple(obs.shape) != (steps + 1, B, od) or not obs.is_contiguous():
+            raise N.NativeError(f"rollout obs must be a contiguous [{steps + 1}, {B}, {od}] tensor, got {tuple(obs.shape)}")
         for name, x in (("actions", actions), ("rewards", rewards), ("terminated", terminated), ("truncated", truncated)):
             if tuple(x.shape) != (steps, B) or not x.is_contiguous():
                 raise N.NativeError(f"rollout {name} must be a contiguous [{steps}, {B}] tensor, got {tuple(x.shape)}")
-        bufs = self._bufs1d({**T, "state_in": None, "u": None, "history": None})
+        for name, x in (("obs_noise", obs_noise), ("obs_seen", obs_seen)):
+            if x is not None and (tuple(x.shape) != (steps, B, od) or not x.is_contiguous() or x.dtype != torch.float32):
+                raise N.NativeError(f"rollout {name} must be a contiguous float32 [{steps}, {B}, {od}] tensor, got {tuple(x.shape)}")
+        bufs = self._bufs1d({**T, "state_in": None, "u": None if full else T["u"], "history": None})
         ro = N.Rollout1D()
         ro.T = steps
         ro.obs, ro.actions, ro.rewards = N.dptr(obs, torch.float32), N.dptr(actions, torch.float32), N.dptr(rewards, torch.float32)
         ro.terminated, ro.truncated = N.dptr(terminated, torch.uint8), N.dptr(truncated, torch.uint8)
         ro.policy = C.addressof(policy) if policy is not None else None
+        ro.obs_noise = N.dptr(obs_noise, torch.float32) if obs_noise is not None else None
+        ro.obs_seen = N.dptr(obs_seen, torch.float32) if obs_seen is not None else None
         N.check(fn(C.byref(P), C.byref(bufs), C.byref(ro), B, N.current_stream_ptr(obs.device)), f"pdegym_{kind}_rollout")
 
     @_on_device_of("obs")

@@ -263,36 +263,43 @@ class PDEBatch1D(EngineCheckpoint):
         return self.t["obs"], self.t["reward"], self.t["terminated"], self.t["truncated"]
 
     def can_rollout(self) -> bool:
-        """True when ``rollout`` applies: the observation is the row (full-state sensing, no history), Dirichlet actuation,
-        float32 operands, register-resident rows, and a reward the rollout kernels evaluate (not the "differential" horizon)."""
-        return bool(self.state_in_obs and self.params.control_type != N.CONTROL["Neumann"] and not self.params.beta_f64
+        """True when ``rollout`` applies: every control / sensing combination (round 4: Neumann actuation and scalar sensing
+        too), as long as the state has ONE home -- the observation slots with full-state sensing (``state_in_obs``), ``u``
+        with scalar sensing -- no history is recorded, the operands are float32, the rows are register-resident, and the
+        reward is one the rollout kernels evaluate (not the "differential" horizon)."""
+        return bool((self.state_in_obs or self.sensing != N.SENSE_FULL) and self.t["history"] is None and not self.params.beta_f64
                     and self.params.reward_horizon == N.HORIZON_TEMPORAL
                     and self.n <= N.MAX_N1D_REG and hasattr(self.backend, "rollout1d"))
 
     def policy_fits_rollout(self, policy) -> bool:
-        """Whether ``policy`` (a ``FusedMLP``) can be evaluated inside the rollout kernel: observation rows of at most 513
-        nodes as its input, layers of at most 64 units, one output, and weights + 16 observation rows within 160 KB of LDS."""
+        """Whether ``policy`` (a ``FusedMLP``) can be evaluated inside the rollout kernel: the observation (the row of at most
+        513 nodes, or the one sensed value) as its input, layers of at most 64 units, one output, and weights + 16 observation
+        rows within 160 KB of LDS."""
         if not (self.can_rollout() and hasattr(policy, "layers") and hasattr(policy, "_net")):
             return False
         dims = [(int(w.shape[1]), int(w.shape[0])) for w, _, _ in policy.layers]
-        if dims[0][0] != self.n or self.n > 513 or dims[-1][1] != 1 or any(o > 64 for _, o in dims):
+        if dims[0][0] != self.obs_dim or self.n > 513 or dims[-1][1] != 1 or any(o > 64 for _, o in dims):
             return False
-        floats = sum((((i + 3) // 4) | 1) * 4 * o + 64 for i, o in dims) + 16 * (((self.n + 3) // 4) * 4 + 128)
+        floats = sum((((i + 3) // 4) | 1) * 4 * o + 64 for i, o in dims) + 16 * (((self.obs_dim + 3) // 4) * 4 + 128)
         return 4 * floats <= 160 * 1024
 
-    def rollout(self, obs, actions, rewards, terminated, truncated, policy=None, clamp="default", noise=None):
-        """T env-steps in ONE launch (include/pdegym.h: pdegym_*_rollout): step t reads the rows from ``obs[t]`` and the
-        commands from ``actions[t]``, writes ``obs[t + 1]``, ``rewards[t]``, ``terminated[t]``, ``truncated[t]`` -- bit-identical
-        to T calls of ``step(actions[t], out_obs=obs[t + 1], ...)`` from the state in ``obs[0]``, fused auto-reset included.
-        Afterwards the engine's current observation (its state) is a copy of ``obs[T]``.
+    def rollout(self, obs, actions, rewards, terminated, truncated, policy=None, clamp="default", noise=None, obs_noise=None,
+                obs_seen=None):
+        """T env-steps in ONE launch (include/pdegym.h: pdegym_*_rollout): step t takes the commands from ``actions[t]`` and
+        writes ``obs[t + 1]`` ([T+1, B, obs_dim]), ``rewards[t]``, ``terminated[t]``, ``truncated[t]`` -- bit-identical to T
+        calls of ``step(actions[t], out_obs=obs[t + 1], ...)``, fused auto-reset included.  With full-state sensing ``obs[0]``
+        is the state the rollout starts from and the engine's current observation (its state) is a copy of ``obs[T]``
+        afterwards; with scalar sensing the state is the engine's own ``u`` (advanced in place) and ``obs[0]`` only feeds a
+        policy.
 
         ``policy`` (a ``FusedMLP`` with layers of at most 64 units and one output, see ``policy_fits_rollout``): evaluated
-        inside the launch on ``obs[t]``; ``actions[t]`` then RECEIVES the command (after ``noise[t]`` [T, B] float32 and the
+        inside the launch on ``obs[t]`` (+ ``obs_noise[t]`` [T, B, obs_dim], the pre-drawn sensing noise; ``obs_seen[t]``
+        receives what the policy read); ``actions[t]`` then RECEIVES the command (after ``noise[t]`` [T, B] float32 and the
         clamp).  The in-kernel network sums each neuron in one fmaf chain, ``policy.forward_into`` in MFMA group order: the
         commands agree to float32 rounding (rtol ~2e-5), NOT bit for bit, and trajectories drift apart accordingly -- only the
         environment arithmetic is bit-identical to step calls (given the same commands)."""
         if not self.can_rollout():
-            raise ValueError("rollout needs full-state sensing without history, Dirichlet actuation and float32 operands")
+            raise ValueError("rollout needs a state with one home (full-state sensing: state_in_obs; no history) and float32 operands")
         self.params.action_kind = N.ACTION_F32
         net = None
         if policy is not None:
@@ -307,10 +314,13 @@ class PDEBatch1D(EngineCheckpoint):
                 if noise.dtype != torch.float32 or tuple(noise.shape) != tuple(actions.shape) or not noise.is_contiguous():
                     raise ValueError("noise must be a contiguous float32 [T, B] tensor")
                 net.noise, net.noise_stride = noise.data_ptr(), 1
+        elif obs_noise is not None or obs_seen is not None:
+            raise ValueError("obs_noise / obs_seen shape the policy's input: they need a policy")
         self.backend.rollout1d(self.kind, self.params, self.t, obs, actions, rewards, terminated, truncated, self.num_envs,
-                               policy=net)
+                               policy=net, obs_noise=obs_noise, obs_seen=obs_seen)
         self.t["obs"].copy_(obs[-1])
-        self.t["u"] = self.t["obs"]
+        if self.state_in_obs:
+            self.t["u"] = self.t["obs"]
         return obs, rewards, terminated, truncated
 
     # ---- checkpoint / resume (pdecontrolgym_amd/checkpoint.py) ---------------------------------------------

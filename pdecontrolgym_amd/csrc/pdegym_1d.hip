@@ -832,6 +832,45 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void rollout1d_kernel(pdegym
 }
 
 
+// The general form (round 4): Neumann actuation and / or scalar sensing -- what the reference's control / sensing table offers
+// beyond the Dirichlet / full-state corner (hyperbolic.py:66-124, parabolic.py:66-122).  Iteration t is the step kernel's body
+// exactly as step1d_kernel instantiates it (select form for Neumann, the fast form otherwise), with the state going through
+// memory between iterations: full-state sensing keeps it in the observation slots (slot t in, slot t + 1 out), scalar sensing in
+// bufs.u (in place) while the observation slots receive the sensed value.  A wave re-reads what its own lanes stored (rows, time
+// index, sums, ring), so iterations are separated by a workgroup-scope release / acquire pair, nothing more.
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool BURGERS>
+__device__ __forceinline__ void rollout1d_general_step(const pdegym_params1d& P, const pdegym_bufs1d& Bf, const pdegym_rollout1d& Ro, int B,
+                                                        int inst, int lane, int t, const float* command) {
+  const bool full = P.sensing == PDEGYM_SENSE_FULL;
+  const size_t slot = (size_t)B * (full ? P.n : 1);
+  pdegym_bufs1d S = Bf;
+  S.history = nullptr;
+  if (full) {
+    S.u = nullptr;
+    S.state_in = Ro.obs + (size_t)t * slot;
+  } else {
+    S.state_in = nullptr;
+  }
+  S.obs = Ro.obs + (size_t)(t + 1) * slot;
+  S.action = Ro.actions + (size_t)t * B;
+  S.reward = Ro.rewards + (size_t)t * B;
+  S.terminated = Ro.terminated + (size_t)t * B;
+  S.truncated = Ro.truncated + (size_t)t * B;
+  step1d_body<EPL, PARABOLIC, NEUMANN, false, BURGERS>(P, S, B, inst, lane, command);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool BURGERS>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void rollout1d_general_kernel(pdegym_params1d P, pdegym_bufs1d Bf, pdegym_rollout1d Ro,
+                                                                                 int B) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (inst >= B) return;  // wave-uniform
+  for (int t = 0; t < Ro.T; ++t) rollout1d_general_step<EPL, PARABOLIC, NEUMANN, BURGERS>(P, Bf, Ro, B, inst, lane, t, nullptr);
+}
+
+
 // ================================================================================================
 // Rows of more than 2048 nodes: the register-resident layout would not fit, so the row ping-pongs between two LDS copies
 // owned by the wave (node j lives in lane j % 64; wave-level ordering only, no workgroup barrier).  This is the plain
@@ -1215,6 +1254,21 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
 }
 
 // ---- the policy inside the rollout kernel (pdegym_policy.h) -----------------------------------------------------------------
+// The sensing-noise hook of the reference (hyperbolic.py:160-164: the agent sees sensing_noise_func(observation)) as pre-drawn
+// additive noise: the wave's LDS copy of observation t (od values) becomes obs + obs_noise[t], which is what the policy reads
+// and what obs_seen[t] receives; the observation slots themselves -- the plant state with full-state sensing -- stay clean.
+__device__ __forceinline__ void sense_noise(const pdegym_rollout1d& Ro, float* xw, int od, int B, int inst, int lane, int t) {
+  if (!Ro.obs_noise && !Ro.obs_seen) return;     // wave-uniform
+  const size_t base = ((size_t)t * B + inst) * od;
+  for (int j = lane; j < od; j += kWave) {
+    float v = xw[j];
+    if (Ro.obs_noise) v += Ro.obs_noise[base + j];
+    xw[j] = v;
+    if (Ro.obs_seen) Ro.obs_seen[base + j] = v;
+  }
+  pdegym_policy::wave_lds_sync();
+}
+
 template <int EPL, bool PARABOLIC, bool BURGERS>
 __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy_kernel(pdegym_params1d P, pdegym_bufs1d Bf,
                                                                                         pdegym_rollout1d Ro, pdegym_mlp N, int B) {
@@ -1240,6 +1294,7 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy
     for (int e = 0; e < EPL; ++e)
       if (s0 + e < ns) xw[J0 + s0 + e] = C.x[e];
     pol::wave_lds_sync();
+    sense_noise(Ro, xw, n, B, inst, lane, t);
     float a = pol::lane_value(pol::eval(N, St, pol_smem, xw, hw, n, lane), 0);      // neuron 0 of the last layer
     if (N.noise) a += N.noise[((size_t)t * B + inst) * N.noise_stride];
     if (N.clamp) a = fminf(fmaxf(a, N.lo), N.hi);
@@ -1258,6 +1313,34 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy
   }
 }
 
+// The policy in front of the general step (Neumann actuation / scalar sensing): its input is observation slot t as stored -- od = n
+// values, or the one sensed value -- read back from memory after the previous iteration's fence.
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool BURGERS>
+__global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy_general_kernel(pdegym_params1d P, pdegym_bufs1d Bf,
+                                                                                                pdegym_rollout1d Ro, pdegym_mlp N, int B) {
+  namespace pol = pdegym_policy;
+  extern __shared__ __attribute__((aligned(16))) float pol_smem[];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int inst = blockIdx.x * pol::kWaves + wave;
+  const int od = P.sensing == PDEGYM_SENSE_FULL ? P.n : 1, xpad = pol::xpad(od);
+  const pol::Staged St = pol::stage(N, pol_smem);      // the launch's only barrier
+  if (inst >= B) return;  // wave-uniform
+  float* const xw = pol_smem + St.end + wave * (xpad + 2 * pol::kMaxWidth);
+  float* const hw = xw + xpad;
+  for (int j = od + lane; j < xpad; j += kWave) xw[j] = 0.f;
+  for (int t = 0; t < Ro.T; ++t) {
+    const float* orow = Ro.obs + ((size_t)t * B + inst) * od;
+    for (int j = lane; j < od; j += kWave) xw[j] = orow[j];
+    pol::wave_lds_sync();
+    sense_noise(Ro, xw, od, B, inst, lane, t);
+    float a = pol::lane_value(pol::eval(N, St, pol_smem, xw, hw, od, lane), 0);
+    if (N.noise) a += N.noise[((size_t)t * B + inst) * N.noise_stride];
+    if (N.clamp) a = fminf(fmaxf(a, N.lo), N.hi);
+    if (lane == 0) Ro.actions[(size_t)t * B + inst] = a;
+    rollout1d_general_step<EPL, PARABOLIC, NEUMANN, BURGERS>(P, Bf, Ro, B, inst, lane, t, &a);
+  }
+}
+
 template <bool PARABOLIC, bool BURGERS = false>
 int launch_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const pdegym_rollout1d* ro, int B, void* stream) {
   if (!prm || !buf || !ro) return pdegym::fail(-1, "null params/bufs/rollout");
@@ -1265,8 +1348,9 @@ int launch_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const p
   const pdegym_params1d& P = *prm;
   if (P.n < 3 || P.n > PDEGYM_MAX_N1D) return pdegym::fail(-2, "rollout: n must be in [3, 2048] (register-resident rows)");
   if (P.nt < 2) return pdegym::fail(-2, "nt must be >= 2");
-  if (P.sensing != PDEGYM_SENSE_FULL) return pdegym::fail(-2, "rollout needs full-state sensing (slot t of obs is the state of step t)");
-  if (P.control_type == PDEGYM_CONTROL_NEUMANN) return pdegym::fail(-2, "rollout: Neumann actuation is not supported");
+  if (P.sensing < PDEGYM_SENSE_FULL || P.sensing > PDEGYM_SENSE_FIRST) return pdegym::fail(-2, "bad sensing code");
+  if (P.sensing != PDEGYM_SENSE_FULL && !buf->u) return pdegym::fail(-3, "rollout with scalar sensing: the state lives in bufs.u (obs slots hold the sensed values)");
+  if (P.control_type != PDEGYM_CONTROL_DIRICHLET && P.control_type != PDEGYM_CONTROL_NEUMANN) return pdegym::fail(-2, "bad control_type");
   if (P.beta_f64 || P.action_kind != PDEGYM_ACTION_F32) return pdegym::fail(-2, "rollout: float32 beta and actions only");
   if (buf->history) return pdegym::fail(-2, "rollout cannot record a history buffer");
   if (P.reward_horizon != PDEGYM_HORIZON_TEMPORAL) return pdegym::fail(-2, "rollout: only the temporal reward horizon is evaluated in the rollout kernels");
@@ -1277,19 +1361,32 @@ int launch_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const p
   hipStream_t st = (hipStream_t)stream;
   const int nslots = P.n - (PARABOLIC ? 1 : 0);
   const int epl = (nslots + kWave - 1) / kWave;
+  // the carried, register-resident form is the Dirichlet / full-state corner; everything else takes the general kernels
+  const bool neumann = P.control_type == PDEGYM_CONTROL_NEUMANN;
+  const bool general = neumann || P.sensing != PDEGYM_SENSE_FULL;
+  if ((ro->obs_noise || ro->obs_seen) && !ro->policy) return pdegym::fail(-2, "rollout: obs_noise / obs_seen belong to the policy's input (policy is NULL)");
   if (ro->policy) {
     const pdegym_mlp& N = *ro->policy;
-    if (const char* why = pdegym_policy::check(N, P.n, 1)) return pdegym::fail(-2, why);
+    const int od = P.sensing == PDEGYM_SENSE_FULL ? P.n : 1;
+    if (const char* why = pdegym_policy::check(N, od, 1)) return pdegym::fail(-2, why);
     if (N.x_f64 || N.y_f64) return pdegym::fail(-2, "policy inside the 1D rollout kernel: float32 observations and commands");
     if (epl > 8) return pdegym::fail(-2, "policy inside the rollout kernel: rows of up to 513 nodes");
-    const int lds_bytes = pdegym_policy::lds_floats(N, P.n) * (int)sizeof(float);
+    const int lds_bytes = pdegym_policy::lds_floats(N, od) * (int)sizeof(float);
     const dim3 pgrid((B + pdegym_policy::kWaves - 1) / pdegym_policy::kWaves), pblock(kWave * pdegym_policy::kWaves);
     bool ok = true;
     auto gop = [&](auto tag) {
       constexpr int E = decltype(tag)::value;
-      static signed char attr[pdegym::kMaxDevices] = {};
-      ok = pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&rollout1d_policy_kernel<E, PARABOLIC, BURGERS>), pdegym_policy::kMaxLdsBytes, attr);
-      if (ok) hipLaunchKernelGGL((rollout1d_policy_kernel<E, PARABOLIC, BURGERS>), pgrid, pblock, lds_bytes, st, P, *buf, *ro, N, B);
+      static signed char attr[3][pdegym::kMaxDevices] = {};
+      if (!general) {
+        ok = pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&rollout1d_policy_kernel<E, PARABOLIC, BURGERS>), pdegym_policy::kMaxLdsBytes, attr[0]);
+        if (ok) hipLaunchKernelGGL((rollout1d_policy_kernel<E, PARABOLIC, BURGERS>), pgrid, pblock, lds_bytes, st, P, *buf, *ro, N, B);
+      } else if (neumann) {
+        ok = pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&rollout1d_policy_general_kernel<E, PARABOLIC, true, BURGERS>), pdegym_policy::kMaxLdsBytes, attr[1]);
+        if (ok) hipLaunchKernelGGL((rollout1d_policy_general_kernel<E, PARABOLIC, true, BURGERS>), pgrid, pblock, lds_bytes, st, P, *buf, *ro, N, B);
+      } else {
+        ok = pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&rollout1d_policy_general_kernel<E, PARABOLIC, false, BURGERS>), pdegym_policy::kMaxLdsBytes, attr[2]);
+        if (ok) hipLaunchKernelGGL((rollout1d_policy_general_kernel<E, PARABOLIC, false, BURGERS>), pgrid, pblock, lds_bytes, st, P, *buf, *ro, N, B);
+      }
     };
     if (epl <= 1) gop(std::integral_constant<int, 1>{});
     else if (epl <= 2) gop(std::integral_constant<int, 2>{});
@@ -1304,7 +1401,9 @@ int launch_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const p
   const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
   auto go = [&](auto tag) {
     constexpr int E = decltype(tag)::value;
-    hipLaunchKernelGGL((rollout1d_kernel<E, PARABOLIC, BURGERS>), grid, block, 0, st, P, *buf, *ro, B);
+    if (!general) hipLaunchKernelGGL((rollout1d_kernel<E, PARABOLIC, BURGERS>), grid, block, 0, st, P, *buf, *ro, B);
+    else if (neumann) hipLaunchKernelGGL((rollout1d_general_kernel<E, PARABOLIC, true, BURGERS>), grid, block, 0, st, P, *buf, *ro, B);
+    else hipLaunchKernelGGL((rollout1d_general_kernel<E, PARABOLIC, false, BURGERS>), grid, block, 0, st, P, *buf, *ro, B);
   };
   // the same slots-per-lane choice as launch_step: the norm reductions (hence rewards) depend on the layout
   if (epl <= 1) go(std::integral_constant<int, 1>{});

@@ -89,20 +89,28 @@ class FakeBackend:
                     T["reset_count"][dm] += 1
                 self.reset1d(P, T, T["reset_init"][rows].contiguous(), torch.from_numpy(done.astype(np.uint8)), B, _keep_flags=True)
 
-    def rollout1d(self, kind, P, T, obs, actions, rewards, terminated, truncated, B, policy=None):
-        # the C ABI's contract: T step calls with the row read from slot t and written to slot t + 1 (and the policy, when
-        # given, evaluated on slot t first)
+    def rollout1d(self, kind, P, T, obs, actions, rewards, terminated, truncated, B, policy=None, obs_noise=None, obs_seen=None):
+        # the C ABI's contract: T step calls -- full-state sensing: the row read from slot t and written to slot t + 1; scalar
+        # sensing: the state in T["u"], slot t + 1 receives the sensed value -- and the policy, when given, evaluated first on
+        # slot t (+ obs_noise[t]; obs_seen[t] receives what it read)
         import ctypes as C
+        full = P.sensing == N.SENSE_FULL
         for t in range(actions.shape[0]):
             if policy is not None:
                 net = type(policy)()
                 C.memmove(C.addressof(net), C.addressof(policy), C.sizeof(policy))
                 if policy.noise:
                     net.noise = policy.noise + 4 * t * B * policy.noise_stride
-                self.mlp_forward(net, obs[t], actions[t].view(B, 1), B)
+                seen = obs[t] if obs_noise is None else obs[t] + obs_noise[t]
+                if obs_seen is not None:
+                    obs_seen[t].copy_(seen)
+                self.mlp_forward(net, seen.contiguous(), actions[t].view(B, 1), B)
             S = dict(T)
-            S.update(state_in=obs[t], u=None, obs=obs[t + 1], action=actions[t], reward=rewards[t], terminated=terminated[t],
-                     truncated=truncated[t], history=None)
+            S.update(obs=obs[t + 1], action=actions[t], reward=rewards[t], terminated=terminated[t], truncated=truncated[t], history=None)
+            if full:
+                S.update(state_in=obs[t], u=None)
+            else:
+                S.update(state_in=None)
             self.step1d(kind, P, S, B)
 
     def reset1d(self, P, T, init, mask, B, _keep_flags=False):

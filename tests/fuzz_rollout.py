@@ -2,7 +2,8 @@
 """Differential fuzz of the rollout kernels (pdegym_*_rollout, pdegym_traffic_rollout) against T step calls of the same HIP
 engines (which tests/fuzz_1d.py / fuzz_more.py pin to the oracle): random grids, sub-step counts, episode lengths, batch
 sizes, rollout lengths, reward kinds, normalisation, truncation thresholds, auto-reset pools (initial conditions and beta),
-zero / tiny / large states; all four traffic simulation types.  Everything must agree bit for bit.
+zero / tiny / large states, every control / sensing combination of the reference's table (round 4: Neumann actuation, the four
+scalar sensing modes); all four traffic simulation types.  Everything must agree bit for bit.
 
     python tests/fuzz_rollout.py [seconds] [seed]
 """
@@ -33,8 +34,11 @@ def case_1d(rng):
     dx = 1.0 / nx
     dt = (0.25 * dx * dx if base == "parabolic" else 0.5 * dx) * float(rng.choice([1.0, 0.5, 0.9]))
     nt_sub = max(ep * S - extra, 2)
-    kw = dict(T=nt_sub * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type="Dirchilet", sensing_loc="full",
-              sensing_type=None, normalize=bool(rng.random() < 0.5), max_control_value=float(rng.choice([20, 1, 3])),
+    control = str(rng.choice(["Dirchilet", "Dirchilet", "Neumann"]))
+    loc = str(rng.choice(["full", "full", "collocated", "opposite"]))
+    stype = None if loc != "opposite" else ("Neumann" if base == "parabolic" else str(rng.choice(["Neumann", "Dirchilet"])))
+    kw = dict(T=nt_sub * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type=control, sensing_loc=loc,
+              sensing_type=stype, normalize=bool(rng.random() < 0.5), max_control_value=float(rng.choice([20, 1, 3])),
               limit_pde_state_size=bool(rng.random() < 0.7), max_state_value=float(rng.choice([1e10, 30.0, 5.0, 1e3])))
     if kind == "burgers":
         kw["flux"] = "burgers"
@@ -66,22 +70,23 @@ def case_1d(rng):
         e.reset(torch.tensor(init), torch.tensor(beta))
         if auto:
             e.enable_auto_reset(torch.tensor(pool_i), keep_final_obs=bool(rng.random() < 2), beta_pool=torch.tensor(pool_b) if bpool else None)
-        obs = torch.zeros(T + 1, B, n, device=DEV)
+        obs = torch.zeros(T + 1, B, e.obs_dim, device=DEV)
         obs[0].copy_(e.t["obs"])
         rew = torch.zeros(T, B, device=DEV)
         te = torch.zeros(T, B, dtype=torch.uint8, device=DEV)
         tr = torch.zeros(T, B, dtype=torch.uint8, device=DEV)
         if mode == "steps":
-            e.t["obs"] = obs[0]
-            e.t["u"] = obs[0]
+            if e.state_in_obs:
+                e.t["obs"] = obs[0]
+                e.t["u"] = obs[0]
             for t in range(T):
                 e.step(acts[t], out_obs=obs[t + 1], out_reward=rew[t], out_terminated=te[t], out_truncated=tr[t])
         else:
             e.rollout(obs, acts, rew, te, tr)
-        keep = [obs, rew, te, tr] + [e.t[k] for k in ("time_index", "bsum", "ring", "norm_now", "norm_back", "beta") if torch.is_tensor(e.t.get(k))]
+        keep = [obs, rew, te, tr] + [e.t[k] for k in ("time_index", "bsum", "ring", "norm_now", "norm_back", "beta", "u") if torch.is_tensor(e.t.get(k))]
         keep += [e.t[k] for k in ("reset_count", "final_obs") if torch.is_tensor(e.t.get(k))]
         outs.append([k.clone() for k in keep])
-    desc = f"{kind} nx={nx} S={S} B={B} T={T} ep={ep} rk={rk} style={style} auto={auto} bpool={bpool} shared_beta={shared_beta}"
+    desc = f"{kind} {control}/{loc}/{stype} nx={nx} S={S} B={B} T={T} ep={ep} rk={rk} style={style} auto={auto} bpool={bpool} shared_beta={shared_beta}"
     for i, (a, b) in enumerate(zip(*outs)):
         if not torch.equal(a.view(torch.uint8) if a.dtype != torch.uint8 else a, b.view(torch.uint8) if b.dtype != torch.uint8 else b):
             # NaN rows compare unequal as floats; the byte views above already handle that -- a real mismatch

@@ -748,12 +748,66 @@ def test_rollout_kernel_equals_step_calls_bitwise(kind, nx, S, burgers, B, T):
     np.testing.assert_array_equal(o_a, o_b)
 
 
+@pytest.mark.parametrize("kind,control,loc,stype,nx,S,B,T", [
+    ("transport", "Neumann", "full", None, 100, 30, 9, 11), ("parabolic", "Neumann", "full", None, 256, 100, 9, 11),
+    ("parabolic", "Neumann", "collocated", None, 64, 7, 9, 11), ("transport", "Dirchilet", "collocated", None, 100, 30, 9, 11),
+    ("transport", "Dirchilet", "opposite", "Dirchilet", 512, 20, 5, 9), ("transport", "Neumann", "opposite", "Neumann", 40, 7, 130, 9),
+    ("parabolic", "Dirchilet", "opposite", "Neumann", 1500, 3, 3, 9), ("parabolic", "Dirchilet", "collocated", None, 2, 1, 9, 9),
+    ("transport", "Neumann", "full", None, 2047, 2, 3, 6), ("transport", "Neumann", "collocated", None, 3, 2, 1, 5)])
+def test_general_rollout_kernel_equals_step_calls_bitwise(kind, control, loc, stype, nx, S, B, T):
+    """Round 4: pdegym_*_rollout for the rest of the reference's control / sensing table (hyperbolic.py:66-124, parabolic.py:66-122):
+    Neumann actuation (state through the observation slots) and scalar sensing (state in ``u``, the slots hold the sensed values).
+    Every output and every piece of engine state equals T step calls bit for bit, across episode ends with the fused auto-reset."""
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
+    dx = 1.0 / nx
+    dt = 0.25 * dx * dx if kind == "parabolic" else 0.5 * dx
+    kw = dict(T=4 * S * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type=control, sensing_loc=loc,
+              sensing_type=stype, normalize=True, max_control_value=5.0, limit_pde_state_size=True, max_state_value=1e6)
+    rng = np.random.default_rng(nx * 11 + S)
+    envs = [PDEBatch1D(kind, reward=RewardSpec(N.REWARD_TUNED1D, int(round(kw["T"] / dt)), -1e3, 3e2), num_envs=B, device="cuda", **kw)
+            for _ in range(2)]
+    n, od = envs[0].n, envs[0].obs_dim
+    assert od == (n if loc == "full" else 1)
+    init = rng.uniform(0.5, 2, (B, n)).astype(np.float32)
+    beta = rng.uniform(-2, 2, (B, n)).astype(np.float32)
+    pool_i = rng.uniform(0.5, 2, (2 * B, n)).astype(np.float32)
+    pool_b = rng.uniform(-2, 2, (2 * B, n)).astype(np.float32)
+    acts = torch.tensor(rng.uniform(-1, 1, (T, B)).astype(np.float32), device="cuda")
+    bufs = []
+    for e in envs:
+        assert e.can_rollout()
+        e.reset(torch.tensor(init), torch.tensor(beta))
+        e.enable_auto_reset(torch.tensor(pool_i), keep_final_obs=True, beta_pool=torch.tensor(pool_b))
+        obs = torch.zeros(T + 1, B, od, device="cuda")
+        obs[0].copy_(e.t["obs"])
+        bufs.append((obs, torch.zeros(T, B, device="cuda"), torch.zeros(T, B, dtype=torch.uint8, device="cuda"),
+                     torch.zeros(T, B, dtype=torch.uint8, device="cuda")))
+    e, (obs, rew, te, tr) = envs[0], bufs[0]
+    if e.state_in_obs:
+        e.t["obs"] = obs[0]
+        e.t["u"] = obs[0]
+    for t in range(T):
+        e.step(acts[t], out_obs=obs[t + 1], out_reward=rew[t], out_terminated=te[t], out_truncated=tr[t])
+    e2, (obs2, rew2, te2, tr2) = envs[1], bufs[1]
+    e2.rollout(obs2, acts, rew2, te2, tr2)
+    for a, b in ((obs, obs2), (rew, rew2), (te, te2), (tr, tr2)):
+        np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    for k in ("time_index", "bsum", "ring", "reset_count", "beta", "final_obs", "norm_now", "norm_back", "u"):
+        np.testing.assert_array_equal(e.t[k].cpu().numpy(), e2.t[k].cpu().numpy(), err_msg=k)
+    np.testing.assert_array_equal(e2.t["obs"].cpu().numpy(), obs2[T].cpu().numpy())
+    assert T < 4 or int(te.sum() + tr.sum()) > 0
+    np.testing.assert_array_equal(e.step(acts[0])[0].cpu().numpy(), e2.step(acts[0])[0].cpu().numpy())
+
+
 def test_rollout_abi_validation():
     from pdecontrolgym_amd.batch1d import PDEBatch1D
-    env = PDEBatch1D("transport", 1, 1e-3, 1, 1e-2, 0.01, num_envs=2, device="cuda", sensing_loc="opposite", sensing_type="Dirchilet")
-    assert not env.can_rollout()
+    env = PDEBatch1D("transport", 1, 1e-3, 1, 1e-2, 0.01, num_envs=2, device="cuda", sensing_loc="full", sensing_type=None, record_history=True)
+    assert not env.can_rollout()            # a recorded history has no place in the rollout kernels
     with pytest.raises(ValueError):
         env.rollout(None, None, None, None, None)
+    env = PDEBatch1D("transport", 1, 1e-3, 1, 1e-2, 0.01, num_envs=2, device="cuda", sensing_loc="opposite", sensing_type="Dirchilet")
+    assert env.can_rollout() and env.obs_dim == 1
     env = PDEBatch1D("transport", 1, 1e-3, 1, 1e-2, 0.01, num_envs=2, device="cuda", sensing_loc="full", sensing_type=None)
     env.reset(torch.ones(2, 100), torch.ones(2, 100))
     n = env.n

@@ -855,3 +855,46 @@ def test_roofline_counters_are_tied_to_the_kernel_sources(monkeypatch):
     assert r["counters_stale"] == (r["counters_kernel_stamp"] != bench.kernel_stamp("parabolic_c2")) and 0.3 < r["frac"] < 0.7
     monkeypatch.setattr(bench, "kernel_stamp", lambda k: "0" * 16)
     assert bench.roofline_block(W(), "parabolic_c2", 0.02, True)["counters_stale"] is True
+
+
+@pytest.mark.parametrize("control,loc", [("Neumann", "full"), ("Dirchilet", "collocated"), ("Neumann", "collocated")])
+def test_engine_rollout_contract_for_neumann_and_scalar_sensing_on_the_double(control, loc):
+    """Host logic of PDEBatch1D.rollout for the general cases (round 4): with full-state sensing the observation slots carry the
+    state, with scalar sensing the engine's own ``u`` does and the slots are [T + 1, B, 1]; either way T step calls and one
+    rollout call leave identical outputs and identical engine state (the CPU double runs the oracle per step)."""
+    import torch
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
+    B, T, nx, S = 3, 7, 40, 5
+    dx = 1.0 / nx
+    dt = 0.5 * dx
+    kw = dict(T=3 * S * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type=control, sensing_loc=loc, sensing_type=None,
+              normalize=True, max_control_value=2.0, limit_pde_state_size=True, max_state_value=1e6)
+    rng = np.random.default_rng(3)
+    init, beta = rng.uniform(0.5, 2, (B, nx)).astype(np.float32), rng.uniform(-1, 1, (B, nx)).astype(np.float32)
+    pool = rng.uniform(0.5, 2, (2 * B, nx)).astype(np.float32)
+    acts = torch.tensor(rng.uniform(-1, 1, (T, B)).astype(np.float32))
+    outs = []
+    for mode in ("steps", "rollout"):
+        e = PDEBatch1D("transport", reward=RewardSpec(N.REWARD_TUNED1D, int(round(kw["T"] / dt)), -1e3, 3e2), num_envs=B, device="cpu",
+                       backend=FakeBackend(), **kw)
+        assert e.can_rollout()
+        e.reset(torch.tensor(init), torch.tensor(beta))
+        e.enable_auto_reset(torch.tensor(pool))
+        od = e.obs_dim
+        obs = torch.zeros(T + 1, B, od)
+        obs[0].copy_(e.t["obs"])
+        rew, te, tr = torch.zeros(T, B), torch.zeros(T, B, dtype=torch.uint8), torch.zeros(T, B, dtype=torch.uint8)
+        if mode == "steps":
+            if e.state_in_obs:
+                e.t["obs"] = e.t["u"] = obs[0]
+            for t in range(T):
+                e.step(acts[t], out_obs=obs[t + 1], out_reward=rew[t], out_terminated=te[t], out_truncated=tr[t])
+        else:
+            e.rollout(obs, acts, rew, te, tr)
+            with pytest.raises(ValueError):
+                e.rollout(obs, acts, rew, te, tr, obs_noise=torch.zeros(T, B, od))        # noise shapes a POLICY's input
+        outs.append([x.numpy().copy() for x in (obs, rew, te, tr, e.t["u"], e.t["time_index"], e.t["bsum"], e.t["reset_count"])])
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    assert outs[0][2].sum() > 0

@@ -270,6 +270,67 @@ def test_one_launch_rollout_with_policy_inside_equals_two_launches_per_step(kind
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,control,loc,stype,nx,S,B,sizes,acts", [
+    ("PDEControlGym-ReactionDiffusionPDE1D", "Neumann", "full", None, 128, 10, 50, [129, 64, 64, 1], ["tanh", "tanh", "tanh"]),
+    ("PDEControlGym-TransportPDE1D", "Neumann", "full", None, 100, 10, 16, [100, 48, 1], ["relu", None]),
+    ("PDEControlGym-TransportPDE1D", "Dirchilet", "collocated", None, 100, 10, 37, [1, 32, 32, 1], ["tanh", "tanh", None]),
+    ("PDEControlGym-ReactionDiffusionPDE1D", "Neumann", "collocated", None, 64, 5, 20, [1, 16, 1], ["tanh", None]),
+    ("PDEControlGym-ReactionDiffusionPDE1D", "Dirchilet", "full", None, 64, 5, 20, [65, 64, 1], ["tanh", None]),
+])
+def test_one_launch_rollout_general_cases_with_sensing_noise(kind, control, loc, stype, nx, S, B, sizes, acts):
+    """Round 4: the one-launch rollout with the policy inside for Neumann actuation and scalar sensing (the policy's input is the
+    one sensed value), with pre-drawn additive sensing noise (``DeviceRollout(sensing_noise=True)``: the policy reads
+    obs[t] + sensing_noise[t], obs_seen records it, the plant state stays clean) and action noise -- against the policy launch +
+    step launch per env-step.  Same tolerances as the Dirichlet / full-state test above; obs_seen == obs + noise exactly."""
+    import pde_control_gym
+    from pde_control_gym import DeviceRollout
+    from pde_control_gym.src import TunedReward1D
+    T, horizon = 9, 4
+    dx = 1.0 / nx
+    dt = 0.25 * dx * dx if "Reaction" in kind else 0.5 * dx
+    nodes = nx + 1 if "Reaction" in kind else nx
+    beta = np.full(nodes, 2.0, np.float32)
+    net = _mlp(sizes, acts, seed=13).cuda()
+    with torch.no_grad():
+        net[0].weight.mul_(0.3)
+    runs = {}
+    for mode in (False, True):
+        p = {"T": horizon * S * dt, "dt": dt, "X": 1, "dx": dx, "reward_class": TunedReward1D(horizon * S, -1e3, 3e2), "normalize": True,
+             "sensing_loc": loc, "control_type": control, "sensing_type": stype, "sensing_noise_func": None,
+             "limit_pde_state_size": True, "max_state_value": 1e10, "max_control_value": 3, "control_sample_rate": S * dt,
+             "batched_reset_func": lambda idx, nx_: (np.random.default_rng(5).uniform(1, 2, (len(idx), 1)).astype(np.float32)
+                                                     * np.linspace(1, 1.5, nodes, dtype=np.float32)[None], np.tile(beta, (len(idx), 1)))}
+        venv = pde_control_gym.make_vec(kind, num_envs=B, **p)
+        venv.reset_tensor()
+        venv.enable_fused_auto_reset()
+        assert venv.core.can_rollout() and venv.core.obs_dim == sizes[0]
+        ro = DeviceRollout(venv, FusedMLP(net), T, action_low=-1.0, action_high=1.0, action_noise=True, sensing_noise=True, one_launch=mode)
+        assert ro.one_launch == mode
+        g = torch.Generator().manual_seed(2)
+        ro.action_noise.copy_(torch.randn(T, B, generator=g).mul(0.2).cuda())
+        ro.sensing_noise.copy_(torch.randn(T + 1, B, sizes[0], generator=g).mul(0.05).cuda())
+        ro.run()
+        torch.cuda.synchronize()
+        runs[mode] = {k: getattr(ro, k).cpu().numpy().copy() for k in ("actions", "obs", "obs_seen", "rewards", "terminated", "truncated")}
+        runs[mode]["noise"] = ro.sensing_noise.cpu().numpy().copy()
+        runs[mode]["time_index"] = venv.core.t["time_index"].cpu().numpy().copy()
+        runs[mode]["u"] = venv.core.t["u"].cpu().numpy().copy()
+        ro.run()
+        torch.cuda.synchronize()
+        runs[mode]["obs2"] = ro.obs.cpu().numpy().copy()
+    a, b = runs[True], runs[False]
+    np.testing.assert_array_equal(a["obs_seen"], a["obs"] + a["noise"])
+    np.testing.assert_array_equal(b["obs_seen"], b["obs"] + b["noise"])
+    np.testing.assert_allclose(a["actions"][0], b["actions"][0], rtol=2e-5, atol=4e-6)
+    for k in ("actions", "obs", "rewards", "u", "obs2"):
+        np.testing.assert_allclose(a[k], b[k], rtol=2e-4, atol=4e-5, err_msg=k)
+    for k in ("terminated", "truncated", "time_index"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    np.testing.assert_array_equal(a["obs2"][0], a["obs"][T])
+    assert a["terminated"].sum() > 0
+
+
+@pytest.mark.gpu
 def test_one_launch_rollout_falls_back_and_validates():
     from pde_control_gym import DeviceRollout
     venv = _rd_env(8, 64, 5, horizon=4)
@@ -346,8 +407,14 @@ def test_policy_fits_rollout_limits_on_cpu_double():
     assert not big.policy_fits_rollout(pol([513, 64, 64, 1]))      # 131 KB of first-layer weights + 16 rows: over 160 KB
     assert big.policy_fits_rollout(pol([513, 32, 64, 1]))
     assert not eng(600).policy_fits_rollout(pol([601, 16, 1]))     # rows of more than 513 nodes
-    assert not eng(64, control_type="Neumann").can_rollout()
+    neu = eng(64, control_type="Neumann")                          # round 4: Neumann actuation and scalar sensing roll out too
+    assert neu.can_rollout() and neu.policy_fits_rollout(pol([65, 64, 1]))
+    dx = 1.0 / 64
+    col = PDEBatch1D("parabolic", 100 * 0.25 * dx * dx, 0.25 * dx * dx, 1, dx, 5 * 0.25 * dx * dx, sensing_loc="collocated", sensing_type=None,
+                     num_envs=2, device="cpu", backend=FakeBackend())
+    assert col.obs_dim == 1 and col.can_rollout() and col.policy_fits_rollout(pol([1, 64, 1])) and not col.policy_fits_rollout(pol([65, 64, 1]))
     assert not eng(64, record_history=True).can_rollout()
+    assert not eng(64, state_in_obs=False).can_rollout()           # full-state sensing with a second copy of the state: two homes
     tr = TrafficBatch(240, 0.25, 500, 10, "both", 40, 0.16, 60, True, 1, num_envs=2, device="cpu", backend=FakeBackend())
     assert tr.can_rollout() and tr.policy_fits_rollout(pol([102, 64, 2])) and not tr.policy_fits_rollout(pol([102, 64, 1]))
     wide = TrafficBatch(240, 0.25, 1000, 10, "inlet", 40, 0.16, 60, True, 1, num_envs=2, device="cpu", backend=FakeBackend())
