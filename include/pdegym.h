@@ -259,6 +259,26 @@ typedef struct pdegym_bufs_ns2d {
 int pdegym_ns2d_step_f32(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int32_t B, void* stream);
 int pdegym_ns2d_step_f64(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, int32_t B, void* stream);
 
+/* T env-steps in ONE launch for small grids (the reference's shipped 21 x 21 example; grids of 8, 11, 16, 21, 26, 31 or 32 rows and at
+ * most 64 columns): the loop of env.step calls of examples/NavierStokes/NS2Dppo.py:52-66 / the forward sweeps of the adjoint example
+ * (NS2Doptimization.py:74-76) with the commands given ahead.  Step t reads the state from obs slot t and the command from actions row
+ * t, writes obs slot t + 1 and rewards / terminated row t; p, time_index, U_ref / action_ref, the auto-reset pools, final_obs and
+ * reset_count come from the pdegym_bufs_ns2d of the call and behave as in T consecutive pdegym_ns2d_step calls with state_in (fused
+ * auto-reset included; the pressure stays in bufs->p) -- the results are bit-identical to those calls.  bufs->u / v / state_in / obs /
+ * action / reward / terminated / p_out are ignored. */
+typedef struct pdegym_rollout_ns2d {
+  int32_t T;                /* env-steps per call                                                              */
+  int32_t reserved_;
+  void* obs;                /* [T + 1, B, ny, nx, 2]  slot 0 = the input state; slots 1 .. T are written       */
+  const void* actions;      /* [T, B, action_dim]                                                             */
+  void* rewards;            /* [T, B]                                                                         */
+  uint8_t* terminated;      /* [T, B]                                                                         */
+} pdegym_rollout_ns2d;
+int pdegym_ns2d_rollout_f32(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, const pdegym_rollout_ns2d* ro, int32_t B,
+                            void* stream);
+int pdegym_ns2d_rollout_f64(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, const pdegym_rollout_ns2d* ro, int32_t B,
+                            void* stream);
+
 /* p_out = K Jacobi sweeps from p_in with rhs = rho/dt*(d/dx u + d/dy v)  (navier_stokes2D.py:94-116).
  * u, v, p_in, p_out: [B, ny, nx]; scratch: [B, 2, ny, nx]. p_out may alias p_in. */
 int pdegym_ns2d_solve_pressure_f32(const pdegym_params_ns2d* prm, const void* u, const void* v, const void* p_in,

@@ -28,7 +28,7 @@ EDGES = ("lower", "upper", "left", "right")
 
 EXPORTS = [
     "pdegym_abi_version", "pdegym_last_error", "pdegym_transport_step", "pdegym_parabolic_step",
-    "pdegym_reset1d_masked", "pdegym_rownorm2_f32", "pdegym_selftest_quotient", "pdegym_ns2d_step_f32", "pdegym_ns2d_step_f64",
+    "pdegym_reset1d_masked", "pdegym_rownorm2_f32", "pdegym_selftest_quotient", "pdegym_ns2d_step_f32", "pdegym_ns2d_step_f64", "pdegym_ns2d_rollout_f32", "pdegym_ns2d_rollout_f64",
     "pdegym_ns2d_solve_pressure_f32", "pdegym_ns2d_solve_pressure_f64", "pdegym_ns2d_reset_masked_f32",
     "pdegym_ns2d_reset_masked_f64", "pdegym_traffic_step", "pdegym_traffic_reset_masked",
     "pdegym_tumor_step", "pdegym_tumor_advance", "pdegym_tumor_reset_masked", "pdegym_mlp_forward",
@@ -64,6 +64,11 @@ class Rollout1D(C.Structure):
     _fields_ = [("T", C.c_int32), ("reserved_", C.c_int32), ("obs", C.c_void_p), ("actions", C.c_void_p),
                 ("rewards", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("policy", C.c_void_p),
                 ("obs_noise", C.c_void_p), ("obs_seen", C.c_void_p)]
+
+
+class RolloutNS2D(C.Structure):
+    _fields_ = [("T", C.c_int32), ("reserved_", C.c_int32), ("obs", C.c_void_p), ("actions", C.c_void_p), ("rewards", C.c_void_p),
+                ("terminated", C.c_void_p)]
 
 
 class ParamsNS2D(C.Structure):
@@ -166,6 +171,9 @@ def load():
     for sfx in ("f32", "f64"):
         f = getattr(lib, "pdegym_ns2d_step_" + sfx)
         f.argtypes = [C.POINTER(ParamsNS2D), C.POINTER(BufsNS2D), C.c_int32, C.c_void_p]
+        f.restype = C.c_int
+        f = getattr(lib, "pdegym_ns2d_rollout_" + sfx)
+        f.argtypes = [C.POINTER(ParamsNS2D), C.POINTER(BufsNS2D), C.POINTER(RolloutNS2D), C.c_int32, C.c_void_p]
         f.restype = C.c_int
         f = getattr(lib, "pdegym_ns2d_solve_pressure_" + sfx)
         f.argtypes = [C.POINTER(ParamsNS2D), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]

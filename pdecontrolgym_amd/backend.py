@@ -163,6 +163,26 @@ class HipBackend:
         N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["p"].device)), "pdegym_ns2d_step")
 
     @_on_device_of("p")
+    def ns2d_rollout(self, P: N.ParamsNS2D, T: dict, obs, actions, rewards, terminated, B: int):
+        """T env-steps in one launch (pdegym_ns2d_rollout_*, small grids): ``obs`` [T+1, B, ny, nx, 2] (slot 0 = the input
+        state), ``actions`` [T, B, action_dim], ``rewards`` / ``terminated`` [T, B]."""
+        import torch
+        dtype = T["p"].dtype
+        steps = int(actions.shape[0])
+        want = {"obs": (steps + 1, B, P.ny, P.nx, 2), "actions": (steps, B, P.action_dim), "rewards": (steps, B), "terminated": (steps, B)}
+        for name, x in (("obs", obs), ("actions", actions), ("rewards", rewards), ("terminated", terminated)):
+            if tuple(x.shape) != want[name] or not x.is_contiguous():
+                raise N.NativeError(f"rollout {name} must be a contiguous {list(want[name])} tensor, got {tuple(x.shape)}")
+        bufs = self._bufs_ns({**T, "u": None, "v": None, "state_in": None, "p_out": None, "obs": obs[0], "action": actions[0],
+                              "reward": rewards[0], "terminated": terminated[0]}, dtype)
+        ro = N.RolloutNS2D()
+        ro.T = steps
+        ro.obs, ro.actions, ro.rewards = N.dptr(obs, dtype), N.dptr(actions, dtype), N.dptr(rewards, dtype)
+        ro.terminated = N.dptr(terminated, torch.uint8)
+        fn = getattr(self.lib, "pdegym_ns2d_rollout_" + self._sfx(dtype))
+        N.check(fn(C.byref(P), C.byref(bufs), C.byref(ro), B, N.current_stream_ptr(T["p"].device)), "pdegym_ns2d_rollout")
+
+    @_on_device_of("p")
     def ns2d_reset(self, P: N.ParamsNS2D, T: dict, u0, v0, p0, mask, B: int):
         import torch
         dtype = T["p"].dtype

@@ -175,6 +175,28 @@ class NSBatch2D(EngineCheckpoint):
             self.t["p"], self.t["p_out"] = self.t["p_out"], self.t["p"]
         return self.t["obs"], self.t["reward"], self.t["terminated"]
 
+    def can_rollout(self) -> bool:
+        """True when ``rollout`` applies: the column-per-lane kernel's grids (8, 11, 16, 21, 26, 31 or 32 rows, at most 64
+        columns -- the reference's shipped 21 x 21 example among them) with the state in the observation tensors."""
+        return bool(self.interleaved_state and self.ny in (8, 11, 16, 21, 26, 31, 32) and 3 <= self.nx <= 64
+                    and hasattr(self.backend, "ns2d_rollout"))
+
+    def rollout(self, obs, actions, rewards, terminated):
+        """T env-steps in ONE launch (include/pdegym.h: pdegym_ns2d_rollout_*), commands given ahead: step t takes ``actions[t]``
+        ([T, B, action_dim]) and writes ``obs[t + 1]`` ([T+1, B, ny, nx, 2]; ``obs[0]`` = the state the rollout starts from),
+        ``rewards[t]``, ``terminated[t]`` -- bit-identical to T calls of ``step(actions[t], out_obs=obs[t + 1], ...)``, fused
+        auto-reset included.  Afterwards the engine's current observation (its state) is a copy of ``obs[T]``."""
+        if not self.can_rollout():
+            raise ValueError("rollout needs one of the column kernel's grids (8 / 11 / 16 / 21 / 26 / 31 / 32 rows, <= 64 columns) "
+                             "and the interleaved state layout")
+        pingpong = self._p_pingpong
+        self.backend.ns2d_rollout(self.params, self.t, obs, actions, rewards, terminated, self.num_envs)
+        assert not pingpong                      # (only the 256 x 256 grids ping-pong their pressure; they cannot roll out)
+        self.t["obs"].copy_(obs[-1])
+        self.t["reward"].copy_(rewards[-1])
+        self.t["terminated"].copy_(terminated[-1])
+        return obs, rewards, terminated
+
     def solve_pressure(self, u, v, p_prev):
         """K Jacobi sweeps of the pressure Poisson problem for arbitrary fields (navier_stokes2D.py:94-116).
         u, v, p_prev: [M, ny, nx] device tensors; returns a new [M, ny, nx] tensor."""

@@ -1328,9 +1328,20 @@ __device__ __forceinline__ T pinned_from_right(T v) {
   return r;
 }
 
+// Fused auto-reset, run right after the step kernels of the same call (same stream, no host round trip): instances whose
+// step ended terminated keep their last observation in final_obs and restart from a pool row.
+template <typename T>
+struct NSAutoReset {
+  const T* u0;
+  const T* v0;
+  const T* p0;
+  T* final_obs;
+  int* reset_count;
+  int pool_rows;
+};
+
 template <typename T, int NY>     // NY = C.ny exactly: every row index below is a compile-time constant
-__global__ __launch_bounds__(64, (sizeof(T) == 8 || NY > 21 ? 2 : 3)) void ns_col_step(NSConst C, NSScal<T> S, NSPtrs<T> P, int B) {
-  __shared__ T red[64];
+__device__ __forceinline__ void ns_col_body(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int B, T* red) {
   static_assert(NY >= 3, "a grid has at least one interior row");
   const int nx = C.nx, ncell = nx * NY;
   const int lane = threadIdx.x;
@@ -1513,6 +1524,80 @@ __global__ __launch_bounds__(64, (sizeof(T) == 8 || NY > 21 ? 2 : 3)) void ns_co
   }
 }
 
+template <typename T, int NY>
+__global__ __launch_bounds__(64, (sizeof(T) == 8 || NY > 21 ? 2 : 3)) void ns_col_step(NSConst C, NSScal<T> S, NSPtrs<T> P, int B) {
+  __shared__ T red[64];
+  ns_col_body<T, NY>(C, S, P, B, red);
+}
+
+// T env-steps in ONE launch (pdegym_ns2d_rollout_*, small grids): iteration t is ns_col_step's body with the state read from
+// observation slot t and written to slot t + 1, the command / reward / flag taken from / written to row t of the rollout arrays,
+// followed by the fused auto-reset of ns_step (final_obs, pool row -> slot t + 1 and p, time index, restart counter) -- every
+// value equals what T pdegym_ns2d_step calls produce, bit for bit.  A wave re-reads only what its own lanes stored (its up to
+// three instances: state slots, p, time index, flag), so iterations are separated by a workgroup-scope release / acquire pair.
+template <typename T>
+struct NSRollout {
+  int T_steps;
+  T* obs;
+  const T* actions;
+  T* rewards;
+  uint8_t* terminated;
+};
+
+// (called, not inlined, from the rollout loop: with the body inlined into a loop clang 22 / ROCm 7.2 crashes in instcombine)
+template <typename T, int NY>
+__device__ __attribute__((noinline)) void ns_col_body_call(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int B, T* red) {
+  ns_col_body<T, NY>(C, S, P, B, red);
+}
+
+template <typename T, int NY>
+__global__ __launch_bounds__(64, (sizeof(T) == 8 || NY > 21 ? 2 : 3)) void ns_col_rollout(NSConst C, NSScal<T> S, NSPtrs<T> P, NSRollout<T> Ro,
+                                                                                         NSAutoReset<T> R, int B) {
+  __shared__ T red[64];
+  const int nx = C.nx, ncell = nx * NY;
+  const int lane = threadIdx.x;
+  const int G = 64 / nx;
+  const int g = lane / nx;
+  const int j = lane - g * nx;
+  const int b = blockIdx.x * G + g;
+  const bool live = g < G && b < B;
+  const size_t slot = (size_t)B * ncell * 2;
+  for (int t = 0; t < Ro.T_steps; ++t) {
+    const NSPtrs<T> Q{nullptr, nullptr, P.p, P.scratch, Ro.actions + (size_t)t * B * C.action_dim, P.time_index, P.U_ref, P.action_ref,
+                      Ro.obs + (size_t)(t + 1) * slot, Ro.rewards + (size_t)t * B, Ro.terminated + (size_t)t * B,
+                      Ro.obs + (size_t)t * slot, nullptr};
+    ns_col_body_call<T, NY>(C, S, Q, B, red);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (R.u0) {                                       // fused auto-reset, as ns_auto_reset_kernel / _finish after a step call
+      const bool done = live && Q.terminated[b] != 0;
+      if (done) {
+        const int rows = R.pool_rows > 0 ? R.pool_rows : B;
+        const long long k = R.reset_count ? (long long)R.reset_count[b] : 0;
+        const size_t src = (size_t)(((long long)b + k * (long long)B) % rows) * ncell, off = (size_t)b * ncell;
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+          const size_t c = off + (size_t)i * nx + j;
+          if (R.final_obs) {
+            R.final_obs[2 * c] = Q.obs[2 * c];
+            R.final_obs[2 * c + 1] = Q.obs[2 * c + 1];
+          }
+          Q.p[c] = R.p0[src + (size_t)i * nx + j];
+          Q.obs[2 * c] = R.u0[src + (size_t)i * nx + j];
+          Q.obs[2 * c + 1] = R.v0[src + (size_t)i * nx + j];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();                // every lane of the group has read reset_count before lane j == 0 bumps it
+      if (done && j == 0) {
+        P.time_index[b] = 0;
+        if (R.reset_count) R.reset_count[b] += 1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  }
+}
+
 // The column kernel is instantiated for the grid height of the reference's shipped example (21 rows) and a few neighbours
 // (8, 11, 16, 26, 31, 32); any width up to 64.  One wave works through all K sweeps of its (up to three) instances alone: in
 // float64 a lone instance finishes sooner on the workgroup-per-instance kernel (seven waves per instance; 0.77 vs 0.98 ms per
@@ -1534,6 +1619,24 @@ bool launch_ns_col(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int
     case 26: hipLaunchKernelGGL((ns_col_step<T, 26>), grid, block, 0, st, C, S, P, B); return true;
     case 31: hipLaunchKernelGGL((ns_col_step<T, 31>), grid, block, 0, st, C, S, P, B); return true;
     case 32: hipLaunchKernelGGL((ns_col_step<T, 32>), grid, block, 0, st, C, S, P, B); return true;
+    default: return false;
+  }
+}
+
+template <typename T>
+bool launch_ns_col_rollout(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, const NSRollout<T>& Ro, const NSAutoReset<T>& R, int B,
+                           hipStream_t st) {
+  if (C.nx < 3 || C.nx > 64) return false;
+  const int G = 64 / C.nx;
+  const dim3 grid((B + G - 1) / G), block(64);
+  switch (C.ny) {
+    case 8: hipLaunchKernelGGL((ns_col_rollout<T, 8>), grid, block, 0, st, C, S, P, Ro, R, B); return true;
+    case 11: hipLaunchKernelGGL((ns_col_rollout<T, 11>), grid, block, 0, st, C, S, P, Ro, R, B); return true;
+    case 16: hipLaunchKernelGGL((ns_col_rollout<T, 16>), grid, block, 0, st, C, S, P, Ro, R, B); return true;
+    case 21: hipLaunchKernelGGL((ns_col_rollout<T, 21>), grid, block, 0, st, C, S, P, Ro, R, B); return true;
+    case 26: hipLaunchKernelGGL((ns_col_rollout<T, 26>), grid, block, 0, st, C, S, P, Ro, R, B); return true;
+    case 31: hipLaunchKernelGGL((ns_col_rollout<T, 31>), grid, block, 0, st, C, S, P, Ro, R, B); return true;
+    case 32: hipLaunchKernelGGL((ns_col_rollout<T, 32>), grid, block, 0, st, C, S, P, Ro, R, B); return true;
     default: return false;
   }
 }
@@ -1583,18 +1686,6 @@ __global__ void ns_reset_kernel(NSConst C, NSPtrs<T> P, const T* u0, const T* v0
     P.terminated[b] = 0;
   }
 }
-
-// Fused auto-reset, run right after the step kernels of the same call (same stream, no host round trip): instances whose
-// step ended terminated keep their last observation in final_obs and restart from a pool row.
-template <typename T>
-struct NSAutoReset {
-  const T* u0;
-  const T* v0;
-  const T* p0;
-  T* final_obs;
-  int* reset_count;
-  int pool_rows;
-};
 
 template <typename T>
 __global__ void ns_auto_reset_kernel(NSConst C, NSPtrs<T> P, NSAutoReset<T> R, int B) {
@@ -1851,9 +1942,38 @@ int ns_reset(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, const v
   return pdegym::check_launch("ns2d_reset");
 }
 
+template <typename T>
+int ns_rollout(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, const pdegym_rollout_ns2d* ro, int B, void* stream) {
+  NSConst C;
+  NSScal<T> S;
+  if (int rc = fill<T>(prm, C, S)) return rc;
+  if (!buf || !ro) return pdegym::fail(-1, "null bufs / rollout descriptor");
+  if (B <= 0 || ro->T <= 0) return 0;
+  if (!buf->p || !buf->scratch || !buf->time_index || !buf->U_ref || !buf->action_ref) return pdegym::fail(-3, "null device buffer");
+  if (!ro->obs || !ro->actions || !ro->rewards || !ro->terminated) return pdegym::fail(-3, "null rollout buffer");
+  if (buf->nt_ref < 1) return pdegym::fail(-2, "nt_ref must be >= 1");
+  if (buf->reset_u0 && (!buf->reset_v0 || !buf->reset_p0)) return pdegym::fail(-3, "reset_u0 needs reset_v0 and reset_p0");
+  C.nt_ref = buf->nt_ref;
+  NSPtrs<T> P{nullptr, nullptr, (T*)buf->p, (T*)buf->scratch, nullptr, buf->time_index, (const T*)buf->U_ref, (const T*)buf->action_ref,
+              nullptr, nullptr, nullptr, nullptr, nullptr};
+  NSRollout<T> Ro{ro->T, (T*)ro->obs, (const T*)ro->actions, (T*)ro->rewards, ro->terminated};
+  NSAutoReset<T> R{(const T*)buf->reset_u0, (const T*)buf->reset_v0, (const T*)buf->reset_p0, (T*)buf->final_obs, buf->reset_count,
+                   buf->reset_pool_rows};
+  if (!launch_ns_col_rollout<T>(C, S, P, Ro, R, B, (hipStream_t)stream))
+    return pdegym::fail(-2, "ns2d rollout: grids of 8, 11, 16, 21, 26, 31 or 32 rows and at most 64 columns (the column-per-lane kernel)");
+  return pdegym::check_launch("ns2d_col_rollout");
+}
+
 }  // namespace
 
 extern "C" {
+
+int pdegym_ns2d_rollout_f32(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, const pdegym_rollout_ns2d* ro, int32_t B, void* stream) {
+  return ns_rollout<float>(prm, buf, ro, B, stream);
+}
+int pdegym_ns2d_rollout_f64(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* buf, const pdegym_rollout_ns2d* ro, int32_t B, void* stream) {
+  return ns_rollout<double>(prm, buf, ro, B, stream);
+}
 
 int32_t pdegym_debug_set(int32_t key, int32_t value) {
   if (key < 0 || key >= PDEGYM_DEBUG_COUNT) return pdegym::fail(-2, "unknown debug key");

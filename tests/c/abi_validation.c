@@ -148,6 +148,18 @@ int main(void) {
   expect_error("ns2d_solve_pressure_f32 NULL params", pdegym_ns2d_solve_pressure_f32(NULL, FAKE(1), FAKE(2), FAKE(3), FAKE(4), FAKE(5), 2, NULL));
   expect_error("ns2d_reset_masked_f32 NULL", pdegym_ns2d_reset_masked_f32(&N2, NULL, NULL, NULL, NULL, NULL, 2, NULL));
   expect_error("ns2d_reset_masked_f64 NULL params", pdegym_ns2d_reset_masked_f64(NULL, &nb, FAKE(1), FAKE(2), FAKE(3), NULL, 2, NULL));
+  {
+    pdegym_rollout_ns2d nr;
+    memset(&nr, 0, sizeof nr);
+    nr.T = 4;
+    expect_error("ns2d_rollout_f64 NULL descriptor", pdegym_ns2d_rollout_f64(&N2, &nb, NULL, 2, NULL));
+    expect_error("ns2d_rollout_f32 empty rollout buffers", pdegym_ns2d_rollout_f32(&N2, &nb, &nr, 2, NULL));
+    nr.obs = FAKE(80); nr.actions = FAKE(81); nr.rewards = FAKE(82); nr.terminated = FAKE(83);
+    N2.nx = N2.ny = 128;
+    expect_error("ns2d_rollout_f32 128x128 (no column kernel)", pdegym_ns2d_rollout_f32(&N2, &nb, &nr, 2, NULL));
+    N2.nx = N2.ny = 21;
+    expect_error("ns2d_rollout_f64 21x21 well-formed, no device", pdegym_ns2d_rollout_f64(&N2, &nb, &nr, 2, NULL));
+  }
   expect_error("debug_set(-1)", pdegym_debug_set(-1, 0));
 
   /* ---- traffic ---- */

@@ -175,6 +175,13 @@ class FakeBackend:
             if T.get("reset_count") is not None:
                 T["reset_count"][dm] += 1
 
+    def ns2d_rollout(self, P, T, obs, actions, rewards, terminated, B):
+        # the C ABI's contract: T step calls with the state read from slot t and written to slot t + 1, the pressure in T["p"]
+        for t in range(actions.shape[0]):
+            S = dict(T)
+            S.update(u=None, v=None, p_out=None, state_in=obs[t], obs=obs[t + 1], action=actions[t], reward=rewards[t], terminated=terminated[t])
+            self.ns2d_step(P, S, B)
+
     def ns2d_reset(self, P, T, u0, v0, p0, mask, B):
         m = torch.ones(B, dtype=torch.bool) if mask is None else mask.bool()
         if T.get("u") is not None:

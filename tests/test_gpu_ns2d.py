@@ -646,3 +646,50 @@ def test_ns_column_kernel_default_dispatch_large_batch():
         np.testing.assert_array_equal(a[0], b[0])
         np.testing.assert_array_equal(a[1], b[1])
         np.testing.assert_allclose(a[2], b[2], rtol=1e-12)
+
+
+@pytest.mark.parametrize("n,dtype,K,B,T,adim", [(21, "float64", 40, 7, 9, 1), (21, "float32", 25, 64, 9, 1), (11, "float64", 7, 5, 6, 11),
+                                                  (32, "float32", 12, 3, 7, 1), (16, "float64", 0, 4, 5, 1), (26, "float32", 3, 1, 4, 26)])
+def test_ns_rollout_kernel_equals_step_calls_bitwise(n, dtype, K, B, T, adim):
+    """pdegym_ns2d_rollout_* (round 4: T env-steps of the small-grid column kernel in ONE launch, commands given ahead -- the loop
+    of examples/NavierStokes/NS2Dppo.py:52-66 / the forward sweep of NS2Doptimization.py) against T step calls: every observation
+    slot, reward and flag, the pressure, the time index, the restart counters and the kept terminal observations agree bit for
+    bit, across episode ends with the fused auto-reset (episodes of 4 steps, pools of 2B rows)."""
+    from pdecontrolgym_amd.batch2d import NSBatch2D
+    td = getattr(torch, dtype)
+    kw, u0, v0, p0, _ = _random_case(n, B, K, 900 + n + K, BC_MIX, adim)
+    kw = dict(kw, action_dim=adim, T=5 * kw["dt"])                  # nt = 5: an episode ends after 4 steps
+    kw["U_ref"], kw["action_ref"] = kw["U_ref"][:5], kw["action_ref"][:5]
+    rng = np.random.default_rng(n * 13 + K)
+    pools = [rng.uniform(-1, 1, (2 * B, n, n)) for _ in range(3)]
+    acts = torch.as_tensor(rng.uniform(2, 4, (T, B, adim)), dtype=td, device="cuda")
+    outs = []
+    # the step calls take the column kernel too (small float64 batches default to the workgroup kernel, whose FIELDS are the same
+    # bits but whose reward sum runs in another order)
+    _dbg("DEBUG_NS_COL_MIN_BATCH", "0")
+    for mode in ("steps", "rollout"):
+        env = NSBatch2D(num_envs=B, device="cuda", dtype=td, **kw)
+        assert env.can_rollout()
+        env.reset(u0, v0, p0)
+        env.enable_auto_reset(*pools)
+        obs = torch.zeros(T + 1, B, n, n, 2, dtype=td, device="cuda")
+        obs[0].copy_(env.t["obs"])
+        rew = torch.zeros(T, B, dtype=td, device="cuda")
+        te = torch.zeros(T, B, dtype=torch.uint8, device="cuda")
+        if mode == "steps":
+            env.t["obs"] = obs[0]
+            for t in range(T):
+                env.step(acts[t], out_obs=obs[t + 1], out_reward=rew[t], out_terminated=te[t])
+        else:
+            env.rollout(obs, acts, rew, te)
+        outs.append([x.cpu().numpy().copy() for x in (obs, rew, te, env.p, env.t["time_index"], env.t["reset_count"], env.t["final_obs"])])
+        nxt = env.step(acts[0])[0].cpu().numpy().copy()           # the engine carries on from slot T with ordinary step calls
+        outs[-1].append(nxt)
+    _dbg("DEBUG_NS_COL_MIN_BATCH", -1)
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    assert outs[0][2].sum() > 0 and np.isfinite(outs[0][0]).all()
+    big = NSBatch2D(num_envs=1, device="cuda", dtype=td, **dict(_random_case(64, 1, 3, 1, BC_MIX)[0]))
+    assert not big.can_rollout()
+    with pytest.raises(ValueError):
+        big.rollout(None, None, None, None)

@@ -898,3 +898,40 @@ def test_engine_rollout_contract_for_neumann_and_scalar_sensing_on_the_double(co
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
     assert outs[0][2].sum() > 0
+
+
+def test_ns_engine_rollout_contract_on_the_double():
+    """NSBatch2D.rollout (pdegym_ns2d_rollout_*, round 4): T step calls and one rollout call leave identical outputs and engine
+    state, fused auto-reset included; grids outside the column kernel's set refuse (host rule = the C ABI's)."""
+    import torch
+    from pdecontrolgym_amd.batch2d import NSBatch2D
+    n, nt, K, B, T = 11, 4, 3, 2, 6
+    rng = np.random.default_rng(8)
+    dx = 1.0 / (n - 1)
+    dt = 0.2 * 0.5 * dx * dx / 0.1
+    kw = dict(T=nt * dt, dt=dt, X=1, dx=dx, Y=1, dy=dx, boundary_condition=NS_BC, U_ref=rng.uniform(-1, 1, (nt, n, n, 2)),
+              action_ref=2.0 * np.ones(nt), gamma=0.1, maximum_pressure_iteration=K)
+    first = [rng.uniform(-1, 1, (B, n, n)) for _ in range(3)]
+    pools = [rng.uniform(-1, 1, (2 * B, n, n)) for _ in range(3)]
+    acts = torch.as_tensor(rng.uniform(2, 4, (T, B, 1)))
+    outs = []
+    for mode in ("steps", "rollout"):
+        env = NSBatch2D(num_envs=B, device="cpu", dtype=torch.float64, backend=FakeBackend(), **kw)
+        assert env.can_rollout()
+        env.reset(*first)
+        env.enable_auto_reset(*pools)
+        obs = torch.zeros(T + 1, B, n, n, 2, dtype=torch.float64)
+        obs[0].copy_(env.t["obs"])
+        rew, te = torch.zeros(T, B, dtype=torch.float64), torch.zeros(T, B, dtype=torch.uint8)
+        if mode == "steps":
+            env.t["obs"] = obs[0]
+            for t in range(T):
+                env.step(acts[t], out_obs=obs[t + 1], out_reward=rew[t], out_terminated=te[t])
+        else:
+            env.rollout(obs, acts, rew, te)
+        outs.append([x.numpy().copy() for x in (obs, rew, te, env.p, env.t["time_index"], env.t["reset_count"], env.t["final_obs"])])
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    assert outs[0][2].sum() >= 2
+    odd = dict(kw, X=1.2, Y=1.2, U_ref=np.zeros((nt, 13, 13, 2)))                  # 13 rows: not one of the column kernel's heights
+    assert not NSBatch2D(num_envs=1, device="cpu", dtype=torch.float64, backend=FakeBackend(), **odd).can_rollout()
