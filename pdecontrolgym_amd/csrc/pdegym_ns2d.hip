@@ -1544,7 +1544,8 @@ struct NSRollout {
   uint8_t* terminated;
 };
 
-// (called, not inlined, from the rollout loop: with the body inlined into a loop clang 22 / ROCm 7.2 crashes in instcombine)
+// (called, not inlined, by the largest instantiations of the rollout loop: with their body inlined into a loop clang 22 / ROCm 7.2
+// crashes in instcombine)
 template <typename T, int NY>
 __device__ __attribute__((noinline)) void ns_col_body_call(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int B, T* red) {
   ns_col_body<T, NY>(C, S, P, B, red);
@@ -1566,7 +1567,8 @@ __global__ __launch_bounds__(64, (sizeof(T) == 8 || NY > 21 ? 2 : 3)) void ns_co
     const NSPtrs<T> Q{nullptr, nullptr, P.p, P.scratch, Ro.actions + (size_t)t * B * C.action_dim, P.time_index, P.U_ref, P.action_ref,
                       Ro.obs + (size_t)(t + 1) * slot, Ro.rewards + (size_t)t * B, Ro.terminated + (size_t)t * B,
                       Ro.obs + (size_t)t * slot, nullptr};
-    ns_col_body_call<T, NY>(C, S, Q, B, red);
+    if constexpr (sizeof(T) == 8 && NY >= 21) ns_col_body_call<T, NY>(C, S, Q, B, red);
+    else ns_col_body<T, NY>(C, S, Q, B, red);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (R.u0) {                                       // fused auto-reset, as ns_auto_reset_kernel / _finish after a step call
