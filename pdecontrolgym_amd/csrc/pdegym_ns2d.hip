@@ -1454,9 +1454,37 @@ __device__ __forceinline__ void ns_col_body(const NSConst& C, const NSScal<T>& S
       below = cur;
     }
   };
+  // every later sweep reads one array and writes the other (p -> q, q -> p): the old row below is still in place when row i
+  // needs it, so nothing is carried along (one 64-bit move per row and sweep less; p, q and rq are 126 float64 registers)
+  auto sweep_into = [&](const T (&src)[NY], T (&dst)[NY]) {
+#pragma unroll
+    for (int i = 1; i < NY - 1; ++i) {
+      const T cur = src[i];
+      const T wl = pinned_from_left(cur), er = pinned_from_right(cur);
+      const T w = next_to_left ? cur : wl;
+      const T e = next_to_right ? cur : er;
+      const T sv = (i == 1) ? cur : src[i - 1];
+      const T nv = (i == NY - 2) ? cur : src[i + 1];
+      const T s4 = ((w + sv) + e) + nv;
+      if constexpr (sizeof(T) == 4) dst[i] = jacobi_update(s4, rq[i]);
+      else dst[i] = (T)0.25 * (s4 - rq[i]);
+    }
+  };
   if (C.iters > 0) {
     sweep(std::true_type{});
-    for (int it = 1; it < C.iters; ++it) sweep(std::false_type{});
+    T q[NY];
+#pragma unroll
+    for (int i = 0; i < NY; ++i) q[i] = p[i];
+    int it = 1;
+    for (; it + 2 <= C.iters; it += 2) {
+      sweep_into(p, q);
+      sweep_into(q, p);
+    }
+    if (it < C.iters) {
+      sweep_into(p, q);
+#pragma unroll
+      for (int i = 1; i < NY - 1; ++i) p[i] = q[i];
+    }
     // the four Neumann copies of the last sweep (:110-113): every wall cell = its nearest interior cell
     p[0] = p[1];
     p[NY - 1] = p[NY - 2];
@@ -1544,8 +1572,9 @@ struct NSRollout {
   uint8_t* terminated;
 };
 
-// (called, not inlined, by the largest instantiations of the rollout loop: with their body inlined into a loop clang 22 / ROCm 7.2
-// crashes in instcombine)
+// (called, not inlined, from the rollout loop: with the step body inlined into a loop clang 22 / ROCm 7.2 crashes in instcombine for
+// one instantiation or another -- which one moves with every change of the body.  The call costs the callee-saved registers a
+// round trip through scratch memory per env-step: tools/bench_ns_rollout.py)
 template <typename T, int NY>
 __device__ __attribute__((noinline)) void ns_col_body_call(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int B, T* red) {
   ns_col_body<T, NY>(C, S, P, B, red);
@@ -1567,8 +1596,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 8 || NY > 21 ? 2 : 3)) void ns_co
     const NSPtrs<T> Q{nullptr, nullptr, P.p, P.scratch, Ro.actions + (size_t)t * B * C.action_dim, P.time_index, P.U_ref, P.action_ref,
                       Ro.obs + (size_t)(t + 1) * slot, Ro.rewards + (size_t)t * B, Ro.terminated + (size_t)t * B,
                       Ro.obs + (size_t)t * slot, nullptr};
-    if constexpr (sizeof(T) == 8 && NY >= 21) ns_col_body_call<T, NY>(C, S, Q, B, red);
-    else ns_col_body<T, NY>(C, S, Q, B, red);
+    ns_col_body_call<T, NY>(C, S, Q, B, red);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (R.u0) {                                       // fused auto-reset, as ns_auto_reset_kernel / _finish after a step call
