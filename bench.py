@@ -402,14 +402,15 @@ class TrafficARZ:
         import torch
         a = (torch.rand(total_steps, self.B, 1, generator=self.gen, dtype=torch.float64) * 0.4 + 0.8) * self.qs.reshape(1, -1, 1)
         self.actions = a.to(self.device).contiguous()          # [T, B, 1]: one outlet command per freeway, used in place
-        self.env.reset(self.rs)
+        self.rs_dev = self.rs.to(self.device)
+        self.env.reset(self.rs_dev)
         self.i = 0
 
     def begin_region(self):
         """Start of every timed region (inside the captured graph): fresh episodes.  An episode lasts T / dt = 960 simulated
         seconds = 3840 env-steps and a finished freeway is not advanced any more, so a graph replayed past that point (the
         untimed warm replays alone are > 2000 env-steps) would time launches that do nothing."""
-        self.env.reset(self.rs)
+        self.env.reset(self.rs_dev)        # (a device tensor: nothing crosses PCIe inside the captured graph)
 
     def step(self):
         out = self.env.step(self.actions[self.i])

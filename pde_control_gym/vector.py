@@ -418,8 +418,9 @@ class PDEVecEnv(BatchedVecEnv):
         self._consume_reset_arguments()
         return obs
 
-    # Most pinned staging buffers kept per output; a caller that holds on to more results than this gets plain copies beyond it.
-    host_buffers = 16
+    # Most pinned staging buffers kept per output (an SB3-style loop cycles through two or three); a caller that holds on to more
+    # results than this gets plain NumPy copies beyond it -- allocating pinned memory costs milliseconds, a pageable copy ~0.3 ms.
+    host_buffers = 4
 
     def _to_host(self, tensors):
         """Device tensors -> NumPy arrays the caller may keep, without a host-side copy: each tensor is copied (asynchronously,

@@ -1359,7 +1359,10 @@ __device__ __forceinline__ void ns_col_body(const NSConst& C, const NSScal<T>& S
   T* vg = P.v ? P.v + (size_t)b * ncell : nullptr;
   T* us = P.scratch + (size_t)b * 4 * ncell;
   T* vs = us + ncell;
-  auto aval = [&](int idx) -> T { return C.action_dim == 1 ? act[0] : act[idx]; };
+  // one command per instance or one per edge node: an unconditional load from a selected index (a conditional LOAD keeps a branch
+  // per use inside the unrolled row loops, and with the branches the register allocator spilled half the kernel)
+  const int per_node = C.action_dim == 1 ? 0 : 1;
+  auto aval = [&](int idx) -> T { return act[idx * per_node]; };
 
   // apply_boundary (navier_stokes2D.py:76-90) on a column-per-lane field: lower / upper rule on every lane's end cells, then
   // the left / right rule on the edge lanes, which for a Neumann edge copies the (already ruled) neighbouring column
@@ -1379,11 +1382,17 @@ __device__ __forceinline__ void ns_col_body(const NSConst& C, const NSScal<T>& S
   };
 
   T u[NY], v[NY];
+  {
+    // either state layout through one pair of base pointers and a stride (no branch per row)
+    const T* bu = sin ? sin : ug;
+    const T* bv = sin ? sin + 1 : vg;
+    const int st = sin ? 2 : 1;
 #pragma unroll
-  for (int i = 0; i < NY; ++i) {
-    const int c = i * nx + j;
-    if (sin) { u[i] = sin[2 * c]; v[i] = sin[2 * c + 1]; }
-    else { u[i] = ug[c]; v[i] = vg[c]; }
+    for (int i = 0; i < NY; ++i) {
+      const int c = (i * nx + j) * st;
+      u[i] = bu[c];
+      v[i] = bv[c];
+    }
   }
   // ---- predictor (navier_stokes2D.py:130-138), in place with the old row below carried along ----
   {
