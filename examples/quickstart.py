@@ -46,6 +46,25 @@ fused = pde_control_gym.FusedMLP(policy)
 rollout = pde_control_gym.DeviceRollout(venv, fused, n_steps=8).run()
 print(f"DeviceRollout + FusedMLP: actions in [{rollout.actions.min().item():.3f}, {rollout.actions.max().item():.3f}]")
 
+# ---- 3b. output feedback: Neumann actuation, the collocated scalar measurement, sensing noise -- still ONE kernel per rollout -------
+# (hyperbolic.py:66-124: control_type / sensing_loc pick one of the reference's ten variants; the policy's input is the one sensed value)
+ofb = dict(params, control_type="Neumann", sensing_loc="collocated", sensing_noise_func=None)
+venv2 = pde_control_gym.make_vec("PDEControlGym-TransportPDE1D", num_envs=1024, **ofb)
+venv2.reset_tensor()
+venv2.enable_fused_auto_reset()
+small = pde_control_gym.FusedMLP(torch.nn.Sequential(torch.nn.Linear(1, 32), torch.nn.Tanh(), torch.nn.Linear(32, 1), torch.nn.Tanh()).cuda())
+ro2 = pde_control_gym.DeviceRollout(venv2, small, n_steps=8, sensing_noise=True)
+ro2.sensing_noise.normal_().mul_(0.01)             # drawn ahead by the caller; the policy reads obs + noise, obs_seen records it
+ro2.run()
+print(f"output-feedback rollout: one launch = {ro2.one_launch}, obs {tuple(ro2.obs.shape)}, max |obs_seen - obs| "
+      f"{(ro2.obs_seen - ro2.obs).abs().max().item():.3f}")
+# a checkpoint of the whole batch (device state as torch tensors; loads copy in place)
+sd = venv2.state_dict()
+before = venv2.step_tensor(torch.zeros(1024, device="cuda"))[0].clone()
+venv2.load_state_dict(sd)
+assert torch.equal(venv2.step_tensor(torch.zeros(1024, device="cuda"))[0], before)
+print("checkpoint: state_dict() -> step -> load_state_dict() -> step reproduces the step bit for bit")
+
 # ---- 4. Navier-Stokes, the parameter dictionary of examples/NavierStokes/NS2Dppo.py:36-50 ---------------------------------
 bc = {"upper": ["Controllable", "Dirchilet"], "lower": ["Dirchilet", "Dirchilet"], "left": ["Dirchilet", "Dirchilet"],
       "right": ["Dirchilet", "Dirchilet"]}

@@ -1257,14 +1257,14 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
 // The sensing-noise hook of the reference (hyperbolic.py:160-164: the agent sees sensing_noise_func(observation)) as pre-drawn
 // additive noise: the wave's LDS copy of observation t (od values) becomes obs + obs_noise[t], which is what the policy reads
 // and what obs_seen[t] receives; the observation slots themselves -- the plant state with full-state sensing -- stay clean.
-__device__ __forceinline__ void sense_noise(const pdegym_rollout1d& Ro, float* xw, int od, int B, int inst, int lane, int t) {
-  if (!Ro.obs_noise && !Ro.obs_seen) return;     // wave-uniform
+__device__ __forceinline__ void sense_noise(const float* obs_noise, float* obs_seen, float* xw, int od, int B, int inst, int lane, int t) {
+  if (!obs_noise && !obs_seen) return;     // wave-uniform
   const size_t base = ((size_t)t * B + inst) * od;
   for (int j = lane; j < od; j += kWave) {
     float v = xw[j];
-    if (Ro.obs_noise) v += Ro.obs_noise[base + j];
+    if (obs_noise) v += obs_noise[base + j];
     xw[j] = v;
-    if (Ro.obs_seen) Ro.obs_seen[base + j] = v;
+    if (obs_seen) obs_seen[base + j] = v;
   }
   pdegym_policy::wave_lds_sync();
 }
@@ -1294,7 +1294,7 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy
     for (int e = 0; e < EPL; ++e)
       if (s0 + e < ns) xw[J0 + s0 + e] = C.x[e];
     pol::wave_lds_sync();
-    sense_noise(Ro, xw, n, B, inst, lane, t);
+    sense_noise(Ro.obs_noise, Ro.obs_seen, xw, n, B, inst, lane, t);
     float a = pol::lane_value(pol::eval(N, St, pol_smem, xw, hw, n, lane), 0);      // neuron 0 of the last layer
     if (N.noise) a += N.noise[((size_t)t * B + inst) * N.noise_stride];
     if (N.clamp) a = fminf(fmaxf(a, N.lo), N.hi);
@@ -1332,7 +1332,7 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy
     const float* orow = Ro.obs + ((size_t)t * B + inst) * od;
     for (int j = lane; j < od; j += kWave) xw[j] = orow[j];
     pol::wave_lds_sync();
-    sense_noise(Ro, xw, od, B, inst, lane, t);
+    sense_noise(Ro.obs_noise, Ro.obs_seen, xw, od, B, inst, lane, t);
     float a = pol::lane_value(pol::eval(N, St, pol_smem, xw, hw, od, lane), 0);
     if (N.noise) a += N.noise[((size_t)t * B + inst) * N.noise_stride];
     if (N.clamp) a = fminf(fmaxf(a, N.lo), N.hi);
