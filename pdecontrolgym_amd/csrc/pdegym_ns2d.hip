@@ -1567,6 +1567,16 @@ __global__ __launch_bounds__(64, (sizeof(T) == 8 || NY > 21 ? 2 : 3)) void ns_co
   ns_col_body<T, NY>(C, S, P, B, red);
 }
 
+// The same kernel built for ONE wave per SIMD (512 registers per lane, arch + accumulation): the float64 instantiations then keep
+// everything on chip -- 372 registers and no scratch memory at 21 rows, where the two-wave build spills 222 -- and a batch that does
+// not fill the chip twice over is quicker on it (21 x 21, K = 2000: B = 1024 1.11 -> 0.88 ms, B = 3072 1.15 -> 0.95 ms); with more
+// than one wave per SIMD to run the two-wave build wins (B = 8192 2.61 vs 2.68 ms, B = 32768 8.75 vs 9.71 ms): launch_ns_col picks.
+template <typename T, int NY>
+__global__ __launch_bounds__(64, 1) void ns_col_step_w1(NSConst C, NSScal<T> S, NSPtrs<T> P, int B) {
+  __shared__ T red[64];
+  ns_col_body<T, NY>(C, S, P, B, red);
+}
+
 // T env-steps in ONE launch (pdegym_ns2d_rollout_*, small grids): iteration t is ns_col_step's body with the state read from
 // observation slot t and written to slot t + 1, the command / reward / flag taken from / written to row t of the rollout arrays,
 // followed by the fused auto-reset of ns_step (final_obs, pool row -> slot t + 1 and p, time index, restart counter) -- every
@@ -1650,6 +1660,16 @@ bool launch_ns_col(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int
   if (B < min_batch) return false;
   const int G = 64 / C.nx;
   const dim3 grid((B + G - 1) / G), block(64);
+  if constexpr (sizeof(T) == 8) {
+    if (grid.x <= 1024) {        // at most one wave per SIMD anyway: the build without spills (ns_col_step_w1)
+      switch (C.ny) {
+        case 16: hipLaunchKernelGGL((ns_col_step_w1<T, 16>), grid, block, 0, st, C, S, P, B); return true;
+        case 21: hipLaunchKernelGGL((ns_col_step_w1<T, 21>), grid, block, 0, st, C, S, P, B); return true;
+        case 26: hipLaunchKernelGGL((ns_col_step_w1<T, 26>), grid, block, 0, st, C, S, P, B); return true;
+        default: break;          // 8 / 11 rows do not spill either way; 31 / 32 rows spill either way
+      }
+    }
+  }
   switch (C.ny) {
     case 8: hipLaunchKernelGGL((ns_col_step<T, 8>), grid, block, 0, st, C, S, P, B); return true;
     case 11: hipLaunchKernelGGL((ns_col_step<T, 11>), grid, block, 0, st, C, S, P, B); return true;
