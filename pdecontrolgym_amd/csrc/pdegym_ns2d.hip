@@ -1650,13 +1650,13 @@ __global__ __launch_bounds__(64, (sizeof(T) == 8 || NY > 21 ? 2 : 3)) void ns_co
 // The column kernel is instantiated for the grid height of the reference's shipped example (21 rows) and a few neighbours
 // (8, 11, 16, 26, 31, 32); any width up to 64.  One wave works through all K sweeps of its (up to three) instances alone: in
 // float64 a lone instance finishes sooner on the workgroup-per-instance kernel (seven waves per instance; 0.77 vs 0.98 ms per
-// env-step at 21 x 21, K = 2000), so batches below a minimum (PDEGYM_DEBUG_NS_COL_MIN_BATCH overrides it; default: 1024 for float64, 1 for float32, where
+// env-step at 21 x 21, K = 2000), so batches below a minimum (PDEGYM_DEBUG_NS_COL_MIN_BATCH overrides it; default: 400 for float64 -- round 4, tools/probe_ns_col_min_batch.py: column kernel 0.87 ms flat up to 3072 instances, workgroup kernel 0.80 ms at 256, 0.96 at 512, 1.30 at 768 -- and 1 for float32, where
 // the two kernels are equal at B = 1) stay there.
 template <typename T>
 bool launch_ns_col(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int B, hipStream_t st) {
   if (C.nx < 3 || C.nx > 64) return false;
   const int dbg = g_debug[PDEGYM_DEBUG_NS_COL_MIN_BATCH];
-  const int min_batch = dbg >= 0 ? dbg : (sizeof(T) == 8 ? 1024 : 1);
+  const int min_batch = dbg >= 0 ? dbg : (sizeof(T) == 8 ? 400 : 1);
   if (B < min_batch) return false;
   const int G = 64 / C.nx;
   const dim3 grid((B + G - 1) / G), block(64);

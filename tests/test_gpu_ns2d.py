@@ -621,12 +621,13 @@ def test_ns_column_kernel_reproduces_target_npz_and_oracle(golden_ns):
         _dbg("DEBUG_NS_COL_MIN_BATCH", -1)
 
 
-def test_ns_column_kernel_default_dispatch_large_batch():
-    """Without any switch a float64 batch of >= 1024 instances on a 21-row grid takes the column kernel (float32: any batch);
-    a full-size batch (1030 instances: the last wave has one live lane group) equals the workgroup kernel bit for bit."""
+@pytest.mark.parametrize("B", [1030, 3100])
+def test_ns_column_kernel_default_dispatch_large_batch(B):
+    """Without any switch a float64 batch of >= 400 instances on a 21-row grid takes the column kernel (float32: any batch): up to
+    1024 waves the one-wave-per-SIMD build without spills (B = 1030: 344 waves, the last one with one live lane group), beyond
+    that the two-wave build (B = 3100: 1034 waves).  Both equal the workgroup kernel bit for bit."""
     import os
     from pdecontrolgym_amd.batch2d import NSBatch2D
-    B = 1030
     kw, u0, v0, p0, acts = _rect_case(21, 21, B, 5, 4321, BC_MIX, 1)
     outs = []
     for no_col in ("0", "1"):
