@@ -935,3 +935,27 @@ def test_ns_engine_rollout_contract_on_the_double():
     assert outs[0][2].sum() >= 2
     odd = dict(kw, X=1.2, Y=1.2, U_ref=np.zeros((nt, 13, 13, 2)))                  # 13 rows: not one of the column kernel's heights
     assert not NSBatch2D(num_envs=1, device="cpu", dtype=torch.float64, backend=FakeBackend(), **odd).can_rollout()
+
+
+@pytest.mark.parametrize("hook", ["numpy", "tensor"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_sensing_noise_hooks_also_see_auto_reset_and_terminal_observations(hook, fused):
+    """The reference applies sensing_noise_func to what step() returns (hyperbolic.py:160-164) AND to what reset() returns (:224), so
+    on the batched face the hook must also cover the first observation of an auto-reset instance and the terminal observation
+    (advisor finding r3: with f = obs + 100 a reset gave mean 101, a normal step 100.8, the step that auto-resets 1.0)."""
+    import torch
+    B = 3
+    kw = {"sensing_noise_func": (lambda o: o + 100.0)} if hook == "numpy" else {"sensing_noise_func": None,
+                                                                                 "sensing_noise_tensor_func": (lambda o: o + 100.0)}
+    env = _vec(B, **kw)                                # episodes of 14 env-steps
+    obs = env.reset()
+    assert obs.min() >= 100
+    if fused:
+        env.enable_fused_auto_reset()
+    a = np.zeros((B, 1), np.float32)
+    for k in range(14):
+        obs, rew, dones, infos = env.step(a)
+        assert obs.min() >= 100, (k, obs.min())        # incl. the step that restarts every instance (un-noised values are < 10)
+    assert dones.all()
+    for i in range(B):
+        assert infos[i]["terminal_observation"].min() >= 100 and infos[i]["terminal_observation"].max() < 100 + 1e4
