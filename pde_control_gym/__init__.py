@@ -17,8 +17,19 @@ _IDS = {
     "PDEControlGym-BurgersPDE1D": "pde_control_gym.src.environments1d.burgers:BurgersPDE1D",
 }
 
+# gymnasium >= 1.0 also takes a vector entry point: ``gymnasium.make_vec(id, num_envs=N, **params)`` then builds the batched GPU
+# environment (pde_control_gym/vector_gymnasium.py) instead of N copies of the single one
+_VECTOR = {"PDEControlGym-TransportPDE1D", "PDEControlGym-ReactionDiffusionPDE1D", "PDEControlGym-NavierStokes2D",
+           "PDEControlGym-TrafficPDE1D", "PDEControlGym-BurgersPDE1D"}
+
 for _id, _entry in _IDS.items():
     try:
+        if _id in _VECTOR:
+            try:
+                register(id=_id, entry_point=_entry, vector_entry_point="pde_control_gym.vector_gymnasium:vector_" + _id.split("-")[-1])
+                continue
+            except TypeError:       # gymnasium 0.2x / the fall-back registry: no vector entry points
+                pass
         register(id=_id, entry_point=_entry)
     except Exception:  # already registered (module re-import under gymnasium)
         pass

@@ -103,8 +103,13 @@ class _Spaces:
 _REGISTRY = {}
 
 
-def _fallback_register(id, entry_point, **kwargs):
+def _fallback_register(id, entry_point, vector_entry_point=None, **kwargs):
     _REGISTRY[id] = (entry_point, kwargs)
+    if vector_entry_point is not None:
+        _VECTOR_REGISTRY[id] = vector_entry_point
+
+
+_VECTOR_REGISTRY = {}
 
 
 def _fallback_make(id, **kwargs):

@@ -76,3 +76,27 @@ class GymnasiumVectorAdapter(VectorEnv):
             return
         self.close_extras(**kwargs)
         self.closed = True
+
+
+
+# ---- gymnasium.make_vec entry points -------------------------------------------------------------------------------------------------
+# gymnasium >= 1.0: ``register(id, entry_point=..., vector_entry_point=...)`` lets ``gymnasium.make_vec(id, num_envs=N, **params)``
+# build a native vector environment instead of N copies of the single one (``vectorization_mode="vector_entry_point"``, the default
+# when the spec has one).  pde_control_gym/__init__.py registers these factories, so the batched GPU environments are reachable
+# through gymnasium's own constructor with the reference's parameter dictionary.
+def _vector_factory(env_id):
+    def make(num_envs: int = 1, **kwargs):
+        from pde_control_gym.vector import make_vec
+        for k in ("render_mode", "max_episode_steps", "disable_env_checker", "autoreset"):      # gymnasium's own keywords
+            kwargs.pop(k, None)
+        return GymnasiumVectorAdapter(make_vec(env_id, num_envs, **kwargs))
+    make.__name__ = make.__qualname__ = "vector_" + env_id.split("-")[-1]
+    make.__doc__ = f"gymnasium vector entry point of {env_id}: GymnasiumVectorAdapter(make_vec({env_id!r}, num_envs, **kwargs))."
+    return make
+
+
+vector_TransportPDE1D = _vector_factory("PDEControlGym-TransportPDE1D")
+vector_ReactionDiffusionPDE1D = _vector_factory("PDEControlGym-ReactionDiffusionPDE1D")
+vector_NavierStokes2D = _vector_factory("PDEControlGym-NavierStokes2D")
+vector_TrafficPDE1D = _vector_factory("PDEControlGym-TrafficPDE1D")
+vector_BurgersPDE1D = _vector_factory("PDEControlGym-BurgersPDE1D")

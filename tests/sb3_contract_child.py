@@ -149,8 +149,9 @@ def main(kind):
 
     # 4. gymnasium.vector face ------------------------------------------------------------------------------------------------
     cyc2 = itertools.cycle(ics)
-    g = pde_control_gym.GymnasiumVectorAdapter(
-        pde_control_gym.make_vec("PDEControlGym-TransportPDE1D", num_envs=B, **bk(), **params(lambda nx: next(cyc2))))
+    # ... built by gymnasium's own constructor through the registered vector entry point
+    g = gymnasium.make_vec("PDEControlGym-TransportPDE1D", num_envs=B, **bk(), **params(lambda nx: next(cyc2)))
+    assert type(g) is pde_control_gym.GymnasiumVectorAdapter and g.num_envs == B
     assert isinstance(g, gymnasium.vector.VectorEnv) and g.unwrapped is g and not g.closed
     assert g.single_observation_space.shape == (nx,) and g.observation_space.shape == (B, nx)
     assert g.single_action_space.shape == (1,) and g.action_space.shape == (B, 1)

@@ -2,7 +2,7 @@
 import importlib
 
 from gymnasium import spaces, vector  # noqa: F401
-from gymnasium.envs.registration import register, registry  # noqa: F401
+from gymnasium.envs.registration import register, registry, vector_registry  # noqa: F401
 
 __version__ = "0.0+contract-stub"
 
@@ -62,3 +62,16 @@ def make(id, **kwargs):
         mod, attr = entry_point.split(":")
         entry_point = getattr(importlib.import_module(mod), attr)
     return entry_point(**{**defaults, **kwargs})
+
+
+def make_vec(id, num_envs=1, vectorization_mode=None, vector_kwargs=None, wrappers=None, **kwargs):
+    """gymnasium >= 1.0: a spec with a vector entry point is built through it (vectorization_mode "vector_entry_point")."""
+    if id not in registry:
+        raise KeyError(f"No registered env with id: {id}")
+    if id not in vector_registry or vectorization_mode in ("sync", "async"):
+        raise NotImplementedError("the stand-in only builds native vector environments")
+    entry = vector_registry[id]
+    if isinstance(entry, str):
+        mod, attr = entry.split(":")
+        entry = getattr(importlib.import_module(mod), attr)
+    return entry(num_envs=num_envs, **{**registry[id][1], **kwargs})
