@@ -12,7 +12,8 @@ Default workload = BASELINE.json configs[1]: ReactionDiffusionPDE1D ("Parabolic1
 per GPU, fp32, S=100 sub-steps per env-step (SURVEY.md section 8d).  Other workloads (--workload NAME prints NAME's own line;
 the default run adds all of them under "also"): transport_c3, burgers_c3 (extension), parabolic_c2_policy_loop (C2 with its MLP
 controller evaluated on the device every step), parabolic_c2_rollout (the same loop as ONE kernel per 25 env-steps: here a
-"step" is one launch and `value` still counts env-steps), parabolic_c2_open_loop_rollout (25 env-steps per launch, commands given ahead),
+"step" is one launch and `value` still counts env-steps), parabolic_c2_policy_loop_256 / parabolic_c2_rollout_256 (the same two with
+the 257-256-256-1 ReLU actor SB3's SAC builds), parabolic_c2_open_loop_rollout (25 env-steps per launch, commands given ahead),
 parabolic_c2_s1 / parabolic_c2_s1_open_loop_rollout / parabolic_c2_s1_rollout (SURVEY 8d "and also S = 1": one sub-step per env-step,
 per-step launch and 100 env-steps per launch without / with the policy inside), ns2d_c4, ns2d_c4_f64, ns2d_c4_b4096,
 ns2d_c4_f64_b4096, ns2d_c5, ns2d_c5_f64 (the _f64 lines: the same workloads at the reference's own precision), ns2d_example (the
@@ -145,15 +146,17 @@ class ParabolicPolicyLoop(Parabolic1D):
     transport1Dppo.py:88-90) evaluated on the observation of the previous step by pdegym_mlp_forward (one launch: forward pass,
     action clamp, store), then the env-step with fused auto-reset: two launches per env-step, nothing on the host."""
     name = "ReactionDiffusionPDE1D nx=256 B=4096 S=100 with a 257-64-64-1 tanh MLP policy in the loop (FusedMLP + env-step)"
+    HIDDEN, ACT = 64, "tanh"
 
     def prepare(self, total_steps):
         import torch
         from pdecontrolgym_amd.policy import FusedMLP
         super().prepare(total_steps)
         torch.manual_seed(0)
-        n = self.env.n
-        net = torch.nn.Sequential(torch.nn.Linear(n, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(),
-                                  torch.nn.Linear(64, 1), torch.nn.Tanh()).to(self.device)
+        n, H = self.env.n, self.HIDDEN
+        act = torch.nn.Tanh if self.ACT == "tanh" else torch.nn.ReLU
+        net = torch.nn.Sequential(torch.nn.Linear(n, H), act(), torch.nn.Linear(H, H), act(),
+                                  torch.nn.Linear(H, 1), torch.nn.Tanh()).to(self.device)
         self.policy = FusedMLP(net, clamp=(-1.0, 1.0))
         self.act = torch.zeros(self.B, dtype=torch.float32, device=self.device)
         self.obs = self.env.t["obs"]
@@ -166,7 +169,7 @@ class ParabolicPolicyLoop(Parabolic1D):
 
     def config(self):
         c = super().config()
-        c["policy"] = "MLP 257-64-64-1 tanh, float32, pdegym_mlp_forward (MFMA), clamp to [-1, 1] fused"
+        c["policy"] = f"MLP 257-{self.HIDDEN}-{self.HIDDEN}-1 {self.ACT}, float32, pdegym_mlp_forward (MFMA), clamp to [-1, 1] fused"
         return c
 
 
@@ -205,9 +208,26 @@ class ParabolicRollout(ParabolicPolicyLoop):
 
     def config(self):
         c = super().config()
-        c["policy"] = "MLP 257-64-64-1 tanh, float32, evaluated inside the rollout kernel (weights in LDS, one fma chain per neuron)"
+        c["policy"] = (f"MLP 257-{self.HIDDEN}-{self.HIDDEN}-1 {self.ACT}, float32, evaluated inside the rollout kernel "
+                       + ("(weights in LDS, one fma chain per neuron)" if self.HIDDEN <= 64 else
+                          "(16 waves per workgroup together: pdegym_mlp_forward's MFMA reduction, weights streamed from L2)"))
         c["env_steps_per_launch"] = self.CHUNK
         return c
+
+
+class ParabolicPolicyLoop256(ParabolicPolicyLoop):
+    """The same loop with the actor SB3's SAC builds (two hidden layers of 256 ReLU units, tanh-squashed output;
+    reactionDiffusion1Dsac.py:95): pdegym_mlp_forward with 16 waves per workgroup + the env-step."""
+    name = "ReactionDiffusionPDE1D nx=256 B=4096 S=100 with a 257-256-256-1 ReLU MLP policy in the loop (FusedMLP + env-step)"
+    HIDDEN, ACT = 256, "relu"
+
+
+class ParabolicRollout256(ParabolicRollout):
+    """... and as ONE kernel per 25 env-steps: the 16 waves of a workgroup evaluate the 256-256 actor together inside the rollout
+    kernel (pdegym_policy.h: eval_wide), bit-identical to the two-launch loop above."""
+    name = ("ReactionDiffusionPDE1D nx=256 B=4096 S=100, 257-256-256-1 ReLU MLP policy, 25 env-steps per launch "
+            "(pdegym_parabolic_rollout: policy + env-step + auto-reset inside one kernel)")
+    HIDDEN, ACT = 256, "relu"
 
 
 class ParabolicOpenLoopRollout(Parabolic1D):
@@ -528,6 +548,8 @@ from bench_ns2d import (NavierStokesC4, NavierStokesC4B4096, NavierStokesC4B4096
                         NavierStokesC5F64, NavierStokesExample)
 WORKLOADS["parabolic_c2_policy_loop"] = ParabolicPolicyLoop
 WORKLOADS["parabolic_c2_rollout"] = ParabolicRollout
+WORKLOADS["parabolic_c2_policy_loop_256"] = ParabolicPolicyLoop256
+WORKLOADS["parabolic_c2_rollout_256"] = ParabolicRollout256
 WORKLOADS["parabolic_c2_open_loop_rollout"] = ParabolicOpenLoopRollout
 WORKLOADS["parabolic_c2_s1"] = ParabolicS1
 WORKLOADS["parabolic_c2_s1_open_loop_rollout"] = ParabolicS1OpenLoopRollout
@@ -547,17 +569,18 @@ WORKLOADS["brain_tumor"] = BrainTumor
 # Which kernel sources each workload's launches are compiled from: the committed PMC counters of a workload are stamped with the
 # fingerprint of these files (build.sources_fingerprint) when they are collected, and roofline_block flags them as stale when the
 # tree has moved on ("roofline counters are not tied to the binary").
-_SRC_1D = ["pdegym_1d.hip", "pdegym_common.h", "pdegym_policy.h"]
+_SRC_1D = ["pdegym_1d.hip", "pdegym_common.h", "pdegym_policy.h", "pdegym_mlp_tile.h"]
 _SRC_NS = ["pdegym_ns2d.hip", "pdegym_ns_common.h", "pdegym_common.h"]
 KERNEL_SOURCES = {
     "parabolic_c2": _SRC_1D, "transport_c3": _SRC_1D, "burgers_c3": _SRC_1D, "parabolic_c2_rollout": _SRC_1D,
     "parabolic_c2_open_loop_rollout": _SRC_1D, "parabolic_c2_s1": _SRC_1D, "parabolic_c2_s1_open_loop_rollout": _SRC_1D,
     "parabolic_c2_s1_rollout": _SRC_1D, "parabolic_c2_policy_loop": _SRC_1D + ["pdegym_mlp.hip"],
+    "parabolic_c2_policy_loop_256": _SRC_1D + ["pdegym_mlp.hip"], "parabolic_c2_rollout_256": _SRC_1D,
     "ns2d_c4": _SRC_NS, "ns2d_c4_b4096": _SRC_NS, "ns2d_c4_f64": _SRC_NS, "ns2d_c4_f64_b4096": _SRC_NS, "ns2d_example": _SRC_NS,
     "ns2d_c5": _SRC_NS + ["pdegym_ns256.hip", "pdegym_ns256_rows.h"],
     "ns2d_c5_f64": _SRC_NS + ["pdegym_ns256_f64.hip", "pdegym_ns256_rows.h"],
-    "traffic_arz": ["pdegym_traffic.hip", "pdegym_common.h", "pdegym_policy.h"],
-    "traffic_arz_rollout": ["pdegym_traffic.hip", "pdegym_common.h", "pdegym_policy.h"],
+    "traffic_arz": ["pdegym_traffic.hip", "pdegym_common.h", "pdegym_policy.h", "pdegym_mlp_tile.h"],
+    "traffic_arz_rollout": ["pdegym_traffic.hip", "pdegym_common.h", "pdegym_policy.h", "pdegym_mlp_tile.h"],
     "brain_tumor": ["pdegym_tumor.hip", "pdegym_common.h"],
 }
 

@@ -175,10 +175,13 @@ typedef struct pdegym_rollout1d {
   uint8_t* terminated;      /* [T, B]                                                                          */
   uint8_t* truncated;       /* [T, B]                                                                          */
   /* Optional policy (HOST pointer, read during the call; see pdegym_mlp below): evaluated INSIDE the launch on observation
-   * slot t -- the caller of env.step of an SB3 rollout (transport1Dppo.py:88-90) without a launch of its own.  Layers of up
-   * to 64 units, first in_dim == n, one output; the whole network must fit into 160 KB of LDS next to 16 observation rows
-   * (n <= 513).  noise, when given, is [T, B] (row t, instance b at noise[(t * B + b) * noise_stride]), added before the
-   * clamp.  Same arithmetic as pdegym_mlp_forward except for the order of the additions inside a group of 16 inputs. */
+   * slot t -- the caller of env.step of an SB3 rollout (transport1Dppo.py:88-90) without a launch of its own.  First in_dim ==
+   * the observation row (n, or 1 with scalar sensing; n <= 513), one output.  Layers of up to 64 units: the whole network must
+   * fit into 160 KB of LDS next to 16 observation rows; same arithmetic as pdegym_mlp_forward except for the order of the
+   * additions inside a group of 16 inputs.  With a layer of 65 .. 256 units (SB3's 256-256 actors, reactionDiffusion1Dsac.py:95)
+   * the 16 waves of a workgroup evaluate the network together with pdegym_mlp_forward's own MFMA reduction, weights streamed from
+   * L2: the commands equal pdegym_mlp_forward's BIT FOR BIT.  noise, when given, is [T, B] (row t, instance b at
+   * noise[(t * B + b) * noise_stride]), added before the clamp. */
   const struct pdegym_mlp_s* policy;
   /* The sensing-noise hook (hyperbolic.py:160-164: the agent sees sensing_noise_func(observation)) for the policy inside the
    * launch, as noise the caller drew ahead: the policy of step t reads obs[t] + obs_noise[t]; obs itself stays clean (with

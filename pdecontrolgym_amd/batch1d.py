@@ -273,14 +273,20 @@ class PDEBatch1D(EngineCheckpoint):
 
     def policy_fits_rollout(self, policy) -> bool:
         """Whether ``policy`` (a ``FusedMLP``) can be evaluated inside the rollout kernel: the observation (the row of at most
-        513 nodes, or the one sensed value) as its input, layers of at most 64 units, one output, and weights + 16 observation
-        rows within 160 KB of LDS."""
+        513 nodes, or the one sensed value) as its input and one output.  Layers of at most 64 units: one neuron per lane, the
+        weights + 16 observation rows within 160 KB of LDS.  A layer of 65..256 units (SB3's 256-256 actors): the 16 waves of a
+        workgroup evaluate the network together on the matrix cores, weights streamed from L2 -- bit-identical to
+        ``pdegym_mlp_forward`` (16 observation rows + the hidden rows within 160 KB of LDS: any row the kernel takes)."""
         if not (self.can_rollout() and hasattr(policy, "layers") and hasattr(policy, "_net")):
             return False
         dims = [(int(w.shape[1]), int(w.shape[0])) for w, _, _ in policy.layers]
-        if dims[0][0] != self.obs_dim or self.n > 513 or dims[-1][1] != 1 or any(o > 64 for _, o in dims):
+        if dims[0][0] != self.obs_dim or self.n > 513 or dims[-1][1] != 1 or any(o > 256 for _, o in dims):
             return False
-        floats = sum((((i + 3) // 4) | 1) * 4 * o + 64 for i, o in dims) + 16 * (((self.obs_dim + 3) // 4) * 4 + 128)
+        stride = lambda w: (w + 63) // 64 * 64 + 4                  # noqa: E731  (pdegym_mlp_tile.h: lds_stride)
+        if any(o > 64 for _, o in dims):
+            floats = 16 * (stride((self.obs_dim + 15) // 16 * 16) + 2 * stride(256)) + 16
+        else:
+            floats = sum((((i + 3) // 4) | 1) * 4 * o + 64 for i, o in dims) + 16 * (((self.obs_dim + 3) // 4) * 4 + 128)
         return 4 * floats <= 160 * 1024
 
     def rollout(self, obs, actions, rewards, terminated, truncated, policy=None, clamp="default", noise=None, obs_noise=None,
@@ -292,7 +298,7 @@ class PDEBatch1D(EngineCheckpoint):
         afterwards; with scalar sensing the state is the engine's own ``u`` (advanced in place) and ``obs[0]`` only feeds a
         policy.
 
-        ``policy`` (a ``FusedMLP`` with layers of at most 64 units and one output, see ``policy_fits_rollout``): evaluated
+        ``policy`` (a ``FusedMLP`` with layers of at most 256 units and one output, see ``policy_fits_rollout``): evaluated
         inside the launch on ``obs[t]`` (+ ``obs_noise[t]`` [T, B, obs_dim], the pre-drawn sensing noise; ``obs_seen[t]``
         receives what the policy read); ``actions[t]`` then RECEIVES the command (after ``noise[t]`` [T, B] float32 and the
         clamp).  The in-kernel network sums each neuron in one fmaf chain, ``policy.forward_into`` in MFMA group order: the

@@ -1269,7 +1269,9 @@ __device__ __forceinline__ void sense_noise(const float* obs_noise, float* obs_s
   pdegym_policy::wave_lds_sync();
 }
 
-template <int EPL, bool PARABOLIC, bool BURGERS>
+// WIDE: a network with a layer of more than 64 units, evaluated by the 16 waves together (pdegym_policy.h: eval_wide) -- every wave of
+// the workgroup, with or without an instance, runs all T iterations because of its barriers.
+template <int EPL, bool PARABOLIC, bool BURGERS, bool WIDE>
 __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy_kernel(pdegym_params1d P, pdegym_bufs1d Bf,
                                                                                         pdegym_rollout1d Ro, pdegym_mlp N, int B) {
   namespace pol = pdegym_policy;
@@ -1277,25 +1279,35 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int inst = blockIdx.x * pol::kWaves + wave;
   const int n = P.n, xpad = pol::xpad(n);
-  const pol::Staged St = pol::stage(N, pol_smem);      // the launch's only barrier
-  if (inst >= B) return;  // wave-uniform
-  float* const xw = pol_smem + St.end + wave * (xpad + 2 * pol::kMaxWidth);
+  pol::Staged St;
+  pol::Wide Wd;
+  if constexpr (WIDE) Wd = pol::wide_setup(N, pol_smem, n, wave, lane);
+  else St = pol::stage(N, pol_smem);      // the launch's only barrier
+  const bool active = inst < B;           // wave-uniform
+  if (!WIDE && !active) return;
+  float* const xw = WIDE ? Wd.X + wave * Wd.ldx : pol_smem + St.end + wave * (xpad + 2 * pol::kMaxWidth);
   float* const hw = xw + xpad;
   const size_t slot = (size_t)B * n;
   constexpr int J0 = PARABOLIC ? 1 : 0;
   const int ns = n - J0, s0 = lane * EPL;
   Carry<EPL> C;       // the state stays in registers over the T env-steps (see rollout1d_kernel)
-  carry_load<EPL, PARABOLIC>(C, P, Bf, Ro.obs, inst, lane);
-  for (int j = n + lane; j < xpad; j += kWave) xw[j] = 0.f;     // zero padding to a multiple of four: written once
+  if (active) carry_load<EPL, PARABOLIC>(C, P, Bf, Ro.obs, inst, lane);
+  if (!WIDE)
+    for (int j = n + lane; j < xpad; j += kWave) xw[j] = 0.f;     // zero padding to a multiple of four: written once
   for (int t = 0; t < Ro.T; ++t) {
-    // observation of this instance -> LDS, straight from the carried row (slot t of Ro.obs holds the same values)
-    if (PARABOLIC && lane == 0) xw[0] = C.bl;
+    if (active) {
+      // observation of this instance -> LDS, straight from the carried row (slot t of Ro.obs holds the same values)
+      if (PARABOLIC && lane == 0) xw[0] = C.bl;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e)
-      if (s0 + e < ns) xw[J0 + s0 + e] = C.x[e];
-    pol::wave_lds_sync();
-    sense_noise(Ro.obs_noise, Ro.obs_seen, xw, n, B, inst, lane, t);
-    float a = pol::lane_value(pol::eval(N, St, pol_smem, xw, hw, n, lane), 0);      // neuron 0 of the last layer
+      for (int e = 0; e < EPL; ++e)
+        if (s0 + e < ns) xw[J0 + s0 + e] = C.x[e];
+      pol::wave_lds_sync();
+      sense_noise(Ro.obs_noise, Ro.obs_seen, xw, n, B, inst, lane, t);
+    }
+    float a;
+    if constexpr (WIDE) a = pol::eval_wide(N, Wd, n, wave, lane);
+    else a = pol::lane_value(pol::eval(N, St, pol_smem, xw, hw, n, lane), 0);      // neuron 0 of the last layer
+    if (!active) continue;
     if (N.noise) a += N.noise[((size_t)t * B + inst) * N.noise_stride];
     if (N.clamp) a = fminf(fmaxf(a, N.lo), N.hi);
     if (lane == 0) Ro.actions[(size_t)t * B + inst] = a;
@@ -1315,7 +1327,7 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy
 
 // The policy in front of the general step (Neumann actuation / scalar sensing): its input is observation slot t as stored -- od = n
 // values, or the one sensed value -- read back from memory after the previous iteration's fence.
-template <int EPL, bool PARABOLIC, bool NEUMANN, bool BURGERS>
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool BURGERS, bool WIDE>
 __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy_general_kernel(pdegym_params1d P, pdegym_bufs1d Bf,
                                                                                                 pdegym_rollout1d Ro, pdegym_mlp N, int B) {
   namespace pol = pdegym_policy;
@@ -1323,17 +1335,27 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int inst = blockIdx.x * pol::kWaves + wave;
   const int od = P.sensing == PDEGYM_SENSE_FULL ? P.n : 1, xpad = pol::xpad(od);
-  const pol::Staged St = pol::stage(N, pol_smem);      // the launch's only barrier
-  if (inst >= B) return;  // wave-uniform
-  float* const xw = pol_smem + St.end + wave * (xpad + 2 * pol::kMaxWidth);
+  pol::Staged St;
+  pol::Wide Wd;
+  if constexpr (WIDE) Wd = pol::wide_setup(N, pol_smem, od, wave, lane);
+  else St = pol::stage(N, pol_smem);      // the launch's only barrier
+  const bool active = inst < B;           // wave-uniform
+  if (!WIDE && !active) return;
+  float* const xw = WIDE ? Wd.X + wave * Wd.ldx : pol_smem + St.end + wave * (xpad + 2 * pol::kMaxWidth);
   float* const hw = xw + xpad;
-  for (int j = od + lane; j < xpad; j += kWave) xw[j] = 0.f;
+  if (!WIDE)
+    for (int j = od + lane; j < xpad; j += kWave) xw[j] = 0.f;
   for (int t = 0; t < Ro.T; ++t) {
-    const float* orow = Ro.obs + ((size_t)t * B + inst) * od;
-    for (int j = lane; j < od; j += kWave) xw[j] = orow[j];
-    pol::wave_lds_sync();
-    sense_noise(Ro.obs_noise, Ro.obs_seen, xw, od, B, inst, lane, t);
-    float a = pol::lane_value(pol::eval(N, St, pol_smem, xw, hw, od, lane), 0);
+    if (active) {
+      const float* orow = Ro.obs + ((size_t)t * B + inst) * od;
+      for (int j = lane; j < od; j += kWave) xw[j] = orow[j];
+      pol::wave_lds_sync();
+      sense_noise(Ro.obs_noise, Ro.obs_seen, xw, od, B, inst, lane, t);
+    }
+    float a;
+    if constexpr (WIDE) a = pol::eval_wide(N, Wd, od, wave, lane);
+    else a = pol::lane_value(pol::eval(N, St, pol_smem, xw, hw, od, lane), 0);
+    if (!active) continue;
     if (N.noise) a += N.noise[((size_t)t * B + inst) * N.noise_stride];
     if (N.clamp) a = fminf(fmaxf(a, N.lo), N.hi);
     if (lane == 0) Ro.actions[(size_t)t * B + inst] = a;
@@ -1368,24 +1390,29 @@ int launch_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const p
   if (ro->policy) {
     const pdegym_mlp& N = *ro->policy;
     const int od = P.sensing == PDEGYM_SENSE_FULL ? P.n : 1;
-    if (const char* why = pdegym_policy::check(N, od, 1)) return pdegym::fail(-2, why);
+    if (const char* why = pdegym_policy::check(N, od, 1, true)) return pdegym::fail(-2, why);
     if (N.x_f64 || N.y_f64) return pdegym::fail(-2, "policy inside the 1D rollout kernel: float32 observations and commands");
     if (epl > 8) return pdegym::fail(-2, "policy inside the rollout kernel: rows of up to 513 nodes");
     const int lds_bytes = pdegym_policy::lds_floats(N, od) * (int)sizeof(float);
     const dim3 pgrid((B + pdegym_policy::kWaves - 1) / pdegym_policy::kWaves), pblock(kWave * pdegym_policy::kWaves);
     bool ok = true;
+    const bool wide = pdegym_policy::is_wide(N);
+    auto launch_pol = [&](auto kernel, signed char (&attr)[pdegym::kMaxDevices]) {
+      ok = pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(kernel), pdegym_policy::kMaxLdsBytes, attr);
+      if (ok) hipLaunchKernelGGL(kernel, pgrid, pblock, lds_bytes, st, P, *buf, *ro, N, B);
+    };
     auto gop = [&](auto tag) {
       constexpr int E = decltype(tag)::value;
-      static signed char attr[3][pdegym::kMaxDevices] = {};
+      static signed char attr[6][pdegym::kMaxDevices] = {};
       if (!general) {
-        ok = pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&rollout1d_policy_kernel<E, PARABOLIC, BURGERS>), pdegym_policy::kMaxLdsBytes, attr[0]);
-        if (ok) hipLaunchKernelGGL((rollout1d_policy_kernel<E, PARABOLIC, BURGERS>), pgrid, pblock, lds_bytes, st, P, *buf, *ro, N, B);
+        if (wide) launch_pol(&rollout1d_policy_kernel<E, PARABOLIC, BURGERS, true>, attr[0]);
+        else launch_pol(&rollout1d_policy_kernel<E, PARABOLIC, BURGERS, false>, attr[1]);
       } else if (neumann) {
-        ok = pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&rollout1d_policy_general_kernel<E, PARABOLIC, true, BURGERS>), pdegym_policy::kMaxLdsBytes, attr[1]);
-        if (ok) hipLaunchKernelGGL((rollout1d_policy_general_kernel<E, PARABOLIC, true, BURGERS>), pgrid, pblock, lds_bytes, st, P, *buf, *ro, N, B);
+        if (wide) launch_pol(&rollout1d_policy_general_kernel<E, PARABOLIC, true, BURGERS, true>, attr[2]);
+        else launch_pol(&rollout1d_policy_general_kernel<E, PARABOLIC, true, BURGERS, false>, attr[3]);
       } else {
-        ok = pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&rollout1d_policy_general_kernel<E, PARABOLIC, false, BURGERS>), pdegym_policy::kMaxLdsBytes, attr[2]);
-        if (ok) hipLaunchKernelGGL((rollout1d_policy_general_kernel<E, PARABOLIC, false, BURGERS>), pgrid, pblock, lds_bytes, st, P, *buf, *ro, N, B);
+        if (wide) launch_pol(&rollout1d_policy_general_kernel<E, PARABOLIC, false, BURGERS, true>, attr[4]);
+        else launch_pol(&rollout1d_policy_general_kernel<E, PARABOLIC, false, BURGERS, false>, attr[5]);
       }
     };
     if (epl <= 1) gop(std::integral_constant<int, 1>{});

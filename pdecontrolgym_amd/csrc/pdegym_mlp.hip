@@ -22,81 +22,15 @@
 
 #include "pdegym.h"
 #include "pdegym_common.h"
+#include "pdegym_mlp_tile.h"
 
 namespace {
 
-typedef float v4f __attribute__((ext_vector_type(4)));
+using namespace pdegym_mlp_tile;     // v4f, lds_stride, kStage, activate, load_w, mma_stage, reduce_blocks
 
 constexpr int kRows = 16;                   // observation rows per workgroup (the M of the MFMA tile)
 constexpr int kMaxWidth = PDEGYM_MLP_MAX_WIDTH;
 constexpr int kXChunk = 512;                // observation entries per row staged in LDS at a time
-// LDS row strides are (a multiple of 64) + 4 floats: 16-byte aligned rows, and 16 rows x one float4 hit 64 distinct banks.
-// The staging area is sized by the launch for the layer widths at hand (dynamic LDS): a 257-64-64-1 policy takes 25 KB per
-// workgroup instead of the 50 KB of the largest shapes, so four workgroups share a CU when the batch is large.
-__host__ __device__ constexpr int lds_stride(int width) { return ((width + 63) / 64) * 64 + 4; }
-constexpr int kStage = 4;                   // k-blocks (of 16 inputs) per software-pipeline stage
-
-__device__ __forceinline__ float activate(float v, int act) {
-  if (act == PDEGYM_MLP_TANH) return tanhf(v);
-  if (act == PDEGYM_MLP_RELU) return v > 0.f ? v : 0.f;
-  return v;
-}
-
-// weights of k-blocks kb0 .. kb0 + kStage - 1 for this lane: group g = 4 kb + l / 16 of the blocked matrix, neuron n (already
-// clamped to the layer width); groups past the end of the (zero-padded) matrix read as zero
-template <int NT>
-__device__ __forceinline__ void load_w(v4f (&w)[kStage][NT], const v4f* __restrict__ wq, int H, int ngroups, int kb0, int lg,
-                                       const int (&col)[NT]) {
-#pragma unroll
-  for (int s = 0; s < kStage; ++s) {
-    const int g = 4 * (kb0 + s) + lg;
-    const bool ok = g < ngroups;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const v4f v = wq[(ok ? g : ngroups - 1) * H + col[t]];
-      w[s][t] = ok ? v : (v4f){0.f, 0.f, 0.f, 0.f};
-    }
-  }
-}
-
-template <int NT>
-__device__ __forceinline__ void mma_stage(v4f (&acc)[NT], const v4f (&w)[kStage][NT], const float* in_row, int kb0, int nblk, int lg) {
-#pragma unroll
-  for (int s = 0; s < kStage; ++s) {
-    if (kb0 + s < nblk) {     // wave-uniform
-      const v4f a = *reinterpret_cast<const v4f*>(in_row + 16 * (kb0 + s) + 4 * lg);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[s][t].x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[s][t].y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[s][t].z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[s][t].w, acc[t], 0, 0, 0);
-      }
-    }
-  }
-}
-
-// acc[t] += in[16 rows, nblk k-blocks] x W^T for this wave's NT tiles; in_row = this lane's input row in LDS (index 0 = first
-// input of the chunk), gofs = k-block offset of the chunk within the weight matrix.  wa: the first stage's weights, loaded
-// by the caller BEFORE it waited for the inputs (the barrier after staging / after the previous layer's epilogue).
-template <int NT>
-__device__ __forceinline__ void reduce_blocks(v4f (&acc)[NT], v4f (&wa)[kStage][NT], const v4f* __restrict__ wq, int H, int ngroups,
-                                              int gofs, int nblk, const float* in_row, int lg, const int (&col)[NT]) {
-  v4f wb[kStage][NT];
-  int kb = 0;
-  while (true) {
-    const bool more_b = kb + kStage < nblk;
-    if (more_b) load_w<NT>(wb, wq, H, ngroups, gofs + kb + kStage, lg, col);
-    mma_stage<NT>(acc, wa, in_row, kb, nblk, lg);
-    kb += kStage;
-    if (!more_b) break;
-    const bool more_a = kb + kStage < nblk;
-    if (more_a) load_w<NT>(wa, wq, H, ngroups, gofs + kb + kStage, lg, col);
-    mma_stage<NT>(acc, wb, in_row, kb, nblk, lg);
-    kb += kStage;
-    if (!more_a) break;
-  }
-}
 
 // NT = 16-neuron tiles per wave, WV = waves per workgroup: one tile per wave throughout -- 4 waves for layers of up to 64
 // units, 8 up to 128, 16 up to 256.  The reduction is bound by the latency of the weight stream, and more waves keep more

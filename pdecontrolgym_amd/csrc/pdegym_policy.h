@@ -6,6 +6,12 @@
 // per four inputs one 16-byte broadcast read of the layer input and one 16-byte read of the lane's weights, four fused
 // multiply-adds; k ascending in ONE chain from zero, bias added last -- the summation order pdegym_mlp_forward documents,
 // up to the MFMA's order inside a group of 16 inputs.
+//
+// Networks with a layer of MORE than 64 units (up to 256: the 256-256 actors of SB3's SAC / a PPO with net_arch [256, 256]) do not
+// fit into LDS (0.5 MB of weights) and have no neuron-per-lane form: they are evaluated COOPERATIVELY (eval_wide) -- the 16 waves
+// put their observation rows into one LDS matrix, wave w computes the 16 x 16 output tile w of every layer with the MFMA reduction
+// of pdegym_mlp_forward (pdegym_mlp_tile.h: weights streamed from L2 in the ABI's blocked layout, same operand order, same bits),
+// one workgroup barrier per layer.
 #ifndef PDEGYM_POLICY_H
 #define PDEGYM_POLICY_H
 
@@ -13,6 +19,7 @@
 
 #include "pdegym.h"
 #include "pdegym_common.h"
+#include "pdegym_mlp_tile.h"
 
 namespace pdegym_policy {
 
@@ -26,27 +33,44 @@ __host__ __device__ inline int xpad(int n) { return (n + 3) & ~3; }
 // so that the 16-byte reads of 16 consecutive lanes (1 KB apart for 257 inputs) fall into distinct banks -- and every read of
 // the reduction loop is base + immediate offset.
 __host__ __device__ inline int groups(int in_dim) { return ((in_dim + 3) >> 2) | 1; }
+constexpr int kWideStage = 1;          // k-blocks per weight-pipeline stage of the cooperative evaluation (registers: 3 stages live)
+constexpr int kWideMax = 256;          // widest layer of the cooperative (MFMA) evaluation: 16 tiles of 16 neurons, one per wave
+__host__ __device__ inline bool is_wide(const pdegym_mlp& N) {
+  bool w = false;
+  for (int l = 0; l < N.n_layers && l < PDEGYM_MLP_MAX_LAYERS; ++l) w = w || N.layer[l].out_dim > kMaxWidth;
+  return w;
+}
+// cooperative evaluation: 16 observation rows (zero-padded to a multiple of 16 inputs), two ping-pong matrices of 16 hidden rows,
+// 16 commands; row strides as in pdegym_mlp_forward
+__host__ __device__ inline int wide_ldx(int n_in) { return pdegym_mlp_tile::lds_stride((n_in + 15) & ~15); }
+constexpr int kWideLdh = pdegym_mlp_tile::lds_stride(kWideMax);
+__host__ __device__ inline int wide_lds_floats(int n_in) { return kWaves * (wide_ldx(n_in) + 2 * kWideLdh) + kWaves; }
 // floats of LDS: per layer its weights and a bias row of 64, then per wave the padded observation row and two hidden rows of 64
 __host__ __device__ inline int lds_floats(const pdegym_mlp& N, int n_in) {
+  if (is_wide(N)) return wide_lds_floats(n_in);
   int f = 0;
   for (int l = 0; l < N.n_layers; ++l) f += groups(N.layer[l].in_dim) * 4 * N.layer[l].out_dim + kMaxWidth;
   return f + kWaves * (xpad(n_in) + 2 * kMaxWidth);
 }
 
 // Host-side check of a descriptor for the in-kernel evaluation: n_in inputs, n_out outputs.  Returns nullptr or the reason.
-inline const char* check(const pdegym_mlp& N, int n_in, int n_out) {
+// allow_wide: the caller has the cooperative evaluation for layers of 65..256 units (the 1D rollout kernels).
+inline const char* check(const pdegym_mlp& N, int n_in, int n_out, bool allow_wide = false) {
   if (N.n_layers < 1 || N.n_layers > PDEGYM_MLP_MAX_LAYERS) return "policy: n_layers must be 1..4";
   for (int l = 0; l < N.n_layers; ++l) {
     const pdegym_mlp_layer& L = N.layer[l];
     if (!L.w) return "policy: null weight pointer";
     if (L.in_dim != (l ? N.layer[l - 1].out_dim : n_in)) return "policy: layer input size must match the observation row / the previous layer";
-    if (L.out_dim < 1 || L.out_dim > kMaxWidth) return "policy inside the rollout kernel: layers of 1..64 units";
+    if (L.out_dim < 1 || L.out_dim > (allow_wide ? kWideMax : kMaxWidth))
+      return allow_wide ? "policy inside the rollout kernel: layers of 1..256 units" : "policy inside the rollout kernel: layers of 1..64 units";
     if (L.act < PDEGYM_MLP_IDENTITY || L.act > PDEGYM_MLP_RELU) return "policy: unknown activation";
   }
   if (N.layer[N.n_layers - 1].out_dim != n_out) return "policy: the last layer must produce one command per actuator";
   if (N.clamp && !(N.lo <= N.hi)) return "policy: clamp bounds must satisfy lo <= hi";
   if (N.noise && N.noise_stride < n_out) return "policy: noise row stride shorter than the command";
-  if (lds_floats(N, n_in) * (int)sizeof(float) > kMaxLdsBytes) return "policy inside the rollout kernel: the network does not fit into 160 KB of LDS";
+  if (lds_floats(N, n_in) * (int)sizeof(float) > kMaxLdsBytes)
+    return is_wide(N) ? "policy inside the rollout kernel: 16 observation rows do not fit into 160 KB of LDS"
+                      : "policy inside the rollout kernel: the network does not fit into 160 KB of LDS";
   return nullptr;
 }
 
@@ -142,6 +166,83 @@ __device__ __forceinline__ float eval(const pdegym_mlp& N, const Staged& S, cons
     }
   }
   return out;
+}
+
+// ---- cooperative evaluation (layers of up to 256 units) ------------------------------------------------------------------------
+struct Wide {
+  float* X;       // [16][ldx] observation rows (row = wave), zero beyond n_in up to a multiple of 16
+  float* H[2];    // [16][kWideLdh] hidden activations, ping-pong
+  float* act;     // [16] neuron 0 of the last layer per row
+  int ldx;
+};
+
+__device__ __forceinline__ Wide wide_setup(const pdegym_mlp& N, float* smem, int n_in, int wave, int lane) {
+  Wide W;
+  W.ldx = wide_ldx(n_in);
+  W.X = smem;
+  W.H[0] = smem + kWaves * W.ldx;
+  W.H[1] = W.H[0] + kWaves * kWideLdh;
+  W.act = W.H[1] + kWaves * kWideLdh;
+  // the row's padding up to a multiple of 16 inputs is written once (every wave, active or not, owns row `wave`)
+  float* xr = W.X + wave * W.ldx;
+  for (int j = lane; j < ((n_in + 15) & ~15); j += kWave) xr[j] = 0.f;
+  return W;
+}
+
+// ALL 16 waves of the workgroup call this in every env-step (waves without an instance too: their row stays zero), having written
+// their observation row into W.X[wave]; returns the value of neuron 0 of the last layer for row `wave`.  Barriers: one ahead of
+// the first layer, one per layer.
+__device__ __forceinline__ float eval_wide(const pdegym_mlp& N, const Wide& W, int n_in, int wave, int lane) {
+  namespace mt = pdegym_mlp_tile;
+  const int li = lane & 15, lg = lane >> 4;
+  auto first_stage = [&](int l, mt::v4f (&w)[kWideStage][1]) {
+    const pdegym_mlp_layer& L = N.layer[l];
+    if (16 * wave < L.out_dim) {
+      const int n = 16 * wave + li;
+      const int col[1] = {n < L.out_dim ? n : L.out_dim - 1};
+      mt::load_w<1, kWideStage>(w, reinterpret_cast<const mt::v4f*>(L.w), L.out_dim, (L.in_dim + 3) >> 2, 0, lg, col);
+    }
+  };
+  mt::v4f wfirst[kWideStage][1];
+  first_stage(0, wfirst);      // requested before the barrier that publishes the observation rows
+  __syncthreads();
+#pragma unroll 1
+  for (int l = 0; l < N.n_layers; ++l) {      // not unrolled: one copy of the reduction, the descriptor read with scalar loads
+    const pdegym_mlp_layer L = N.layer[l];
+    const int K = L.in_dim, H = L.out_dim;
+    const bool last = l == N.n_layers - 1, any_tile = 16 * wave < H;
+    const int n = 16 * wave + li;
+    const int col[1] = {n < H ? n : H - 1};
+    const float bias = (L.b && n < H) ? L.b[n] : 0.f;
+    mt::v4f acc[1] = {(mt::v4f){0.f, 0.f, 0.f, 0.f}};
+    mt::v4f wnext[kWideStage][1];
+    if (!last) first_stage(l + 1, wnext);     // travels while this layer is reduced
+    const float* in_row = l == 0 ? W.X + li * W.ldx : W.H[(l + 1) & 1] + li * kWideLdh;
+    if (any_tile)
+      mt::reduce_blocks<1, kWideStage>(acc, wfirst, reinterpret_cast<const mt::v4f*>(L.w), H, (K + 3) >> 2, 0, (K + 15) >> 4, in_row, lg, col);
+    if (!last) {
+#pragma unroll
+      for (int s2 = 0; s2 < kWideStage; ++s2) wfirst[s2][0] = wnext[s2][0];
+    }
+    // bias, activation: D[row = 4 lg + v][neuron = li] of tile `wave`; hidden layers zero-padded to a multiple of 16 columns
+    const int Hpad = (H + 15) & ~15;
+    if (n < Hpad) {
+      const float av[4] = {acc[0].x, acc[0].y, acc[0].z, acc[0].w};
+      float* hout = W.H[l & 1];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = 4 * lg + v;
+        const float o = n < H ? mt::activate(av[v] + bias, L.act) : 0.f;
+        if (last) {
+          if (n == 0) W.act[r] = o;
+        } else {
+          hout[r * kWideLdh + n] = o;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  return W.act[wave];
 }
 
 __device__ __forceinline__ float lane_value(float v, int l) {

@@ -227,6 +227,11 @@ def _rd_env(B, nx, S, horizon, kind="PDEControlGym-ReactionDiffusionPDE1D", seed
     ("PDEControlGym-TransportPDE1D", 100, 10, 16, [100, 64, 33, 20, 1], ["tanh", "relu", "tanh", "tanh"]),
     ("PDEControlGym-TransportPDE1D", 512, 4, 5, [512, 32, 64, 1], ["tanh", "tanh", None]),
     ("PDEControlGym-TransportPDE1D", 30, 3, 200, [30, 1], [None]),
+    # layers of more than 64 units: the cooperative MFMA evaluation, bit-identical to the two-launch path
+    ("PDEControlGym-ReactionDiffusionPDE1D", 256, 20, 100, [257, 256, 256, 1], ["relu", "relu", "tanh"]),
+    ("PDEControlGym-ReactionDiffusionPDE1D", 64, 5, 37, [65, 100, 1], ["tanh", None]),
+    ("PDEControlGym-TransportPDE1D", 100, 10, 16, [100, 64, 130, 20, 1], ["tanh", "relu", "tanh", "tanh"]),
+    ("PDEControlGym-TransportPDE1D", 512, 4, 5, [512, 256, 17, 1], ["tanh", "tanh", None]),
 ])
 def test_one_launch_rollout_with_policy_inside_equals_two_launches_per_step(kind, nx, S, B, sizes, acts):
     """DeviceRollout(one_launch=True): policy + env-step + auto-reset of all T steps in ONE kernel (pdegym_*_rollout with a
@@ -253,6 +258,9 @@ def test_one_launch_rollout_with_policy_inside_equals_two_launches_per_step(kind
         torch.cuda.synchronize()
         runs[mode]["obs2"] = ro.obs.cpu().numpy().copy()
     a, b = runs[True], runs[False]
+    if max(sizes[1:]) > 64:       # the wide evaluation IS pdegym_mlp_forward's reduction: everything equal bit for bit
+        for k in ("actions", "obs", "rewards", "cur", "obs2", "terminated", "truncated", "time_index"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     np.testing.assert_allclose(a["actions"][0], b["actions"][0], rtol=2e-5, atol=4e-6)      # same input: forward passes only
     # ... and against the torch module itself on the first observation slot (noise added before the clamp)
     with torch.no_grad():
@@ -276,6 +284,10 @@ def test_one_launch_rollout_with_policy_inside_equals_two_launches_per_step(kind
     ("PDEControlGym-TransportPDE1D", "Dirchilet", "collocated", None, 100, 10, 37, [1, 32, 32, 1], ["tanh", "tanh", None]),
     ("PDEControlGym-ReactionDiffusionPDE1D", "Neumann", "collocated", None, 64, 5, 20, [1, 16, 1], ["tanh", None]),
     ("PDEControlGym-ReactionDiffusionPDE1D", "Dirchilet", "full", None, 64, 5, 20, [65, 64, 1], ["tanh", None]),
+    # wide policies (bit-identical to the two-launch path)
+    ("PDEControlGym-ReactionDiffusionPDE1D", "Neumann", "full", None, 128, 10, 50, [129, 256, 256, 1], ["relu", "relu", "tanh"]),
+    ("PDEControlGym-TransportPDE1D", "Dirchilet", "collocated", None, 100, 10, 37, [1, 256, 72, 1], ["tanh", "tanh", None]),
+    ("PDEControlGym-TransportPDE1D", "Neumann", "opposite", "Dirchilet", 100, 10, 16, [1, 80, 1], ["relu", None]),
 ])
 def test_one_launch_rollout_general_cases_with_sensing_noise(kind, control, loc, stype, nx, S, B, sizes, acts):
     """Round 4: the one-launch rollout with the policy inside for Neumann actuation and scalar sensing (the policy's input is the
@@ -321,6 +333,9 @@ def test_one_launch_rollout_general_cases_with_sensing_noise(kind, control, loc,
     a, b = runs[True], runs[False]
     np.testing.assert_array_equal(a["obs_seen"], a["obs"] + a["noise"])
     np.testing.assert_array_equal(b["obs_seen"], b["obs"] + b["noise"])
+    if max(sizes[1:]) > 64:
+        for k in ("actions", "obs", "rewards", "u", "obs2", "obs_seen"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     np.testing.assert_allclose(a["actions"][0], b["actions"][0], rtol=2e-5, atol=4e-6)
     for k in ("actions", "obs", "rewards", "u", "obs2"):
         np.testing.assert_allclose(a[k], b[k], rtol=2e-4, atol=4e-5, err_msg=k)
@@ -335,21 +350,22 @@ def test_one_launch_rollout_falls_back_and_validates():
     from pde_control_gym import DeviceRollout
     venv = _rd_env(8, 64, 5, horizon=4)
     wide = FusedMLP(_mlp([65, 128, 1], ["tanh", None]).cuda())
-    assert not venv.core.policy_fits_rollout(wide)
-    assert not DeviceRollout(venv, wide, 3).one_launch            # wider than 64 units: policy launch + step launch per env-step
-    with pytest.raises(ValueError):
-        DeviceRollout(venv, wide, 3, one_launch=True)
+    assert venv.core.policy_fits_rollout(wide) and DeviceRollout(venv, wide, 3).one_launch       # 65..256 units: cooperative evaluation
     two_out = FusedMLP(_mlp([65, 16, 2], ["tanh", None]).cuda())
     assert not venv.core.policy_fits_rollout(two_out)
+    assert not DeviceRollout(venv, two_out, 3).one_launch         # two outputs: policy launch + step launch per env-step
+    with pytest.raises(ValueError):
+        DeviceRollout(venv, two_out, 3, one_launch=True)
     assert not DeviceRollout(venv, torch.nn.Linear(65, 1).cuda(), 3).one_launch          # a plain torch module
     # the C ABI itself refuses what the wrapper filters
     core = venv.core
     T, B, n = 3, 8, core.n
     obs = torch.zeros(T + 1, B, n, device="cuda")
     z = lambda dt: torch.zeros(T, B, dtype=dt, device="cuda")      # noqa: E731
-    with pytest.raises(N.NativeError, match="64 units"):
+    mism = FusedMLP(_mlp([64, 128, 1], ["tanh", None]).cuda())
+    with pytest.raises(N.NativeError, match="must match the observation row"):
         core.backend.rollout1d(core.kind, core.params, core.t, obs, z(torch.float32), z(torch.float32), z(torch.uint8), z(torch.uint8), B,
-                               policy=wide._net(None))
+                               policy=mism._net(None))
     with pytest.raises(N.NativeError, match="one command"):
         core.backend.rollout1d(core.kind, core.params, core.t, obs, z(torch.float32), z(torch.float32), z(torch.uint8), z(torch.uint8), B,
                                policy=two_out._net(None))
@@ -399,7 +415,7 @@ def test_policy_fits_rollout_limits_on_cpu_double():
 
     e = eng(256)
     assert e.can_rollout() and e.policy_fits_rollout(pol([257, 64, 64, 1]))
-    assert not e.policy_fits_rollout(pol([257, 65, 1]))            # wider than a wave
+    assert e.policy_fits_rollout(pol([257, 65, 1])) and e.policy_fits_rollout(pol([257, 256, 256, 1]))     # cooperative evaluation
     assert not e.policy_fits_rollout(pol([257, 64, 2]))            # one command per instance
     assert not e.policy_fits_rollout(pol([256, 64, 1]))            # input size != row length
     assert not e.policy_fits_rollout(torch.nn.Linear(257, 1))      # not a FusedMLP

@@ -5,7 +5,7 @@
 # Counters are collected in their own passes with --kernel-trace only (never combined with sys/hip traces).
 TAG=${1:-rXX}
 shift
-WLS=${@:-parabolic_c2 parabolic_c2_s1 parabolic_c2_s1_open_loop_rollout parabolic_c2_s1_rollout parabolic_c2_policy_loop parabolic_c2_rollout parabolic_c2_open_loop_rollout transport_c3 burgers_c3 ns2d_c4 ns2d_c4_b4096 ns2d_c5 ns2d_c4_f64 ns2d_c4_f64_b4096 ns2d_c5_f64 ns2d_example traffic_arz traffic_arz_rollout brain_tumor}
+WLS=${@:-parabolic_c2 parabolic_c2_s1 parabolic_c2_s1_open_loop_rollout parabolic_c2_s1_rollout parabolic_c2_policy_loop parabolic_c2_rollout parabolic_c2_policy_loop_256 parabolic_c2_rollout_256 parabolic_c2_open_loop_rollout transport_c3 burgers_c3 ns2d_c4 ns2d_c4_b4096 ns2d_c5 ns2d_c4_f64 ns2d_c4_f64_b4096 ns2d_c5_f64 ns2d_example traffic_arz traffic_arz_rollout brain_tumor}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
