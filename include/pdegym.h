@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PDEGYM_ABI_VERSION 14
+#define PDEGYM_ABI_VERSION 15
 #define PDEGYM_RING 128          /* slots of the per-instance row-norm ring (look-back is 100 rows) */
 #define PDEGYM_LOOKBACK 100      /* tuned_reward_1d.py:25,40: int(1/0.01) rows */
 #define PDEGYM_MAX_N1D 2048      /* nodes per 1D row kept in registers by the wave-per-instance kernels */
@@ -71,10 +71,13 @@ enum {
   PDEGYM_REWARD_NORM_L2 = 3,
   PDEGYM_REWARD_NORM_LINF = 4
 };
-/* NormReward horizon (rewards/norm_reward.py:52-59); "t-horizon" stays on the host path */
+/* NormReward horizon (rewards/norm_reward.py:52-73) */
 enum {
   PDEGYM_HORIZON_TEMPORAL = 0,     /* -||u[t]||                                                                */
-  PDEGYM_HORIZON_DIFFERENTIAL = 1  /* +||u[t] - u[t-1]|| over fine-time rows (t > 0), evaluated by pdegym_step1d_* */
+  PDEGYM_HORIZON_DIFFERENTIAL = 1, /* +||u[t] - u[t-1]|| over fine-time rows (t > 0), evaluated by pdegym_step1d_* */
+  PDEGYM_HORIZON_T = 2             /* "t-horizon": -(||u[t]|| + ... + ||u[t-k+1]||) / k over fine-time rows, k =
+                                      min(reward_t_horizon, t + 1), one float32 chain starting at row t; pdegym_*_step only.
+                                      The ring then holds the reward's own norms (norm_back is meaningless)        */
 };
 
 /* Scalars of one 1D environment family (same for every instance of the batch). */
@@ -107,6 +110,8 @@ typedef struct pdegym_params1d {
   int32_t reward_horizon;   /* PDEGYM_HORIZON_* (NormReward kinds only; pdegym_step1d, not the rollout entry points)      */
   double dt64, dx64;        /* the Python doubles themselves (used where they meet a float64 operand)                     */
   double max_control64;
+  int32_t reward_t_horizon; /* PDEGYM_HORIZON_T: t_horizon_length of NormReward (norm_reward.py:19), 1 .. PDEGYM_RING             */
+  int32_t reserved1_;
 } pdegym_params1d;
 
 /* Per-instance device buffers of a 1D batch (B instances). */

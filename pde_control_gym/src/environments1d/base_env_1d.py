@@ -71,11 +71,14 @@ def reward_spec_for(reward_class):
     if type(reward_class) is TunedReward1D:
         return RewardSpec(N.REWARD_TUNED1D, int(reward_class.nt), float(reward_class.truncate_penalty),
                           float(reward_class.terminate_reward))
-    if type(reward_class) is NormReward and reward_class.horizon in ("temporal", "differential"):
+    if type(reward_class) is NormReward:
         kind = {"1": N.REWARD_NORM_L1, "2": N.REWARD_NORM_L2, "inf": N.REWARD_NORM_LINF}[reward_class.norm]
-        horizon = N.HORIZON_DIFFERENTIAL if reward_class.horizon == "differential" else N.HORIZON_TEMPORAL
+        horizon = {"temporal": N.HORIZON_TEMPORAL, "differential": N.HORIZON_DIFFERENTIAL, "t-horizon": N.HORIZON_T}[reward_class.horizon]
+        k = reward_class.t_horizon_length
+        if horizon == N.HORIZON_T and not (isinstance(k, (int, np.integer)) and 1 <= k <= N.RING):
+            return None          # a mean over more rows than the ring of row norms keeps: host path on the recorded trajectory
         return RewardSpec(kind, int(reward_class.nt), float(reward_class.truncate_penalty),
-                          float(reward_class.terminate_reward), horizon)
+                          float(reward_class.terminate_reward), horizon, int(k) if horizon == N.HORIZON_T else 5)
     return None
 
 

@@ -6,7 +6,7 @@ documented intent (reference docs/source/utils/preimplementedrewards.rst:10-14):
 
   horizon="temporal"      -||u_t||                      (evaluated inside the step kernel)
   horizon="differential"  ||u_t - u_{t-1}||  (t > 0)    (evaluated inside the step kernel: PDEGYM_HORIZON_DIFFERENTIAL)
-  horizon="t-horizon"     -mean of the last k norms     (host path)
+  horizon="t-horizon"     -mean of the last k norms     (evaluated inside the step kernel for k <= 128: PDEGYM_HORIZON_T)
 """
 import numpy as np
 

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libpdegym_hip.so")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 RING = 128
 LOOKBACK = 100
 MAX_N1D = 8192
@@ -22,7 +22,7 @@ FLUX_LINEAR, FLUX_BURGERS = 0, 1
 ACTION_F32, ACTION_F64, ACTION_WEAK = 0, 1, 2
 SENSE_FULL, SENSE_LAST, SENSE_LAST_DERIV, SENSE_FIRST_DERIV, SENSE_FIRST = range(5)
 REWARD_NONE, REWARD_TUNED1D, REWARD_NORM_L1, REWARD_NORM_L2, REWARD_NORM_LINF = range(5)
-HORIZON_TEMPORAL, HORIZON_DIFFERENTIAL = 0, 1      # NormReward horizon evaluated by the step kernels
+HORIZON_TEMPORAL, HORIZON_DIFFERENTIAL, HORIZON_T = 0, 1, 2      # NormReward horizon evaluated by the step kernels
 BC = {"Neumann": 0, "Dirchilet": 1, "Controllable": 2}
 EDGES = ("lower", "upper", "left", "right")
 
@@ -47,7 +47,8 @@ class Params1D(C.Structure):
                 ("F", C.c_float), ("max_control", C.c_float), ("max_state", C.c_float),
                 ("truncate_penalty", C.c_float), ("terminate_reward", C.c_float), ("rdx", C.c_double),
                 ("flux", C.c_int32), ("beta_f64", C.c_int32), ("action_kind", C.c_int32), ("reward_horizon", C.c_int32),
-                ("dt64", C.c_double), ("dx64", C.c_double), ("max_control64", C.c_double)]
+                ("dt64", C.c_double), ("dx64", C.c_double), ("max_control64", C.c_double),
+                ("reward_t_horizon", C.c_int32), ("reserved1_", C.c_int32)]
 
 
 class Bufs1D(C.Structure):

@@ -30,7 +30,8 @@ class RewardSpec:
     nt: int = 0
     truncate_penalty: float = -1e-4
     terminate_reward: float = 1e2
-    horizon: int = N.HORIZON_TEMPORAL      # NormReward kinds: HORIZON_DIFFERENTIAL = +||u[t] - u[t-1]|| (step kernels only)
+    horizon: int = N.HORIZON_TEMPORAL      # NormReward kinds: HORIZON_DIFFERENTIAL = +||u[t] - u[t-1]||, HORIZON_T = -(mean of the
+    t_horizon: int = 5                     # last t_horizon row norms) -- both evaluated by the step kernels only
 
 
 _BAD_SENSING_LOC = "Invalid sensing_loc parameter. Please use 'full', 'collocated', or 'opposite'. See documentation for details."
@@ -98,6 +99,7 @@ class PDEBatch1D(EngineCheckpoint):
         P.reward_kind = self.reward_spec.kind
         P.reward_nt = int(self.reward_spec.nt)
         P.reward_horizon = int(self.reward_spec.horizon) if self.reward_spec.kind >= N.REWARD_NORM_L1 else N.HORIZON_TEMPORAL
+        P.reward_t_horizon = int(self.reward_spec.t_horizon) if P.reward_horizon == N.HORIZON_T else 0
         P.dt, P.dx = dt, dx                       # ctypes c_float rounds the Python double to float32
         P.F = dt / (dx ** 2)                      # parabolic.py:138, computed in double then cast
         P.rdx = 1.0 / float(C.c_float(dx).value)  # reciprocal of the float32 dx, in double (see pdegym.h)

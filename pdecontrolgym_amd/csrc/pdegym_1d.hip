@@ -162,6 +162,25 @@ struct Carry {
   double bsum;
 };
 
+// The reward's own norm of a register-resident row (NormReward kinds; same expressions as the epilogue of step1d_body), for the
+// "t-horizon" reward: -(mean of the norms of the last k fine-time rows), norm_reward.py:60-73.
+template <int EPL>
+__device__ __forceinline__ float kind_norm(const float (&x)[EPL], float bl, int s0, int ns, int kind) {
+  if (kind == PDEGYM_REWARD_NORM_L1) {
+    float s1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s1 += (s0 + e < ns) ? fabsf(x[e]) : 0.f;
+    return wave_sum(s1) + fabsf(bl);
+  }
+  if (kind == PDEGYM_REWARD_NORM_LINF) {
+    float m = fabsf(bl);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) m = mag_max(m, (s0 + e < ns) ? fabsf(x[e]) : 0.f);
+    return wave_mag_max(m);
+  }
+  return sqrtf(slots_sumsq<EPL>(x, s0, ns) + bl * bl);
+}
+
 // S sub-steps of one instance.  FAST: boundary/padding slots are frozen by zero coefficients (no selects);
 // otherwise explicit selects (exact for non-finite states, and required when the boundary value changes every
 // sub-step, i.e. parabolic Neumann control).
@@ -170,8 +189,10 @@ struct Carry {
 template <int EPL, bool PARABOLIC, bool NEUMANN, bool FAST, bool HIST, bool BURGERS = false, bool M64 = false, bool ROLL = false>
 __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EPL], const pdegym_params1d& P, int nsub,
                                              float a, float* ring, float* hist, int lane, const double* b64 = nullptr, double a64 = 0.0,
-                                             float* xprev = nullptr, float* blprev = nullptr) {
+                                             float* xprev = nullptr, float* blprev = nullptr, int thor_k = 0) {
   // xprev/blprev (select form only): the row BEFORE the last sub-step, for NormReward's "differential" horizon
+  // thor_k (select form only): NormReward "t-horizon" of length thor_k -- the reward's norm of each of the last thor_k - 1 rows
+  // before the final one goes into the ring (the final row's is the epilogue's)
   static_assert(!(FAST && (NEUMANN || HIST)), "fast mode is the Dirichlet, history-free path");
   static_assert(!(FAST && M64), "the mixed-precision mode uses the select form");
   constexpr int J0 = PARABOLIC ? 1 : 0;
@@ -423,6 +444,10 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
         }
       }
       record_norm(s + 1);
+      if (thor_k > 0 && s + 1 < nsub && nsub - (s + 1) < thor_k) {    // wave-uniform; after record_norm: this slot holds the reward's norm
+        const float nk = kind_norm<EPL>(R.x, R.bl, s0, ns, P.reward_kind);
+        if (lane == 0) ring[R.t & (PDEGYM_RING - 1)] = nk;
+      }
     }
   }
   if constexpr (!NEUMANN) R.bsum += (double)nsub * (double)fabsf(bval);
@@ -528,6 +553,16 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
   float xprev[kFast ? 1 : EPL], blprev = 0.f;
 #pragma unroll
   for (int e = 0; e < (kFast ? 1 : EPL); ++e) xprev[e] = 0.f;
+  // NormReward "t-horizon" (norm_reward.py:60-73): the ring holds the reward's own norm of the rows the mean looks back at --
+  // the row this call starts from (recorded here: independent of how the previous call or the reset left the slot), the last
+  // rows of the sub-step loop, the final row (epilogue).  Select-form instantiations only, like "differential".
+  const int thor_k = (!kFast && P.reward_horizon == PDEGYM_HORIZON_T && P.reward_kind >= PDEGYM_REWARD_NORM_L1) ? P.reward_t_horizon : 0;
+  if constexpr (!kFast) {
+    if (thor_k > 0) {
+      const float nk0 = kind_norm<EPL>(R.x, R.bl, s0, ns, P.reward_kind);
+      if (lane == 0) ring[t_in & (PDEGYM_RING - 1)] = nk0;
+    }
+  }
   float norm_now;
   if constexpr (kFast) {
     // The fast loop freezes the controlled boundary slot with zero coefficients: x + 0*t keeps every x except -0.0
@@ -586,7 +621,7 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
     }
   } else {
     run_substeps<EPL, PARABOLIC, NEUMANN, false, HIST, BURGERS, M64>(R, beta, P, nsub, a, ring, hist, lane, b64, a64,
-                                                                     differential ? xprev : nullptr, &blprev);
+                                                                     differential ? xprev : nullptr, &blprev, thor_k);
     norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
   }
   const int t = R.t;
@@ -632,6 +667,16 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
     for (int e = 0; e < EPL; ++e) m = mag_max(m, (s0 + e < ns) ? fabsf(R.x[e]) : 0.f);
     nr_alt = wave_mag_max(m);
   }
+  float thor_mean = 0.f;
+  if constexpr (!kFast) {
+    if (thor_k > 0 && lane == 0) {      // -sum(norm(u[t - i]) for i in range(k)) / k, k = min(t_horizon_length, t + 1): one float32 chain
+      if (nsub > 0) ring[t & (PDEGYM_RING - 1)] = nr_alt;
+      const int kk = thor_k < t + 1 ? thor_k : t + 1;
+      float acc = nr_alt;
+      for (int i = 1; i < kk; ++i) acc += ring[(t - i) & (PDEGYM_RING - 1)];
+      thor_mean = acc / (float)kk;
+    }
+  }
   // look-back norm: fetched before the loop, captured inside it, the final row itself (nsub == 100 ends on it only
   // when LOOKBACK == 0, never), or 0 for an unwritten row
   float norm_back = 0.f;
@@ -650,7 +695,7 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
       // documented intent of norm_reward.py:48-54 ("temporal" horizon)
       reward = terminate ? P.terminate_reward
                          : (truncate ? (float)((double)P.truncate_penalty * (double)(P.reward_nt - t))
-                                     : (nr_diff ? nr_alt : -nr_alt));
+                                     : (nr_diff ? nr_alt : (thor_k > 0 ? -thor_mean : -nr_alt)));
     }
   }
 
@@ -931,7 +976,26 @@ __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, p
     for (int j = lane; j < n; j += kWave) ss += row[j] * row[j];
     return sqrtf(wave_sum(ss));
   };
+  // the reward's own norm of a row (NormReward kinds), for the "t-horizon" reward (see step1d_body)
+  auto kind_norm_row = [&](const float* row) {
+    if (P.reward_kind == PDEGYM_REWARD_NORM_L1) {
+      float s1 = 0.f;
+      for (int j = lane; j < n; j += kWave) s1 += fabsf(row[j]);
+      return wave_sum(s1);
+    }
+    if (P.reward_kind == PDEGYM_REWARD_NORM_LINF) {
+      float m = 0.f;
+      for (int j = lane; j < n; j += kWave) m = mag_max(m, fabsf(row[j]));
+      return wave_mag_max(m);
+    }
+    return row_norm(row);
+  };
+  const int thor_k = (P.reward_horizon == PDEGYM_HORIZON_T && P.reward_kind >= PDEGYM_REWARD_NORM_L1) ? P.reward_t_horizon : 0;
   wave_lds_sync();
+  if (thor_k > 0) {
+    const float nk0 = kind_norm_row(cur);
+    if (lane == 0) ring[t_in & (PDEGYM_RING - 1)] = nk0;
+  }
   for (int s = 0; s < nsub; ++s) {
     if (PARABOLIC && neumann) bval = boundary_value<M64>(P, a, a64, cur[n - 2], true);   // parabolic.py:148-150
     const float p0 = cur[0];
@@ -992,6 +1056,10 @@ __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, p
       if (lane == 0) ring[t & (PDEGYM_RING - 1)] = nr;
       if (t == back_row) back_norm = nr;
     }
+    if (thor_k > 0 && s + 1 < nsub && nsub - (s + 1) < thor_k) {
+      const float nk = kind_norm_row(cur);
+      if (lane == 0) ring[t & (PDEGYM_RING - 1)] = nk;
+    }
   }
   if (!neumann) bsum += (double)nsub * (double)fabsf(bval);
   const float norm_now = row_norm(cur);
@@ -1023,6 +1091,14 @@ __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, p
     nr_alt = wave_mag_max(m);
   }
   const float norm_back = from_ring ? norm_back_pre : ((back_row >= 0) ? ((back_row == t) ? norm_now : back_norm) : 0.f);
+  float thor_mean = 0.f;
+  if (thor_k > 0 && lane == 0) {
+    if (nsub > 0) ring[t & (PDEGYM_RING - 1)] = nr_alt;
+    const int kk = thor_k < t + 1 ? thor_k : t + 1;
+    float acc = nr_alt;
+    for (int i = 1; i < kk; ++i) acc += ring[(t - i) & (PDEGYM_RING - 1)];
+    thor_mean = acc / (float)kk;
+  }
   float reward = 0.f;
   if (P.reward_kind == PDEGYM_REWARD_TUNED1D) {
     if (terminate && norm_now < 20.0f) reward = (P.terminate_reward - ((float)bsum) / 1000.0f) - norm_now;
@@ -1030,7 +1106,8 @@ __global__ __launch_bounds__(kWave) void step1d_wide_kernel(pdegym_params1d P, p
     else reward = norm_back - norm_now;
   } else if (P.reward_kind >= PDEGYM_REWARD_NORM_L1) {
     reward = terminate ? P.terminate_reward
-                       : (truncate ? (float)((double)P.truncate_penalty * (double)(P.reward_nt - t)) : (nr_diff ? nr_alt : -nr_alt));
+                       : (truncate ? (float)((double)P.truncate_penalty * (double)(P.reward_nt - t))
+                                   : (nr_diff ? nr_alt : (thor_k > 0 ? -thor_mean : -nr_alt)));
   }
   const bool auto_reset = (Bf.reset_init != nullptr) && (terminate || truncate);
   auto emit_obs = [&](float* obs_base, const float* row) {
@@ -1173,7 +1250,8 @@ template <int EPL, bool PARABOLIC, bool BURGERS = false>
 int launch_epl(const pdegym_params1d& P, const pdegym_bufs1d& Bf, int B, hipStream_t st) {
   const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
   // the select-form (HIST) instantiation also serves NormReward's "differential" horizon: it keeps the row before the last sub-step
-  const bool differential = P.reward_horizon == PDEGYM_HORIZON_DIFFERENTIAL && P.reward_kind >= PDEGYM_REWARD_NORM_L1;
+  // ... and its "t-horizon" (norms of the last rows of the sub-step loop)
+  const bool differential = P.reward_horizon != PDEGYM_HORIZON_TEMPORAL && P.reward_kind >= PDEGYM_REWARD_NORM_L1;
   const bool neu = P.control_type == PDEGYM_CONTROL_NEUMANN, hist = Bf.history != nullptr || differential;
   // (a dummy dynamic-LDS request that capped resident workgroups per CU was A/B-tested and removed: profiles/r02_ab_lds_balance.txt)
   constexpr int lds = 0;
@@ -1206,8 +1284,10 @@ int launch_step(const pdegym_params1d* prm, const pdegym_bufs1d* buf, int B, voi
   if (P.reward_kind != PDEGYM_REWARD_NONE && !buf->reward) return pdegym::fail(-3, "null reward buffer");
   hipStream_t st = (hipStream_t)stream;
   if (P.action_kind < PDEGYM_ACTION_F32 || P.action_kind > PDEGYM_ACTION_WEAK) return pdegym::fail(-2, "bad action_kind");
-  if (P.reward_horizon != PDEGYM_HORIZON_TEMPORAL && P.reward_horizon != PDEGYM_HORIZON_DIFFERENTIAL)
-    return pdegym::fail(-2, "bad reward_horizon");
+  if (P.reward_horizon < PDEGYM_HORIZON_TEMPORAL || P.reward_horizon > PDEGYM_HORIZON_T) return pdegym::fail(-2, "bad reward_horizon");
+  if (P.reward_horizon == PDEGYM_HORIZON_T && P.reward_kind >= PDEGYM_REWARD_NORM_L1 &&
+      (P.reward_t_horizon < 1 || P.reward_t_horizon > PDEGYM_RING))
+    return pdegym::fail(-2, "reward_t_horizon must be in [1, 128] (the ring of row norms)");
   if (P.beta_f64 || P.action_kind != PDEGYM_ACTION_F32) {   // the reference's float64-operand arithmetic (parity mode)
     const int slots = P.n - (PARABOLIC ? 1 : 0), epl64 = (slots + kWave - 1) / kWave;
     if (!BURGERS && epl64 <= 8) {      // rows of up to 512 nodes stay in registers in this mode too

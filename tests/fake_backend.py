@@ -27,7 +27,8 @@ class FakeBackend:
             rw = po.TunedReward1DOracle(P.reward_nt, P.truncate_penalty, P.terminate_reward)
         elif P.reward_kind >= N.REWARD_NORM_L1:
             rw = po.NormRewardOracle(P.reward_nt, {2: "1", 3: "2", 4: "inf"}[P.reward_kind], P.truncate_penalty, P.terminate_reward,
-                                     "differential" if P.reward_horizon == N.HORIZON_DIFFERENTIAL else "temporal")
+                                     {N.HORIZON_TEMPORAL: "temporal", N.HORIZON_DIFFERENTIAL: "differential", N.HORIZON_T: "t-horizon"}[P.reward_horizon],
+                                     P.reward_t_horizon or 5)
         else:
             rw = None
         cls = po.ParabolicOracle if c.kind == "parabolic" else (po.BurgersOracle if getattr(c, "flux", "linear") == "burgers" else po.TransportOracle)
@@ -50,6 +51,10 @@ class FakeBackend:
         orc.time_index = T["time_index"].numpy().astype(np.int64)
         orc.bsum = T["bsum"].numpy().copy()
         orc.ring = T["ring"].numpy().copy()
+        orc._thor = isinstance(orc.reward, po.NormRewardOracle) and orc.reward.horizon == "t-horizon"
+        if orc._thor:        # include/pdegym.h PDEGYM_HORIZON_T: the ring holds the reward's own norms; the start row's is recorded by the call
+            orc.kring = orc.ring.copy()
+            orc.kring[np.arange(B), orc.time_index & 127] = orc.reward.row_norms(orc.row)
         if T.get("history") is not None:
             orc.keep_history = True
             orc.hist = T["history"].numpy()          # shares memory with the tensor: rows are written in place
@@ -59,7 +64,7 @@ class FakeBackend:
             T["u"].copy_(torch.from_numpy(orc.row))
         T["time_index"].copy_(torch.from_numpy(orc.time_index.astype(np.int32)))
         T["bsum"].copy_(torch.from_numpy(orc.bsum))
-        T["ring"].copy_(torch.from_numpy(orc.ring))
+        T["ring"].copy_(torch.from_numpy(orc.kring if getattr(orc, "_thor", False) else orc.ring))
 
     def step1d(self, kind, P, T, B):
         orc = self._orc1d(P)

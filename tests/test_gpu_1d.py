@@ -223,7 +223,7 @@ def test_burgers_extension_matches_own_restatement(nx, S, B, ctrl):
         np.testing.assert_array_equal(env.t["history"].cpu().numpy(), orc.hist)
 
 
-@pytest.mark.parametrize("horizon", ["temporal", "differential"])
+@pytest.mark.parametrize("horizon", ["temporal", "differential", "t-horizon:5", "t-horizon:25", "t-horizon:1"])
 @pytest.mark.parametrize("norm", ["1", "2", "inf"])
 @pytest.mark.parametrize("kind,nx,beta64", [("parabolic", 256, False), ("transport", 100, False), ("transport", 2100, False),
                                             ("parabolic", 2500, False), ("parabolic", 200, True), ("transport", 64, True)])
@@ -231,8 +231,10 @@ def test_norm_reward_epilogues_match_oracle(kind, nx, beta64, norm, horizon):
     """PDEGYM_REWARD_NORM_L1 / L2 / LINF (NormReward, parity unpinned: the reference class raises) through the
     register-resident kernel (n <= 2048), the wide LDS kernel (n > 2048) and the mixed-precision kernel (float64 beta) against
     NormRewardOracle: -||u_t|| ("temporal") or +||u_t - u_{t-1}|| over fine-time rows ("differential", evaluated by the
-    select-form kernel, which keeps the row before its last sub-step) per step, the truncation penalty and the terminal
-    reward.  rtol 1e-6 (reduction order); the differential norm is a sum of rounded differences, so atol 1e-6 of the row scale."""
+    select-form kernel, which keeps the row before its last sub-step) or -(mean of the norms of the last k fine-time rows)
+    ("t-horizon:k": k = 5 inside one env-step of 10 sub-steps, 25 across three, 1 = "temporal") per step, the truncation penalty and
+    the terminal reward.  rtol 1e-6 (reduction order); the differential norm is a sum of rounded differences, so atol 1e-6 of the
+    row scale."""
     from oracle import pde_oracle as po
     from pdecontrolgym_amd import _native as N
     from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
@@ -254,10 +256,12 @@ def test_norm_reward_epilogues_match_oracle(kind, nx, beta64, norm, horizon):
     l2_0 = float(np.linalg.norm(init[0]))
     kw["max_state_value"] = 0.5 * l2_0
     init[1:] *= np.float32(0.2 * l2_0 / np.max(np.linalg.norm(init[1:], axis=1)))
+    horizon, _, klen = horizon.partition(":")
+    klen = int(klen or 5)
     orc = (po.ParabolicOracle if kind == "parabolic" else po.TransportOracle)(
-        reward=po.NormRewardOracle(rargs[0], norm, rargs[1], rargs[2], horizon), keep_history=False, **_oracle_kwargs(kw))
-    hz = N.HORIZON_DIFFERENTIAL if horizon == "differential" else N.HORIZON_TEMPORAL
-    env = PDEBatch1D(kind, reward=RewardSpec(code, *rargs, hz), num_envs=B, device="cuda", **kw)
+        reward=po.NormRewardOracle(rargs[0], norm, rargs[1], rargs[2], horizon, klen), keep_history=False, **_oracle_kwargs(kw))
+    hz = {"temporal": N.HORIZON_TEMPORAL, "differential": N.HORIZON_DIFFERENTIAL, "t-horizon": N.HORIZON_T}[horizon]
+    env = PDEBatch1D(kind, reward=RewardSpec(code, *rargs, hz, klen), num_envs=B, device="cuda", **kw)
     orc.reset(init, beta)
     env.reset(torch.tensor(init), torch.tensor(beta))
     assert env.can_rollout() == (horizon == "temporal" and not beta64 and n <= N.MAX_N1D_REG)

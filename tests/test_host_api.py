@@ -253,14 +253,16 @@ def test_vecenv_with_a_separate_state_tolerates_in_place_edits_of_the_observatio
 def test_norm_reward_differential_is_evaluated_by_the_step_kernel(bk, norm):
     """NormReward(horizon="differential") maps onto the in-kernel reward (reward_horizon of pdegym_params1d; no host callback,
     no recorded trajectory on the batched face) and equals the host definition ||u[t] - u[t-1]|| over fine-time rows, evaluated
-    on the trajectory of a single environment that records it; "t-horizon" stays on the host path."""
+    on the trajectory of a single environment that records it; "t-horizon" maps onto PDEGYM_HORIZON_T (test below)."""
     import pde_control_gym
     from pde_control_gym.src import NormReward, TransportPDE1D
     from pde_control_gym.src.environments1d.base_env_1d import reward_spec_for
     from pdecontrolgym_amd import _native as N
     assert reward_spec_for(NormReward(10, norm, "differential")).horizon == N.HORIZON_DIFFERENTIAL
     assert reward_spec_for(NormReward(10, norm, "temporal")).horizon == N.HORIZON_TEMPORAL
-    assert reward_spec_for(NormReward(10, norm, "t-horizon")) is None
+    th = reward_spec_for(NormReward(10, norm, "t-horizon", t_horizon_length=7))
+    assert th.horizon == N.HORIZON_T and th.t_horizon == 7
+    assert reward_spec_for(NormReward(10, norm, "t-horizon", t_horizon_length=129)) is None       # beyond the ring of row norms: host path
     B, T, dt = 3, 0.05, 1e-4
     ics = [np.linspace(1.0, 2.0 + k, 100).astype(np.float32) for k in range(B)]
     import itertools
@@ -285,6 +287,43 @@ def test_norm_reward_differential_is_evaluated_by_the_step_kernel(bk, norm):
             want = rw.reward(e.u, e.time_index, te, tr, a[b])
             assert r1 == pytest.approx(want, rel=1e-5, abs=1e-6) and r[b] == pytest.approx(want, rel=1e-5, abs=1e-6)
             assert (want == 55.0) == te and (te or want > 0)
+    assert dones.all()
+
+
+@pytest.mark.parametrize("bk", BACKENDS)
+@pytest.mark.parametrize("norm,klen", [("1", 3), ("2", 150), ("inf", 30)])
+def test_norm_reward_t_horizon_is_evaluated_by_the_step_kernel(bk, norm, klen):
+    """NormReward(horizon="t-horizon") -- host-only until round 4 -- maps onto PDEGYM_HORIZON_T: -(mean of the norms of the last
+    min(t_horizon_length, t + 1) fine-time rows), no recorded trajectory on the batched face; equals the host definition evaluated
+    on the trajectory of single environments (100 sub-steps per env-step: lengths inside one step; 150 > the ring of 128 norms takes
+    the host path on the recorded trajectory, same values)."""
+    import itertools
+    import pde_control_gym
+    from pde_control_gym.src import NormReward, TransportPDE1D
+    B, T, dt = 3, 0.05, 1e-4
+    ics = [np.linspace(1.0, 2.0 + k, 100).astype(np.float32) for k in range(B)]
+    it = itertools.cycle(ics)
+    rw = NormReward(int(round(T / dt)), norm, "t-horizon", -2.0, 55.0, klen)
+    p = _transport_params(T=T, dt=dt, control_sample_rate=0.01, reward_class=rw, reset_init_condition_func=lambda nx: next(it))
+    venv = pde_control_gym.make_vec("PDEControlGym-TransportPDE1D", num_envs=B, **_bk(bk), **p)
+    in_kernel = klen <= 128
+    assert venv._host_reward == (not in_kernel) and (venv.core.t["history"] is None) == in_kernel and not venv.core.can_rollout()
+    venv.reset()
+    singles = []
+    for b in range(B):
+        e = TransportPDE1D(**_bk(bk), **_transport_params(T=T, dt=dt, control_sample_rate=0.01, reward_class=rw,
+                                                          reset_init_condition_func=lambda nx, b=b: ics[b]))
+        e.reset()
+        singles.append(e)
+    rng = np.random.default_rng(6)
+    for i in range(5):
+        a = rng.uniform(-1, 1, (B, 1)).astype(np.float32)
+        _, r, dones, _ = venv.step(a)
+        for b, e in enumerate(singles):
+            _, r1, te, tr, _ = e.step(a[b])
+            want = rw.reward(e.u, e.time_index, te, tr, a[b])
+            assert r1 == pytest.approx(want, rel=1e-5, abs=1e-6) and r[b] == pytest.approx(want, rel=1e-5, abs=1e-6)
+            assert (want == 55.0) == te and (te or want < 0)
     assert dones.all()
 
 
