@@ -76,10 +76,12 @@ def one_case(rng, idx):
     rkind = str(rng.choice(["tuned", "tuned", "tuned", "n1", "n2", "ninf"]))
     rcode = {"tuned": N.REWARD_TUNED1D, "n1": N.REWARD_NORM_L1, "n2": N.REWARD_NORM_L2, "ninf": N.REWARD_NORM_LINF}[rkind]
     # ... or its "differential" horizon on every other NormReward case (no extra draw: the case stream stays what it was)
-    hz = "differential" if (rkind != "tuned" and idx % 2 == 1) else "temporal"
-    hcode = N.HORIZON_DIFFERENTIAL if hz == "differential" else N.HORIZON_TEMPORAL
+    # ... and "t-horizon" (mean of the last k row norms, k from the case index) on every fourth
+    hz = "temporal" if rkind == "tuned" else ("t-horizon" if idx % 4 == 3 else ("differential" if idx % 2 == 1 else "temporal"))
+    hcode = {"temporal": N.HORIZON_TEMPORAL, "differential": N.HORIZON_DIFFERENTIAL, "t-horizon": N.HORIZON_T}[hz]
+    klen = (1, 3, 7, 40, 128)[(idx // 4) % 5]
     mk_reward = (lambda: po.TunedReward1DOracle(*rargs)) if rkind == "tuned" else \
-        (lambda: po.NormRewardOracle(rargs[0], {"n1": "1", "n2": "2", "ninf": "inf"}[rkind], rargs[1], rargs[2], hz))
+        (lambda: po.NormRewardOracle(rargs[0], {"n1": "1", "n2": "2", "ninf": "inf"}[rkind], rargs[1], rargs[2], hz, klen))
     # the reference's mixed-precision modes: float64 plant parameter, float64 / Python-scalar control input
     beta64 = bool(rng.random() < 0.2)
     akind = str(rng.choice(["f32", "f32", "f32", "f64", "weak"]))
@@ -96,16 +98,16 @@ def one_case(rng, idx):
     use_bpool = auto and (not shared) and bool(rng.random() < 0.5)
     bpool = (amp * rng.uniform(0, 1) * np.cos(rng.uniform(1, 8.5, (P, 1)) * np.arccos(x)))
     bpool = bpool if beta64 else bpool.astype(np.float32)
-    desc = f"#{idx} P={P} bpool={use_bpool} reward={rkind}/{hz} beta64={beta64} act={akind} auto={auto} {kind} nx={nx} S={S} nt={nt} B={B} {ctrl} {sloc}/{kw['sensing_type']} norm={normalize} limit={limit}/{max_state} ic={style} hist={hist} shared_beta={shared}"
+    desc = f"#{idx} P={P} bpool={use_bpool} reward={rkind}/{hz}{klen if hz == 't-horizon' else ''} beta64={beta64} act={akind} auto={auto} {kind} nx={nx} S={S} nt={nt} B={B} {ctrl} {sloc}/{kw['sensing_type']} norm={normalize} limit={limit}/{max_state} ic={style} hist={hist} shared_beta={shared}"
     try:
         orc = ocls(reward=mk_reward(), keep_history=True, **okw)
     except Exception as ex:      # invalid option combination: the product must refuse it too
         try:
-            PDEBatch1D(base, reward=RewardSpec(rcode, *rargs, hcode), num_envs=B, device="cuda", flux=flux, **kw)
+            PDEBatch1D(base, reward=RewardSpec(rcode, *rargs, hcode, klen), num_envs=B, device="cuda", flux=flux, **kw)
         except Exception:
             return desc + " (both refuse)"
         raise AssertionError(desc + f": oracle refuses ({ex}) but the engine accepts")
-    env = PDEBatch1D(base, reward=RewardSpec(rcode, *rargs, hcode), num_envs=B, device="cuda", record_history=hist, flux=flux, **kw)
+    env = PDEBatch1D(base, reward=RewardSpec(rcode, *rargs, hcode, klen), num_envs=B, device="cuda", record_history=hist, flux=flux, **kw)
     bfull = np.tile(beta, (B, 1)) if shared else beta
     o_ref = orc.reset(init, bfull)
     o_gpu = env.reset(torch.tensor(init), torch.tensor(beta[0] if shared else beta))
@@ -141,6 +143,8 @@ def one_case(rng, idx):
                 orc.time_index[done] = 0
                 orc.bsum[done] = fresh.bsum[done]
                 orc.ring[done, 0] = po._rownorm(fresh.row[done])
+                if orc._thor:
+                    orc.kring[done, 0] = orc.reward.row_norms(fresh.row[done])
                 orc.hist[done] = 0
                 orc.hist[done, 0] = fresh.row[done]
                 orf = orf.copy()

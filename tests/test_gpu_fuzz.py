@@ -62,3 +62,17 @@ def test_fuzz_rollout_kernels_against_step_calls(seed):
             d = fuzz_rollout.case_traffic(rng) if which == "traffic" else fuzz_rollout.case_1d(rng)
         n[which] += d is not None
     assert n["1d"] >= 150 and n["traffic"] >= 50
+
+
+def test_fuzz_policy_inside_rollout_against_two_launch_path():
+    """tests/fuzz_policy_rollout.py: random networks (1 .. 4 layers, up to 256 units) inside the 1D rollout kernels against
+    pdegym_mlp_forward + step calls; layers of more than 64 units (cooperative MFMA evaluation) bit for bit."""
+    import fuzz_policy_rollout as fp
+    rng = np.random.default_rng(4)
+    wide = done = 0
+    for k in range(250):
+        d = fp.one_case(rng, k)
+        wide += d.endswith("[wide]")
+        done += not d.endswith(")")
+    assert done >= 200 and wide >= 60
+
