@@ -741,6 +741,12 @@ def roofline_block(wl, key, step_ms, default_config):
         a = ctr["valu_insts_per_step"] / t / 1e9
         valu = {"wave_insts_per_step": ctr["valu_insts_per_step"], "achieved": a, "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s",
                 "frac": a / VALU_PEAK_GINST}
+        if ctr.get("f64_insts_per_step") is not None:
+            # a float64 add / mul / fma occupies the SIMD for 4 cycles (16 lanes per clock) where everything else takes 2: the share
+            # of the SIMDs' time the instruction stream needs = 2 x (all + float64 ones) cycles / (1024 SIMDs x step time x 2.4 GHz).
+            # `frac` above counts every instruction once (comparable across workloads); this one is the truer figure for float64 kernels
+            valu["f64_wave_insts_per_step"] = ctr["f64_insts_per_step"]
+            valu["frac_f64_weighted"] = (ctr["valu_insts_per_step"] + ctr["f64_insts_per_step"]) / t / 1e9 / VALU_PEAK_GINST
     if ctr and ctr.get("hbm_bytes_per_step"):
         a = ctr["hbm_bytes_per_step"] / t / 1e9
         hbm = {"bytes_per_step": ctr["hbm_bytes_per_step"], "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS}

@@ -13,6 +13,8 @@ export TMPDIR=/tmp
 cd /tmp
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE"
 SQ2="SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
+# float64 arithmetic occupies a SIMD for 4 cycles per wave-instruction (16 lanes per clock) against 2 for float32 / integer: counted apart
+SQ3="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_F32 SQ_VALU_MFMA_BUSY_CYCLES"
 for wl in $WLS; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -o p -- python3 $R/bench.py --steps 200 --warmup 20 --repeats 2 --no-also --no-cpu-baseline --workload $wl > $OUT/stats_$wl.json 2> $OUT/stats_$wl.err
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -20,6 +22,7 @@ for wl in $WLS; do
   done
   rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $OUT/pmc_sq1_$wl -o p -- python3 $R/bench.py --steps 30 --warmup 5 --repeats 1 --no-also --no-cpu-baseline --workload $wl > /dev/null 2>&1
   rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d $OUT/pmc_sq2_$wl -o p -- python3 $R/bench.py --steps 30 --warmup 5 --repeats 1 --no-also --no-cpu-baseline --workload $wl > /dev/null 2>&1
+  rocprofv3 --pmc $SQ3 --kernel-trace --output-format csv -d $OUT/pmc_sq3_$wl -o p -- python3 $R/bench.py --steps 30 --warmup 5 --repeats 1 --no-also --no-cpu-baseline --workload $wl > /dev/null 2>&1
 done
 cd $R
 python3 tools/summarize_profiles.py $TAG

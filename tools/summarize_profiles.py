@@ -87,7 +87,7 @@ def counters_by_kernel(path):
 
 for wl in DOM:
     merged = {}
-    for grp in ("sq1", "sq2"):
+    for grp in ("sq1", "sq2", "sq3"):
         f = os.path.join(src, f"pmc_{grp}_{wl}", "p_counter_collection.csv")
         if os.path.exists(f):
             for k, d in counters_by_kernel(f).items():
@@ -133,6 +133,19 @@ for wl in DOM:
             e = kernels.setdefault(k, {})
             e["launches_per_step"] = cnt[k][counter] / n_steps
             e[counter + "_per_step"] = v.get(counter, 0.0) * (scale if counter != "SQ_INSTS_VALU" else 1.0) / n_steps
+    # float64 arithmetic wave-instructions (add / mul / fma / transcendental): each occupies the SIMD for 4 cycles instead of 2
+    f3 = os.path.join(src, f"pmc_sq3_{wl}", "p_counter_collection.csv")
+    if os.path.exists(f3) and "valu_insts_per_step" in per:
+        tot, cnt = totals_by_kernel(f3)
+        names = ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")
+        step_k = {k: v for k, v in tot.items() if is_step_kernel(k) and cnt[k].get(names[0], 0) >= 10}
+        if step_k:
+            n_steps = min(cnt[k][names[0]] for k in step_k)
+            per["f64_insts_per_step"] = sum(v.get(c, 0.0) for v in step_k.values() for c in names) / n_steps
+            per["mfma_f32_insts_per_step"] = sum(v.get("SQ_INSTS_VALU_MFMA_F32", 0.0) for v in step_k.values()) / n_steps
+            for k, v in step_k.items():
+                e = kernels.setdefault(k, {})
+                e["F64_INSTS_per_step"] = sum(v.get(c, 0.0) for c in names) / n_steps
     if "_fetch" in per and "_write" in per:
         per["hbm_bytes_per_step"] = per.pop("_fetch") + per.pop("_write")
     per = {k: v for k, v in per.items() if not k.startswith("_")}
