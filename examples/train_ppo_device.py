@@ -7,8 +7,9 @@ algorithm in plain torch on the batched engine:
 
   * rollout  -- ``DeviceRollout``: the whole T-step rollout is ONE kernel launch (``pdegym_parabolic_rollout``: per env-step
                 the actor mean is evaluated inside the kernel from weights held in LDS, exploration noise added, the command
-                clamped and stored, then the env-step with fused auto-reset; bigger networks fall back to one
-                ``pdegym_mlp_forward`` launch + one env-step launch per step inside a hipGraph);
+                clamped and stored, then the env-step with fused auto-reset; layers of 65 .. 256 units -- ``hidden`` below --
+                are evaluated in the same kernel by the 16 waves of a workgroup together on the matrix cores; anything else
+                falls back to one ``pdegym_mlp_forward`` launch + one env-step launch per step inside a hipGraph);
   * update   -- ordinary torch autograd on the same ``torch.nn.Sequential`` the rollout evaluates (``FusedMLP`` picks the new
                 weights up at the next ``run()``).
 
@@ -16,7 +17,7 @@ The plant is the reference's unstable reaction-diffusion benchmark u_t = u_xx + 
 (ReactionDiffusionPDE1D, Dirichlet control at x = 1).  Uncontrolled, ||u|| grows; the printed mean ||u|| over an episode falls
 as the policy learns to damp it.
 
-    python examples/train_ppo_device.py [iterations] [num_envs]
+    python examples/train_ppo_device.py [iterations] [num_envs] [hidden units per layer: 64]
 """
 import os
 import sys
@@ -58,15 +59,17 @@ def mlp(sizes, out_tanh=False):
     return torch.nn.Sequential(*mods)
 
 
-def main(iterations=30, B=2048, T=64, quiet=False):
+def main(iterations=30, B=2048, T=64, quiet=False, hidden=64):
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     venv = make_env(B, horizon=T)        # one rollout = one episode of every environment
     obs0 = venv.reset_tensor()
     venv.enable_fused_auto_reset()
     D = obs0.shape[1]
-    actor = mlp([D, 64, 64, 1]).to(dev)                  # mean of a Gaussian policy (SB3's MlpPolicy shape)
-    critic = mlp([D, 64, 64, 1]).to(dev)
+    # mean of a Gaussian policy: SB3's MlpPolicy shape (64-64), or e.g. hidden = 256 for net_arch [256, 256] -- layers of more
+    # than 64 units are evaluated inside the same rollout kernel by the workgroup's 16 waves together (matrix cores)
+    actor = mlp([D, hidden, hidden, 1]).to(dev)
+    critic = mlp([D, hidden, hidden, 1]).to(dev)
     with torch.no_grad():
         actor[0].weight.mul_(0.1)                        # observations are O(10)
         critic[0].weight.mul_(0.1)
@@ -133,4 +136,5 @@ def main(iterations=30, B=2048, T=64, quiet=False):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 2048)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 2048,
+         hidden=int(sys.argv[3]) if len(sys.argv) > 3 else 64)

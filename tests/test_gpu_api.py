@@ -292,6 +292,9 @@ def test_ppo_example_trains_on_device():
     last = sum(h["episode_return"] for h in hist[-3:]) / 3
     assert last > first + 15.0, (first, last)
     assert hist[-1]["mean_norm"] < hist[0]["mean_norm"]
+    # the same with SB3's 256-256 width: the rollout stays ONE launch (cooperative MFMA evaluation inside the kernel) and learns
+    hist = mod.main(iterations=10, B=512, quiet=True, hidden=256)
+    assert sum(h["episode_return"] for h in hist[-3:]) / 3 > hist[0]["episode_return"] + 10.0, hist
 
 
 @pytest.mark.parametrize("family", ["burgers", "traffic"])
