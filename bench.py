@@ -868,7 +868,9 @@ def main():
                 rf = roofline_block(w2, name, r2["step_ms_events"], True)
                 also[name] = {"value": w2.units_per_step() * n2 / r2["seconds"], "unit": "env-steps/s", "ms_per_step": r2["seconds"] / n2 * 1e3,
                               "dtype": w2.dtype, "timed_regions_s": r2["all_regions_s"],
-                              "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "step_ms", "counters_stale")},
+                              "roofline": dict({k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "step_ms", "counters_stale")},
+                                               valu_issue_frac=(rf.get("valu_issue") or {}).get("frac"), hbm_frac=(rf.get("hbm") or {}).get("frac"),
+                                               valu_issue_frac_f64_weighted=(rf.get("valu_issue") or {}).get("frac_f64_weighted")),
                               "config": w2.config()}
                 del w2
             except Exception as ex:  # keep the headline line alive
