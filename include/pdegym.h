@@ -354,7 +354,8 @@ int pdegym_traffic_step(const pdegym_params_traffic* prm, const pdegym_bufs_traf
  * step t takes the command(s) from actions row t and writes observation slot t + 1,
  * rewards / done / truncated row t; r, y, time of the pdegym_bufs_traffic are read once and written back at the end
  * (bufs->action / obs / reward / done / truncated are ignored).  Bit-identical to T pdegym_traffic_step calls; like them it
- * keeps stepping a finished episode.  With a policy (HOST pointer; layers of <= 64 units, 2M inputs, action_stride outputs)
+ * keeps stepping a finished episode.  With a policy (HOST pointer; layers of <= 256 units -- more than 64: evaluated cooperatively with
+ * pdegym_mlp_forward's MFMA reduction, see pdegym_rollout1d.policy --, 2M inputs, action_stride outputs)
  * the command of step t is computed inside the launch from observation slot t (slot 0 = the caller's current observation)
  * rounded to float32, plus noise [T, B, action_stride] (row stride noise_stride), clamped, widened and stored to actions. */
 typedef struct pdegym_rollout_traffic {

@@ -286,7 +286,7 @@ class PDEBatch1D(EngineCheckpoint):
             return False
         stride = lambda w: (w + 63) // 64 * 64 + 4                  # noqa: E731  (pdegym_mlp_tile.h: lds_stride)
         if any(o > 64 for _, o in dims):
-            floats = 16 * (stride((self.obs_dim + 15) // 16 * 16) + 2 * stride(256)) + 16
+            floats = 16 * (stride((self.obs_dim + 15) // 16 * 16) + 2 * stride(256)) + 32
         else:
             floats = sum((((i + 3) // 4) | 1) * 4 * o + 64 for i, o in dims) + 16 * (((self.obs_dim + 3) // 4) * 4 + 128)
         return 4 * floats <= 160 * 1024

@@ -96,15 +96,20 @@ class TrafficBatch(EngineCheckpoint):
         return self.M <= 64 and hasattr(self.backend, "traffic_rollout")
 
     def policy_fits_rollout(self, policy) -> bool:
-        """Whether ``policy`` (a ``FusedMLP``) can run inside the rollout kernel: 2M inputs, layers of at most 64 units, one
-        output per command, weights + 16 observation rows within 160 KB of LDS."""
+        """Whether ``policy`` (a ``FusedMLP``) can run inside the rollout kernel: 2M inputs, one output per command.  Layers of
+        at most 64 units: weights + 16 observation rows within 160 KB of LDS; a layer of 65 .. 256 units: evaluated by the
+        workgroup's 16 waves together on the matrix cores (bit-identical to ``FusedMLP`` itself), as in the 1D engines."""
         if not (self.can_rollout() and hasattr(policy, "layers") and hasattr(policy, "_net")):
             return False
         dims = [(int(w.shape[1]), int(w.shape[0])) for w, _, _ in policy.layers]
         D = 2 * self.M
-        if dims[0][0] != D or dims[-1][1] != self.action_dim or any(o > 64 for _, o in dims):
+        if dims[0][0] != D or dims[-1][1] != self.action_dim or any(o > 256 for _, o in dims):
             return False
-        floats = sum((((i + 3) // 4) | 1) * 4 * o + 64 for i, o in dims) + 16 * (((D + 3) // 4) * 4 + 128)
+        if any(o > 64 for _, o in dims):
+            stride = lambda w: (w + 63) // 64 * 64 + 4                  # noqa: E731  (pdegym_mlp_tile.h: lds_stride)
+            floats = 16 * (stride((D + 15) // 16 * 16) + 2 * stride(256)) + 32
+        else:
+            floats = sum((((i + 3) // 4) | 1) * 4 * o + 64 for i, o in dims) + 16 * (((D + 3) // 4) * 4 + 128)
         return 4 * floats <= 160 * 1024
 
     def rollout(self, obs, actions, rewards, done, truncated, policy=None, clamp="default", noise=None):

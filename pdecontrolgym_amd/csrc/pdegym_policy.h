@@ -44,7 +44,8 @@ __host__ __device__ inline bool is_wide(const pdegym_mlp& N) {
 // 16 commands; row strides as in pdegym_mlp_forward
 __host__ __device__ inline int wide_ldx(int n_in) { return pdegym_mlp_tile::lds_stride((n_in + 15) & ~15); }
 constexpr int kWideLdh = pdegym_mlp_tile::lds_stride(kWideMax);
-__host__ __device__ inline int wide_lds_floats(int n_in) { return kWaves * (wide_ldx(n_in) + 2 * kWideLdh) + kWaves; }
+constexpr int kWideOut = 2;            // outputs kept per row (neurons 0 and 1 of the last layer: the traffic engine's two commands)
+__host__ __device__ inline int wide_lds_floats(int n_in) { return kWaves * (wide_ldx(n_in) + 2 * kWideLdh) + kWideOut * kWaves; }
 // floats of LDS: per layer its weights and a bias row of 64, then per wave the padded observation row and two hidden rows of 64
 __host__ __device__ inline int lds_floats(const pdegym_mlp& N, int n_in) {
   if (is_wide(N)) return wide_lds_floats(n_in);
@@ -172,7 +173,7 @@ __device__ __forceinline__ float eval(const pdegym_mlp& N, const Staged& S, cons
 struct Wide {
   float* X;       // [16][ldx] observation rows (row = wave), zero beyond n_in up to a multiple of 16
   float* H[2];    // [16][kWideLdh] hidden activations, ping-pong
-  float* act;     // [16] neuron 0 of the last layer per row
+  float* act;     // [16][kWideOut] neurons 0 .. kWideOut - 1 of the last layer per row
   int ldx;
 };
 
@@ -190,8 +191,8 @@ __device__ __forceinline__ Wide wide_setup(const pdegym_mlp& N, float* smem, int
 }
 
 // ALL 16 waves of the workgroup call this in every env-step (waves without an instance too: their row stays zero), having written
-// their observation row into W.X[wave]; returns the value of neuron 0 of the last layer for row `wave`.  Barriers: one ahead of
-// the first layer, one per layer.
+// their observation row into W.X[wave]; returns the value of neuron 0 of the last layer for row `wave` (wide_out: the others).
+// Barriers: one ahead of the first layer, one per layer.
 __device__ __forceinline__ float eval_wide(const pdegym_mlp& N, const Wide& W, int n_in, int wave, int lane) {
   namespace mt = pdegym_mlp_tile;
   const int li = lane & 15, lg = lane >> 4;
@@ -234,7 +235,7 @@ __device__ __forceinline__ float eval_wide(const pdegym_mlp& N, const Wide& W, i
         const int r = 4 * lg + v;
         const float o = n < H ? mt::activate(av[v] + bias, L.act) : 0.f;
         if (last) {
-          if (n == 0) W.act[r] = o;
+          if (n < kWideOut) W.act[r * kWideOut + n] = o;
         } else {
           hout[r * kWideLdh + n] = o;
         }
@@ -242,8 +243,10 @@ __device__ __forceinline__ float eval_wide(const pdegym_mlp& N, const Wide& W, i
     }
     __syncthreads();
   }
-  return W.act[wave];
+  return W.act[wave * kWideOut];
 }
+
+__device__ __forceinline__ float wide_out(const Wide& W, int wave, int k) { return W.act[wave * kWideOut + k]; }
 
 __device__ __forceinline__ float lane_value(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));

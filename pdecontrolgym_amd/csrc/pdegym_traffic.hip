@@ -217,18 +217,25 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pde
 // caller's business in this engine).  With a policy (pdegym_policy.h) the command of step t is computed inside the launch
 // from observation slot t rounded to float32 -- the cast SB3 makes in front of its float32 network -- widened back to
 // float64, plus noise, clamped, and stored to actions row t.
+// WIDE: a policy with a layer of more than 64 units -- the 16 waves of the workgroup evaluate it together (pdegym_policy.h: eval_wide),
+// so every wave, with or without a freeway, runs all T iterations (barriers).
+template <bool WIDE>
 __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void traffic_rollout_kernel(pdegym_params_traffic P, pdegym_bufs_traffic Bf,
                                                                                        pdegym_rollout_traffic Ro, pdegym_mlp N, TrafficConsts K,
                                                                                        int has_policy, int B) {
   namespace pol = pdegym_policy;
   extern __shared__ __attribute__((aligned(16))) float pol_smem[];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  const int inst = blockIdx.x * pol::kWaves + wave;
+  const int inst_raw = blockIdx.x * pol::kWaves + wave;
   const int M = P.M, D = 2 * M, xpad = pol::xpad(D);
   pol::Staged St = {};
-  if (has_policy) St = pol::stage(N, pol_smem);        // the launch's only barrier (uniform over the grid)
-  if (inst >= B) return;
-  float* const xw = pol_smem + St.end + wave * (xpad + 2 * pol::kMaxWidth);
+  pol::Wide Wd;
+  if constexpr (WIDE) Wd = pol::wide_setup(N, pol_smem, D, wave, lane);
+  else if (has_policy) St = pol::stage(N, pol_smem);        // the launch's only barrier (uniform over the grid)
+  const bool active = inst_raw < B;      // wave-uniform
+  if (!WIDE && !active) return;
+  const int inst = active ? inst_raw : 0;      // a wave without a freeway only attends the barriers: it reads instance 0, stores nothing
+  float* const xw = WIDE ? Wd.X + wave * Wd.ldx : pol_smem + St.end + wave * (xpad + 2 * pol::kMaxWidth);
   float* const hw = xw + xpad;
   const bool in = lane < M;
   double r = in ? Bf.r[(size_t)inst * M + lane] : 1.0;
@@ -245,10 +252,21 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void traffic_rollout_
     double a0, a1 = 0.0;
     if (has_policy) {
       const double* xrow = Ro.obs + (size_t)t * slot + (size_t)inst * D;
-      for (int j = lane; j < xpad; j += kWave) xw[j] = j < D ? (float)xrow[j] : 0.f;
-      pol::wave_lds_sync();
-      const float o = pol::eval(N, St, pol_smem, xw, hw, D, lane);
-      float c0 = pol::lane_value(o, 0), c1 = A > 1 ? pol::lane_value(o, 1) : 0.f;
+      float c0, c1;
+      if constexpr (WIDE) {
+        if (active)
+          for (int j = lane; j < D; j += kWave) xw[j] = (float)xrow[j];
+        pol::eval_wide(N, Wd, D, wave, lane);
+        if (!active) continue;
+        c0 = pol::wide_out(Wd, wave, 0);
+        c1 = A > 1 ? pol::wide_out(Wd, wave, 1) : 0.f;
+      } else {
+        for (int j = lane; j < xpad; j += kWave) xw[j] = j < D ? (float)xrow[j] : 0.f;
+        pol::wave_lds_sync();
+        const float o = pol::eval(N, St, pol_smem, xw, hw, D, lane);
+        c0 = pol::lane_value(o, 0);
+        c1 = A > 1 ? pol::lane_value(o, 1) : 0.f;
+      }
       if (N.noise) {
         const float* nz = N.noise + ((size_t)t * B + inst) * N.noise_stride;
         c0 += nz[0];
@@ -295,6 +313,7 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void traffic_rollout_
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
+  if (!active) return;
   if (in) {
     Bf.r[(size_t)inst * M + lane] = r;
     Bf.y[(size_t)inst * M + lane] = y;
@@ -514,16 +533,23 @@ int pdegym_traffic_rollout(const pdegym_params_traffic* prm, const pdegym_bufs_t
   if (A > 2) return pdegym::fail(-2, "action_stride must be 1 or 2");
   pdegym_mlp net = {};
   size_t lds_bytes = 0;
+  bool wide = false;
   if (ro->policy) {
     net = *ro->policy;
-    if (const char* why = pdegym_policy::check(net, 2 * prm->M, A)) return pdegym::fail(-2, why);
+    if (A > pdegym_policy::kWideOut) return pdegym::fail(-2, "policy: at most two commands");
+    if (const char* why = pdegym_policy::check(net, 2 * prm->M, A, true)) return pdegym::fail(-2, why);
+    wide = pdegym_policy::is_wide(net);
     lds_bytes = (size_t)pdegym_policy::lds_floats(net, 2 * prm->M) * sizeof(float);
-    static signed char attr[pdegym::kMaxDevices] = {};
-    if (!pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(&traffic_rollout_kernel), pdegym_policy::kMaxLdsBytes, attr))
+    static signed char attr[2][pdegym::kMaxDevices] = {};
+    const void* fn = wide ? reinterpret_cast<const void*>(&traffic_rollout_kernel<true>) : reinterpret_cast<const void*>(&traffic_rollout_kernel<false>);
+    if (!pdegym::raise_dynamic_lds_limit(fn, pdegym_policy::kMaxLdsBytes, attr[wide ? 1 : 0]))
       return pdegym::fail(-4, "cannot raise the dynamic LDS limit of traffic_rollout_kernel");
   }
   const dim3 grid((B + pdegym_policy::kWaves - 1) / pdegym_policy::kWaves), block(kWave * pdegym_policy::kWaves);
-  hipLaunchKernelGGL(traffic_rollout_kernel, grid, block, lds_bytes, (hipStream_t)stream, *prm, *buf, *ro, net, traffic_consts(*prm), ro->policy ? 1 : 0, B);
+  if (wide)
+    hipLaunchKernelGGL(traffic_rollout_kernel<true>, grid, block, lds_bytes, (hipStream_t)stream, *prm, *buf, *ro, net, traffic_consts(*prm), 1, B);
+  else
+    hipLaunchKernelGGL(traffic_rollout_kernel<false>, grid, block, lds_bytes, (hipStream_t)stream, *prm, *buf, *ro, net, traffic_consts(*prm), ro->policy ? 1 : 0, B);
   return pdegym::check_launch("traffic_rollout");
 }
 

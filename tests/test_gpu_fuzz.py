@@ -71,7 +71,7 @@ def test_fuzz_policy_inside_rollout_against_two_launch_path():
     rng = np.random.default_rng(4)
     wide = done = 0
     for k in range(250):
-        d = fp.one_case(rng, k)
+        d = fp.traffic_case(rng, k) if k % 5 == 4 else fp.one_case(rng, k)
         wide += d.endswith("[wide]")
         done += not d.endswith(")")
     assert done >= 200 and wide >= 60

@@ -433,6 +433,7 @@ def test_policy_fits_rollout_limits_on_cpu_double():
     assert not eng(64, state_in_obs=False).can_rollout()           # full-state sensing with a second copy of the state: two homes
     tr = TrafficBatch(240, 0.25, 500, 10, "both", 40, 0.16, 60, True, 1, num_envs=2, device="cpu", backend=FakeBackend())
     assert tr.can_rollout() and tr.policy_fits_rollout(pol([102, 64, 2])) and not tr.policy_fits_rollout(pol([102, 64, 1]))
+    assert tr.policy_fits_rollout(pol([102, 256, 256, 2]))          # cooperative evaluation, two commands
     wide = TrafficBatch(240, 0.25, 1000, 10, "inlet", 40, 0.16, 60, True, 1, num_envs=2, device="cpu", backend=FakeBackend())
     assert wide.M == 101 and not wide.can_rollout()
 

@@ -245,10 +245,12 @@ def test_traffic_rollout_kernel_equals_step_calls_bitwise(sim, cf, B, T):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sim,sizes", [("outlet", [102, 32, 1]), ("both", [102, 64, 64, 2]), ("outlet-train", [102, 1])])
+@pytest.mark.parametrize("sim,sizes", [("outlet", [102, 32, 1]), ("both", [102, 64, 64, 2]), ("outlet-train", [102, 1]),
+                                       ("both", [102, 256, 256, 2]), ("inlet", [102, 100, 1]), ("outlet-train", [102, 48, 130, 1])])
 def test_traffic_one_launch_rollout_with_policy_inside(sim, sizes):
     """DeviceRollout on TrafficPDE1D as ONE kernel (policy evaluated inside pdegym_traffic_rollout on the float64 observation
-    rounded to float32) against policy launch + step launch per env-step: commands to float32 rounding, trajectories follow."""
+    rounded to float32) against policy launch + step launch per env-step: commands to float32 rounding, trajectories follow.
+    A layer of more than 64 units takes the cooperative MFMA evaluation: everything equal bit for bit."""
     import pde_control_gym
     from pde_control_gym import DeviceRollout, FusedMLP
     from pde_control_gym.src import TrafficARZReward
@@ -277,6 +279,9 @@ def test_traffic_one_launch_rollout_with_policy_inside(sim, sizes):
                                                        venv.core.t["time"])]
     a, b = runs[True], runs[False]
     assert a[0].dtype == np.float64 and a[0].std() > 0
+    if max(sizes[1:]) > 64:
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
     np.testing.assert_allclose(a[0][0], b[0][0], rtol=2e-6, atol=1e-6)       # same observation: forward passes only
     for x, y in zip(a[:3], b[:3]):
         np.testing.assert_allclose(x, y, rtol=1e-4, atol=1e-6)
