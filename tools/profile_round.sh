@@ -24,5 +24,9 @@ for wl in $WLS; do
   rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d $OUT/pmc_sq2_$wl -o p -- python3 $R/bench.py --steps 30 --warmup 5 --repeats 1 --no-also --no-cpu-baseline --workload $wl > /dev/null 2>&1
   rocprofv3 --pmc $SQ3 --kernel-trace --output-format csv -d $OUT/pmc_sq3_$wl -o p -- python3 $R/bench.py --steps 30 --warmup 5 --repeats 1 --no-also --no-cpu-baseline --workload $wl > /dev/null 2>&1
 done
+# gpurun merges at most 64 MiB back: the per-dispatch traces are not read by tools/summarize_profiles.py (it takes p_kernel_stats.csv and
+# p_counter_collection.csv), so they stay on the box
+find $OUT -name p_kernel_trace.csv -delete
+find $OUT -name p_agent_info.csv -delete
 cd $R
 python3 tools/summarize_profiles.py $TAG
