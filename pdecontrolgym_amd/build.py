@@ -6,6 +6,7 @@ in-tree (git-ignored) and travels to the GPU box with the repository snapshot.
 from __future__ import annotations
 
 import hashlib
+import re
 import os
 import shutil
 import subprocess
@@ -35,15 +36,26 @@ def _fingerprint() -> str:
     return h.hexdigest()
 
 
+_COMMENT = re.compile(rb'//[^\n]*|/\*.*?\*/|("(?:\\.|[^"\\\n])*")', re.S)
+
+
+def _code_only(text: bytes) -> bytes:
+    """The source without comments and with runs of white space collapsed: what the compiler's output depends on (string literals
+    are kept as they are).  A reworded comment -- in particular in the public header, which every workload's fingerprint includes --
+    must not make committed counters look stale."""
+    text = _COMMENT.sub(lambda m: m.group(1) or b" ", text)
+    return b" ".join(text.split())
+
+
 def sources_fingerprint(files) -> str:
-    """Hash of a SUBSET of the kernel sources (+ the public header and the compiler options): what one workload's kernels are
-    compiled from.  bench.py stamps the committed PMC counters of a workload with it, so that a roofline fraction computed from
-    counters of an older kernel is flagged (``counters_stale``) instead of silently wrong."""
+    """Hash of a SUBSET of the kernel sources (+ the public header and the compiler options), comments and white space apart: what
+    one workload's kernels are compiled from.  bench.py stamps the committed PMC counters of a workload with it, so that a roofline
+    fraction computed from counters of an older kernel is flagged (``counters_stale``) instead of silently wrong."""
     h = hashlib.sha256()
     for f in sorted(files) + ["../../include/pdegym.h"]:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(os.path.basename(f).encode())
-            h.update(fh.read())
+            h.update(_code_only(fh.read()))
     h.update(" ".join(OPTS).encode())
     return h.hexdigest()[:16]
 

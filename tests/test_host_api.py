@@ -894,6 +894,13 @@ def test_roofline_counters_are_tied_to_the_kernel_sources(monkeypatch):
     assert r["counters_stale"] == (r["counters_kernel_stamp"] != bench.kernel_stamp("parabolic_c2")) and 0.3 < r["frac"] < 0.7
     monkeypatch.setattr(bench, "kernel_stamp", lambda k: "0" * 16)
     assert bench.roofline_block(W(), "parabolic_c2", 0.02, True)["counters_stale"] is True
+    # the fingerprint follows the CODE: comments and white space apart (the public header is part of every workload's fingerprint,
+    # and a reworded comment there must not make every committed counter look stale); string literals are code
+    from pdecontrolgym_amd import build
+    base = b'int a = 1;  /* x */ const char* s = "// kept /* kept */";\n// tail\n'
+    assert build._code_only(base) == build._code_only(b'int a = 1; const char* s = "// kept /* kept */"; // other words\n/* more */')
+    assert build._code_only(base) != build._code_only(base.replace(b"a = 1", b"a = 2"))
+    assert build._code_only(base) != build._code_only(base.replace(b"// kept", b"// changed"))
 
 
 @pytest.mark.parametrize("control,loc", [("Neumann", "full"), ("Dirchilet", "collocated"), ("Neumann", "collocated")])
