@@ -569,13 +569,14 @@ WORKLOADS["brain_tumor"] = BrainTumor
 # Which kernel sources each workload's launches are compiled from: the committed PMC counters of a workload are stamped with the
 # fingerprint of these files (build.sources_fingerprint) when they are collected, and roofline_block flags them as stale when the
 # tree has moved on ("roofline counters are not tied to the binary").
-_SRC_1D = ["pdegym_1d.hip", "pdegym_common.h", "pdegym_policy.h", "pdegym_mlp_tile.h"]
+_SRC_1D = ["pdegym_1d.hip", "pdegym_1d_body.h", "pdegym_common.h"]                                       # the step kernels
+_SRC_1D_ROLL = ["pdegym_1d_rollout.hip", "pdegym_1d_body.h", "pdegym_common.h", "pdegym_policy.h", "pdegym_mlp_tile.h"]   # the rollout kernels
 _SRC_NS = ["pdegym_ns2d.hip", "pdegym_ns_common.h", "pdegym_common.h"]
 KERNEL_SOURCES = {
-    "parabolic_c2": _SRC_1D, "transport_c3": _SRC_1D, "burgers_c3": _SRC_1D, "parabolic_c2_rollout": _SRC_1D,
-    "parabolic_c2_open_loop_rollout": _SRC_1D, "parabolic_c2_s1": _SRC_1D, "parabolic_c2_s1_open_loop_rollout": _SRC_1D,
-    "parabolic_c2_s1_rollout": _SRC_1D, "parabolic_c2_policy_loop": _SRC_1D + ["pdegym_mlp.hip"],
-    "parabolic_c2_policy_loop_256": _SRC_1D + ["pdegym_mlp.hip"], "parabolic_c2_rollout_256": _SRC_1D,
+    "parabolic_c2": _SRC_1D, "transport_c3": _SRC_1D, "burgers_c3": _SRC_1D, "parabolic_c2_rollout": _SRC_1D_ROLL,
+    "parabolic_c2_open_loop_rollout": _SRC_1D_ROLL, "parabolic_c2_s1": _SRC_1D, "parabolic_c2_s1_open_loop_rollout": _SRC_1D_ROLL,
+    "parabolic_c2_s1_rollout": _SRC_1D_ROLL, "parabolic_c2_policy_loop": _SRC_1D + ["pdegym_mlp.hip", "pdegym_mlp_tile.h"],
+    "parabolic_c2_policy_loop_256": _SRC_1D + ["pdegym_mlp.hip", "pdegym_mlp_tile.h"], "parabolic_c2_rollout_256": _SRC_1D_ROLL,
     "ns2d_c4": _SRC_NS, "ns2d_c4_b4096": _SRC_NS, "ns2d_c4_f64": _SRC_NS, "ns2d_c4_f64_b4096": _SRC_NS, "ns2d_example": _SRC_NS,
     "ns2d_c5": _SRC_NS + ["pdegym_ns256.hip", "pdegym_ns256_rows.h"],
     "ns2d_c5_f64": _SRC_NS + ["pdegym_ns256_f64.hip", "pdegym_ns256_rows.h"],

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpdegym_hip.so")
-SOURCES = ["pdegym_abi.hip", "pdegym_1d.hip", "pdegym_ns2d.hip", "pdegym_ns256.hip", "pdegym_ns256_f64.hip", "pdegym_traffic.hip", "pdegym_tumor.hip", "pdegym_mlp.hip"]
+SOURCES = ["pdegym_abi.hip", "pdegym_1d.hip", "pdegym_1d_rollout.hip", "pdegym_ns2d.hip", "pdegym_ns256.hip", "pdegym_ns256_f64.hip", "pdegym_traffic.hip", "pdegym_tumor.hip", "pdegym_mlp.hip"]
 # -ffp-contract=off: NumPy rounds after every operation; a fused multiply-add would break bit parity.
 # -fno-slp-vectorize: v_pk_*_f32 has the same per-element issue cost as the scalar forms on gfx950 (tools/ubench_valu.hip:
 # 5.1 vs 2.8 cycles per wave-instruction at 4 waves/SIMD) and packing adjacent stencil nodes costs shuffle moves.

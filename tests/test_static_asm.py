@@ -1,6 +1,6 @@
-"""Static hazard check of the shipped gfx950 code objects (advisor finding r3, pdegym_1d.hip ROLL stencil).
+"""Static hazard check of the shipped gfx950 code objects (advisor finding r3, the ROLL stencil of pdegym_1d_body.h).
 
-Some DPP operations are written out in ``asm volatile`` blocks with hand-counted wait states (pdegym_1d.hip: the ROLL form of the
+Some DPP operations are written out in ``asm volatile`` blocks with hand-counted wait states (pdegym_1d_body.h, instantiated by pdegym_1d_rollout.hip: the ROLL form of the
 parabolic stencil; pdegym_ns_common.h: the Jacobi row blocks).  The compiler's hazard recognizer does not look inside an asm
 block, so a compiler upgrade that schedules differently AROUND the blocks could silently violate
   * VALU writes a VGPR  -> DPP reads that VGPR:     2 wait states,
@@ -78,7 +78,7 @@ def _check(text):
 
 
 @pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm toolchain not found")
-@pytest.mark.parametrize("unit", ["pdegym_1d", "pdegym_ns2d", "pdegym_ns256", "pdegym_ns256_f64", "pdegym_traffic"])
+@pytest.mark.parametrize("unit", ["pdegym_1d", "pdegym_1d_rollout", "pdegym_ns2d", "pdegym_ns256", "pdegym_ns256_f64", "pdegym_traffic"])
 def test_every_dpp_instruction_has_its_wait_states(unit, tmp_path):
     from pdecontrolgym_amd import build
     build.build()
