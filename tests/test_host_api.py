@@ -1005,3 +1005,19 @@ def test_sensing_noise_hooks_also_see_auto_reset_and_terminal_observations(hook,
     assert dones.all()
     for i in range(B):
         assert infos[i]["terminal_observation"].min() >= 100 and infos[i]["terminal_observation"].max() < 100 + 1e4
+
+
+def test_integration_md_binding_stub_matches_the_abi():
+    """The ctypes structures INTEGRATION.md section 2 shows a reference maintainer are executed as written and compared with the
+    bindings this repo uses (field names, order, size): a stub that lags an ABI bump would corrupt memory for whoever copies it."""
+    import ctypes as C
+    from pdecontrolgym_amd import _native as N
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    ns = {}
+    for name, end, real in (("Params1D", "class Bufs1D", N.Params1D), ("Bufs1D", "def reset(self", N.Bufs1D),
+                            ("Rollout1D", "ro = Rollout1D", N.Rollout1D)):
+        i = text.index(f"class {name}(C.Structure):")
+        exec("import ctypes as C\n" + text[i:text.index(end, i)], ns)
+        stub = ns[name]
+        assert [f[0] for f in stub._fields_] == [f[0] for f in real._fields_], name
+        assert C.sizeof(stub) == C.sizeof(real), name
