@@ -727,6 +727,15 @@ def vecenv_host_rate(device, B=4096, steps=60, warmup=8):
                     "synchronisation per step; PCIe-inclusive (never the headline value)"}
 
 
+def hbm_probe(device):
+    """The measured HBM yardstick of THIS box, printed beside the 8 TB/s specification: hand-written float4 copy / read / fill
+    (tools/hbm_probe.hip, 1 GiB, best of two grid sizes x plain / non-temporal).  ~0.1 s."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import hbm_probe as hp
+    r = hp.measure(device, quick=True)
+    return {k: r[k] for k in ("copy_GBps", "read_GBps", "fill_GBps", "at_MiB", "kernel")}
+
+
 def roofline_block(wl, key, step_ms, default_config):
     """The resource that binds the step and how close the step is to it.  Two candidates, both reported:
       * VALU issue: SQ_INSTS_VALU of one step (profiled) x 2 cycles / (1024 SIMDs x step time x 2.4 GHz);
@@ -853,12 +862,17 @@ def main():
         out["process_group"] = dist.get_backend()
     if cpu_rep is not None:
         out["cpu_baseline"] = cpu_rep
+    also = None
     if rank == 0 and world == 1 and not args.no_also and args.workload == "parabolic_c2" and not args.batch:
         also = {}
         try:            # first: a process that has built and dropped nineteen workloads hands out host memory far more slowly
             also["vecenv_host"] = vecenv_host_rate(device)
         except Exception as ex:
             also["vecenv_host"] = {"error": repr(ex)}
+        try:
+            also["hbm_probe"] = hbm_probe(device)
+        except Exception as ex:
+            also["hbm_probe"] = {"error": repr(ex)}
         for name, cls in WORKLOADS.items():
             if name == args.workload:
                 continue
@@ -878,10 +892,90 @@ def main():
                 also[name] = {"error": repr(ex)}
         out["also"] = also
     if rank == 0:
-        print(json.dumps(out))
+        # The LAST stdout line is what the driver parses: it stays under 4 KB (the 23 KB line of round 4 was not
+        # parsed).  Everything else -- per-region times, the full roofline dicts, every secondary workload -- goes to
+        # bench_also.json next to this script (and to gpurun_out/ when that exists).
+        for path in (os.path.join(ROOT, "bench_also.json"), os.path.join(ROOT, "gpurun_out", "bench_also.json")):
+            try:
+                if os.path.isdir(os.path.dirname(path)):
+                    with open(path, "w") as fh:
+                        json.dump(out, fh, indent=1)
+            except OSError:
+                pass
+        print(final_line(out))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+SECONDARY = ("ns2d_c4_b4096", "ns2d_c4_f64_b4096", "transport_c3", "ns2d_c4", "ns2d_c4_f64", "ns2d_c5", "ns2d_c5_f64",
+             "parabolic_c2_s1_open_loop_rollout", "traffic_arz")      # the other BASELINE configs (+ the two kernels VERDICT r4 names)
+MAX_LINE = 4096
+
+
+def _r(x, sig=6):
+    """Floats to `sig` significant digits (the full-precision numbers are in bench_also.json)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float(f"{x:.{sig}g}")
+
+
+def final_line(out):
+    """The one line the driver parses, from the full result dict: headline + roofline + cpu_baseline + a compact `secondary`
+    list; < MAX_LINE bytes whatever the workload names and notes grow to (tests/test_bench_line.py)."""
+    rf = out.get("roofline") or {}
+    cfg = out.get("config") or {}
+    line = {k: _r(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data") if k in out}
+    line["config"] = {k: cfg[k] for k in ("workload", "env", "nx", "ny", "nodes", "batch_per_gpu", "substeps_per_env_step",
+                                          "jacobi_sweeps_per_step", "env_steps_per_launch", "reward", "launch", "parallelism") if k in cfg}
+    line["roofline"] = {
+        "bound": rf.get("bound"), "achieved": _r(rf.get("achieved")), "peak": rf.get("peak"), "unit": rf.get("unit"), "frac": _r(rf.get("frac"), 4),
+        "traffic": _r(rf.get("traffic")), "algorithmic_bytes_per_step": rf.get("algorithmic_bytes_per_step"),
+        "kernel_avg_ns": _r(rf["step_ms"] * 1e6) if rf.get("step_ms") else None,
+        "counters_round": ((rf.get("counters_source") or "").split(":")[0].replace("round ", "") or None),
+        "counters_stale": rf.get("counters_stale"),
+        "hbm_frac": _r((rf.get("hbm") or {}).get("frac"), 4), "valu_issue_frac": _r((rf.get("valu_issue") or {}).get("frac"), 4),
+        "hbm_copy_measured_GBps": _r(((out.get("also") or {}).get("hbm_probe") or {}).get("copy_GBps"), 4),
+    }
+    cb = out.get("cpu_baseline")
+    if cb:
+        c = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+             "sample": (cb.get("sample") or "")[:160]}
+        ac = cb.get("all_cores") or {}
+        if "value" in ac:
+            c["all_cores"] = {"value": _r(ac["value"]), "logical_cpus": ac.get("logical_cpus")}
+        line["cpu_baseline"] = c
+    if "per_rank_env_steps_per_s" in out:
+        line["per_rank_env_steps_per_s"] = [_r(v) for v in out["per_rank_env_steps_per_s"]]
+        line["n1_equivalent"] = _r(out["n1_equivalent"]["value"])
+        line["process_group"] = out.get("process_group")
+    also = out.get("also")
+    if also:
+        sec = []
+        for name in SECONDARY:
+            a = also.get(name)
+            if not a or "error" in a:
+                if a:
+                    sec.append({"name": name, "error": a["error"][:60]})
+                continue
+            r2 = a.get("roofline") or {}
+            sec.append({"name": name, "value": _r(a["value"]), "ms_per_step": _r(a["ms_per_step"], 5), "dtype": a.get("dtype"),
+                        "bound": r2.get("bound"), "frac": _r(r2.get("frac"), 3)})
+        line["secondary"] = sec
+        vh = also.get("vecenv_host") or {}
+        if "value" in vh:
+            line["vecenv_host_env_steps_per_s"] = _r(vh["value"])
+        line["details"] = "bench_also.json"
+    s = json.dumps(line, separators=(",", ":"))
+    while len(s) >= MAX_LINE and line.get("secondary"):      # never expected; keeps the contract if names / notes grow
+        line["secondary"].pop()
+        s = json.dumps(line, separators=(",", ":"))
+    if len(s) >= MAX_LINE:
+        line["cpu_baseline"] = {k: v for k, v in (line.get("cpu_baseline") or {}).items() if k != "sample"}
+        line["config"] = {"workload": str(cfg.get("workload"))[:200]}
+        s = json.dumps(line, separators=(",", ":"))
+    return s
 
 
 if __name__ == "__main__":

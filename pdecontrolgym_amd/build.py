@@ -103,5 +103,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+PROBE_SRC = os.path.join(ROOT, "tools", "hbm_probe.hip")
+PROBE_LIB = os.path.join(LIBDIR, "libpdegym_probe.so")
+
+
+def build_probe(force: bool = False) -> str:
+    """The HBM yardstick (tools/hbm_probe.hip: float4 copy / read / fill) as its own small library: measurement tooling, not part
+    of the product ABI, and kept out of csrc/ so that the product's kernel fingerprints do not depend on it."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not force and os.path.exists(PROBE_LIB) and os.path.getmtime(PROBE_LIB) >= os.path.getmtime(PROBE_SRC):
+        return PROBE_LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", PROBE_LIB, PROBE_SRC],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed on hbm_probe.hip:\n" + r.stdout.decode())
+    return PROBE_LIB
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_probe(force=True))

@@ -1,0 +1,76 @@
+"""bench.py's LAST stdout line is the driver's measurement channel: it must stay small enough to be parsed (the 23 KB
+line of round 4 gave BENCH_r04.json `parsed: null`).  Built here from a real full result (profiles/r04p_bench_steps20.json, the
+line round 4 printed) and from a synthetic worst case -- no GPU."""
+import json
+import os
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _round4_result():
+    with open(os.path.join(ROOT, "profiles", "r04p_bench_steps20.json")) as fh:
+        return json.loads(fh.read().strip().splitlines()[-1])
+
+
+def test_final_line_from_the_round4_result_is_small_and_complete():
+    full = _round4_result()
+    assert len(json.dumps(full)) > 20000                      # the line that was not parsed
+    line = bench.final_line(full)
+    assert "\n" not in line and len(line) < bench.MAX_LINE == 4096
+    d = json.loads(line)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["value"] == bench._r(full["value"]) and d["config"]["workload"] == full["config"]["workload"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_step", "kernel_avg_ns", "counters_stale",
+              "hbm_frac", "valu_issue_frac", "hbm_copy_measured_GBps"):
+        assert k in rf, k
+    assert abs(rf["frac"] - full["roofline"]["frac"]) < 1e-3 and rf["bound"] == full["roofline"]["bound"]
+    assert abs(rf["kernel_avg_ns"] - full["roofline"]["step_ms"] * 1e6) < 1.0
+    cb = d["cpu_baseline"]
+    assert cb["cores"] == 1 and cb["kind"] == "port" and cb["all_cores"]["logical_cpus"] == full["cpu_baseline"]["all_cores"]["logical_cpus"]
+    names = [s["name"] for s in d["secondary"]]
+    for must in ("ns2d_c4_b4096", "ns2d_c4_f64_b4096", "transport_c3", "ns2d_c4_f64", "ns2d_c5_f64"):
+        assert must in names
+    for s in d["secondary"]:
+        assert set(s) == {"name", "value", "ms_per_step", "dtype", "bound", "frac"}
+        assert abs(s["value"] / full["also"][s["name"]]["value"] - 1) < 1e-5
+    assert "also" not in d and "timed_regions_s" not in d
+
+
+def test_final_line_stays_under_the_cap_when_names_and_notes_grow():
+    full = _round4_result()
+    full["config"]["workload"] = "W" * 3000
+    full["cpu_baseline"]["sample"] = "s" * 5000
+    for k in list(full["also"]):
+        full["also"][k + "_" + "x" * 200] = full["also"][k]
+    line = bench.final_line(full)
+    assert len(line) < bench.MAX_LINE
+    d = json.loads(line)
+    assert d["value"] == bench._r(full["value"]) and d["roofline"]["bound"] and d["cpu_baseline"]["value"]
+
+
+def test_final_line_multi_gpu_fields_fit():
+    full = _round4_result()
+    full.pop("also")
+    full["n_gpus"] = 8
+    full["per_rank_env_steps_per_s"] = [2.0912345678e8 + i for i in range(8)]
+    full["n1_equivalent"] = {"value": 2.09e8, "note": "x" * 300}
+    full["process_group"] = "nccl"
+    line = bench.final_line(full)
+    d = json.loads(line)
+    assert len(line) < bench.MAX_LINE and len(d["per_rank_env_steps_per_s"]) == 8 and d["process_group"] == "nccl"
+    assert d["n1_equivalent"] == 2.09e8 and "secondary" not in d
+
+
+def test_final_line_survives_an_error_in_a_secondary_workload_and_missing_counters():
+    full = _round4_result()
+    full["also"]["ns2d_c5_f64"] = {"error": "RuntimeError('boom')" * 20}
+    full["roofline"] = {"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "step_ms": 0.02}
+    d = json.loads(bench.final_line(full))
+    assert any(s["name"] == "ns2d_c5_f64" and "error" in s for s in d["secondary"])
+    assert d["roofline"]["frac"] is None and d["roofline"]["traffic"] is None

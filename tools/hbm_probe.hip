@@ -1,0 +1,107 @@
+// hbm_probe.hip -- the HBM yardstick of this box, hand-written for gfx950 (the torch copy_ figure of
+// tools/hbm_copy_bw.py understated the practical ceiling; MI355X_MICROARCH.md measures 6.29 TB/s with a float4 copy).
+//
+// Three kernels, 16 bytes per lane and access, grid-stride with a workgroup-contiguous 4 KiB chunk per iteration (every wave's
+// load is one fully coalesced 1 KiB request group), UNROLL independent loads in flight per lane before the first use:
+//   copy : dst[i] = src[i]                   (read + write: 2 x bytes of traffic)
+//   read : sum of src (one atomic per wave)  (read only)
+//   fill : dst[i] = const                    (write only)
+// Built into pdecontrolgym_amd/lib/libpdegym_probe.so by pdecontrolgym_amd/build.py; NOT part of the product ABI
+// (include/pdegym.h) and not under csrc/, so the kernel fingerprints of the product library do not depend on it.
+// C entry point: pdegym_probe_hbm(kind, dst, src, bytes, workgroups, nontemporal, stream) -> 0 / -1.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int BLOCK = 256;
+constexpr int UNROLL = 4;
+
+template <bool NT>
+__device__ __forceinline__ f4 ld(const f4* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st(f4* p, f4 v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <bool NT>
+__global__ __launch_bounds__(BLOCK) void probe_copy(f4* __restrict__ dst, const f4* __restrict__ src, size_t n) {
+    const size_t stride = (size_t)gridDim.x * BLOCK * UNROLL;
+    for (size_t base = (size_t)blockIdx.x * BLOCK * UNROLL + threadIdx.x; base < n; base += stride) {
+        f4 v[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {
+            size_t i = base + (size_t)k * BLOCK;
+            if (i < n) v[k] = ld<NT>(src + i);
+        }
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {
+            size_t i = base + (size_t)k * BLOCK;
+            if (i < n) st<NT>(dst + i, v[k]);
+        }
+    }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(BLOCK) void probe_read(float* __restrict__ out, const f4* __restrict__ src, size_t n) {
+    const size_t stride = (size_t)gridDim.x * BLOCK * UNROLL;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t base = (size_t)blockIdx.x * BLOCK * UNROLL + threadIdx.x; base < n; base += stride) {
+        f4 v[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {
+            size_t i = base + (size_t)k * BLOCK;
+            v[k] = (i < n) ? ld<NT>(src + i) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) acc += v[k];
+    }
+    float s = acc.x + acc.y + acc.z + acc.w;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+template <bool NT>
+__global__ __launch_bounds__(BLOCK) void probe_fill(f4* __restrict__ dst, size_t n, float value) {
+    const size_t stride = (size_t)gridDim.x * BLOCK * UNROLL;
+    const f4 v = {value, value, value, value};
+    for (size_t base = (size_t)blockIdx.x * BLOCK * UNROLL + threadIdx.x; base < n; base += stride) {
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {
+            size_t i = base + (size_t)k * BLOCK;
+            if (i < n) st<NT>(dst + i, v);
+        }
+    }
+}
+
+extern "C" int pdegym_probe_hbm(int kind, void* dst, const void* src, uint64_t bytes, int workgroups, int nontemporal, void* stream) {
+    if (bytes % 16 != 0 || workgroups <= 0) return -1;
+    const size_t n = bytes / 16;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(workgroups), b(BLOCK);
+    switch (kind) {
+    case 0:
+        if (!dst || !src) return -1;
+        if (nontemporal) hipLaunchKernelGGL(probe_copy<true>, g, b, 0, s, (f4*)dst, (const f4*)src, n);
+        else hipLaunchKernelGGL(probe_copy<false>, g, b, 0, s, (f4*)dst, (const f4*)src, n);
+        break;
+    case 1:      // dst = one float accumulator (the caller zeroes it)
+        if (!dst || !src) return -1;
+        if (nontemporal) hipLaunchKernelGGL(probe_read<true>, g, b, 0, s, (float*)dst, (const f4*)src, n);
+        else hipLaunchKernelGGL(probe_read<false>, g, b, 0, s, (float*)dst, (const f4*)src, n);
+        break;
+    case 2:
+        if (!dst) return -1;
+        if (nontemporal) hipLaunchKernelGGL(probe_fill<true>, g, b, 0, s, (f4*)dst, n, 1.0f);
+        else hipLaunchKernelGGL(probe_fill<false>, g, b, 0, s, (f4*)dst, n, 1.0f);
+        break;
+    default:
+        return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
