@@ -63,25 +63,30 @@ enum : int { kPassFront = 1, kPassBack = 2 };
 __device__ __forceinline__ double shr_f64(double v) { return lane_left(v); }     // lane i <- lane i-1 (lane 0: 0, a domain-edge lane)
 __device__ __forceinline__ double shl_f64(double v) { return lane_right(v); }    // lane i <- lane i+1
 
-struct D4 {
-  double2 a, b;
-};
+// LDS layout (round 5): a thread's four doubles are kept as TWO 16-byte halves in two PLANES (plane a: columns 0-1, plane b: columns
+// 2-3), each plane indexed by the thread id -- so every ds_read_b128 / ds_write_b128 is lane-contiguous (16-byte lane stride).  The
+// round-4 array-of-struct form (32 bytes per thread) put the 16-lane groups of a ds_read_b128 on each bank twice: SQ_LDS_BANK_CONFLICT
+// 30.7 M cycles per launch against 12.0 M SQ_ACTIVE_INST_LDS (profiles/r04o_summary.json; MI355X_MICROARCH.md, LDS table).
+// halo area: [buffer 0/1][top, bottom][plane a, b][kNT] double2; parked rq rows: [row][plane a, b][kNT] double2
+constexpr int kPlane = kNT;                                   // double2 elements per plane
 
 // top / bottom halo rows of a 4-wide double patch through LDS: ht = last row of the wave above, hb = first row of the wave below
 // (the first / last wave of the slab re-reads its own row: a domain wall, or a cut whose rows are allowed to go stale)
 __device__ __forceinline__ void halo_tb4(const double (&top)[4], const double (&bot)[4], double (&ht)[4], double (&hb)[4], char* lds,
                                          int& xc, int tid, int w) {
-  D4* base = reinterpret_cast<D4*>(lds) + (xc & 1) * (2 * kNT);
+  double2* base = reinterpret_cast<double2*>(lds) + (xc & 1) * (4 * kPlane);
   ++xc;
-  D4* eT = base;
-  D4* eB = base + kNT;
-  eT[tid] = D4{make_double2(top[0], top[1]), make_double2(top[2], top[3])};
-  eB[tid] = D4{make_double2(bot[0], bot[1]), make_double2(bot[2], bot[3])};
+  double2* eT = base;                     // planes a, b of the top rows
+  double2* eB = base + 2 * kPlane;        // planes a, b of the bottom rows
+  eT[tid] = make_double2(top[0], top[1]);
+  eT[kPlane + tid] = make_double2(top[2], top[3]);
+  eB[tid] = make_double2(bot[0], bot[1]);
+  eB[kPlane + tid] = make_double2(bot[2], bot[3]);
   __syncthreads();
   const int up = (w > 0) ? tid - 64 : tid, dn = (w < kNW - 1) ? tid + 64 : tid;
-  const D4 x = eB[up], y = eT[dn];
-  ht[0] = x.a.x; ht[1] = x.a.y; ht[2] = x.b.x; ht[3] = x.b.y;
-  hb[0] = y.a.x; hb[1] = y.a.y; hb[2] = y.b.x; hb[3] = y.b.y;
+  const double2 xa = eB[up], xb = eB[kPlane + up], ya = eT[dn], yb = eT[kPlane + dn];
+  ht[0] = xa.x; ht[1] = xa.y; ht[2] = xb.x; ht[3] = xb.y;
+  hb[0] = ya.x; hb[1] = ya.y; hb[2] = yb.x; hb[3] = yb.y;
 }
 
 // the four Neumann copies (:110-113) on the new rows, which sit in state ST.  Selects, not branches: with control flow in the
@@ -105,7 +110,7 @@ __device__ __forceinline__ void walls4(double (&ph)[kPR + 1][4], const EdgeFlags
 
 // one sweep from state ST (0: UP, rows 0 -> PR-1; 1: DOWN): new row a lands in the registers of the old row it no longer needs
 template <int ST>
-__device__ __forceinline__ void sweep4(double (&ph)[kPR + 1][4], const double (&rq)[kRR][4], const D4* rql, const EdgeFlags& E, char* lds,
+__device__ __forceinline__ void sweep4(double (&ph)[kPR + 1][4], const double (&rq)[kRR][4], const double2* rql, const EdgeFlags& E, char* lds,
                                        int& xc, int tid, int w) {
   constexpr int PR = kPR;
   double hlast[4];
@@ -114,8 +119,8 @@ __device__ __forceinline__ void sweep4(double (&ph)[kPR + 1][4], const double (&
 #pragma unroll
       for (int k = 0; k < 4; ++k) q[k] = rq[a][k];
     } else {
-      const D4 v = rql[(a - kRR) * kNT];
-      q[0] = v.a.x; q[1] = v.a.y; q[2] = v.b.x; q[3] = v.b.y;
+      const double2 va = rql[(a - kRR) * (2 * kPlane)], vb = rql[(a - kRR) * (2 * kPlane) + kPlane];
+      q[0] = va.x; q[1] = va.y; q[2] = vb.x; q[3] = vb.y;
     }
   };
   auto update = [&](double (&dst)[4], const double (&x)[4], const double (&sv)[4], const double (&nv)[4], const double (&q)[4])
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(kNT, 2) void ns256_pass_f64(NSConst C, NSScal<doubl
   {
     const double* ps = p_src + (size_t)b * src_stride + (size_t)g0 * kN + c0;
     const double* rs = rhs + (size_t)g0 * kN + c0;
-    D4* rql = reinterpret_cast<D4*>(smem_raw + kHaloBytes) + tid;        // row j of this thread: rql[j * kNT]
+    double2* rql = reinterpret_cast<double2*>(smem_raw + kHaloBytes) + tid;        // row j of this thread: planes rql[j * 2 kPlane], rql[j * 2 kPlane + kPlane]
     double ph[kPR + 1][4], rq[kRR][4];
 #pragma unroll
     for (int a = 0; a < kPR; ++a) {
@@ -354,7 +359,8 @@ __global__ __launch_bounds__(kNT, 2) void ns256_pass_f64(NSConst C, NSScal<doubl
       if (a < kRR) {
         rq[a][0] = q0; rq[a][1] = q1; rq[a][2] = q2; rq[a][3] = q3;
       } else {
-        rql[(a - kRR) * kNT] = D4{make_double2(q0, q1), make_double2(q2, q3)};
+        rql[(a - kRR) * (2 * kPlane)] = make_double2(q0, q1);
+        rql[(a - kRR) * (2 * kPlane) + kPlane] = make_double2(q2, q3);
       }
     }
 #pragma unroll

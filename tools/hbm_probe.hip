@@ -4,7 +4,7 @@
 // Three kernels, 16 bytes per lane and access, grid-stride with a workgroup-contiguous 4 KiB chunk per iteration (every wave's
 // load is one fully coalesced 1 KiB request group), UNROLL independent loads in flight per lane before the first use:
 //   copy : dst[i] = src[i]                   (read + write: 2 x bytes of traffic)
-//   read : sum of src (one atomic per wave)  (read only)
+//   read : sum of src, never stored          (read only)
 //   fill : dst[i] = const                    (write only)
 // Built into pdecontrolgym_amd/lib/libpdegym_probe.so by pdecontrolgym_amd/build.py; NOT part of the product ABI
 // (include/pdegym.h) and not under csrc/, so the kernel fingerprints of the product library do not depend on it.
@@ -60,10 +60,10 @@ __global__ __launch_bounds__(BLOCK) void probe_read(float* __restrict__ out, con
 #pragma unroll
         for (int k = 0; k < UNROLL; ++k) acc += v[k];
     }
-    float s = acc.x + acc.y + acc.z + acc.w;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+    // keep the loads alive without write traffic or same-address atomics (8192+ atomics on one word serialise at ~10 ns each and
+    // were the whole time of the 64 MiB read in the first version): a store that data of this probe (normal deviates) never takes
+    const float s = acc.x + acc.y + acc.z + acc.w;
+    if (s == 1.2345678e38f) out[0] = s;
 }
 
 template <bool NT>
