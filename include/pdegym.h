@@ -272,8 +272,12 @@ int pdegym_ns2d_step_f64(const pdegym_params_ns2d* prm, const pdegym_bufs_ns2d* 
  * (NS2Doptimization.py:74-76) with the commands given ahead.  Step t reads the state from obs slot t and the command from actions row
  * t, writes obs slot t + 1 and rewards / terminated row t; p, time_index, U_ref / action_ref, the auto-reset pools, final_obs and
  * reset_count come from the pdegym_bufs_ns2d of the call and behave as in T consecutive pdegym_ns2d_step calls with state_in (fused
- * auto-reset included; the pressure stays in bufs->p) -- the results are bit-identical to those calls.  bufs->u / v / state_in / obs /
- * action / reward / terminated / p_out are ignored. */
+ * auto-reset included; the pressure stays in bufs->p).  Observation slots, pressure, flags, time index and restart counters are
+ * bit-identical to those calls.  The REWARDS are bit-identical to step calls that take the same (column-per-lane) kernel -- the
+ * default for float32 at any batch and for float64 batches of at least 400 instances per 1024 SIMDs of the device; a smaller float64
+ * batch steps on the workgroup-per-instance kernel, which adds the reward's squared distances in another order: same fields, rewards
+ * equal to ~1e-15 relative (so a float64 instance's reward BITS depend on whether its batch is below or above that size).
+ * bufs->u / v / state_in / obs / action / reward / terminated / p_out are ignored. */
 typedef struct pdegym_rollout_ns2d {
   int32_t T;                /* env-steps per call                                                              */
   int32_t reserved_;

@@ -41,15 +41,16 @@ class DeviceRollout:
         # caller fills the buffer in place before each run() (e.g. ``ro.action_noise.normal_().mul_(std)``): a replayed graph
         # reads the new draws.
         self.action_noise = torch.zeros_like(self.actions, dtype=torch.float32) if action_noise else None
-        # transport / reaction-diffusion with full-state sensing, or traffic, and a small FusedMLP: the WHOLE rollout is one
+        # transport / reaction-diffusion (any control / sensing combination), or traffic, and a FusedMLP of <= 256-unit layers: the WHOLE rollout is one
         # kernel launch (pdegym_*_rollout with the policy inside: no kernel boundary between env-steps, none between policy and step).
         # one_launch=None: whenever it applies; True: required; False: T x (policy launch + step launch) as for the others.
         self._traffic = kind == "traffic"
         fits = bool(hasattr(core, "policy_fits_rollout") and core.policy_fits_rollout(policy)
                     and dt == (torch.float64 if self._traffic else torch.float32))
         if one_launch and not fits:
-            raise ValueError("one_launch=True needs a transport / reaction-diffusion engine with full-state sensing or a traffic "
-                             "engine of <= 64 nodes, and a FusedMLP of <= 64-unit layers")
+            raise ValueError("one_launch=True needs a transport / reaction-diffusion engine whose state has one home (any control / "
+                             "sensing combination, no history, float32 operands) or a traffic engine of <= 64 nodes, and a FusedMLP "
+                             "that fits the rollout kernel (layers of <= 256 units, see policy_fits_rollout)")
         self.one_launch = fits if one_launch is None else bool(one_launch)
         # device-side sensing noise (PDEVecEnv(sensing_noise_tensor_func=...)): the policy reads obs_seen[t] = f(obs[t]) while
         # obs[t] -- the plant state with full-state sensing -- stays clean; the call is part of the captured graph (torch's

@@ -18,7 +18,12 @@ from __future__ import annotations
 
 import numpy as np
 
+import sys
+
 from pde_control_gym._compat import VecEnv, spaces
+
+# sys.getrefcount is exact only on CPython with the GIL (PyPy has no reference counts, a free-threaded build defers / biases them)
+_REFCOUNT_IS_EXACT = sys.implementation.name == "cpython" and getattr(sys, "_is_gil_enabled", lambda: True)()
 
 _KINDS = {
     "PDEControlGym-TransportPDE1D": "transport", "transport": "transport", "TransportPDE1D": "transport",
@@ -89,9 +94,22 @@ class BatchedVecEnv(VecEnv):
         return {"core": self.core.state_dict(), "face": face, "fused_reset": bool(getattr(self, "_fused_reset", False))}
 
     def load_state_dict(self, sd):
+        import torch
+        face = sd.get("face", {})
+        mine = {k: getattr(self, k, None) for k in self._checkpoint_attrs}
+        mine = {k: v for k, v in mine.items() if torch.is_tensor(v)}
+        # the face's own tensors (e.g. the NavierStokes2D frame history kept for a host-side reward) exist only in some
+        # configurations: a checkpoint from another one is refused before anything is copied
+        if set(face) != set(mine):
+            raise ValueError(f"checkpoint holds the face tensors {sorted(face)}, this environment keeps {sorted(mine)} "
+                             "(built with another reward / sensing configuration?)")
+        for k, v in face.items():
+            if tuple(mine[k].shape) != tuple(v.shape) or mine[k].dtype != v.dtype:
+                raise ValueError(f"checkpoint tensor {k!r} is {tuple(v.shape)} {v.dtype}, this environment's is "
+                                 f"{tuple(mine[k].shape)} {mine[k].dtype}")
         self.core.load_state_dict(sd["core"])
-        for k, v in sd["face"].items():
-            getattr(self, k).copy_(v)
+        for k, v in face.items():
+            mine[k].copy_(v)
         if hasattr(self, "_fused_reset"):
             self._fused_reset = bool(sd["fused_reset"])
         self._actions = None
@@ -101,7 +119,7 @@ class PDEVecEnv(BatchedVecEnv):
     _checkpoint_attrs = ("_ns_hist",)
 
     def __init__(self, env_id: str, num_envs: int, device="cuda", backend=None, batched_reset_func=None,
-                 dtype=None, copy_outputs: bool = True, **kw):
+                 dtype=None, copy_outputs=None, **kw):
         import torch
         if env_id not in _KINDS:
             raise KeyError(f"No registered env with id: {env_id}")
@@ -112,10 +130,12 @@ class PDEVecEnv(BatchedVecEnv):
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
         self.batched_reset_func = batched_reset_func
-        # The arrays step() returns stay valid for as long as the caller references them, as the reference's do (_to_host: pinned
-        # staging buffers recycled by reference count).  ``copy_outputs`` is accepted for compatibility with round-3 callers and
-        # has no effect any more.
-        self.copy_outputs = bool(copy_outputs)
+        # The arrays step() returns stay valid for as long as the caller references them, as the reference's do.  copy_outputs=None
+        # (default): views of pinned staging buffers recycled by reference count (_to_host) -- on CPython with the GIL, for
+        # consumers that read the arrays on the host or on the stream the environment runs on; plain NumPy copies on any other
+        # interpreter.  copy_outputs=True: always plain copies (a consumer that starts its own asynchronous copy from the array on
+        # ANOTHER stream and drops it before that copy has run, tools that hold hidden references).  False: as None (round-3 callers).
+        self.copy_outputs = None if copy_outputs is None else bool(copy_outputs)
         # state_in_obs=False (1D) / interleaved_state=False (NavierStokes2D) in the parameters: the engine keeps the plant state in
         # its own tensors and the observation is a separate output -- for torch callers that normalise or perturb the tensors
         # returned by step_tensor() / reset_tensor() IN PLACE (by default those tensors ARE the state: read-only).
@@ -427,7 +447,9 @@ class PDEVecEnv(BatchedVecEnv):
         ONE stream synchronisation for all of them; ``t.cpu()`` per tensor goes through pageable memory and synchronises every
         time) into a pinned staging buffer THAT NOBODY REFERENCES ANY MORE, and the NumPy view of that buffer is what the caller
         gets.  "Nobody references" is the reference count of the view: an array the caller still holds -- directly or through
-        any view or slice of it, which keep their base alive -- is never written again; once dropped it is recycled.  An
+        any view or slice of it, which keep their base alive -- is never written again; once dropped it is recycled (so a consumer
+        must be done with the array when it drops it: reading it on the host, or enqueueing work on the environment's own stream,
+        is; an asynchronous copy on another stream that outlives the array is not -- ``copy_outputs=True`` serves that).  An
         SB3-style loop (copies what it keeps into its rollout buffer) therefore cycles through two or three buffers; a caller
         that appends every observation to a list keeps getting new ones (``host_buffers`` pinned, plain NumPy copies beyond)."""
         import sys
@@ -436,10 +458,13 @@ class PDEVecEnv(BatchedVecEnv):
             return [t.numpy().copy() for t in tensors]
         pools = self.__dict__.setdefault("_pins", {})
         out, spill = [], []
+        # "the caller has dropped it" is read off the reference count: exact on CPython with the GIL, not on PyPy or a free-threaded
+        # build (and copy_outputs=True asks for copies outright) -- there every result is a plain copy staged through one pinned buffer
+        recycle = _REFCOUNT_IS_EXACT and self.copy_outputs is not True
         for i, t in enumerate(tensors):
             pool = pools.setdefault(("out", i, tuple(t.shape), t.dtype), [])
-            k = next((k for k in range(len(pool)) if sys.getrefcount(pool[k][1]) == 2), None)    # the pool's reference + the argument
-            if k is None and len(pool) < max(2, int(self.host_buffers)):
+            k = next((k for k in range(len(pool)) if sys.getrefcount(pool[k][1]) == 2), None) if recycle else None   # the pool's reference + the argument
+            if recycle and k is None and len(pool) < max(2, int(self.host_buffers)):
                 pin = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
                 pool.append((pin, pin.numpy()))
                 k = len(pool) - 1

@@ -303,9 +303,11 @@ class PDEBatch1D(EngineCheckpoint):
         ``policy`` (a ``FusedMLP`` with layers of at most 256 units and one output, see ``policy_fits_rollout``): evaluated
         inside the launch on ``obs[t]`` (+ ``obs_noise[t]`` [T, B, obs_dim], the pre-drawn sensing noise; ``obs_seen[t]``
         receives what the policy read); ``actions[t]`` then RECEIVES the command (after ``noise[t]`` [T, B] float32 and the
-        clamp).  The in-kernel network sums each neuron in one fmaf chain, ``policy.forward_into`` in MFMA group order: the
-        commands agree to float32 rounding (rtol ~2e-5), NOT bit for bit, and trajectories drift apart accordingly -- only the
-        environment arithmetic is bit-identical to step calls (given the same commands)."""
+        clamp).  A policy with a layer of 65 .. 256 units is evaluated by the 16 waves of a workgroup in ``policy.forward_into``'s
+        own MFMA reduction order: commands -- hence whole trajectories -- are bit-identical to the two-launch loop
+        (``forward_into`` + ``step``).  A policy whose layers all have <= 64 units sums each neuron in one fmaf chain instead:
+        its commands agree with ``forward_into`` to float32 rounding (rtol ~2e-5), NOT bit for bit, and trajectories drift apart
+        accordingly -- the environment arithmetic is bit-identical to step calls either way (given the same commands)."""
         if not self.can_rollout():
             raise ValueError("rollout needs a state with one home (full-state sensing: state_in_obs; no history) and float32 operands")
         self.params.action_kind = N.ACTION_F32
@@ -333,8 +335,14 @@ class PDEBatch1D(EngineCheckpoint):
 
     # ---- checkpoint / resume (pdecontrolgym_amd/checkpoint.py) ---------------------------------------------
     def _checkpoint_meta(self):
+        # the reward kind / horizon decide what the norm ring HOLDS (TunedReward1D: 2-norms of look-back rows; NormReward "t-horizon":
+        # the reward's own norm of every recent row), sensing / control what the observation and the boundary sums mean: a
+        # checkpoint of one configuration must not load silently into another
         return {"engine": "PDEBatch1D", "kind": self.kind, "flux": self.flux, "num_envs": self.num_envs, "n": self.n,
-                "nt": self.nt, "substeps": self.substeps, "obs_dim": self.obs_dim, "state_in_obs": bool(self.state_in_obs)}
+                "nt": self.nt, "substeps": self.substeps, "obs_dim": self.obs_dim, "state_in_obs": bool(self.state_in_obs),
+                "reward_kind": int(self.params.reward_kind), "reward_horizon": int(self.params.reward_horizon),
+                "reward_t_horizon": int(self.params.reward_t_horizon), "sensing": int(self.sensing),
+                "control_type": str(self.control_type)}
 
     def _after_load(self, sd):
         import torch

@@ -184,8 +184,11 @@ class NSBatch2D(EngineCheckpoint):
     def rollout(self, obs, actions, rewards, terminated):
         """T env-steps in ONE launch (include/pdegym.h: pdegym_ns2d_rollout_*), commands given ahead: step t takes ``actions[t]``
         ([T, B, action_dim]) and writes ``obs[t + 1]`` ([T+1, B, ny, nx, 2]; ``obs[0]`` = the state the rollout starts from),
-        ``rewards[t]``, ``terminated[t]`` -- bit-identical to T calls of ``step(actions[t], out_obs=obs[t + 1], ...)``, fused
-        auto-reset included.  Afterwards the engine's current observation (its state) is a copy of ``obs[T]``."""
+        ``rewards[t]``, ``terminated[t]`` -- fields, flags and counters bit-identical to T calls of ``step(actions[t],
+        out_obs=obs[t + 1], ...)``, fused auto-reset included.  Rewards are bit-identical to step calls that run on the same
+        (column-per-lane) kernel: float32 always, float64 from 400 instances per 1024 SIMDs; smaller float64 batches step on the
+        workgroup kernel, which sums the reward in another order (equal to ~1e-15 relative; include/pdegym.h).  Afterwards the
+        engine's current observation (its state) is a copy of ``obs[T]``."""
         if not self.can_rollout():
             raise ValueError("rollout needs one of the column kernel's grids (8 / 11 / 16 / 21 / 26 / 31 / 32 rows, <= 64 columns) "
                              "and the interleaved state layout")

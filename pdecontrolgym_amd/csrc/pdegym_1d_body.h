@@ -100,6 +100,80 @@ __device__ __forceinline__ float slots_sumsq(const float (&x)[EPL], int s0, int 
 // (a+1)*m-m, base_env_1d.py:36-39
 __device__ __forceinline__ float normalize_ctrl(float a, float m, int on) { return on ? (a + 1.0f) * m - m : a; }
 
+// s_waitcnt vmcnt(0) as a real instruction (the compiler's wait-count pass sees it): the carried rollout loop ends every RARE
+// path that loads (exact redo, auto-reset) with it, so that no register is "possibly still being loaded" at the loop's back edge --
+// otherwise the pass puts a static vmcnt(0) in front of the first use of each such register in EVERY iteration, and on gfx9 that
+// also waits for all the stores in flight (vmcnt counts both).
+__device__ __forceinline__ void drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0), expcnt / lgkmcnt untouched
+
+// The norm ring of one instance (PDEGYM_RING slots, slot = fine time index mod PDEGYM_RING) as the step body sees it.
+// RingMem: the ring in memory, written and read by lane 0 alone (program order of one lane).
+// RingReg (the carried rollout kernels, round 5): the 128 slots live in TWO registers per lane for the whole launch (lane l holds
+// slots l and 64 + l) -- a rollout step neither loads from nor stores to the ring, so nothing in its steady state waits on vmcnt
+// (gfx9 counts loads AND stores in vmcnt: the one ring load per env-step made every step wait for the 13 stores of the step before;
+// SQ_WAIT_ANY was 57 % of the wave cycles of parabolic_c2_s1_open_loop_rollout, profiles/r04p_summary.json).  The memory ring is
+// read once at the head of the launch and written back once at its end (rollout1d_kernel).  Values are wave-uniform.
+struct RingMem {
+  float* mem;
+  __device__ __forceinline__ void put(int idx, float v, int lane) {
+    if (lane == 0) mem[idx] = v;
+  }
+  __device__ __forceinline__ float get(int idx, int lane) const { return lane == 0 ? mem[idx] : 0.f; }   // lane 0's value
+};
+struct RingReg {
+  float lo, hi;
+  __device__ __forceinline__ void put(int idx, float v, int lane) {
+    lo = (lane == idx) ? v : lo;
+    hi = (lane + kWave == idx) ? v : hi;
+  }
+  __device__ __forceinline__ float get(int idx, int) const {
+    const float src = (idx & kWave) ? hi : lo;
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, src), idx & (kWave - 1)));
+  }
+};
+static_assert(PDEGYM_RING == 2 * kWave, "RingReg keeps the ring in two registers per lane");
+
+// EPL consecutive floats of one lane from / to a row (`base` = the row's first slot: 4-byte aligned, rows of 257 floats are not
+// 16-byte aligned): a lane whose slots are all inside the row moves them as dwordx4 / x2 pieces (gfx950 global accesses need no
+// alignment beyond the dword; the type says so to the compiler), the row's last lanes fall back to guarded dwords.
+typedef float pdegym_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float pdegym_f2u __attribute__((ext_vector_type(2), aligned(4)));
+template <int EPL>
+__device__ __forceinline__ void store_slots(float* base, const float (&x)[EPL], int s0, int ns) {
+  if (s0 + EPL <= ns) {
+    float* p = base + s0;
+    constexpr int Q = EPL / 4 * 4, D = (EPL - Q) / 2 * 2;
+#pragma unroll
+    for (int e = 0; e < Q; e += 4) *reinterpret_cast<pdegym_f4u*>(p + e) = pdegym_f4u{x[e], x[e + 1], x[e + 2], x[e + 3]};
+    if constexpr (D == 2) *reinterpret_cast<pdegym_f2u*>(p + Q) = pdegym_f2u{x[Q], x[Q + 1]};
+    if constexpr (Q + D < EPL) p[EPL - 1] = x[EPL - 1];
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+      if (s0 + e < ns) base[s0 + e] = x[e];
+  }
+}
+template <int EPL>
+__device__ __forceinline__ void load_slots(const float* base, float (&x)[EPL], int s0, int ns) {
+  if (s0 + EPL <= ns) {
+    const float* p = base + s0;
+    constexpr int Q = EPL / 4 * 4, D = (EPL - Q) / 2 * 2;
+#pragma unroll
+    for (int e = 0; e < Q; e += 4) {
+      const pdegym_f4u v = *reinterpret_cast<const pdegym_f4u*>(p + e);
+      x[e] = v.x; x[e + 1] = v.y; x[e + 2] = v.z; x[e + 3] = v.w;
+    }
+    if constexpr (D == 2) {
+      const pdegym_f2u v = *reinterpret_cast<const pdegym_f2u*>(p + Q);
+      x[Q] = v.x; x[Q + 1] = v.y;
+    }
+    if constexpr (Q + D < EPL) x[EPL - 1] = p[EPL - 1];
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) x[e] = (s0 + e < ns) ? base[s0 + e] : 0.f;
+  }
+}
+
 // Row of the reset pools that the next restart of instance `inst` takes (see pdegym_bufs1d.reset_pool_rows).
 __device__ __forceinline__ int pool_row(const pdegym_bufs1d& Bf, int inst, int B) {
   const int rows = Bf.reset_pool_rows > 0 ? Bf.reset_pool_rows : B;
@@ -148,6 +222,7 @@ struct Carry {
   float norm;     // ||row||_2 as the previous step (or the prologue) computed it: an upper bound of max |row[j]|
   int t;
   double bsum;
+  RingReg ring;   // the instance's norm ring, register-resident for the launch
 };
 
 // The reward's own norm of a register-resident row (NormReward kinds; same expressions as the epilogue of step1d_body), for the
@@ -174,9 +249,10 @@ __device__ __forceinline__ float kind_norm(const float (&x)[EPL], float bl, int 
 // sub-step, i.e. parabolic Neumann control).
 // M64: float64 beta and/or float64 / Python-float control (pdegym_params1d.beta_f64 / action_kind): the select form with the
 // reference's mixed-precision expressions (see step1d_wide_kernel for the same arithmetic on LDS-resident rows).
-template <int EPL, bool PARABOLIC, bool NEUMANN, bool FAST, bool HIST, bool BURGERS = false, bool M64 = false, bool ROLL = false>
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool FAST, bool HIST, bool BURGERS = false, bool M64 = false, bool ROLL = false,
+          typename RingT = RingMem>
 __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EPL], const pdegym_params1d& P, int nsub,
-                                             float a, float* ring, float* hist, int lane, const double* b64 = nullptr, double a64 = 0.0,
+                                             float a, RingT& ring, float* hist, int lane, const double* b64 = nullptr, double a64 = 0.0,
                                              float* xprev = nullptr, float* blprev = nullptr, int thor_k = 0) {
   // xprev/blprev (select form only): the row BEFORE the last sub-step, for NormReward's "differential" horizon
   // thor_k (select form only): NormReward "t-horizon" of length thor_k -- the reward's norm of each of the last thor_k - 1 rows
@@ -374,7 +450,7 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
   auto record_norm = [&](int done) {
     if (done < nsub && (rec_all || R.k == 0 || R.t + PDEGYM_LOOKBACK == P.nt - 1)) {
       const float nr = sqrtf(slots_sumsq<EPL>(R.x, s0, ns));  // node 0 is 0 after any sub-step
-      if (lane == 0) ring[R.t & (PDEGYM_RING - 1)] = nr;
+      ring.put(R.t & (PDEGYM_RING - 1), nr, lane);
       if (R.t == R.back_row) R.back_norm = nr;                // this call's own look-back row: no memory round trip
     }
   };
@@ -434,7 +510,7 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
       record_norm(s + 1);
       if (thor_k > 0 && s + 1 < nsub && nsub - (s + 1) < thor_k) {    // wave-uniform; after record_norm: this slot holds the reward's norm
         const float nk = kind_norm<EPL>(R.x, R.bl, s0, ns, P.reward_kind);
-        if (lane == 0) ring[R.t & (PDEGYM_RING - 1)] = nk;
+        ring.put(R.t & (PDEGYM_RING - 1), nk, lane);
       }
     }
   }
@@ -446,22 +522,21 @@ __device__ __forceinline__ void load_row(Row<EPL>& R, float (&beta)[EPL], const 
                                          int lane) {
   constexpr int J0 = PARABOLIC ? 1 : 0;
   const int ns = n - J0, s0 = lane * EPL;
-#pragma unroll
-  for (int e = 0; e < EPL; ++e) {
-    const bool ok = s0 + e < ns;
-    R.x[e] = ok ? urow[J0 + s0 + e] : 0.f;
-    beta[e] = ok ? brow[J0 + s0 + e] : 0.f;
-  }
+  load_slots<EPL>(urow + J0, R.x, s0, ns);
+  load_slots<EPL>(brow + J0, beta, s0, ns);
   R.bl = PARABOLIC ? urow[0] : 0.f;
 }
 
 // One env-step of one instance by one wave: the body of step1d_kernel, and of every iteration of rollout1d_kernel.
-// CARRY (rollout1d_kernel): the state enters and leaves through *carry instead of memory -- no row / beta / time-index / sum
-// loads at the head of the step; the stores stay (observation slot t + 1, scalars), nothing waits for them.
+// CARRY (rollout1d_kernel): the state enters and leaves through *carry instead of memory -- no row / beta / time-index / sum /
+// ring loads at the head of the step.  What a step stores is what a caller can see of it afterwards: observation slot t + 1 and
+// row t of the reward / flag arrays always; the per-instance state words that every step would overwrite (norm_now, norm_back,
+// time_index, bsum -- and the ring, kept in registers) only when store_state says this is the launch's last step.
 template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false, bool M64 = false, bool ROLL = false,
           bool CARRY = false>
 __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdegym_bufs1d& Bf, const int B, const int inst,
-                                            const int lane, const float* command = nullptr, Carry<EPL>* carry = nullptr) {
+                                            const int lane, const float* command = nullptr, Carry<EPL>* carry = nullptr,
+                                            const bool store_state = true) {
   constexpr int J0 = PARABOLIC ? 1 : 0;
   constexpr bool kFast = !NEUMANN && !HIST && !M64;
   static_assert(!CARRY || kFast, "the carried state is the float32 Dirichlet rollout path");
@@ -479,7 +554,11 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
   const bool beta64 = M64 && P.beta_f64;
   // float32 beta row; in the mixed-precision mode with a float64 beta it is read as double below (beta then stays zero)
   const float* brow = beta64 ? urow_in : static_cast<const float*>(Bf.beta) + (size_t)inst * Bf.beta_stride;
-  float* ring = Bf.ring + (size_t)inst * PDEGYM_RING;
+  float* const ring_mem = Bf.ring + (size_t)inst * PDEGYM_RING;
+  using RingT = std::conditional_t<CARRY, RingReg, RingMem>;
+  RingT ring;
+  if constexpr (CARRY) ring = carry->ring;
+  else ring.mem = ring_mem;
   float* hist = (HIST && Bf.history) ? Bf.history + (size_t)inst * P.nt * n : nullptr;
 
   Row<EPL> R;
@@ -528,7 +607,7 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
   const bool zero_row = (tb < 0 && src_row > t_end) || src_row < 0;
   const bool from_ring = !zero_row && src_row <= t_in;
   float norm_back_pre = 0.f;
-  if (from_ring && lane == 0) norm_back_pre = ring[src_row & (PDEGYM_RING - 1)];
+  if (from_ring) norm_back_pre = ring.get(src_row & (PDEGYM_RING - 1), lane);
   R.back_row = (!zero_row && !from_ring) ? src_row : -1;
   R.back_norm = 0.f;
 
@@ -548,7 +627,7 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
   if constexpr (!kFast) {
     if (thor_k > 0) {
       const float nk0 = kind_norm<EPL>(R.x, R.bl, s0, ns, P.reward_kind);
-      if (lane == 0) ring[t_in & (PDEGYM_RING - 1)] = nk0;
+      ring.put(t_in & (PDEGYM_RING - 1), nk0, lane);
     }
   }
   float norm_now;
@@ -596,7 +675,10 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         load_row<EPL, PARABOLIC>(R, beta, urow_in, brow, n, lane);
-        if constexpr (CARRY) R.bl = carry->bl;
+        if constexpr (CARRY) {
+          R.bl = carry->bl;
+          drain_vmem();
+        }
         R.t = t_in;
         R.k = (t_in + PDEGYM_LOOKBACK) % S;
         R.bsum = bsum_in;
@@ -620,7 +702,7 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
   // ---- epilogue: norms, flags, reward, observation ------------------------------------------------
   const bool rec_all = P.nt <= PDEGYM_RING;
   if (nsub > 0 && (rec_all || R.k == 0 || t + PDEGYM_LOOKBACK == P.nt - 1)) {
-    if (lane == 0) ring[t & (PDEGYM_RING - 1)] = norm_now;
+    ring.put(t & (PDEGYM_RING - 1), norm_now, lane);
   }
   const bool terminate = t >= P.nt - 1;                                 // hyperbolic.py:171-180
   const bool truncate = P.limit_state && (norm_now >= P.max_state);     // hyperbolic.py:182-194
@@ -658,10 +740,10 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
   float thor_mean = 0.f;
   if constexpr (!kFast) {
     if (thor_k > 0 && lane == 0) {      // -sum(norm(u[t - i]) for i in range(k)) / k, k = min(t_horizon_length, t + 1): one float32 chain
-      if (nsub > 0) ring[t & (PDEGYM_RING - 1)] = nr_alt;
+      if (nsub > 0) ring.mem[t & (PDEGYM_RING - 1)] = nr_alt;
       const int kk = thor_k < t + 1 ? thor_k : t + 1;
       float acc = nr_alt;
-      for (int i = 1; i < kk; ++i) acc += ring[(t - i) & (PDEGYM_RING - 1)];
+      for (int i = 1; i < kk; ++i) acc += ring.mem[(t - i) & (PDEGYM_RING - 1)];
       thor_mean = acc / (float)kk;
     }
   }
@@ -694,9 +776,7 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
     if (P.sensing == PDEGYM_SENSE_FULL) {
       float* orow = obs_base + (size_t)inst * n;
       if (PARABOLIC && lane == 0) orow[0] = R.bl;
-#pragma unroll
-      for (int e = 0; e < EPL; ++e)
-        if (s0 + e < ns) orow[J0 + s0 + e] = R.x[e];
+      store_slots<EPL>(orow + J0, R.x, s0, ns);
     } else {
       float o;
       if (P.sensing == PDEGYM_SENSE_LAST) o = node(n - 1);
@@ -708,20 +788,20 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
   };
   if (lane == 0) {
     if (P.reward_kind != PDEGYM_REWARD_NONE) Bf.reward[inst] = reward;
-    Bf.norm_now[inst] = norm_now;
-    Bf.norm_back[inst] = norm_back;
+    if (store_state) {
+      Bf.norm_now[inst] = norm_now;
+      Bf.norm_back[inst] = norm_back;
+    }
     Bf.terminated[inst] = terminate ? 1 : 0;
     Bf.truncated[inst] = truncate ? 1 : 0;
   }
   if (!auto_reset) {
     if (nsub > 0 && urow) {
       if (PARABOLIC && lane == 0) urow[0] = R.bl;
-#pragma unroll
-      for (int e = 0; e < EPL; ++e)
-        if (s0 + e < ns) urow[J0 + s0 + e] = R.x[e];
+      store_slots<EPL>(urow + J0, R.x, s0, ns);
     }
     emit_obs(Bf.obs);
-    if (lane == 0) {
+    if (lane == 0 && store_state) {
       Bf.time_index[inst] = t;
       Bf.bsum[inst] = R.bsum;
     }
@@ -770,26 +850,28 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
     const float n0 = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
     const float last = node(n - 1);
     emit_obs(Bf.obs);
-    if (lane == 0) {
+    if (lane == 0 && store_state) {
       Bf.time_index[inst] = 0;
       Bf.bsum[inst] = (double)fabsf(last);
-      ring[0] = n0;
     }
+    ring.put(0, n0, lane);
     if constexpr (CARRY) {
       carry->t = 0;
       carry->bsum = (double)fabsf(last);
       carry->norm = n0;
+      drain_vmem();
     }
   }
   if constexpr (CARRY) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) carry->x[e] = R.x[e];
     carry->bl = R.bl;
+    carry->ring = ring;
   }
 #ifdef PDEGYM_TIMING
   if (lane == 0) {
     const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
-    unsigned int* dbg = reinterpret_cast<unsigned int*>(ring) + 116;
+    unsigned int* dbg = reinterpret_cast<unsigned int*>(ring_mem) + 116;
     dbg[0] = (unsigned int)tm0; dbg[1] = (unsigned int)(tm0 >> 32);
     dbg[2] = (unsigned int)(tm1 - tm0); dbg[3] = (unsigned int)(tm2 - tm1); dbg[4] = (unsigned int)(tm3 - tm2);
     dbg[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
@@ -820,6 +902,18 @@ __device__ __forceinline__ void carry_load(Carry<EPL>& C, const pdegym_params1d&
   C.norm = sqrtf(slots_sumsq<EPL>(C.x, s0, ns) + C.bl * C.bl);
   C.t = __builtin_amdgcn_readfirstlane(Bf.time_index[inst]);
   C.bsum = Bf.bsum[inst];
+  const float* ring = Bf.ring + (size_t)inst * PDEGYM_RING;
+  C.ring.lo = ring[lane];
+  C.ring.hi = ring[kWave + lane];
+  drain_vmem();
+}
+
+// ... and the ring written back at the end of the launch (the other state words were stored by the last step, store_state).
+template <int EPL>
+__device__ __forceinline__ void carry_store_ring(const Carry<EPL>& C, const pdegym_bufs1d& Bf, int inst, int lane) {
+  float* ring = Bf.ring + (size_t)inst * PDEGYM_RING;
+  ring[lane] = C.ring.lo;
+  ring[kWave + lane] = C.ring.hi;
 }
 
 }  // namespace

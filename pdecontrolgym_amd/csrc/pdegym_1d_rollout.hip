@@ -18,13 +18,23 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void rollout1d_kernel(pdegym
   const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (inst >= B) return;  // wave-uniform
   const size_t slot = (size_t)B * P.n;
-  // The state stays in registers over the T env-steps (Carry); each step still stores its observation slot and scalars, but
-  // no step waits for memory at its head -- the next command is fetched one step ahead, and the norm ring is read and written
-  // by lane 0 alone (program order of one lane).
+  // The state -- row, beta, time index, sums AND the norm ring -- stays in registers over the T env-steps (Carry).  Round 5: the
+  // steady state of the loop has NO load at all: the commands of 64 env-steps arrive in one load per lane (lane l holds step
+  // t0 + l; handed out by v_readlane), the ring is two registers per lane, and the per-instance
+  // state words that every step would overwrite are stored by the last step only.  gfx9 counts loads and stores in one counter
+  // (vmcnt), so the single ring / command load per env-step of the round-4 loop made every step wait for the stores of the step
+  // before (SQ_WAIT_ANY 57 % of the wave cycles at S = 1); now only the batch hand-over, once per 64 env-steps, waits.
   Carry<EPL> C;
   carry_load<EPL, PARABOLIC>(C, P, Bf, Ro.obs, inst, lane);
-  float a_next = Ro.actions[inst];
+  auto command_batch = [&](int t0) { return (t0 + lane < Ro.T) ? Ro.actions[(size_t)(t0 + lane) * B + inst] : 0.f; };
+  float a_cur = command_batch(0);
+  drain_vmem();
   for (int t = 0; t < Ro.T; ++t) {
+    const int j = t & (kWave - 1);
+    if (j == 0 && t) {      // wave-uniform; once per 64 env-steps, the loop's only wait for memory
+      a_cur = command_batch(t);
+      drain_vmem();
+    }
     pdegym_bufs1d S = Bf;
     S.u = nullptr;
     S.history = nullptr;
@@ -34,10 +44,10 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void rollout1d_kernel(pdegym
     S.reward = Ro.rewards + (size_t)t * B;
     S.terminated = Ro.terminated + (size_t)t * B;
     S.truncated = Ro.truncated + (size_t)t * B;
-    const float a = a_next;
-    if (t + 1 < Ro.T) a_next = Ro.actions[(size_t)(t + 1) * B + inst];
-    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false, true, true>(P, S, B, inst, lane, &a, &C);
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_cur), j));
+    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false, true, true>(P, S, B, inst, lane, &a, &C, t == Ro.T - 1);
   }
+  carry_store_ring<EPL>(C, Bf, inst, lane);
 }
 
 
@@ -149,8 +159,9 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy
     S.reward = Ro.rewards + (size_t)t * B;
     S.terminated = Ro.terminated + (size_t)t * B;
     S.truncated = Ro.truncated + (size_t)t * B;
-    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false, true, true>(P, S, B, inst, lane, &a, &C);
+    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false, true, true>(P, S, B, inst, lane, &a, &C, t == Ro.T - 1);
   }
+  if (active) carry_store_ring<EPL>(C, Bf, inst, lane);
 }
 
 // The policy in front of the general step (Neumann actuation / scalar sensing): its input is observation slot t as stored -- od = n

@@ -25,4 +25,17 @@ inline bool raise_dynamic_lds_limit(const void* kernel, int bytes, signed char (
   return slots[dev] > 0;
 }
 
+// SIMDs of the current device (compute units x 4), cached per device: launch heuristics that mean "at most one wave per SIMD" ask
+// here instead of assuming the 256 CUs of an unpartitioned MI355X (a CPX / DPX partition or another SKU has fewer).
+inline int simd_count() {
+  static int cached[kMaxDevices] = {};
+  const int dev = current_device();
+  if (cached[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cached[dev] = cus * 4;
+  }
+  return cached[dev];
+}
+
 }  // namespace pdegym

@@ -1656,12 +1656,15 @@ template <typename T>
 bool launch_ns_col(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int B, hipStream_t st) {
   if (C.nx < 3 || C.nx > 64) return false;
   const int dbg = g_debug[PDEGYM_DEBUG_NS_COL_MIN_BATCH];
-  const int min_batch = dbg >= 0 ? dbg : (sizeof(T) == 8 ? 400 : 1);
+  // float64 crossover: 400 instances on the 1024 SIMDs of an unpartitioned MI355X (three instances per wave at 21 columns), scaled
+  // with the SIMD count of the device the call runs on
+  const int simds = pdegym::simd_count();
+  const int min_batch = dbg >= 0 ? dbg : (sizeof(T) == 8 ? (int)((400LL * simds + 512) / 1024) : 1);
   if (B < min_batch) return false;
   const int G = 64 / C.nx;
   const dim3 grid((B + G - 1) / G), block(64);
   if constexpr (sizeof(T) == 8) {
-    if (grid.x <= 1024) {        // at most one wave per SIMD anyway: the build without spills (ns_col_step_w1)
+    if ((int)grid.x <= simds) {  // at most one wave per SIMD anyway: the build without spills (ns_col_step_w1)
       switch (C.ny) {
         case 16: hipLaunchKernelGGL((ns_col_step_w1<T, 16>), grid, block, 0, st, C, S, P, B); return true;
         case 21: hipLaunchKernelGGL((ns_col_step_w1<T, 21>), grid, block, 0, st, C, S, P, B); return true;

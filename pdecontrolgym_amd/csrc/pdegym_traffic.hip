@@ -17,10 +17,29 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 
+// Wave-wide float64 sum on DPP (result in every lane).  Round 5: __shfl_xor compiles to ds_bpermute_b32 -- two per double and
+// step, 24 LDS round trips for the two reward norms of an env-step, each ~25 cycles of the wave's SIMD (DESIGN.md section 4:
+// tools/ab_ns_col.py).  Same scheme as wave_reduce of the 1D kernels: lane pair, quad (quad_perm), half row, row (row_half_mirror /
+// row_mirror), lane 15 of rows 0 and 2 into rows 1 and 3 (row_bcast:15), lane 31 into rows 2, 3 (row_bcast:31); lane 63 holds the
+// total and v_readlane hands it to everybody.  A fixed order (deterministic): the reward norms were never bitwise against BLAS
+// ddot (tests: rtol 1e-12); step and rollout kernels share it, so they stay bit-identical to each other.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_d(double v) {      // lanes without a source (or masked rows) read 0.0
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_move_d<0xB1, 0xf>(v);     // quad_perm:[1,0,3,2]
+  v += dpp_move_d<0x4E, 0xf>(v);     // quad_perm:[2,3,0,1]
+  v += dpp_move_d<0x141, 0xf>(v);    // row_half_mirror
+  v += dpp_move_d<0x140, 0xf>(v);    // row_mirror
+  v += dpp_move_d<0x142, 0xa>(v);    // row_bcast:15 -> rows 1, 3
+  v += dpp_move_d<0x143, 0xc>(v);    // row_bcast:31 -> rows 2, 3
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
 // Neighbouring lanes of a double: two v_mov_b32_dpp each (wave_shl / wave_shr; the lane without a source reads 0, which no
@@ -98,12 +117,18 @@ __device__ __forceinline__ TrafficStepOut traffic_step_wave(const pdegym_params_
   const double c1 = K.c1, c2 = K.c2, c3 = K.c3, c4 = K.c4;
   if (time < P.T) {                               // :172  (time does not change inside the loop)
     for (int s = 0; s < P.control_freq; ++s) {
-      // boundary conditions :174-190
+      // boundary conditions :174-190: the end nodes take their neighbour's density, then y = q - r Veq(r).  Round 5: that Veq(r)
+      // IS the Veq(r) the nodal fluxes below evaluate for the same lane (same expression, same operand), so the density is set
+      // first, Veq is formed ONCE for the whole wave and the two end lanes pick their y by select -- the round-4 form ran two more
+      // float64 division sequences per sub-step under single-lane branches (a third of the loop's divisions).
       const double r1 = lane_value(r, 1), rm2 = lane_value(r, M - 2);
-      if (lane == 0) { r = r1; y = q_in - r * Veq(vm, rm, r); }
-      if (lane == M - 1) { r = rm2; y = q_out - r * Veq(vm, rm, r); }
+      const bool first = lane == 0, last = lane == M - 1;
+      r = first ? r1 : (last ? rm2 : r);
+      const double ve = Veq(vm, rm, r);
+      const double yb = (first ? q_in : q_out) - r * ve;
+      y = (first || last) ? yb : y;
       // nodal fluxes and the "plus" midpoint (:201-216)
-      const double fr = F_r(vm, rm, r, y), fy = F_y(vm, rm, r, y);
+      const double fr = y + r * ve, fy = y * (y / r + ve);      // F_r, F_y with the shared Veq(r)
       const double r_p = lane_next(r), y_p = lane_next(y), fr_p = lane_next(fr), fy_p = lane_next(fy);
       const double r_pm = 0.5 * (r_p + r) - c1 * (fr_p - fr);
       const double y_pm = (0.5 * (y_p + y) - c1 * (fy_p - fy)) - c2 * (y_p + y);

@@ -162,3 +162,34 @@ def test_checkpoint_traffic_and_tumor(bk):
         return v
     doses = rng.uniform(0.15, 0.3, (16, B))
     _roundtrip(make_tumor, lambda k: doses[k], n_before=2, n_after=9)
+
+
+@pytest.mark.parametrize("bk", BACKENDS)
+def test_checkpoint_of_another_reward_or_sensing_configuration_is_refused(bk):
+    """the engine's meta now names the reward kind / horizon, the sensing mode and the control type (they decide what the
+    norm ring and the observation hold), and the face checks its own tensors' names, shapes and dtypes before anything is copied --
+    a checkpoint of a NormReward("t-horizon") environment must not load into a TunedReward1D one, nor a Neumann one into a Dirchilet one."""
+    import pde_control_gym
+    from pde_control_gym.src import NormReward, TunedReward1D
+    B, nx, dt, S, nt = 3, 100, 1e-4, 30, 150
+    base = {"T": nt * dt, "dt": dt, "X": 1, "dx": 1e-2, "control_sample_rate": S * dt, "sensing_loc": "full", "control_type": "Dirchilet",
+            "sensing_type": None, "normalize": True, "limit_pde_state_size": True, "max_state_value": 1e10, "max_control_value": 3,
+            "batched_reset_func": lambda idx, nx_: (np.ones((len(idx), nx), np.float32), np.ones((len(idx), nx), np.float32))}
+
+    def make(**over):
+        v = pde_control_gym.make_vec("PDEControlGym-TransportPDE1D", num_envs=B, **_bk(bk), **dict(base, **over))
+        v.reset()
+        return v
+    tuned = make(reward_class=TunedReward1D(nt - 1, -1e3, 3e2))
+    sd = tuned.state_dict()
+    make(reward_class=TunedReward1D(nt - 1, -1e3, 3e2)).load_state_dict(sd)             # the same configuration loads
+    for other in (dict(reward_class=NormReward(nt - 1, "2", "t-horizon", -1e3, 3e2, t_horizon_length=7)),
+                  dict(reward_class=NormReward(nt - 1, "1", "temporal", -1e3, 3e2)),
+                  dict(reward_class=TunedReward1D(nt - 1, -1e3, 3e2), control_type="Neumann"),
+                  dict(reward_class=TunedReward1D(nt - 1, -1e3, 3e2), sensing_loc="collocated", sensing_type="Neumann")):
+        with pytest.raises(ValueError, match="checkpoint"):
+            make(**other).load_state_dict(sd)
+    # the face's own tensors: a checkpoint that carries one this environment does not keep (or the other way round) is refused
+    bad = dict(sd, face={"_ns_hist": torch.zeros(2, 2)})
+    with pytest.raises(ValueError, match="face tensors"):
+        tuned.load_state_dict(bad)

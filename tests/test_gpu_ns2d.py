@@ -694,3 +694,33 @@ def test_ns_rollout_kernel_equals_step_calls_bitwise(n, dtype, K, B, T, adim):
     assert not big.can_rollout()
     with pytest.raises(ValueError):
         big.rollout(None, None, None, None)
+
+
+def test_ns_rollout_vs_default_dispatch_small_float64_batch():
+    """with the DEFAULT dispatch a float64 batch below the column kernel's minimum (400 per 1024 SIMDs) steps on the
+    workgroup kernel while the rollout always runs the column kernel: every FIELD, flag and counter is still the same bits, the
+    rewards agree to rounding (another summation order), as include/pdegym.h states."""
+    from pdecontrolgym_amd.batch2d import NSBatch2D
+    n, K, B, T = 21, 30, 9, 6
+    kw, u0, v0, p0, _ = _random_case(n, B, K, 7321, BC_MIX, 1)
+    kw = dict(kw, action_dim=1)
+    acts = torch.as_tensor(np.random.default_rng(5).uniform(2, 4, (T, B, 1)), dtype=torch.float64, device="cuda")
+    _dbg("DEBUG_NS_COL_MIN_BATCH", -1)
+    outs = []
+    for mode in ("steps", "rollout"):
+        env = NSBatch2D(num_envs=B, device="cuda", dtype=torch.float64, **kw)
+        env.reset(u0, v0, p0)
+        obs = torch.zeros(T + 1, B, n, n, 2, dtype=torch.float64, device="cuda")
+        obs[0].copy_(env.t["obs"])
+        rew = torch.zeros(T, B, dtype=torch.float64, device="cuda")
+        te = torch.zeros(T, B, dtype=torch.uint8, device="cuda")
+        if mode == "steps":
+            env.t["obs"] = obs[0]
+            for t in range(T):
+                env.step(acts[t], out_obs=obs[t + 1], out_reward=rew[t], out_terminated=te[t])
+        else:
+            env.rollout(obs, acts, rew, te)
+        outs.append([x.cpu().numpy().copy() for x in (obs, te, env.p, env.t["time_index"], rew)])
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_allclose(outs[0][4], outs[1][4], rtol=1e-13)
