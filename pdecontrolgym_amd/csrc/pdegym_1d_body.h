@@ -221,9 +221,29 @@ struct Carry {
   float cm;       // wave_max |dt * beta[j]| (the fast-loop overflow pre-check)
   float norm;     // ||row||_2 as the previous step (or the prologue) computed it: an upper bound of max |row[j]|
   int t;
+  int k;          // (t + LOOKBACK) mod S, advanced with t (no division per env-step)
   double bsum;
   RingReg ring;   // the instance's norm ring, register-resident for the launch
+  float glog;     // log2 of the growth bound g(cm): constant between resets (follows beta)
 };
+
+// growth bound of one parabolic sub-step (see the overflow pre-check in step1d_body)
+__device__ __forceinline__ float growth_bound(const pdegym_params1d& P, float cm) {
+  return ((P.F >= 0.0f && P.F <= 0.5f) ? 1.0f : 1.0f + 4.0f * fabsf(P.F)) + cm + 9.5367431640625e-7f;
+}
+// what follows a (re)draw of the carried beta: wave maximum of |dt*beta| and log2 of the growth bound.  (Carrying the fast loop's
+// coefficients as well saved ~12 instructions per env-step of the open-loop kernel and cost 8 registers: the policy kernels -- 16 waves
+// per workgroup, 128 registers per lane -- spilled 78 of them; with FULL rows the coefficients are four multiplications and one select.)
+template <int EPL, bool PARABOLIC>
+__device__ __forceinline__ void carry_refresh_beta(Carry<EPL>& C, const pdegym_params1d& P, int s0, int ns) {
+  float cm = 0.f;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) cm = fmaxf(cm, fabsf(P.dt * C.beta[e]));
+  C.cm = wave_max(cm);
+  C.glog = __log2f(growth_bound(P, C.cm));
+  (void)s0;
+  (void)ns;
+}
 
 // The reward's own norm of a register-resident row (NormReward kinds; same expressions as the epilogue of step1d_body), for the
 // "t-horizon" reward: -(mean of the norms of the last k fine-time rows), norm_reward.py:60-73.
@@ -250,7 +270,7 @@ __device__ __forceinline__ float kind_norm(const float (&x)[EPL], float bl, int 
 // M64: float64 beta and/or float64 / Python-float control (pdegym_params1d.beta_f64 / action_kind): the select form with the
 // reference's mixed-precision expressions (see step1d_wide_kernel for the same arithmetic on LDS-resident rows).
 template <int EPL, bool PARABOLIC, bool NEUMANN, bool FAST, bool HIST, bool BURGERS = false, bool M64 = false, bool ROLL = false,
-          typename RingT = RingMem>
+          typename RingT = RingMem, bool FULL = false>
 __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EPL], const pdegym_params1d& P, int nsub,
                                              float a, RingT& ring, float* hist, int lane, const double* b64 = nullptr, double a64 = 0.0,
                                              float* xprev = nullptr, float* blprev = nullptr, int thor_k = 0) {
@@ -260,7 +280,9 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
   static_assert(!(FAST && (NEUMANN || HIST)), "fast mode is the Dirichlet, history-free path");
   static_assert(!(FAST && M64), "the mixed-precision mode uses the select form");
   constexpr int J0 = PARABOLIC ? 1 : 0;
-  const int n = P.n, ns = n - J0, s0 = lane * EPL;
+  // FULL (round 5): the row fills the wave exactly (n - J0 == 64 EPL, checked by the launcher) -- with the slot count a compile-time
+  // constant every "is this slot inside the row" select folds away and "is this the boundary slot" becomes lane 63's last slot
+  const int n = FULL ? kWave * EPL + J0 : P.n, ns = n - J0, s0 = lane * EPL;
   const float dx = P.dx, dt = P.dt, F = P.F;
   const int S = P.substeps > 0 ? P.substeps : 1;
   const bool rec_all = P.nt <= PDEGYM_RING;
@@ -518,7 +540,7 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
 }
 
 template <int EPL, bool PARABOLIC>
-__device__ __forceinline__ void load_row(Row<EPL>& R, float (&beta)[EPL], const float* urow, const float* brow, int n,
+__device__ __forceinline__ void load_row(Row<EPL>& R, float (&beta)[EPL], const float* urow, const float* brow, const int n,
                                          int lane) {
   constexpr int J0 = PARABOLIC ? 1 : 0;
   const int ns = n - J0, s0 = lane * EPL;
@@ -533,7 +555,7 @@ __device__ __forceinline__ void load_row(Row<EPL>& R, float (&beta)[EPL], const 
 // row t of the reward / flag arrays always; the per-instance state words that every step would overwrite (norm_now, norm_back,
 // time_index, bsum -- and the ring, kept in registers) only when store_state says this is the launch's last step.
 template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false, bool M64 = false, bool ROLL = false,
-          bool CARRY = false>
+          bool CARRY = false, bool FULL = false>
 __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdegym_bufs1d& Bf, const int B, const int inst,
                                             const int lane, const float* command = nullptr, Carry<EPL>* carry = nullptr,
                                             const bool store_state = true) {
@@ -544,7 +566,8 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
   const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
   const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const int n = P.n, ns = n - J0, s0 = lane * EPL;
+  static_assert(!FULL || kFast, "FULL rows: the float32 Dirichlet fast path only");
+  const int n = FULL ? kWave * EPL + J0 : P.n, ns = n - J0, s0 = lane * EPL;
 #ifdef PDEGYM_TIMING
   const unsigned long long tmk = __builtin_amdgcn_s_memtime() + (unsigned long long)(n == 0x7fffffff);  // kernarg arrived
 #endif
@@ -597,7 +620,8 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
   const float a = command ? *command : (act64 ? 0.f : static_cast<const float*>(Bf.action)[inst]);
   const double a64 = act64 ? static_cast<const double*>(Bf.action)[inst] : 0.0;
   R.t = t_in;
-  R.k = (t_in + PDEGYM_LOOKBACK) % S;
+  if constexpr (CARRY) R.k = __builtin_amdgcn_readfirstlane(carry->k);
+  else R.k = (t_in + PDEGYM_LOOKBACK) % S;
   R.bsum = bsum_in;
   // look-back row of this call's reward (tuned_reward_1d.py:40): t_end - 100, Python negative index wraps into the
   // zero-filled tail of the history.  Rows that predate this call are fetched NOW (latency hidden by the loop).
@@ -658,12 +682,19 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
         mx = wave_max(mx);
         cm = wave_max(cm);
       }
-      const float g = ((P.F >= 0.0f && P.F <= 0.5f) ? 1.0f : 1.0f + 4.0f * fabsf(P.F)) + cm + 9.5367431640625e-7f;
-      exact = exact || !(__log2f(mx) + (float)nsub * __log2f(g) < 126.0f);   // NaN / inf anywhere -> exact
+      if constexpr (CARRY) {
+        // log2 g is carried, and log2 mx is only formed when the bound could matter: mx <= 2^40 and nsub log2 g <= 80 give
+        // log2 mx + nsub log2 g <= 120 < 126 in the formula below as well -- the same decision, two v_log_f32 fewer per env-step
+        const float budget = (float)nsub * carry->glog;
+        if (!(mx <= 1.099511627776e12f && budget <= 80.0f)) exact = exact || !(__log2f(mx) + budget < 126.0f);
+        (void)cm;
+      } else {
+        exact = exact || !(__log2f(mx) + (float)nsub * __log2f(growth_bound(P, cm)) < 126.0f);   // NaN / inf anywhere -> exact
+      }
     }
     norm_now = 0.f;
     if (!exact) {
-      run_substeps<EPL, PARABOLIC, false, true, false, BURGERS, false, ROLL>(R, beta, P, nsub, a, ring, nullptr, lane);
+      run_substeps<EPL, PARABOLIC, false, true, false, BURGERS, false, ROLL, RingT, FULL>(R, beta, P, nsub, a, ring, nullptr, lane);
       norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
       // inf/NaN somewhere (or a squared overflow): 0*inf may have leaked into a frozen slot -> redo exactly
       exact = !(fabsf(norm_now) <= 3.4028234663852886e38f);
@@ -686,7 +717,7 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
       }
     }
     if (exact) {
-      run_substeps<EPL, PARABOLIC, false, false, false, BURGERS>(R, beta, P, nsub, a, ring, nullptr, lane);
+      run_substeps<EPL, PARABOLIC, false, false, false, BURGERS, false, false, RingT, FULL>(R, beta, P, nsub, a, ring, nullptr, lane);
       norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
     }
   } else {
@@ -807,6 +838,7 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
     }
     if constexpr (CARRY) {
       carry->t = t;
+      carry->k = R.k;
       carry->bsum = R.bsum;
       carry->norm = norm_now;
     }
@@ -825,13 +857,9 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
         const float* bsrc = static_cast<const float*>(Bf.reset_beta) + (size_t)prow * n;
         for (int j = lane; j < n; j += kWave) bdst[j] = bsrc[j];
         if constexpr (CARRY) {      // the carried copy follows the redraw
-          float cm = 0.f;
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            carry->beta[e] = (s0 + e < ns) ? bsrc[J0 + s0 + e] : 0.f;
-            cm = fmaxf(cm, fabsf(P.dt * carry->beta[e]));
-          }
-          carry->cm = wave_max(cm);
+          for (int e = 0; e < EPL; ++e) carry->beta[e] = (s0 + e < ns) ? bsrc[J0 + s0 + e] : 0.f;
+          carry_refresh_beta<EPL, PARABOLIC>(*carry, P, s0, ns);
         }
       }
     }
@@ -857,6 +885,7 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
     ring.put(0, n0, lane);
     if constexpr (CARRY) {
       carry->t = 0;
+      carry->k = PDEGYM_LOOKBACK % S;
       carry->bsum = (double)fabsf(last);
       carry->norm = n0;
       drain_vmem();
@@ -884,23 +913,20 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
 }
 
 // The state a rollout launch starts from, read ONCE: row (observation slot 0), beta, time index and |u[-1]| sum.
-template <int EPL, bool PARABOLIC>
+template <int EPL, bool PARABOLIC, bool FULL = false>
 __device__ __forceinline__ void carry_load(Carry<EPL>& C, const pdegym_params1d& P, const pdegym_bufs1d& Bf, const float* row0, int inst,
                                            int lane) {
   constexpr int J0 = PARABOLIC ? 1 : 0;
-  const int ns = P.n - J0, s0 = lane * EPL;
+  const int n = FULL ? kWave * EPL + J0 : P.n, ns = n - J0, s0 = lane * EPL;
   Row<EPL> R0;
-  load_row<EPL, PARABOLIC>(R0, C.beta, row0 + (size_t)inst * P.n, static_cast<const float*>(Bf.beta) + (size_t)inst * Bf.beta_stride, P.n, lane);
-  float cm = 0.f;
+  load_row<EPL, PARABOLIC>(R0, C.beta, row0 + (size_t)inst * n, static_cast<const float*>(Bf.beta) + (size_t)inst * Bf.beta_stride, n, lane);
 #pragma unroll
-  for (int e = 0; e < EPL; ++e) {
-    C.x[e] = R0.x[e];
-    cm = fmaxf(cm, fabsf(P.dt * C.beta[e]));
-  }
+  for (int e = 0; e < EPL; ++e) C.x[e] = R0.x[e];
   C.bl = R0.bl;
-  C.cm = wave_max(cm);
+  carry_refresh_beta<EPL, PARABOLIC>(C, P, s0, ns);
   C.norm = sqrtf(slots_sumsq<EPL>(C.x, s0, ns) + C.bl * C.bl);
   C.t = __builtin_amdgcn_readfirstlane(Bf.time_index[inst]);
+  C.k = (C.t + PDEGYM_LOOKBACK) % (P.substeps > 0 ? P.substeps : 1);
   C.bsum = Bf.bsum[inst];
   const float* ring = Bf.ring + (size_t)inst * PDEGYM_RING;
   C.ring.lo = ring[lane];

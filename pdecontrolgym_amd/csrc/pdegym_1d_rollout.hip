@@ -11,13 +11,15 @@ namespace {
 // -- every value equals what T separate step calls produce, bit for bit.  What it removes is the kernel boundary between
 // env-steps: no dispatch gap, no load phase (the state stays in registers, Carry), and the waves of a SIMD drift apart
 // instead of finishing in two generations.
-template <int EPL, bool PARABOLIC, bool BURGERS>
+// FULL: the row fills the wave exactly (n - J0 == 64 EPL): the slot masks fold away (pdegym_1d_body.h: run_substeps).
+template <int EPL, bool PARABOLIC, bool BURGERS, bool FULL>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void rollout1d_kernel(pdegym_params1d P, pdegym_bufs1d Bf, pdegym_rollout1d Ro,
                                                                          int B) {
   const int lane = threadIdx.x & (kWave - 1);
   const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (inst >= B) return;  // wave-uniform
-  const size_t slot = (size_t)B * P.n;
+  const int n = FULL ? kWave * EPL + (PARABOLIC ? 1 : 0) : P.n;
+  const size_t slot = (size_t)B * n;
   // The state -- row, beta, time index, sums AND the norm ring -- stays in registers over the T env-steps (Carry).  Round 5: the
   // steady state of the loop has NO load at all: the commands of 64 env-steps arrive in one load per lane (lane l holds step
   // t0 + l; handed out by v_readlane), the ring is two registers per lane, and the per-instance
@@ -25,7 +27,17 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void rollout1d_kernel(pdegym
   // (vmcnt), so the single ring / command load per env-step of the round-4 loop made every step wait for the stores of the step
   // before (SQ_WAIT_ANY 57 % of the wave cycles at S = 1); now only the batch hand-over, once per 64 env-steps, waits.
   Carry<EPL> C;
-  carry_load<EPL, PARABOLIC>(C, P, Bf, Ro.obs, inst, lane);
+  carry_load<EPL, PARABOLIC, FULL>(C, P, Bf, Ro.obs, inst, lane);
+  // the per-step views of the rollout arrays advance by one slot / row per env-step (no 64-bit multiplications in the loop)
+  pdegym_bufs1d S = Bf;
+  S.u = nullptr;
+  S.history = nullptr;
+  S.state_in = Ro.obs;
+  S.obs = Ro.obs + slot;
+  S.action = Ro.actions;
+  S.reward = Ro.rewards;
+  S.terminated = Ro.terminated;
+  S.truncated = Ro.truncated;
   auto command_batch = [&](int t0) { return (t0 + lane < Ro.T) ? Ro.actions[(size_t)(t0 + lane) * B + inst] : 0.f; };
   float a_cur = command_batch(0);
   drain_vmem();
@@ -35,17 +47,14 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void rollout1d_kernel(pdegym
       a_cur = command_batch(t);
       drain_vmem();
     }
-    pdegym_bufs1d S = Bf;
-    S.u = nullptr;
-    S.history = nullptr;
-    S.state_in = Ro.obs + (size_t)t * slot;
-    S.obs = Ro.obs + (size_t)(t + 1) * slot;
-    S.action = Ro.actions + (size_t)t * B;
-    S.reward = Ro.rewards + (size_t)t * B;
-    S.terminated = Ro.terminated + (size_t)t * B;
-    S.truncated = Ro.truncated + (size_t)t * B;
     const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_cur), j));
-    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false, true, true>(P, S, B, inst, lane, &a, &C, t == Ro.T - 1);
+    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false, true, true, FULL>(P, S, B, inst, lane, &a, &C, t == Ro.T - 1);
+    S.state_in = S.obs;
+    S.obs += slot;
+    S.action = static_cast<const float*>(S.action) + B;
+    S.reward += B;
+    S.terminated += B;
+    S.truncated += B;
   }
   carry_store_ring<EPL>(C, Bf, inst, lane);
 }
@@ -109,13 +118,16 @@ __device__ __forceinline__ void sense_noise(const float* obs_noise, float* obs_s
 
 // WIDE: a network with a layer of more than 64 units, evaluated by the 16 waves together (pdegym_policy.h: eval_wide) -- every wave of
 // the workgroup, with or without an instance, runs all T iterations because of its barriers.
-template <int EPL, bool PARABOLIC, bool BURGERS, bool WIDE>
+template <int EPL, bool PARABOLIC, bool BURGERS, bool WIDE, bool FULL>
 __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy_kernel(pdegym_params1d P, pdegym_bufs1d Bf,
                                                                                         pdegym_rollout1d Ro, pdegym_mlp N, int B) {
   namespace pol = pdegym_policy;
   extern __shared__ __attribute__((aligned(16))) float pol_smem[];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int inst = blockIdx.x * pol::kWaves + wave;
+  constexpr int J0 = PARABOLIC ? 1 : 0;
+  // (the policy's loops take the row length from the kernel argument even when FULL makes it a compile-time constant for the
+  // env-step: with a constant trip count the compiler unrolls the whole reduction and spills 74 registers)
   const int n = P.n, xpad = pol::xpad(n);
   pol::Staged St;
   pol::Wide Wd;
@@ -126,10 +138,9 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy
   float* const xw = WIDE ? Wd.X + wave * Wd.ldx : pol_smem + St.end + wave * (xpad + 2 * pol::kMaxWidth);
   float* const hw = xw + xpad;
   const size_t slot = (size_t)B * n;
-  constexpr int J0 = PARABOLIC ? 1 : 0;
   const int ns = n - J0, s0 = lane * EPL;
   Carry<EPL> C;       // the state stays in registers over the T env-steps (see rollout1d_kernel)
-  if (active) carry_load<EPL, PARABOLIC>(C, P, Bf, Ro.obs, inst, lane);
+  if (active) carry_load<EPL, PARABOLIC, FULL>(C, P, Bf, Ro.obs, inst, lane);
   if (!WIDE)
     for (int j = n + lane; j < xpad; j += kWave) xw[j] = 0.f;     // zero padding to a multiple of four: written once
   for (int t = 0; t < Ro.T; ++t) {
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void rollout1d_policy
     S.reward = Ro.rewards + (size_t)t * B;
     S.terminated = Ro.terminated + (size_t)t * B;
     S.truncated = Ro.truncated + (size_t)t * B;
-    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false, true, true>(P, S, B, inst, lane, &a, &C, t == Ro.T - 1);
+    step1d_body<EPL, PARABOLIC, false, false, BURGERS, false, true, true, FULL>(P, S, B, inst, lane, &a, &C, t == Ro.T - 1);
   }
   if (active) carry_store_ring<EPL>(C, Bf, inst, lane);
 }
@@ -232,20 +243,29 @@ int launch_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const p
     if (const char* why = pdegym_policy::check(N, od, 1, true)) return pdegym::fail(-2, why);
     if (N.x_f64 || N.y_f64) return pdegym::fail(-2, "policy inside the 1D rollout kernel: float32 observations and commands");
     if (epl > 8) return pdegym::fail(-2, "policy inside the rollout kernel: rows of up to 513 nodes");
-    const int lds_bytes = pdegym_policy::lds_floats(N, od) * (int)sizeof(float);
     const dim3 pgrid((B + pdegym_policy::kWaves - 1) / pdegym_policy::kWaves), pblock(kWave * pdegym_policy::kWaves);
     bool ok = true;
+    // (round 5, measured again after the loop lost its waits: the cooperative MFMA evaluation forced onto a 64-64 network is slower
+    // than one fma chain per neuron -- 0.99 against 0.73 ms per 100 env-steps at S = 1, 0.55 against 0.45 ms per 25 at S = 100: four
+    // workgroup barriers per env-step and twelve of sixteen waves without an output tile)
     const bool wide = pdegym_policy::is_wide(N);
+    const int lds_bytes = pdegym_policy::lds_floats(N, od) * (int)sizeof(float);
     auto launch_pol = [&](auto kernel, signed char (&attr)[pdegym::kMaxDevices]) {
       ok = pdegym::raise_dynamic_lds_limit(reinterpret_cast<const void*>(kernel), pdegym_policy::kMaxLdsBytes, attr);
       if (ok) hipLaunchKernelGGL(kernel, pgrid, pblock, lds_bytes, st, P, *buf, *ro, N, B);
     };
     auto gop = [&](auto tag) {
       constexpr int E = decltype(tag)::value;
-      static signed char attr[6][pdegym::kMaxDevices] = {};
+      static signed char attr[8][pdegym::kMaxDevices] = {};
       if (!general) {
-        if (wide) launch_pol(&rollout1d_policy_kernel<E, PARABOLIC, BURGERS, true>, attr[0]);
-        else launch_pol(&rollout1d_policy_kernel<E, PARABOLIC, BURGERS, false>, attr[1]);
+        constexpr bool kHasFull = E == 1 || E == 2 || E == 4 || E == 8;      // rows of 64 / 128 / 256 / 512 slots
+        if (kHasFull && nslots == kWave * E) {
+          if (wide) launch_pol(&rollout1d_policy_kernel<E, PARABOLIC, BURGERS, true, kHasFull>, attr[6]);
+          else launch_pol(&rollout1d_policy_kernel<E, PARABOLIC, BURGERS, false, kHasFull>, attr[7]);
+        } else {
+          if (wide) launch_pol(&rollout1d_policy_kernel<E, PARABOLIC, BURGERS, true, false>, attr[0]);
+          else launch_pol(&rollout1d_policy_kernel<E, PARABOLIC, BURGERS, false, false>, attr[1]);
+        }
       } else if (neumann) {
         if (wide) launch_pol(&rollout1d_policy_general_kernel<E, PARABOLIC, true, BURGERS, true>, attr[2]);
         else launch_pol(&rollout1d_policy_general_kernel<E, PARABOLIC, true, BURGERS, false>, attr[3]);
@@ -267,7 +287,9 @@ int launch_rollout(const pdegym_params1d* prm, const pdegym_bufs1d* buf, const p
   const dim3 grid((B + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
   auto go = [&](auto tag) {
     constexpr int E = decltype(tag)::value;
-    if (!general) hipLaunchKernelGGL((rollout1d_kernel<E, PARABOLIC, BURGERS>), grid, block, 0, st, P, *buf, *ro, B);
+    constexpr bool kHasFull = E == 1 || E == 2 || E == 4 || E == 8;      // rows of 64 / 128 / 256 / 512 slots
+    if (!general && kHasFull && nslots == kWave * E) hipLaunchKernelGGL((rollout1d_kernel<E, PARABOLIC, BURGERS, kHasFull>), grid, block, 0, st, P, *buf, *ro, B);
+    else if (!general) hipLaunchKernelGGL((rollout1d_kernel<E, PARABOLIC, BURGERS, false>), grid, block, 0, st, P, *buf, *ro, B);
     else if (neumann) hipLaunchKernelGGL((rollout1d_general_kernel<E, PARABOLIC, true, BURGERS>), grid, block, 0, st, P, *buf, *ro, B);
     else hipLaunchKernelGGL((rollout1d_general_kernel<E, PARABOLIC, false, BURGERS>), grid, block, 0, st, P, *buf, *ro, B);
   };

@@ -146,8 +146,12 @@ __device__ __forceinline__ TrafficStepOut traffic_step_wave(const pdegym_params_
   o.v = y / r + Veq(vm, rm, r);                    // :227
   // reward (traffic_arz_reward.py:22)
   const double dv = in ? o.v - vs : 0.0, dr = in ? r - rs : 0.0;
-  const double nv = sqrt(wave_sum_d(dv * dv)), nr = sqrt(wave_sum_d(dr * dr));
-  o.reward = -(nv / vs + nr / rs);
+  // ||v - vs|| / vs + ||r - rs|| / rs: the two square roots and the two divisions act on wave-uniform values, so they share ONE
+  // float64 sqrt and ONE division sequence -- lane 0 takes the speed term, every other lane the density term (same operands, same
+  // operations: the same bits as two scalar evaluations)
+  const double sv = wave_sum_d(dv * dv), sr = wave_sum_d(dr * dr);
+  const double term_ = sqrt(lane == 0 ? sv : sr) / (lane == 0 ? vs : rs);
+  o.reward = -(lane_value(term_, 0) + lane_value(term_, 1));
   const bool term = time >= K.t_end;               // :106 (seconds compared with a step count -- kept)
   if (term) time = 0.0;
   bool trunc = false;

@@ -22,7 +22,7 @@ import bench  # noqa: E402  (kernel_stamp: fingerprint of the sources a workload
 from pdecontrolgym_amd import build as _build  # noqa: E402
 DOM = {"parabolic_c2_s1": "step1d_kernel", "parabolic_c2_s1_open_loop_rollout": "rollout1d_kernel", "parabolic_c2_s1_rollout": "rollout1d_policy_kernel",
        "parabolic_c2": "step1d_kernel", "parabolic_c2_policy_loop": "step1d_kernel", "parabolic_c2_rollout": "rollout1d_policy_kernel", "parabolic_c2_policy_loop_256": "mlp_forward_kernel", "parabolic_c2_rollout_256": "rollout1d_policy_kernel", "parabolic_c2_open_loop_rollout": "rollout1d_kernel", "transport_c3": "step1d_kernel", "burgers_c3": "step1d_kernel", "ns2d_c4": "ns_tile_step",
-       "ns2d_c4_b4096": "ns_tile_step", "ns2d_c5": "ns256_fused_step", "ns2d_c5_f64": "ns256_slab_f64", "ns2d_c4_f64_b4096": "ns_", "ns2d_c4_f64": "ns_", "ns2d_example": "ns_col_step", "traffic_arz": "traffic_step_kernel", "traffic_arz_rollout": "traffic_rollout_kernel",
+       "ns2d_c4_b4096": "ns_tile_step", "ns2d_c5": "ns256_fused_step", "ns2d_c5_f64": "ns256_pass_f64", "ns2d_c4_f64_b4096": "ns_", "ns2d_c4_f64": "ns_", "ns2d_example": "ns_col_step", "traffic_arz": "traffic_step_kernel", "traffic_arz_rollout": "traffic_rollout_kernel",
        "brain_tumor": "tumor_step_kernel"}
 if os.path.exists(os.path.join(root, "tools", "dominant_kernels.json")):
     DOM.update(json.load(open(os.path.join(root, "tools", "dominant_kernels.json"))))
