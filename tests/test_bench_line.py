@@ -74,3 +74,14 @@ def test_final_line_survives_an_error_in_a_secondary_workload_and_missing_counte
     d = json.loads(bench.final_line(full))
     assert any(s["name"] == "ns2d_c5_f64" and "error" in s for s in d["secondary"])
     assert d["roofline"]["frac"] is None and d["roofline"]["traffic"] is None
+
+
+def test_hbm_probe_library_builds_and_exports_its_entry_point():
+    """tools/hbm_probe.hip is built by __graft_entry__.build() into its own small library (not part of the product ABI); no GPU is
+    needed to load it and find the symbol."""
+    import ctypes
+    from pdecontrolgym_amd import build
+    lib = ctypes.CDLL(build.build_probe())
+    assert hasattr(lib, "pdegym_probe_hbm")
+    # ... and it does not touch the product library's fingerprint (it lives outside csrc/)
+    assert not os.path.exists(os.path.join(build.CSRC, "hbm_probe.hip"))

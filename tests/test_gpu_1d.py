@@ -700,7 +700,11 @@ def test_state_in_abi_validation():
 @pytest.mark.parametrize("kind,nx,S,burgers,B,T", [
     ("parabolic", 256, 100, False, 9, 11), ("transport", 100, 30, False, 9, 11), ("transport", 512, 20, True, 9, 11),
     ("parabolic", 40, 7, False, 9, 11), ("transport", 1500, 3, False, 9, 11),
-    ("transport", 3, 2, False, 1, 5), ("parabolic", 2, 1, False, 130, 9), ("parabolic", 2047, 2, False, 3, 6), ("transport", 64, 5, False, 5, 1)])
+    ("transport", 3, 2, False, 1, 5), ("parabolic", 2, 1, False, 130, 9), ("parabolic", 2047, 2, False, 3, 6), ("transport", 64, 5, False, 5, 1),
+    # round 5: launches longer than one command batch (64 env-steps per load), S = 1, rows that fill the wave exactly (FULL kernels:
+    # 64 / 128 / 256 / 512 slots) and rows that do not
+    ("parabolic", 256, 1, False, 5, 130), ("transport", 128, 1, False, 3, 64), ("transport", 128, 3, False, 3, 65),
+    ("parabolic", 100, 1, False, 4, 200), ("parabolic", 64, 2, False, 6, 129), ("transport", 512, 1, True, 2, 70)])
 def test_rollout_kernel_equals_step_calls_bitwise(kind, nx, S, burgers, B, T):
     """pdegym_*_rollout (T env-steps in one launch, the row never leaves the wave's cache path) against T step calls: every
     observation slot, reward, flag, the time index, |u| sum, norm ring, restart counters, redrawn beta rows and the kept
@@ -750,6 +754,45 @@ def test_rollout_kernel_equals_step_calls_bitwise(kind, nx, S, burgers, B, T):
     o_a = e.step(acts[0])[0].cpu().numpy()
     o_b = e2.step(acts[0])[0].cpu().numpy()
     np.testing.assert_array_equal(o_a, o_b)
+
+
+@pytest.mark.parametrize("kind,nx,S,T", [("parabolic", 256, 1, 150), ("transport", 100, 2, 70), ("parabolic", 128, 3, 9)])
+def test_rollout_without_auto_reset_runs_past_the_episode_end_like_step_calls(kind, nx, S, T):
+    """Round 5 (the carried rollout stores time_index / bsum / norm_now / norm_back and the norm ring once, at the end of the
+    launch): without reset pools an episode that ends inside the launch just stops advancing (nsub = 0), exactly as step calls do --
+    every slot, flag and every word of engine state equals T step calls, also when the launch ends long after the episode."""
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
+    B = 5
+    dx = 1.0 / nx
+    dt = 0.25 * dx * dx if kind == "parabolic" else 0.5 * dx
+    kw = dict(T=37 * S * dt, dt=dt, X=1, dx=dx, control_sample_rate=S * dt, control_type="Dirchilet", sensing_loc="full",
+              sensing_type=None, normalize=True, max_control_value=5.0, limit_pde_state_size=True, max_state_value=1e6)
+    rng = np.random.default_rng(nx + S)
+    envs = [PDEBatch1D(kind, reward=RewardSpec(N.REWARD_TUNED1D, int(round(kw["T"] / dt)), -1e3, 3e2), num_envs=B, device="cuda", **kw)
+            for _ in range(2)]
+    n = envs[0].n
+    init = rng.uniform(0.5, 2, (B, n)).astype(np.float32)
+    beta = rng.uniform(-2, 2, (B, n)).astype(np.float32)
+    acts = torch.tensor(rng.uniform(-1, 1, (T, B)).astype(np.float32), device="cuda")
+    outs = []
+    for mode, e in zip(("steps", "rollout"), envs):
+        e.reset(torch.tensor(init), torch.tensor(beta))
+        obs = torch.zeros(T + 1, B, n, device="cuda")
+        obs[0].copy_(e.t["obs"])
+        rew, te, tr = torch.zeros(T, B, device="cuda"), torch.zeros(T, B, dtype=torch.uint8, device="cuda"), torch.zeros(T, B, dtype=torch.uint8, device="cuda")
+        if mode == "steps":
+            e.t["obs"] = obs[0]
+            e.t["u"] = obs[0]
+            for t in range(T):
+                e.step(acts[t], out_obs=obs[t + 1], out_reward=rew[t], out_terminated=te[t], out_truncated=tr[t])
+        else:
+            e.rollout(obs, acts, rew, te, tr)
+        outs.append([x.cpu().numpy().copy() for x in (obs, rew, te, tr)] + [e.t[k].cpu().numpy().copy() for k in
+                                                                            ("time_index", "bsum", "ring", "norm_now", "norm_back")])
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    assert (T < 37) == (outs[0][2].sum() == 0)              # the long launches end after the episode did
 
 
 @pytest.mark.parametrize("kind,control,loc,stype,nx,S,B,T", [

@@ -2,6 +2,7 @@
 reference's PUBLISHED known answers reproduced in closed loop (backstepping controller episodes; notebook
 stored outputs cited in SURVEY.md section 6 / BASELINE.md)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -12,6 +13,7 @@ from tests.test_oracle_golden import KAT_PUBLISHED
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_loaded_backend_is_the_hip_library():
@@ -370,3 +372,52 @@ def test_vecenv_host_arrays_are_never_overwritten_while_referenced():
         venv.step(a)
     for view, copy in rows:
         np.testing.assert_array_equal(view, copy)
+
+
+@pytest.mark.gpu
+def test_vecenv_copy_outputs_true_hands_out_plain_copies_and_non_cpython_rule():
+    """``copy_outputs=True`` is honoured -- every result is a plain NumPy copy (no pinned pool is kept per output), with
+    the same values as the recycling default; and the recycling path is only taken where sys.getrefcount is exact (CPython + GIL)."""
+    import pde_control_gym
+    from pde_control_gym import vector as V
+    assert V._REFCOUNT_IS_EXACT == (sys.implementation.name == "cpython" and getattr(sys, "_is_gil_enabled", lambda: True)())
+    B = 6
+    p = _transport_params(T=0.5, dt=1e-4, control_sample_rate=0.01)
+    a = np.full((B, 1), 0.25, np.float32)
+    res = {}
+    for mode in (None, True):
+        venv = pde_control_gym.make_vec("PDEControlGym-TransportPDE1D", num_envs=B, copy_outputs=mode, **p)
+        venv.reset()
+        outs = [venv.step(a * (1 + 0.2 * k)) for k in range(6)]
+        res[mode] = [(o.copy(), r.copy(), d.copy()) for o, r, d, _ in outs]
+        pools = [v for k, v in venv._pins.items() if k[0] == "out"]
+        if mode is True:
+            assert all(len(v) == 0 for v in pools)                       # nothing recycled: staged through the scratch buffer, copied out
+            assert len({id(o) for o, _, _, _ in outs}) == 6
+            assert not any(np.shares_memory(outs[0][0], o) for o, _, _, _ in outs[1:])
+        else:
+            assert any(len(v) > 0 for v in pools)
+    for x, y in zip(res[None], res[True]):
+        for u, v in zip(x, y):
+            np.testing.assert_array_equal(u, v)
+
+
+@pytest.mark.gpu
+def test_hbm_probe_copies_and_reports_plausible_rates():
+    """tools/hbm_probe.hip (the yardstick bench.py prints beside the 8 TB/s specification): the copy kernel really copies, read and
+    fill run, and the rates are those of an HBM3E part, not of a mis-timed launch (256 MiB: above 1 TB/s, below the specification
+    plus what the 256 MiB memory-side cache can add)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import hbm_probe as hp
+    r = hp.measure("cuda", sizes_mib=(256,), grids=(4096, 16384))
+    for k in ("copy_GBps", "read_GBps", "fill_GBps"):
+        assert 1000.0 < r[k] < 20000.0, (k, r[k])
+    n = 1 << 22
+    src = torch.randn(n, device="cuda")
+    dst = torch.zeros_like(src)
+    for nt in (0, 1):
+        dst.zero_()
+        assert hp.lib().pdegym_probe_hbm(0, dst.data_ptr(), src.data_ptr(), n * 4, 333, nt, torch.cuda.current_stream().cuda_stream) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(dst, src)
+    assert hp.lib().pdegym_probe_hbm(0, dst.data_ptr(), src.data_ptr(), n * 4 + 4, 333, 0, None) == -1      # not a multiple of 16 bytes
