@@ -238,31 +238,16 @@ __device__ __forceinline__ double back_rows(const NSConst& C, const NSScal<doubl
   double s0u[4], s0v[4], s1u[4], s1v[4], s2u[4], s2v[4];
   double c1u[4], c1v[4], c2u[4], c2v[4];                          // C(r-1), C(r-2)
   double ps[4], pc[4], pn[4];                                     // p rows r-1, r, r+1
-  // Round 5: the loads run TWO rows ahead of the arithmetic (n1: row r + 2, requested an iteration ago; n2: row r + 3, requested
-  // now) and the reference row of the observation that is finished in an iteration is requested at its head.  At two waves per
-  // SIMD one row of arithmetic (~1 us) does not cover a load's round trip under load; the sweeps' registers are dead here, so the
-  // 24 + 16 extra registers are free.
-  double n1u[4], n1v[4], n1p[4];
-  double actc[4];                                                 // this lane's columns of a per-node command (wall rows), fetched once
-  column_commands<double>(act, C.action_dim, a0, c0, actc);
   load_state_row<INTERLEAVED, double>(su, sv, r0 - 1, c0, s0u, s0v);
   load_state_row<INTERLEAVED, double>(su, sv, r0, c0, s1u, s1v);
   load_state_row<INTERLEAVED, double>(su, sv, r0 + 1, c0, s2u, s2v);
   prow(r0 - 1, ps);
   prow(r0, pc);
   prow(r0 + 1, pn);
-  load_state_row<INTERLEAVED, double>(su, sv, r0 + 2, c0, n1u, n1v);
-  prow(r0 + 2, n1p);
 #pragma unroll
   for (int k = 0; k < 4; ++k) c1u[k] = c1v[k] = c2u[k] = c2v[k] = 0.0;
   double acc = 0.0;
-  auto ref_row = [&](int rr, double2 (&ref)[4]) __attribute__((always_inline)) {
-    const int rc = rr < 0 ? 0 : (rr > kN - 1 ? kN - 1 : rr);
-    const double2* rrow = reinterpret_cast<const double2*>(uref + ((size_t)rc * kN + c0) * 2);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ref[k] = rrow[k];
-  };
-  auto finish_row = [&](int rr, const double (&cu)[4], const double (&cv)[4], const double2 (&ref)[4], double ai) __attribute__((always_inline)) {
+  auto finish_row = [&](int rr, const double (&cu)[4], const double (&cv)[4]) __attribute__((always_inline)) {
     double fu[4], fv[4], nbu[4], nbv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -270,28 +255,26 @@ __device__ __forceinline__ double back_rows(const NSConst& C, const NSScal<doubl
       nbu[k] = rr == 0 ? cu[k] : c2u[k];
       nbv[k] = rr == 0 ? cv[k] : c2v[k];
     }
-    bc_row_regs<double>(fu, nbu, rr, C.bc, 0, bsel, actc, ai);
-    bc_row_regs<double>(fv, nbv, rr, C.bc, 1, bsel, actc, ai);
+    bc_row<double>(fu, nbu, rr, c0, C.bc, 0, bsel, act, C.action_dim, a0);
+    bc_row<double>(fv, nbv, rr, c0, C.bc, 1, bsel, act, C.action_dim, a0);
     const size_t o = ((size_t)rr * kN + c0) * 2;
+    const double2* rrow = reinterpret_cast<const double2*>(uref + o);
     double2* orow = reinterpret_cast<double2*>(obs + o);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      const double2 ref = rrow[k];
       orow[k] = make_double2(fu[k], fv[k]);
-      const double du = fu[k] - ref[k].x, dv = fv[k] - ref[k].y;
+      const double du = fu[k] - ref.x, dv = fv[k] - ref.y;
       acc += du * du;
       acc += dv * dv;
     }
   };
-  // one row of the pipeline; in: the row requested an iteration ago (consumed at the end: it becomes s2 / pn), out: the row requested
-  // now.  The loop below alternates two register sets in these roles, so that data in flight is never copied (a copy would wait).
-  auto body = [&](int it, const double (&inu)[4], const double (&inv)[4], const double (&inp)[4], double (&outu)[4], double (&outv)[4],
-                  double (&outp)[4]) __attribute__((always_inline)) {
+#pragma unroll 1
+  for (int it = 0; it < len; ++it) {
     const int r = r0 + it;
-    double2 ref[4];
-    const double ai = row_command<double>(act, C.action_dim, a0, r - 1);      // the wall command of the row finished below, then its
-    ref_row(r - 1, ref);                                          // reference row; requested FIRST: loads return in order,
-    load_state_row<INTERLEAVED, double>(su, sv, r + 3, c0, outu, outv);      // so the wait for it does not drain the row requested here
-    prow(r + 3, outp);
+    double nu_[4], nv_[4], pnn[4];
+    load_state_row<INTERLEAVED, double>(su, sv, r + 2, c0, nu_, nv_);
+    prow(r + 2, pnn);
     double cu[4], cv[4];
     predictor_row<double>(S, r, lane, s1u, s1v, s0u, s0v, s2u, s2v, cu, cv);
     {
@@ -306,31 +289,19 @@ __device__ __forceinline__ double back_rows(const NSConst& C, const NSScal<doubl
         cv[k] = edge ? cv[k] : cv[k] - S.dt_over_rho * dpdy;
       }
     }
-    if (it >= 1) finish_row(r - 1, cu, cv, ref, ai);
+    if (it >= 1) finish_row(r - 1, cu, cv);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       c2u[k] = c1u[k]; c2v[k] = c1v[k]; c1u[k] = cu[k]; c1v[k] = cv[k];
-      ps[k] = pc[k]; pc[k] = pn[k]; pn[k] = inp[k];
-      s0u[k] = s1u[k]; s0v[k] = s1v[k]; s1u[k] = s2u[k]; s1v[k] = s2v[k]; s2u[k] = inu[k]; s2v[k] = inv[k];
-    }
-  };
-  double n2u[4], n2v[4], n2p[4];
-#pragma unroll 1
-  for (int it = 0; it < len; it += 2) {
-    body(it, n1u, n1v, n1p, n2u, n2v, n2p);
-    if (it + 1 < len) {      // wave-uniform
-      body(it + 1, n2u, n2v, n2p, n1u, n1v, n1p);
-    } else {                 // odd length: nothing is in flight into n1 any more
-      break;
+      ps[k] = pc[k]; pc[k] = pn[k]; pn[k] = pnn[k];
+      s0u[k] = s1u[k]; s0v[k] = s1v[k]; s1u[k] = s2u[k]; s1v[k] = s2v[k]; s2u[k] = nu_[k]; s2v[k] = nv_[k];
     }
   }
   // the range's last row: C(r0 + len - 1) is in c1.  It is the lower wall row only in a one-row range (never: len >= 2); the upper
   // wall row (255) reads C(254) = c2.  A range whose first row is the lower wall was finished inside the loop with C(1).
   {
     double dummy_u[4] = {0.0, 0.0, 0.0, 0.0}, dummy_v[4] = {0.0, 0.0, 0.0, 0.0};
-    double2 ref[4];
-    ref_row(r0 + len - 1, ref);
-    finish_row(r0 + len - 1, dummy_u, dummy_v, ref, row_command<double>(act, C.action_dim, a0, r0 + len - 1));
+    finish_row(r0 + len - 1, dummy_u, dummy_v);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);

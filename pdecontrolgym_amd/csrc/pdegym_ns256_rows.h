@@ -101,45 +101,6 @@ __device__ __forceinline__ BcSel make_bc_sel(const int (&bc)[4][2], int lane) {
   return m;
 }
 
-// The command that the left / right walls of grid row i take (scalar action: a0; per-node actions: act[i]), and the commands of this
-// lane's four columns on the lower / upper wall rows.  A pipeline that keeps loads in flight across rows (the back phase of the float64
-// passes) fetches them AHEAD -- the column commands once before its loop, the row command at the head of an iteration before its other
-// loads -- and hands them to bc_row_regs, which touches no memory: a conditional load next to its use makes the compiler wait for
-// vmcnt(0) at the join in EVERY iteration, which drains the prefetched rows as well.
-template <typename T>
-__device__ __forceinline__ T row_command(const T* act, int action_dim, T a0, int i) {
-  // rows outside the grid pass through the pipelines' first / last iterations: keep the action index inside the array
-  return action_dim != 1 ? act[i < 0 ? 0 : (i > kN - 1 ? kN - 1 : i)] : a0;
-}
-template <typename T>
-__device__ __forceinline__ void column_commands(const T* act, int action_dim, T a0, int c0, T (&actc)[4]) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) actc[k] = action_dim != 1 ? act[c0 + k] : a0;
-}
-
-template <typename T>
-__device__ __forceinline__ void bc_row_regs(T (&f)[4], const T (&nb)[4], int i, const int (&bc)[4][2], int comp, const BcSel& m,
-                                            const T (&actc)[4], T ai) {
-  if (i == 0 || i == kN - 1) {        // wave-uniform, two rows per instance
-    const int c = bc[i == 0 ? PDEGYM_EDGE_LOWER : PDEGYM_EDGE_UPPER][comp];
-    if (c == PDEGYM_BC_NEUMANN) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) f[k] = nb[k];
-    } else if (c == PDEGYM_BC_DIRICHLET) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) f[k] = (T)0;
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) f[k] = actc[k];
-    }
-  }
-  const T wl = m.ld[comp] ? (T)0 : ai, wr = m.rd[comp] ? (T)0 : ai;
-  f[0] = m.ln[comp] ? f[1] : f[0];
-  f[0] = m.lw[comp] ? wl : f[0];
-  f[3] = m.rn[comp] ? f[2] : f[3];
-  f[3] = m.rw[comp] ? wr : f[3];
-}
-
 template <typename T>
 __device__ __forceinline__ void bc_row(T (&f)[4], const T (&nb)[4], int i, int c0, const int (&bc)[4][2], int comp,
                                        const BcSel& m, const T* act, int action_dim, T a0) {
@@ -156,7 +117,9 @@ __device__ __forceinline__ void bc_row(T (&f)[4], const T (&nb)[4], int i, int c
       for (int k = 0; k < 4; ++k) f[k] = action_dim == 1 ? a0 : act[c0 + k];
     }
   }
-  const T ai = row_command<T>(act, action_dim, a0, i);
+  // rows outside the grid pass through here on the pipelines' first / last iterations: keep the action index inside the array
+  T ai = a0;
+  if (action_dim != 1) ai = act[i < 0 ? 0 : (i > kN - 1 ? kN - 1 : i)];
   const T wl = m.ld[comp] ? (T)0 : ai, wr = m.rd[comp] ? (T)0 : ai;
   f[0] = m.ln[comp] ? f[1] : f[0];
   f[0] = m.lw[comp] ? wl : f[0];
