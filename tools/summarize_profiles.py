@@ -4,7 +4,11 @@ profiles/: per-workload kernel stats, per-launch HBM traffic (PMC), and SQ count
 
 HBM traffic follows MI355X_MICROARCH.md section HBM: bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 per launch
 (gfx950's FETCH_SIZE tallies 128-byte fabric reads at 64 bytes, hence the factor 2 on the read side; WRITE_SIZE is
-taken as is).  Check: the parabolic kernel's known compulsory traffic (row + beta in, row + obs out) is reproduced."""
+taken as is).  Check: the parabolic kernel's known compulsory traffic (row + beta in, row + obs out) is reproduced.
+
+Run it on the tree that was PROFILED: every workload's entry of profiles/counters_latest.json is stamped with the fingerprint of the
+kernel sources of the tree this script runs in (bench.kernel_stamp) -- summarising after an experiment has edited a kernel stamps the old
+counters with the new sources' fingerprint (round 5 did that once; re-run after reverting)."""
 import collections
 import csv
 import json
