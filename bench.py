@@ -10,7 +10,7 @@ A "step" = one env-step of EVERY instance of the batch = one launch of the fused
 (S PDE sub-steps + norms + reward + observation + auto-reset), inputs already resident in HBM.
 Default workload = BASELINE.json configs[1]: ReactionDiffusionPDE1D ("Parabolic1D") nx=256, batch 4096
 per GPU, fp32, S=100 sub-steps per env-step (SURVEY.md section 8d).  Other workloads (--workload NAME prints NAME's own line;
-the default run adds all of them under "also"): transport_c3, burgers_c3 (extension), parabolic_c2_policy_loop (C2 with its MLP
+the default run measures all of them too: a compact `secondary` list in the printed line, everything in bench_also.json): transport_c3, burgers_c3 (extension), parabolic_c2_policy_loop (C2 with its MLP
 controller evaluated on the device every step), parabolic_c2_rollout (the same loop as ONE kernel per 25 env-steps: here a
 "step" is one launch and `value` still counts env-steps), parabolic_c2_policy_loop_256 / parabolic_c2_rollout_256 (the same two with
 the 257-256-256-1 ReLU actor SB3's SAC builds), parabolic_c2_open_loop_rollout (25 env-steps per launch, commands given ahead),
@@ -18,9 +18,13 @@ parabolic_c2_s1 / parabolic_c2_s1_open_loop_rollout / parabolic_c2_s1_rollout (S
 per-step launch and 100 env-steps per launch without / with the policy inside), ns2d_c4, ns2d_c4_f64, ns2d_c4_b4096,
 ns2d_c4_f64_b4096, ns2d_c5, ns2d_c5_f64 (the _f64 lines: the same workloads at the reference's own precision), ns2d_example (the
 reference's shipped 21x21 K=2000 float64 configuration), traffic_arz, traffic_arz_rollout (25 env-steps per launch), brain_tumor;
-"also" additionally carries vecenv_host: the SB3-facing PDEVecEnv.step (NumPy in / out, PCIe-inclusive) at the C2 shape.
+bench_also.json additionally carries vecenv_host: the SB3-facing PDEVecEnv.step (NumPy in / out, PCIe-inclusive) at the C2 shape,
+and hbm_probe: the measured copy / read / fill rate of the box (tools/hbm_probe.hip).
 
-Prints ONE JSON line (rank 0).
+Prints ONE JSON line (rank 0), kept under 4 KB (final_line): metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+higher_is_better / scaling / vs_baseline / dtype / data / config + roofline + cpu_baseline + secondary (+ the per-rank fields for N > 1).
+The complete result of the run -- every workload's configuration, region times and full roofline block -- is written to
+bench_also.json next to this script (and to gpurun_out/ when that directory exists).
 """
 from __future__ import annotations
 
