@@ -20,7 +20,11 @@ SOURCES = ["pdegym_abi.hip", "pdegym_1d.hip", "pdegym_1d_rollout.hip", "pdegym_n
 # -ffp-contract=off: NumPy rounds after every operation; a fused multiply-add would break bit parity.
 # -fno-slp-vectorize: v_pk_*_f32 has the same per-element issue cost as the scalar forms on gfx950 (tools/ubench_valu.hip:
 # 5.1 vs 2.8 cycles per wave-instruction at 4 waves/SIMD) and packing adjacent stencil nodes costs shuffle moves.
-OPTS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC"]
+# -falign-loops=32 (round 5): loop headers on 32-byte boundaries.  The headline kernel's 26-instruction sub-step loop is identical in
+# two builds that differ only in where it starts, and runs 4 % apart (16.3 against 17.0 us per launch; any of 32 / 64 / 128 gives the
+# quicker figure, every other workload moves by < 1 %: profiles/r05_ab_notes.txt section 8) -- instruction fetch of a tight loop
+# depends on how many fetch windows its body straddles, so the placement is pinned instead of left to what precedes the loop.
+OPTS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-falign-loops=32", "-fPIC"]
 FLAGS = OPTS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

@@ -248,10 +248,14 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void traffic_step_kernel(pde
 // float64, plus noise, clamped, and stored to actions row t.
 // WIDE: a policy with a layer of more than 64 units -- the 16 waves of the workgroup evaluate it together (pdegym_policy.h: eval_wide),
 // so every wave, with or without a freeway, runs all T iterations (barriers).
-template <bool WIDE>
+// POLICY: compiled apart, so that the commands-given-ahead form carries none of the policy's loads (a load under a run-time branch
+// leaves the compiler's wait-count pass with "may be pending" registers at every join of the loop).
+template <bool WIDE, bool POLICY>
 __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void traffic_rollout_kernel(pdegym_params_traffic P, pdegym_bufs_traffic Bf,
                                                                                        pdegym_rollout_traffic Ro, pdegym_mlp N, TrafficConsts K,
-                                                                                       int has_policy, int B) {
+                                                                                       int B) {
+  static_assert(POLICY || !WIDE, "the cooperative evaluation belongs to a policy");
+  constexpr bool has_policy = POLICY;
   namespace pol = pdegym_policy;
   extern __shared__ __attribute__((aligned(16))) float pol_smem[];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void traffic_rollout_
   pol::Staged St = {};
   pol::Wide Wd;
   if constexpr (WIDE) Wd = pol::wide_setup(N, pol_smem, D, wave, lane);
-  else if (has_policy) St = pol::stage(N, pol_smem);        // the launch's only barrier (uniform over the grid)
+  else if constexpr (has_policy) St = pol::stage(N, pol_smem);        // the launch's only barrier (uniform over the grid)
   const bool active = inst_raw < B;      // wave-uniform
   if (!WIDE && !active) return;
   const int inst = active ? inst_raw : 0;      // a wave without a freeway only attends the barriers: it reads instance 0, stores nothing
@@ -276,10 +280,26 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void traffic_rollout_
   const double prof = (Bf.reset_rs && in) ? Bf.reset_profile[lane] : 1.0;
   const int A = Bf.action_stride > 0 ? Bf.action_stride : 2;
   const size_t slot = (size_t)B * D;
+  // commands given ahead (no policy): 64 env-steps per load -- lane l holds the command(s) of step t0 + l, handed out by v_readlane --
+  // and no fence between iterations (nothing stored by an iteration is read by the next): as in rollout1d_kernel, a load or a
+  // fence per env-step makes every step wait for the stores of the step before (gfx9 counts both in vmcnt)
+  auto command_batch = [&](int t0, int col) {
+    return (!has_policy && t0 + lane < Ro.T && col < A) ? Ro.actions[((size_t)(t0 + lane) * B + inst) * A + col] : 0.0;
+  };
+  double b0 = command_batch(0, 0), b1 = command_batch(0, 1);
+  // vmcnt(0) as a real instruction wherever the open-loop form loads (here, at a batch hand-over, after a restart): the wait-count pass
+  // then knows that nothing is pending at the joins of the loop and puts no static wait into its steady state
+  if constexpr (!has_policy) __builtin_amdgcn_s_waitcnt(0x0F70);
   for (int t = 0; t < Ro.T; ++t) {
     double* arow = Ro.actions + ((size_t)t * B + inst) * A;
     double a0, a1 = 0.0;
-    if (has_policy) {
+    const int tj = t & (kWave - 1);
+    if (!has_policy && tj == 0 && t) {      // wave-uniform, once per 64 env-steps; the loop's only wait for memory
+      b0 = command_batch(t, 0);
+      b1 = command_batch(t, 1);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    if constexpr (has_policy) {
       const double* xrow = Ro.obs + (size_t)t * slot + (size_t)inst * D;
       float c0, c1;
       if constexpr (WIDE) {
@@ -312,8 +332,8 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void traffic_rollout_
         if (A > 1) arow[1] = a1;
       }
     } else {
-      a0 = arow[0];
-      if (A > 1) a1 = arow[1];
+      a0 = lane_value(b0, tj);
+      a1 = lane_value(b1, tj);
     }
     const TrafficStepOut o = traffic_step_wave(P, K, r, y, time, rs, qc, a0, a1, lane);
     double* onext = Ro.obs + (size_t)(t + 1) * slot + (size_t)inst * D;
@@ -330,6 +350,7 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void traffic_rollout_
         onext[M + lane] = v0;
       }
       time = 0.0;
+      if constexpr (!has_policy) __builtin_amdgcn_s_waitcnt(0x0F70);
     } else {
       traffic_emit_obs(P, onext, r, o.v, rs, o.vs, lane);
     }
@@ -338,9 +359,10 @@ __global__ __launch_bounds__(kWave* pdegym_policy::kWaves) void traffic_rollout_
       Ro.done[(size_t)t * B + inst] = o.done ? 1 : 0;
       Ro.truncated[(size_t)t * B + inst] = o.trunc ? 1 : 0;
     }
-    // the observation row just stored is read back (by other lanes) at the start of the next iteration
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if constexpr (has_policy) {      // the observation row just stored is read back (by other lanes) at the start of the next iteration
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
   }
   if (!active) return;
   if (in) {
@@ -570,15 +592,17 @@ int pdegym_traffic_rollout(const pdegym_params_traffic* prm, const pdegym_bufs_t
     wide = pdegym_policy::is_wide(net);
     lds_bytes = (size_t)pdegym_policy::lds_floats(net, 2 * prm->M) * sizeof(float);
     static signed char attr[2][pdegym::kMaxDevices] = {};
-    const void* fn = wide ? reinterpret_cast<const void*>(&traffic_rollout_kernel<true>) : reinterpret_cast<const void*>(&traffic_rollout_kernel<false>);
+    const void* fn = wide ? reinterpret_cast<const void*>(&traffic_rollout_kernel<true, true>) : reinterpret_cast<const void*>(&traffic_rollout_kernel<false, true>);
     if (!pdegym::raise_dynamic_lds_limit(fn, pdegym_policy::kMaxLdsBytes, attr[wide ? 1 : 0]))
       return pdegym::fail(-4, "cannot raise the dynamic LDS limit of traffic_rollout_kernel");
   }
   const dim3 grid((B + pdegym_policy::kWaves - 1) / pdegym_policy::kWaves), block(kWave * pdegym_policy::kWaves);
   if (wide)
-    hipLaunchKernelGGL(traffic_rollout_kernel<true>, grid, block, lds_bytes, (hipStream_t)stream, *prm, *buf, *ro, net, traffic_consts(*prm), 1, B);
+    hipLaunchKernelGGL((traffic_rollout_kernel<true, true>), grid, block, lds_bytes, (hipStream_t)stream, *prm, *buf, *ro, net, traffic_consts(*prm), B);
+  else if (ro->policy)
+    hipLaunchKernelGGL((traffic_rollout_kernel<false, true>), grid, block, lds_bytes, (hipStream_t)stream, *prm, *buf, *ro, net, traffic_consts(*prm), B);
   else
-    hipLaunchKernelGGL(traffic_rollout_kernel<false>, grid, block, lds_bytes, (hipStream_t)stream, *prm, *buf, *ro, net, traffic_consts(*prm), ro->policy ? 1 : 0, B);
+    hipLaunchKernelGGL((traffic_rollout_kernel<false, false>), grid, block, lds_bytes, (hipStream_t)stream, *prm, *buf, *ro, net, traffic_consts(*prm), B);
   return pdegym::check_launch("traffic_rollout");
 }
 
