@@ -600,7 +600,8 @@ CLOCK_GHZ = 2.4          # MI355X peak shader clock (MI355X_MICROARCH.md); susta
 N_SIMD = 256 * 4         # 256 CUs x 4 SIMDs
 VALU_PEAK_GINST = N_SIMD * CLOCK_GHZ / 2.0     # one wave64 VALU instruction per SIMD every 2 cycles -> 1228.8 G wave-inst/s
 REPEATS = 5              # median of 5 repeats of the K timed steps
-WARM_SECONDS = 0.05      # untimed graph replays before the first timed region
+WARM_SECONDS = 0.05      # untimed graph replays before the first timed region: at least this long ...
+WARM_MAX_SECONDS = 1.0   # ... and until two consecutive replays agree to 1 %, but no longer than this
 
 
 def profiled_counters(workload_key):
@@ -659,11 +660,20 @@ def run_workload(wl, steps, warmup, world, graph=False, repeats=REPEATS):
         torch.cuda.current_stream().wait_stream(side)
         # untimed replays (graph upload, clocks, caches) until at least WARM_SECONDS have passed: short regions used to be
         # timed while the box was still speeding up (five consecutive regions fell monotonically by 6-10 %)
+        # ... and, round 5, until two consecutive replays agree to 1 % (at most WARM_MAX_SECONDS): after a different workload the
+        # clocks of a box settle over hundreds of milliseconds, and a region of 10 ms replays (the NS workloads) was still drifting by
+        # 8-22 % across its five timed regions when only the 50 ms rule applied (profiles/r05d_bench_also.json: timed_regions_s)
         t_warm = time.perf_counter()
+        last, agree = None, 0
         while True:
+            t_r = time.perf_counter()
             g.replay()
             torch.cuda.synchronize()
-            if time.perf_counter() - t_warm >= WARM_SECONDS:
+            now = time.perf_counter()
+            dur = now - t_r
+            agree = agree + 1 if (last is not None and abs(dur - last) <= 0.01 * dur) else 0
+            last = dur
+            if now - t_warm >= WARM_SECONDS and (agree >= 2 or now - t_warm >= WARM_MAX_SECONDS):
                 break
         for _ in range(repeats):
             regions.append(_timed(g.replay, world))
