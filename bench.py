@@ -435,8 +435,23 @@ class TrafficARZ:
         seconds = 3840 env-steps and a finished freeway is not advanced any more, so a graph replayed past that point (the
         untimed warm replays alone are > 2000 env-steps) would time launches that do nothing."""
         self.env.reset(self.rs_dev)        # (a device tensor: nothing crosses PCIe inside the captured graph)
+        self.since_reset = 0
+
+    # The reference advances `time` by dt per env-step and runs the sub-steps only `while self.time < self.T` (traffic_arz_env.py:146,
+    # :172) while the episode ends at time >= T / dt (:106, seconds compared with a step count -- kept): with T = 240 s, dt = 0.25 s the
+    # PDE is advanced during the first 960 env-steps and merely re-observed during the following 2880.  A region must stay inside the
+    # live part, or it times launches whose sub-steps are skipped (round 5: 310 us per rollout launch of 25 live env-steps, 170 us beyond).
+    LIVE_ENV_STEPS = 950
+
+    def _stay_live(self, env_steps):
+        """Restart the freeways (inside the captured graph) before `env_steps` more would leave the live part of the episode."""
+        if getattr(self, "since_reset", 0) + env_steps > self.LIVE_ENV_STEPS:
+            self.env.reset(self.rs_dev)
+            self.since_reset = 0
+        self.since_reset = getattr(self, "since_reset", 0) + env_steps
 
     def step(self):
+        self._stay_live(1)
         out = self.env.step(self.actions[self.i])
         self.i += 1
         return out
@@ -475,6 +490,7 @@ class TrafficARZRollout(TrafficARZ):
 
     def step(self):
         T = self.CHUNK
+        self._stay_live(T)       # long regions (--steps 200 = 5000 env-steps): restart before the live part of the episode ends
         self.env.rollout(self.robs, self.actions[self.i * T:(self.i + 1) * T], self.rrew, self.rdn, self.rtr)
         self.i += 1
 
