@@ -207,7 +207,9 @@ def test_traffic_device_rollout_with_fused_policy():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("sim,cf,B,T", [("inlet", 1, 37, 12), ("outlet", 2, 64, 9), ("both", 1, 5, 30), ("outlet-train", 3, 130, 7),
-                                        ("outlet", 2, 1, 1)])
+                                        ("outlet", 2, 1, 1),
+                                        # round 5: launches longer than one command batch (64 env-steps per load; one and two commands)
+                                        ("both", 1, 3, 130), ("outlet", 2, 4, 65), ("inlet", 1, 2, 64), ("outlet-train", 2, 5, 129)])
 def test_traffic_rollout_kernel_equals_step_calls_bitwise(sim, cf, B, T):
     """pdegym_traffic_rollout (T env-steps in one launch, (r, y) in registers across steps) against T step calls: every
     observation slot, reward, flag and the final r, y, time agree bit for bit."""
