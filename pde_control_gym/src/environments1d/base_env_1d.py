@@ -112,13 +112,16 @@ class PDEEnv1D(Env):
         self._fused_reward = spec is not None
         if not self._fused_reward:
             record_history = True           # a user reward callback receives the trajectory
+        # state_in_obs=False: the row lives in its own HBM tensor, so the observation can be a pure OUTPUT -- written by the kernel
+        # straight into pinned host memory (PDEBatch1D.enable_host_io): one launch + one synchronisation per step() call
         self._core = PDEBatch1D(self._kind, self.T, self.dt, self.X, self.dx, self.control_sample_rate,
                                 control_type=self.control_type, sensing_loc=self.sensing_loc,
                                 sensing_type=self.sensing_type, normalize=self._normalize_flag,
                                 max_control_value=self.max_control_value,
                                 limit_pde_state_size=self.limit_pde_state_size, max_state_value=self.max_state_value,
                                 reward=spec, num_envs=1, device=device, backend=backend,
-                                record_history=record_history, flux=self._flux)
+                                record_history=record_history, flux=self._flux, state_in_obs=False)
+        self._io = self._core.enable_host_io()
         self._terminated = False
         self._truncated = False
 
@@ -139,8 +142,10 @@ class PDEEnv1D(Env):
         """True if ``limit_pde_state_size`` and ||u||_2 >= max_state_value (reference hyperbolic.py:182-194)."""
         return bool(self._truncated)
 
-    def _obs_to_user(self, obs_row):
-        o = obs_row.cpu().numpy()
+    def _obs_to_user(self):
+        """The observation the last launch wrote into the pinned host view, as an array of the caller's own (the view is
+        overwritten by the next step), through the sensing-noise hook (hyperbolic.py:160-164)."""
+        o = self._io["obs"]
         o = o[0].copy() if self._core.obs_dim > 1 else np.float32(o[0, 0])
         return self.sensing_noise_func(o)
 
@@ -165,26 +170,28 @@ class PDEEnv1D(Env):
             b = b.astype(np.float64)
         if b.shape[0] != n:
             raise Exception(_RESET_ERR)
-        obs = self._core.reset(init[None], b)
+        self._core.reset(init[None], b)
+        self._core.sync_host()
         self.time_index = 0
         self._terminated = self._truncated = False
-        return self._obs_to_user(obs), {}
+        return self._obs_to_user(), {}
 
     def step(self, control):
         """Advance ``control_sample_rate/dt`` PDE sub-steps under boundary input ``control`` (a float, 0-d or
-        size-1 array).  Returns ``(obs, reward, terminated, truncated, {})``."""
-        import torch
-        from pdecontrolgym_amd import _native as N
+        size-1 array).  Returns ``(obs, reward, terminated, truncated, {})``.
+
+        One kernel launch and one stream synchronisation: the command goes to the kernel through a pinned host slot, the
+        observation / reward / flags come back through pinned host views (no copies in either direction)."""
         a, kind = classify_control(control)
-        obs, rew, te, tr = self._core.step(torch.tensor([a], dtype=torch.float32 if kind == N.ACTION_F32 else torch.float64),
-                                           action_kind=kind)
-        flags = torch.stack([te, tr]).cpu().numpy()
-        self._terminated, self._truncated = bool(flags[0, 0]), bool(flags[1, 0])
-        self.time_index = int(self._core.time_index.cpu()[0])
+        core, io = self._core, self._io
+        core.step_host(a, kind)
+        self._terminated, self._truncated = bool(io["terminated"][0]), bool(io["truncated"][0])
+        # hyperbolic.py:140 ``while i < sample_rate and self.time_index < self.nt - 1``: the host mirrors the device's counter
+        self.time_index = min(self.time_index + core.substeps, self.nt - 1)
         if self._fused_reward:
-            reward = rew.cpu().numpy()[0]
+            reward = io["reward"][0]
             if self._truncated and type(self.reward_class) is TunedReward1D and not (
-                    self._terminated and float(self._core.t["norm_now"].cpu()[0]) < 20):
+                    self._terminated and float(io["norm_now"][0]) < 20):
                 # tuned_reward_1d.py:38-39: this branch is Python arithmetic on the constructor's numbers -- a Python float, formed
                 # in double (the kernel's float32 value is what the batched faces return)
                 reward = self.reward_class.truncate_penalty * (self.reward_class.nt - self.time_index)
@@ -192,7 +199,7 @@ class PDEEnv1D(Env):
             view = HistoryView(self._core.t["history"][0])
             reward = self.reward_class.reward(view, self.time_index, self._terminated, self._truncated,
                                               view[self.time_index][-1])
-        return self._obs_to_user(obs), reward, self._terminated, self._truncated, {}
+        return self._obs_to_user(), reward, self._terminated, self._truncated, {}
 
 
 def validate_1d_options(kind, sensing_loc, control_type, sensing_type):

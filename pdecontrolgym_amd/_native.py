@@ -238,8 +238,11 @@ def dptr(t, dtype=None):
     """Device pointer of a torch tensor, with the checks the C side cannot do."""
     if t is None:
         return None
-    if not t.is_cuda:
-        raise NativeError("pdegym kernels need tensors on a HIP device (got a CPU tensor); there is no CPU path")
+    if not t.is_cuda and not t.is_pinned():
+        # pinned host memory (hipHostMalloc: mapped into the device's address space, fine-grained coherent) is device-accessible:
+        # the batch-of-one faces pass their command and take their results through it (PDEBatch1D.enable_host_io)
+        raise NativeError("pdegym kernels need tensors on a HIP device or in pinned host memory (got a pageable CPU tensor); "
+                          "there is no CPU path")
     if not t.is_contiguous():
         raise NativeError("pdegym kernels need contiguous tensors")
     if dtype is not None and t.dtype != dtype:

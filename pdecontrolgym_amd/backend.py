@@ -77,7 +77,7 @@ class HipBackend:
             raise N.NativeError("reset_beta needs a per-instance beta [B, n] and the shape of reset_init")
         return b
 
-    @_on_device_of("obs")
+    @_on_device_of("bsum")        # (a state tensor: the outputs of a host-facing engine may live in pinned host memory)
     def step1d(self, kind: str, P: N.Params1D, T: dict, B: int):
         import torch
         fn = self.lib.pdegym_transport_step if kind == "transport" else self.lib.pdegym_parabolic_step
@@ -86,7 +86,31 @@ class HipBackend:
         if T["action"].dtype != (torch.float32 if P.action_kind == N.ACTION_F32 else torch.float64):
             raise N.NativeError(f"action is {T['action'].dtype} but params.action_kind = {P.action_kind}")
         bufs = self._bufs1d(T)
-        N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["obs"].device)), f"pdegym_{kind}_step")
+        N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["bsum"].device)), f"pdegym_{kind}_step")
+
+    def prepare_step1d(self, kind: str, P: N.Params1D, T: dict, B: int):
+        """The step call with its argument structures built ONCE: returns a zero-argument callable that launches
+        pdegym_{kind}_step on the current stream of the state's device.  ``P`` is passed by reference (fields such as
+        ``action_kind`` may change between calls); the tensors of ``T`` must stay alive and in place."""
+        import torch
+        fn = self.lib.pdegym_transport_step if kind == "transport" else self.lib.pdegym_parabolic_step
+        if T["beta"].dtype != (torch.float64 if P.beta_f64 else torch.float32):
+            raise N.NativeError(f"beta is {T['beta'].dtype} but params.beta_f64 = {P.beta_f64}")
+        bufs = self._bufs1d(T)
+        dev = T["bsum"].device                     # (outputs may live in pinned host memory: the state names the device)
+        pP, pB, what = C.byref(P), C.byref(bufs), f"pdegym_{kind}_step"
+        current_stream, current_device = torch.cuda.current_stream, torch.cuda.current_device
+
+        def call(_keep=(bufs, T)):
+            if current_device() != dev.index:
+                with torch.cuda.device(dev):
+                    rc = fn(pP, pB, B, current_stream(dev).cuda_stream)
+            else:
+                rc = fn(pP, pB, B, current_stream(dev).cuda_stream)
+            if rc:
+                N.check(rc, what)
+        return call
+    prepare_step1d.device_guard_key = "bsum"     # the guard is inside the prepared call (the state's device made current)
 
     @_on_device_of("obs")
     def rollout1d(self, kind: str, P: N.Params1D, T: dict, obs, actions, rewards, terminated, truncated, B: int, policy=None,
@@ -119,13 +143,13 @@ class HipBackend:
         ro.obs_seen = N.dptr(obs_seen, torch.float32) if obs_seen is not None else None
         N.check(fn(C.byref(P), C.byref(bufs), C.byref(ro), B, N.current_stream_ptr(obs.device)), f"pdegym_{kind}_rollout")
 
-    @_on_device_of("obs")
+    @_on_device_of("bsum")
     def reset1d(self, P: N.Params1D, T: dict, init, mask, B: int):
         import torch
         bufs = self._bufs1d(T)
         m = N.dptr(mask, torch.uint8) if mask is not None else None
         N.check(self.lib.pdegym_reset1d_masked(C.byref(P), C.byref(bufs), N.dptr(init, torch.float32), m, B,
-                                               N.current_stream_ptr(T["obs"].device)), "pdegym_reset1d_masked")
+                                               N.current_stream_ptr(T["bsum"].device)), "pdegym_reset1d_masked")
 
     @_on_device_of("u")
     def rownorm2(self, rows, out):

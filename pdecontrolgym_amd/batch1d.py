@@ -264,6 +264,86 @@ class PDEBatch1D(EngineCheckpoint):
             self.t["u"] = self.t["obs"]
         return self.t["obs"], self.t["reward"], self.t["terminated"], self.t["truncated"]
 
+    # ---- batch-of-one face: command in / results out through ONE pinned host allocation ------------------------------
+    def enable_host_io(self):
+        """Host-facing mode of a small batch (the single environments, ``num_envs=1``): the command and everything a host caller
+        reads after a step -- observation, reward, ||u||, terminated, truncated -- live in ONE pinned host allocation that is
+        mapped into the device's address space (hipHostMalloc).  The step kernel reads the command from it and writes its
+        results into it directly, so an env-step is ONE stream operation (the kernel launch) + ONE stream synchronisation: no
+        host-to-device copy of the command, no device-to-host copies of the results, no torch dispatch.  The plant state (row,
+        beta, ring, running sums, time index, history) stays in HBM.  Not for ``state_in_obs`` engines (their observation IS
+        the state).  Returns the NumPy views ``{"obs", "reward", "norm_now", "terminated", "truncated"}`` (valid after
+        ``step_host`` / ``sync_host``; overwritten by the next step)."""
+        import torch
+        if self.state_in_obs:
+            raise ValueError("host I/O needs the state in its own tensor (build the engine with state_in_obs=False)")
+        if getattr(self, "_hio", None) is not None:
+            return self._hio["np"]
+        B, od = self.num_envs, self.obs_dim
+        sizes = (("action", 8 * B), ("obs", 4 * B * od), ("reward", 4 * B), ("norm_now", 4 * B), ("terminated", B), ("truncated", B))
+        pack = torch.zeros((sum(s for _, s in sizes) + 63) // 64 * 64, dtype=torch.uint8, pin_memory=self.device.type == "cuda")
+        raw, off, sl = pack.numpy(), 0, {}
+        for k, nb in sizes:
+            sl[k] = slice(off, off + nb)
+            off += nb
+        f32 = torch.float32
+        tv = {"action": pack[sl["action"]].view(torch.float64), "obs": pack[sl["obs"]].view(f32).view(B, od),
+              "reward": pack[sl["reward"]].view(f32), "norm_now": pack[sl["norm_now"]].view(f32),
+              "terminated": pack[sl["terminated"]], "truncated": pack[sl["truncated"]]}
+        import numpy as np
+        nv = {"obs": raw[sl["obs"]].view(np.float32).reshape(B, od), "reward": raw[sl["reward"]].view(np.float32),
+              "norm_now": raw[sl["norm_now"]].view(np.float32), "terminated": raw[sl["terminated"]],
+              "truncated": raw[sl["truncated"]]}
+        # one 8-byte slot per instance: a float32 command occupies its first four bytes, a float64 one all eight (the kernel reads
+        # the slot as params.action_kind says)
+        a64 = raw[sl["action"]].view(np.float64)
+        a32 = raw[sl["action"]].view(np.float32)[::2]
+        for k in ("obs", "reward", "norm_now", "terminated", "truncated"):
+            self.t[k] = tv[k]
+        self._obs = [tv["obs"], tv["obs"]]
+        self._hio = {"pack": pack, "action": tv["action"], "a32": a32, "a64": a64, "np": nv, "call": None, "key": None}
+        return nv
+
+    def _host_call(self):
+        """The prepared C-ABI call of ``step_host`` (argument structures filled once; rebuilt when a tensor of the dictionary
+        has been replaced, e.g. a new beta at reset)."""
+        io = self._hio
+        self.t["action"] = io["action"]
+        key = (self.t["beta"].data_ptr(), self.t["u"].data_ptr(), None if self.t["history"] is None else self.t["history"].data_ptr(),
+               int(self.params.beta_f64))
+        if io["call"] is None or io["key"] != key:
+            prep = getattr(self.backend, "prepare_step1d", None)
+            if prep is not None:
+                io["call"] = prep(self.kind, self.params, self.t, self.num_envs)
+            else:                        # (the CPU tests' oracle double: the plain entry point, the command as a typed tensor)
+                def call():
+                    import torch
+                    f32 = self.params.action_kind == N.ACTION_F32
+                    self.t["action"] = torch.from_numpy((io["a32"] if f32 else io["a64"]).copy())
+                    self.backend.step1d(self.kind, self.params, self.t, self.num_envs)
+                io["call"] = call
+            io["key"] = key
+        return io["call"]
+
+    def sync_host(self):
+        """Wait until the results of the last launch are in the host views."""
+        if self.device.type == "cuda":
+            import torch
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def step_host(self, value: float, action_kind: int = N.ACTION_F32):
+        """One env-step of a batch of one commanded from the host: ``value`` (a Python float) is written into the pinned command
+        slot in the precision ``action_kind`` names, the step kernel is launched, the stream is synchronised.  The results are in
+        the views ``enable_host_io`` returned."""
+        io = self._hio
+        if action_kind == N.ACTION_F32:
+            io["a32"][:] = value
+        else:
+            io["a64"][:] = value
+        self.params.action_kind = action_kind
+        self._host_call()()
+        self.sync_host()
+
     def can_rollout(self) -> bool:
         """True when ``rollout`` applies: every control / sensing combination (round 4: Neumann actuation and scalar sensing
         too), as long as the state has ONE home -- the observation slots with full-state sensing (``state_in_obs``), ``u``

@@ -243,3 +243,31 @@ def test_traffic_oracle_matches_reference(golden_traffic, case):
             np.testing.assert_array_equal(o[0], g.obs[keep[k + 1]], err_msg=f"step {k}")
         assert r[0] == g.reward[k] and bool(d[0]) == bool(g.done[k]) and bool(t[0]) == bool(g.trunc[k])
         assert orc.time_index[0] == g.time[k]
+
+
+# ---- un-batched oracle (oracle/single_env.py: the CPU leg of bench.py's single_env block) ------------------------------------
+def _single_cases():
+    full = lambda d: {k: v for k, v in d.items() if v["sensing_loc"] == "full"}
+    return ([("transport", c) for c in sorted(full(TRANSPORT_CASES))] +
+            [("parabolic", c) for c in sorted(full(PARABOLIC_CASES)) if c != "P1"])       # (P1: 80 MB of history)
+
+
+@pytest.mark.parametrize("kind,case", _single_cases())
+def test_single_env_oracle_matches_reference_goldens(golden_transport, golden_parabolic, kind, case):
+    """The single-environment restatement reproduces the reference-generated fixtures directly: rows bit-exact, rewards to the
+    same tolerance as the batched oracle."""
+    from oracle.single_env import SingleEnv1D
+    kw = (TRANSPORT_CASES if kind == "transport" else PARABOLIC_CASES)[case]
+    g = (golden_transport if kind == "transport" else golden_parabolic)[case]
+    env = SingleEnv1D(kind, kw["T"], kw["dt"], kw["X"], kw["dx"], kw["control_sample_rate"], control_type=kw["control_type"],
+                      normalize=kw["normalize"], max_control_value=kw["max_control_value"],
+                      limit_pde_state_size=kw["limit_pde_state_size"], max_state_value=kw["max_state_value"],
+                      reward=(int(g.reward_args[0]), g.reward_args[1], g.reward_args[2]))
+    np.testing.assert_array_equal(env.reset(g.init, g.beta), g.obs[0])
+    for i, a in enumerate(g.actions):
+        with np.errstate(all="ignore"):
+            row, r, te, tr = env.step(np.array([a], dtype=g.actions.dtype))
+        np.testing.assert_array_equal(row, g.rows[i], err_msg=f"row step {i}")
+        assert env.t == int(g.time_index[i]) and bool(te) == bool(g.terminate[i]) and bool(tr) == bool(g.truncate[i])
+        if np.isfinite(g.reward[i]):
+            np.testing.assert_allclose(r, g.reward[i], rtol=1e-6, atol=1e-6 * max(1.0, float(np.linalg.norm(row))))
