@@ -19,6 +19,7 @@ per-step launch and 100 env-steps per launch without / with the policy inside), 
 ns2d_c4_f64_b4096, ns2d_c5, ns2d_c5_f64 (the _f64 lines: the same workloads at the reference's own precision), ns2d_example (the
 reference's shipped 21x21 K=2000 float64 configuration), traffic_arz, traffic_arz_rollout (25 env-steps per launch), brain_tumor;
 bench_also.json additionally carries vecenv_host: the SB3-facing PDEVecEnv.step (NumPy in / out, PCIe-inclusive) at the C2 shape,
+single_env: microseconds per env.step() of ONE environment through the drop-in face beside the un-batched NumPy oracle (bench_single.py),
 and hbm_probe: the measured copy / read / fill rate of the box (tools/hbm_probe.hip).
 
 Prints ONE JSON line (rank 0), kept under 4 KB (final_line): metric / value / unit / n_gpus / steps / warmup / ms_per_step /
@@ -57,6 +58,8 @@ def _dist_setup(n_gpus):
         # The step path has no collective; the process group only carries the timing barrier and one MAX all-reduce.
         # RCCL ("nccl") first, gloo as a fallback so a fabric hiccup cannot lose the measurement.
         try:
+            if os.environ.get("PDEGYM_BENCH_FAIL_NCCL") == "1":      # test hook: the fallback below is otherwise unreachable on a healthy box
+                raise RuntimeError("PDEGYM_BENCH_FAIL_NCCL=1: simulated RCCL initialisation failure")
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
             t = torch.zeros(1, device="cuda")
             dist.all_reduce(t)
@@ -634,6 +637,68 @@ def profiled_counters(workload_key):
         return None, None
 
 
+def live_counters(workload_key, budget_s=90.0, first_timeout_s=75.0, timeout_s=40.0):
+    """Counters of THIS run's headline kernel, collected on THIS box: before the parent process touches the
+    GPU, four fresh child processes run the headline workload under rocprofv3 -- `--kernel-trace --stats` (the kernel's average
+    duration), then `--pmc SQ_INSTS_VALU`, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` in passes of their own (never combined with a
+    sys / hip trace; `python3` directly after `--`).  Returns {"kernel", "kernel_avg_ns", "calls", "valu_insts_per_step",
+    "hbm_bytes_per_step", ...} or None (any failure, profiler missing, time budget spent: the caller falls back to the committed
+    counters).  Never retried, and never run from a process that has used the GPU."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    ksub = {"parabolic_c2": "step1d_kernel"}.get(workload_key)
+    if ksub is None:
+        return None
+    t_begin = time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="pdegym_live_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = ["python3", os.path.abspath(__file__), "--workload", workload_key, "--no-also", "--no-cpu-baseline", "--no-live-counters",
+             "--steps", "30", "--warmup", "5", "--repeats", "1"]
+    out = {"collected": "rocprofv3 children of this bench.py run, before the parent initialised the GPU"}
+
+    def run(tag, opts):
+        left = budget_s - (time.perf_counter() - t_begin)
+        if left <= 5.0:
+            raise TimeoutError("live-counter time budget spent")
+        d = os.path.join(tmp, tag)
+        cmd = [rocprof] + opts + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + child
+        subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, cwd="/tmp", check=True,
+                       timeout=min(left, first_timeout_s if tag == "stats" else timeout_s))
+        for base, _, files in os.walk(d):          # (rocprofv3 may add a host-name level under -d)
+            for f in files:
+                if f in ("p_kernel_stats.csv", "p_counter_collection.csv"):
+                    return os.path.join(base, f)
+        raise FileNotFoundError(tag)
+    try:
+        for r in csv.DictReader(open(run("stats", ["--kernel-trace", "--stats"]))):
+            if ksub in r["Name"]:
+                out.update(kernel=r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-80:],
+                           calls=int(r["Calls"]), kernel_avg_ns=float(r["AverageNs"]), kernel_min_ns=float(r["MinNs"]))
+                break
+        else:
+            return None
+        for counter, scale, key in (("SQ_INSTS_VALU", 1.0, "valu_insts_per_step"), ("FETCH_SIZE", 2048.0, "_fetch"), ("WRITE_SIZE", 1024.0, "_write")):
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(run(counter, ["--pmc", counter, "--kernel-trace"])))
+                    if ksub in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if len(vals) < 10:
+                return None
+            out[key] = sum(vals) / len(vals) * scale
+        # MI355X_MICROARCH.md (HBM / rocprofv3): gfx950's FETCH_SIZE tallies 128-byte reads at 64 bytes -> x 2 on the read side
+        out["hbm_bytes_per_step"] = out.pop("_fetch") + out.pop("_write")
+        out["seconds"] = time.perf_counter() - t_begin
+        return out
+    except Exception as ex:
+        sys.stderr.write(f"live counters unavailable ({ex!r}); the roofline block uses the committed counters\n")
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _timed(fn, world):
     """barrier + synchronize on both sides; HIP events on the launch stream bracket the same region."""
     import torch
@@ -778,7 +843,7 @@ def hbm_probe(device):
     return {k: r[k] for k in ("copy_GBps", "read_GBps", "fill_GBps", "at_MiB", "kernel")}
 
 
-def roofline_block(wl, key, step_ms, default_config):
+def roofline_block(wl, key, step_ms, default_config, live=None):
     """The resource that binds the step and how close the step is to it.  Two candidates, both reported:
       * VALU issue: SQ_INSTS_VALU of one step (profiled) x 2 cycles / (1024 SIMDs x step time x 2.4 GHz);
       * HBM: PMC bytes of one step (profiled) / step time against the 8 TB/s specification.
@@ -788,6 +853,9 @@ def roofline_block(wl, key, step_ms, default_config):
     t = step_ms * 1e-3
     alg = wl.algorithmic_bytes_per_step()
     ctr, src = profiled_counters(key) if default_config else (None, None)
+    if live and default_config:          # counters collected by this very run (live_counters) take the place of the committed ones
+        ctr = dict(live, kernel_stamp=kernel_stamp(key), kernels={live.get("kernel"): {"avg_ns": live.get("kernel_avg_ns")}})
+        src = live["collected"]
     valu = hbm = None
     if ctr and ctr.get("valu_insts_per_step"):
         a = ctr["valu_insts_per_step"] / t / 1e9
@@ -822,6 +890,9 @@ def roofline_block(wl, key, step_ms, default_config):
         out["counters_kernel_stamp"] = ctr.get("kernel_stamp")
         lib = build.library_stamp()
         out["counters_stale"] = bool(ctr.get("kernel_stamp") != now or (lib != "" and lib != build._fingerprint()))
+    out["counters_live"] = bool(live and default_config)
+    if live and default_config:
+        out["kernel_avg_ns"] = live.get("kernel_avg_ns")        # rocprofv3 --stats average of the dominant kernel, this run, this box
     out.update({"valu_issue": valu, "hbm": hbm, "step_ms": step_ms, "counters_source": src,
                 "kernels_per_step": (ctr or {}).get("kernels"),
                 "effective_streaming_GBps": alg / t / 1e9, "effective_streaming_frac_of_hbm_peak": alg / t / 1e9 / HBM_PEAK_GBPS,
@@ -840,6 +911,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads in the default run")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="do not collect the headline kernel's counters with rocprofv3 children first (committed counters are used)")
     ap.add_argument("--repeats", type=int, default=REPEATS, help="timed regions of K steps each; the median is reported")
     ap.add_argument("--eager", action="store_true",
                     help="one Python call per launch instead of replaying the K timed launches from one captured hipGraph")
@@ -849,7 +922,11 @@ def main():
     if args.cpu_worker:                      # child of cpu_baseline_report: NumPy only, prints env-steps/s
         print(cpu_port_rate(args.cpu_worker, args.cpu_seconds, args.seed)[0])
         return
-    # CPU baseline first: it must run (and fork its workers) before this process initialises the GPU
+    # Live counters + CPU baseline first: their children must be started before this process initialises the GPU
+    live = None
+    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_live_counters and not args.no_also and not args.batch
+            and not args.substeps and args.workload == "parabolic_c2"):
+        live = live_counters(args.workload)
     cpu_rep = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
         cpu_rep = cpu_baseline_report(args.workload, args.cpu_seconds)
@@ -886,7 +963,7 @@ def main():
         "config": dict(wl.config(), launch="hipGraph replay of the K timed launches" if use_graph else "eager (one Python call per launch)",
                        timing=f"median of {args.repeats} regions of exactly K steps, each bracketed by barrier + synchronize; max over ranks"),
         "timed_regions_s": res["all_regions_s"],
-        "roofline": roofline_block(wl, args.workload, res["step_ms_events"], default_config),
+        "roofline": roofline_block(wl, args.workload, res["step_ms_events"], default_config, live),
     }
     out["roofline"]["isolated_step_ms_median"] = res["isolated_step_ms_median"]
     if world > 1:
@@ -905,12 +982,43 @@ def main():
     if cpu_rep is not None:
         out["cpu_baseline"] = cpu_rep
     also = None
+    if world > 1 and not args.no_also and args.workload == "parabolic_c2" and not args.batch:
+        # BASELINE configs[4] is the one configuration DEFINED on 8 GPUs (NavierStokes2D 256 x 256, 4096 instances sharded 512 per
+        # GPU): every rank steps its own 512 instances (no data-path collective), regions bracketed by the barrier, time = MAX over
+        # ranks.  Node totals + the per-rank rates; float32 and the reference's own float64.
+        import torch.distributed as dist
+        multi = {}
+        for name in MULTI_GPU_SECONDARY:
+            try:
+                w2 = WORKLOADS[name](device, 99 + rank)
+                n2 = 20
+                r2 = run_workload(w2, n2, 5, world, graph=use_graph, repeats=3)
+                mine = torch.tensor([w2.units_per_step() * n2 / r2["seconds_this_rank"]], dtype=torch.float64,
+                                    device="cpu" if dist.get_backend() == "gloo" else device)
+                allv = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allv, mine)
+                multi[name] = {"value": w2.units_per_step() * n2 * world / r2["seconds"], "unit": "env-steps/s",
+                               "ms_per_step": r2["seconds"] / n2 * 1e3, "dtype": w2.dtype, "timed_regions_s": r2["all_regions_s"],
+                               "per_rank_env_steps_per_s": [float(v.item()) for v in allv], "instances_per_gpu": w2.B,
+                               "instances_whole_node": w2.B * world, "config": w2.config(),
+                               "roofline": {"bound": None, "frac": None, "step_ms": r2["step_ms_events"]}}
+                del w2
+            except Exception as ex:          # every rank takes the same path: a failure here fails on all of them alike
+                multi[name] = {"error": repr(ex)}
+        if rank == 0:
+            also = multi
+            out["also"] = also
     if rank == 0 and world == 1 and not args.no_also and args.workload == "parabolic_c2" and not args.batch:
         also = {}
         try:            # first: a process that has built and dropped nineteen workloads hands out host memory far more slowly
             also["vecenv_host"] = vecenv_host_rate(device)
         except Exception as ex:
             also["vecenv_host"] = {"error": repr(ex)}
+        try:            # the single-environment drop-in face (batch of one) beside the un-batched NumPy oracle (bench_single.py)
+            from bench_single import single_env_block
+            also["single_env"] = single_env_block(device)
+        except Exception as ex:
+            also["single_env"] = {"error": repr(ex)}
         try:
             also["hbm_probe"] = hbm_probe(device)
         except Exception as ex:
@@ -937,7 +1045,10 @@ def main():
         # The LAST stdout line is what the driver parses: it stays under 4 KB (the 23 KB line of round 4 was not
         # parsed).  Everything else -- per-region times, the full roofline dicts, every secondary workload -- goes to
         # bench_also.json next to this script (and to gpurun_out/ when that exists).
-        for path in (os.path.join(ROOT, "bench_also.json"), os.path.join(ROOT, "gpurun_out", "bench_also.json")):
+        # (only the full default run owns bench_also.json; a --workload X / --no-also run writes bench_<workload>.json instead, so
+        # that tools looping over workloads do not replace "the full result of the run" the printed line points to)
+        fname = "bench_also.json" if also is not None else f"bench_{args.workload}.json"
+        for path in (os.path.join(ROOT, fname), os.path.join(ROOT, "gpurun_out", fname)):
             try:
                 if os.path.isdir(os.path.dirname(path)):
                     with open(path, "w") as fh:
@@ -952,6 +1063,7 @@ def main():
 
 SECONDARY = ("ns2d_c4_b4096", "ns2d_c4_f64_b4096", "transport_c3", "ns2d_c4", "ns2d_c4_f64", "ns2d_c5", "ns2d_c5_f64",
              "parabolic_c2_s1_open_loop_rollout", "traffic_arz")      # the other BASELINE configs (+ the two kernels VERDICT r4 names)
+MULTI_GPU_SECONDARY = ("ns2d_c5", "ns2d_c5_f64")    # measured rank-locally when world > 1 (BASELINE configs[4]: 512 instances per GPU)
 MAX_LINE = 4096
 
 
@@ -960,6 +1072,12 @@ def _r(x, sig=6):
     if isinstance(x, bool) or not isinstance(x, float):
         return x
     return float(f"{x:.{sig}g}")
+
+
+def _committed_kernel_avg(rf):
+    """rocprofv3's average duration of the step's dominant (longest) kernel in the committed counters, if they carry one."""
+    ks = [k.get("avg_ns") for k in (rf.get("kernels_per_step") or {}).values() if isinstance(k, dict) and k.get("avg_ns")]
+    return max(ks) if ks else None
 
 
 def final_line(out):
@@ -974,8 +1092,13 @@ def final_line(out):
     line["roofline"] = {
         "bound": rf.get("bound"), "achieved": _r(rf.get("achieved")), "peak": rf.get("peak"), "unit": rf.get("unit"), "frac": _r(rf.get("frac"), 4),
         "traffic": _r(rf.get("traffic")), "algorithmic_bytes_per_step": rf.get("algorithmic_bytes_per_step"),
-        "kernel_avg_ns": _r(rf["step_ms"] * 1e6) if rf.get("step_ms") else None,
-        "counters_round": ((rf.get("counters_source") or "").split(":")[0].replace("round ", "") or None),
+        # step_event_ns: this run's HIP-event time per step over the timed region (what `achieved` / `frac` divide by);
+        # kernel_avg_ns: rocprofv3 --stats average duration of the dominant kernel -- live (counters_live) or of the committed round
+        "step_event_ns": _r(rf["step_ms"] * 1e6) if rf.get("step_ms") else None,
+        "kernel_avg_ns": _r(rf.get("kernel_avg_ns") or _committed_kernel_avg(rf)),
+        "counters_live": rf.get("counters_live"),
+        "valu_wave_insts_per_step": _r((rf.get("valu_issue") or {}).get("wave_insts_per_step")),
+        "counters_round": "live" if rf.get("counters_live") else ((rf.get("counters_source") or "").split(":")[0].replace("round ", "") or None),
         "counters_stale": rf.get("counters_stale"),
         "hbm_frac": _r((rf.get("hbm") or {}).get("frac"), 4), "valu_issue_frac": _r((rf.get("valu_issue") or {}).get("frac"), 4),
         "hbm_copy_measured_GBps": _r(((out.get("also") or {}).get("hbm_probe") or {}).get("copy_GBps"), 4),
@@ -1002,12 +1125,24 @@ def final_line(out):
                     sec.append({"name": name, "error": a["error"][:60]})
                 continue
             r2 = a.get("roofline") or {}
-            sec.append({"name": name, "value": _r(a["value"]), "ms_per_step": _r(a["ms_per_step"], 5), "dtype": a.get("dtype"),
-                        "bound": r2.get("bound"), "frac": _r(r2.get("frac"), 3)})
+            e = {"name": name, "value": _r(a["value"]), "ms_per_step": _r(a["ms_per_step"], 5), "dtype": a.get("dtype"),
+                 "bound": r2.get("bound"), "frac": _r(r2.get("frac"), 3)}
+            if "per_rank_env_steps_per_s" in a:          # an N > 1 run: node total in `value`, every rank's own rate beside it
+                e["per_rank"] = [_r(v, 4) for v in a["per_rank_env_steps_per_s"]]
+                e["instances_per_gpu"] = a.get("instances_per_gpu")
+            sec.append(e)
         line["secondary"] = sec
         vh = also.get("vecenv_host") or {}
         if "value" in vh:
             line["vecenv_host_env_steps_per_s"] = _r(vh["value"])
+        se = also.get("single_env") or {}
+        if se and "error" not in se:
+            # microseconds per env.step() of ONE environment through the drop-in face: [GPU (history kept, the default), GPU without
+            # history, un-batched NumPy oracle]; the reference's callers (DummyVecEnv(n=1)) drive exactly this path
+            line["single_env_us_per_step"] = {k: [_r(v["gpu"]["us_per_step"], 4), _r((v.get("gpu_no_history") or v["gpu"])["us_per_step"], 4),
+                                                  _r(v["numpy"]["us_per_step"], 4)]
+                                              for k, v in se.items() if isinstance(v, dict) and "gpu" in v and "numpy" in v}
+            line["single_env_gpu_wins_above_substeps"] = _r((se.get("crossover") or {}).get("substeps_above_which_gpu_wins"), 3)
         line["details"] = "bench_also.json"
     s = json.dumps(line, separators=(",", ":"))
     while len(s) >= MAX_LINE and line.get("secondary"):      # never expected; keeps the contract if names / notes grow

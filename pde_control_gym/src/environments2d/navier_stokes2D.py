@@ -78,8 +78,10 @@ class NavierStokes2D(PDEEnv2D):
                                U_ref=np.asarray(U_ref), action_ref=np.asarray(action_ref), action_dim=self.action_dim,
                                gamma=gamma, viscosity=viscosity, density=density,
                                maximum_pressure_iteration=int(maximum_pressure_iteration), stable_factor=stable_factor,
-                               num_envs=1, device=device, dtype=tdtype, backend=backend)
+                               num_envs=1, device=device, dtype=tdtype, backend=backend, interleaved_state=False)
         assert (self._core.nt, self._core.nx, self._core.ny) == (self.nt, self.nx, self.ny)
+        # the command goes to the kernels and observation / reward come back through ONE pinned host allocation (no copies)
+        self._io = self._core.enable_host_io()
         self.BoundaryControlInit(boundary_condition)
 
     def BoundaryControlInit(self, boundary_condition: dict):
@@ -132,17 +134,19 @@ class NavierStokes2D(PDEEnv2D):
             raise Exception(_RESET_ERR)
         self.U = np.zeros((self.nt, self.nx, self.ny, 2))
         self.time_index = 0
-        obs = self._core.reset(np.asarray(init_u), np.asarray(init_v), np.asarray(init_p))
-        self.U[0] = obs[0].cpu().numpy()
+        self._core.reset(np.asarray(init_u), np.asarray(init_v), np.asarray(init_p))
+        self._core.sync_host()
+        self.U[0] = self._io["obs"][0]
         return self.U[0], {}
 
     def step(self, action: Union[float, np.ndarray]):
         a = np.asarray(action, dtype=np.float64).reshape(-1)
         if a.size == 1 and self.action_dim != 1:
             a = np.full(self.action_dim, a[0])
-        obs, rew, te = self._core.step(a[None])
+        self._io["action"][0] = a                       # (cast to the engine's dtype by the store, as torch.as_tensor did)
+        self._core.step_host()
         self.time_index += 1
-        o = obs[0].cpu().numpy()
+        o = self._io["obs"][0]
         if self.time_index >= self.nt:
             # navier_stokes2D.py:147-148 stores U[time_index] after the increment: the nt-th step of an episode (one past the
             # terminal one) fails there with NumPy's IndexError, the flow fields already advanced -- same here
@@ -151,7 +155,7 @@ class NavierStokes2D(PDEEnv2D):
         o = self.U[self.time_index]
         terminate = self.terminate()
         if self._fused_reward:
-            reward = float(rew.cpu().numpy()[0])
+            reward = float(self._io["reward"][0])
         else:
             reward = self.reward_class.reward(self.U, self.time_index, self.U_ref, action, self.action_ref)
         return o, reward, terminate, False, {}

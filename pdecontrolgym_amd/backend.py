@@ -186,6 +186,27 @@ class HipBackend:
         fn = getattr(self.lib, "pdegym_ns2d_step_" + self._sfx(dtype))
         N.check(fn(C.byref(P), C.byref(bufs), B, N.current_stream_ptr(T["p"].device)), "pdegym_ns2d_step")
 
+    def prepare_ns2d_step(self, P: N.ParamsNS2D, T: dict, B: int):
+        """pdegym_ns2d_step_* with its argument structures built once (see prepare_step1d): a zero-argument callable."""
+        import torch
+        dtype = T["p"].dtype
+        bufs = self._bufs_ns(T, dtype)
+        fn = getattr(self.lib, "pdegym_ns2d_step_" + self._sfx(dtype))
+        dev = T["p"].device
+        pP, pB = C.byref(P), C.byref(bufs)
+        current_stream, current_device = torch.cuda.current_stream, torch.cuda.current_device
+
+        def call(_keep=(bufs, T)):
+            if current_device() != dev.index:
+                with torch.cuda.device(dev):
+                    rc = fn(pP, pB, B, current_stream(dev).cuda_stream)
+            else:
+                rc = fn(pP, pB, B, current_stream(dev).cuda_stream)
+            if rc:
+                N.check(rc, "pdegym_ns2d_step")
+        return call
+    prepare_ns2d_step.device_guard_key = "p"
+
     @_on_device_of("p")
     def ns2d_rollout(self, P: N.ParamsNS2D, T: dict, obs, actions, rewards, terminated, B: int):
         """T env-steps in one launch (pdegym_ns2d_rollout_*, small grids): ``obs`` [T+1, B, ny, nx, 2] (slot 0 = the input

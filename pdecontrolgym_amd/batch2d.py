@@ -175,6 +175,56 @@ class NSBatch2D(EngineCheckpoint):
             self.t["p"], self.t["p_out"] = self.t["p_out"], self.t["p"]
         return self.t["obs"], self.t["reward"], self.t["terminated"]
 
+    # ---- batch-of-one face: command in / results out through ONE pinned host allocation ------------------------------
+    def enable_host_io(self):
+        """Host-facing mode of a small batch (the single environment): the command, the observation, the reward and the terminated
+        flag live in ONE pinned host allocation mapped into the device's address space -- the kernels read the command from it and
+        write their results into it, so an env-step is the step's launches + ONE stream synchronisation, no copies in either
+        direction.  Needs the velocity state in its own tensors (``interleaved_state=False``: the observation is a pure output).
+        Returns the NumPy views ``{"action", "obs", "reward", "terminated"}``."""
+        import numpy as np
+        import torch
+        if self.interleaved_state:
+            raise ValueError("host I/O needs the velocity state in its own tensors (interleaved_state=False)")
+        if getattr(self, "_hio", None) is not None:
+            return self._hio["np"]
+        B, ny, nx, A = self.num_envs, self.ny, self.nx, self.action_dim
+        w = 8 if self.dtype == torch.float64 else 4
+        sizes = (("action", w * B * A), ("obs", w * B * ny * nx * 2), ("reward", w * B), ("terminated", B))
+        pack = torch.zeros((sum((nb + 7) // 8 * 8 for _, nb in sizes) + 63) // 64 * 64, dtype=torch.uint8,
+                           pin_memory=self.device.type == "cuda")
+        raw, off, tv, nv = pack.numpy(), 0, {}, {}
+        npdt = np.float64 if w == 8 else np.float32
+        shapes = {"action": (B, A), "obs": (B, ny, nx, 2), "reward": (B,)}
+        for k, nb in sizes:
+            if k == "terminated":
+                tv[k], nv[k] = pack[off:off + nb], raw[off:off + nb]
+            else:
+                tv[k] = pack[off:off + nb].view(self.dtype).view(shapes[k])
+                nv[k] = raw[off:off + nb].view(npdt).reshape(shapes[k])
+            off += (nb + 7) // 8 * 8
+        for k in ("action", "obs", "reward", "terminated"):
+            self.t[k] = tv[k]
+        self._obs = [tv["obs"], tv["obs"]]
+        self._hio = {"pack": pack, "np": nv, "call": None}
+        return nv
+
+    def sync_host(self):
+        if self.device.type == "cuda":
+            import torch
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def step_host(self):
+        """One env-step commanded from the host: the caller has written the command into the ``"action"`` view; launches the step
+        and synchronises the stream.  Results are in the views ``enable_host_io`` returned."""
+        io = self._hio
+        if io["call"] is None:
+            prep = getattr(self.backend, "prepare_ns2d_step", None)
+            io["call"] = (prep(self.params, self.t, self.num_envs) if prep is not None
+                          else (lambda: self.backend.ns2d_step(self.params, self.t, self.num_envs)))
+        io["call"]()
+        self.sync_host()
+
     def can_rollout(self) -> bool:
         """True when ``rollout`` applies: the column-per-lane kernel's grids (8, 11, 16, 21, 26, 31 or 32 rows, at most 64
         columns -- the reference's shipped 21 x 21 example among them) with the state in the observation tensors."""

@@ -24,12 +24,14 @@ namespace {
 
 // FULL (round 5): the row fills the wave exactly (n - J0 == 64 EPL; the BASELINE shapes nx = 256 and nx = 512 do) -- the slot
 // masks of prologue / epilogue fold away (pdegym_1d_body.h: run_substeps).  The float32 Dirichlet fast path only.
-template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false, bool M64 = false, bool FULL = false>
+// HFAST (round 6): the fast loop + one trajectory-row store per sub-step -- what a single environment with record_history (the
+// reference's env.u) runs: 0.23 -> see DESIGN.md us per sub-step of one instance against the select form.
+template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false, bool M64 = false, bool FULL = false, bool HFAST = false>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_params1d P, pdegym_bufs1d Bf, int B) {
   const int lane = threadIdx.x & (kWave - 1);
   const int inst = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (inst >= B) return;  // wave-uniform
-  step1d_body<EPL, PARABOLIC, NEUMANN, HIST, BURGERS, M64, false, false, FULL>(P, Bf, B, inst, lane);
+  step1d_body<EPL, PARABOLIC, NEUMANN, HIST, BURGERS, M64, false, false, FULL, HFAST>(P, Bf, B, inst, lane);
 }
 
 // Rows of more than 2048 nodes: the register-resident layout would not fit, so the row ping-pongs between two LDS copies
@@ -374,9 +376,14 @@ int launch_epl(const pdegym_params1d& P, const pdegym_bufs1d& Bf, int B, hipStre
     hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, true, true, BURGERS>), grid, block, lds, st, P, Bf, B);
   else if (neu)
     hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, true, false, BURGERS>), grid, block, lds, st, P, Bf, B);
-  else if (hist)
-    hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, false, true, BURGERS>), grid, block, lds, st, P, Bf, B);
-  else {
+  else if (hist) {
+    // a trajectory buffer and a reward the fast loop serves, rows of up to 512 slots, the reference's flux: fast arithmetic + row stores
+    constexpr bool kHasHFast = !BURGERS && EPL <= 8;
+    if (kHasHFast && Bf.history != nullptr && !differential)
+      hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, false, true, BURGERS, false, false, kHasHFast>), grid, block, lds, st, P, Bf, B);
+    else
+      hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, false, true, BURGERS>), grid, block, lds, st, P, Bf, B);
+  } else {
     constexpr bool kHasFull = EPL == 1 || EPL == 2 || EPL == 4 || EPL == 8;      // rows of 64 / 128 / 256 / 512 slots
     if (kHasFull && P.n - (PARABOLIC ? 1 : 0) == kWave * EPL)
       hipLaunchKernelGGL((step1d_kernel<EPL, PARABOLIC, false, false, BURGERS, false, kHasFull>), grid, block, lds, st, P, Bf, B);

@@ -277,7 +277,9 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
   // xprev/blprev (select form only): the row BEFORE the last sub-step, for NormReward's "differential" horizon
   // thor_k (select form only): NormReward "t-horizon" of length thor_k -- the reward's norm of each of the last thor_k - 1 rows
   // before the final one goes into the ring (the final row's is the epilogue's)
-  static_assert(!(FAST && (NEUMANN || HIST)), "fast mode is the Dirichlet, history-free path");
+  // FAST && HIST (round 6): the fast arithmetic with one row store per sub-step into the trajectory -- the single environments'
+  // default configuration (record_history: env.u is the whole trajectory, as in the reference)
+  static_assert(!(FAST && NEUMANN), "fast mode is the Dirichlet path");
   static_assert(!(FAST && M64), "the mixed-precision mode uses the select form");
   constexpr int J0 = PARABOLIC ? 1 : 0;
   // FULL (round 5): the row fills the wave exactly (n - J0 == 64 EPL, checked by the launcher) -- with the slot count a compile-time
@@ -481,11 +483,30 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
     // 2.8 cycles with four resident waves), so the sub-steps between two norm records run in a bare inner loop and the
     // time index / phase counters advance once per run.
     int s = 0;
+    // HIST: row R.t of the trajectory after every sub-step (frozen boundary slot = the commanded value, node 0 = 0: the row
+    // as the reference stores it); the stores are fire-and-forget, nothing in the loop waits for them
+    float* hrow = nullptr;
+    bool hmask[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) hmask[e] = s0 + e < ns;
+    if constexpr (HIST) hrow = hist ? hist + (size_t)R.t * n + J0 + s0 : nullptr;
+    auto store_row = [&]() {
+      if constexpr (HIST) {
+        if (hrow) {
+          hrow += n;
+          if (PARABOLIC && lane == 0) hrow[-J0] = 0.0f;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e)
+            if (hmask[e]) hrow[e] = R.x[e];
+        }
+      }
+    };
     if (nsub > 0) {
       pde_substep(std::true_type{}, std::false_type{});
       ++R.t;
       R.k = (R.k + 1 == S) ? 0 : R.k + 1;
       s = 1;
+      store_row();
       record_norm(s);
     }
     while (s < nsub) {
@@ -499,9 +520,15 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
         if (to_lookback > 0) run = run < to_lookback ? run : to_lookback;
       }
       if (pow2_dx) {
-        for (int i = 0; i < run; ++i) pde_substep(std::false_type{}, std::true_type{});
+        for (int i = 0; i < run; ++i) {
+          pde_substep(std::false_type{}, std::true_type{});
+          store_row();
+        }
       } else {
-        for (int i = 0; i < run; ++i) pde_substep(std::false_type{}, std::false_type{});
+        for (int i = 0; i < run; ++i) {
+          pde_substep(std::false_type{}, std::false_type{});
+          store_row();
+        }
       }
       R.t += run;
       R.k += run;
@@ -554,13 +581,16 @@ __device__ __forceinline__ void load_row(Row<EPL>& R, float (&beta)[EPL], const 
 // ring loads at the head of the step.  What a step stores is what a caller can see of it afterwards: observation slot t + 1 and
 // row t of the reward / flag arrays always; the per-instance state words that every step would overwrite (norm_now, norm_back,
 // time_index, bsum -- and the ring, kept in registers) only when store_state says this is the launch's last step.
+// HFAST (round 6, with HIST): the fast sub-step loop storing every row into the trajectory buffer (bufs.history must be given; the
+// launcher keeps the NormReward "differential" / "t-horizon" requests on the select form).
 template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false, bool M64 = false, bool ROLL = false,
-          bool CARRY = false, bool FULL = false>
+          bool CARRY = false, bool FULL = false, bool HFAST = false>
 __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdegym_bufs1d& Bf, const int B, const int inst,
                                             const int lane, const float* command = nullptr, Carry<EPL>* carry = nullptr,
                                             const bool store_state = true) {
   constexpr int J0 = PARABOLIC ? 1 : 0;
-  constexpr bool kFast = !NEUMANN && !HIST && !M64;
+  static_assert(!HFAST || HIST, "HFAST is a history mode");
+  constexpr bool kFast = !NEUMANN && !M64 && (!HIST || HFAST);
   static_assert(!CARRY || kFast, "the carried state is the float32 Dirichlet rollout path");
 #ifdef PDEGYM_TIMING
   const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
@@ -694,7 +724,7 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
     }
     norm_now = 0.f;
     if (!exact) {
-      run_substeps<EPL, PARABOLIC, false, true, false, BURGERS, false, ROLL, RingT, FULL>(R, beta, P, nsub, a, ring, nullptr, lane);
+      run_substeps<EPL, PARABOLIC, false, true, HFAST, BURGERS, false, ROLL, RingT, FULL>(R, beta, P, nsub, a, ring, hist, lane);
       norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
       // inf/NaN somewhere (or a squared overflow): 0*inf may have leaked into a frozen slot -> redo exactly
       exact = !(fabsf(norm_now) <= 3.4028234663852886e38f);
@@ -717,7 +747,8 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
       }
     }
     if (exact) {
-      run_substeps<EPL, PARABOLIC, false, false, false, BURGERS, false, false, RingT, FULL>(R, beta, P, nsub, a, ring, nullptr, lane);
+      // (HFAST: the exact loop rewrites the same trajectory rows)
+      run_substeps<EPL, PARABOLIC, false, false, HFAST, BURGERS, false, false, RingT, FULL>(R, beta, P, nsub, a, ring, hist, lane);
       norm_now = sqrtf(slots_sumsq<EPL>(R.x, s0, ns) + R.bl * R.bl);
     }
   } else {

@@ -26,11 +26,15 @@ def test_final_line_from_the_round4_result_is_small_and_complete():
         assert k in d, k
     assert d["value"] == bench._r(full["value"]) and d["config"]["workload"] == full["config"]["workload"]
     rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_step", "kernel_avg_ns", "counters_stale",
-              "hbm_frac", "valu_issue_frac", "hbm_copy_measured_GBps"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_step", "kernel_avg_ns", "step_event_ns",
+              "counters_stale", "counters_live", "valu_wave_insts_per_step", "hbm_frac", "valu_issue_frac", "hbm_copy_measured_GBps"):
         assert k in rf, k
     assert abs(rf["frac"] - full["roofline"]["frac"]) < 1e-3 and rf["bound"] == full["roofline"]["bound"]
-    assert abs(rf["kernel_avg_ns"] - full["roofline"]["step_ms"] * 1e6) < 1.0
+    assert abs(rf["step_event_ns"] - full["roofline"]["step_ms"] * 1e6) < 1.0          # the bench's own HIP-event time per step
+    # `frac` can be recomputed from the line alone: wave-instructions x 2 cycles / (1024 SIMDs x 2.4 GHz x step time)
+    if rf["bound"] == "valu_issue":
+        again = rf["valu_wave_insts_per_step"] * 2 / (1024 * 2.4e9 * rf["step_event_ns"] * 1e-9)
+        assert abs(again - rf["frac"]) < 2e-3
     cb = d["cpu_baseline"]
     assert cb["cores"] == 1 and cb["kind"] == "port" and cb["all_cores"]["logical_cpus"] == full["cpu_baseline"]["all_cores"]["logical_cpus"]
     names = [s["name"] for s in d["secondary"]]
@@ -85,3 +89,53 @@ def test_hbm_probe_library_builds_and_exports_its_entry_point():
     assert hasattr(lib, "pdegym_probe_hbm")
     # ... and it does not touch the product library's fingerprint (it lives outside csrc/)
     assert not os.path.exists(os.path.join(build.CSRC, "hbm_probe.hip"))
+
+
+def test_final_line_carries_live_counters_and_rocprof_kernel_average():
+    """A run whose rocprofv3 children delivered counters (bench.live_counters): counters_live is true, kernel_avg_ns is rocprof's
+    average of the dominant kernel (not the bench's event time) and frac follows from the line's own numbers."""
+    full = _round4_result()
+    live = {"collected": "rocprofv3 children", "kernel": "step1d_kernel<4, true, false, false, false, false, true>", "calls": 77,
+            "kernel_avg_ns": 16335.0, "valu_insts_per_step": 11141120.0, "hbm_bytes_per_step": 14.28e6}
+
+    class WL:
+        def algorithmic_bytes_per_step(self):
+            return 1267482624
+
+        def compulsory_bytes_per_step(self):
+            return 12_800_000
+    rf = bench.roofline_block(WL(), "parabolic_c2", 0.018010, True, live)
+    assert rf["counters_live"] is True and rf["kernel_avg_ns"] == 16335.0 and rf["traffic"] == 14.28e6 and rf["bound"] == "valu_issue"
+    assert abs(rf["frac"] - 11141120.0 * 2 / (1024 * 2.4e9 * 18010e-9)) < 1e-6
+    full["roofline"] = rf
+    d = json.loads(bench.final_line(full))["roofline"]
+    assert d["counters_live"] is True and d["kernel_avg_ns"] == 16335.0 and abs(d["step_event_ns"] - 18010.0) < 1.0
+    assert abs(d["valu_wave_insts_per_step"] * 2 / (1024 * 2.4e9 * d["step_event_ns"] * 1e-9) - d["frac"]) < 2e-3
+    # without live counters the committed ones serve and the line says so
+    rf2 = bench.roofline_block(WL(), "parabolic_c2", 0.018010, True, None)
+    assert rf2["counters_live"] is False
+
+
+def test_final_line_single_env_block_and_multi_gpu_secondary():
+    full = _round4_result()
+    with open(os.path.join(ROOT, "profiles", "r06a_single_env_after.json")) as fh:
+        full["also"]["single_env"] = json.load(fh)
+    line = bench.final_line(full)
+    d = json.loads(line)
+    assert len(line) < bench.MAX_LINE
+    se = d["single_env_us_per_step"]
+    assert set(se) == {"transport_c1", "parabolic_example", "transport_s1", "ns2d_example"}
+    for gpu, gpu_nohist, cpu in se.values():
+        assert gpu > 0 and gpu_nohist > 0 and cpu > 0
+    assert se["transport_c1"][0] < se["transport_c1"][2] and se["parabolic_example"][0] < se["parabolic_example"][2]
+    assert d["single_env_gpu_wins_above_substeps"] > 0
+    # an N > 1 run: the C5 shard workloads carry the node total and every rank's own rate
+    multi = _round4_result()
+    multi["n_gpus"] = 8
+    multi["also"] = {n: {"value": 8e6, "ms_per_step": 0.5, "dtype": dt, "per_rank_env_steps_per_s": [1.01e6 + i for i in range(8)],
+                         "instances_per_gpu": 512, "roofline": {"bound": None, "frac": None}}
+                     for n, dt in (("ns2d_c5", "f32"), ("ns2d_c5_f64", "f64"))}
+    line = bench.final_line(multi)
+    sec = {e["name"]: e for e in json.loads(line)["secondary"]}
+    assert len(line) < bench.MAX_LINE and set(sec) == {"ns2d_c5", "ns2d_c5_f64"}
+    assert all(len(e["per_rank"]) == 8 and e["instances_per_gpu"] == 512 for e in sec.values())

@@ -124,3 +124,24 @@ def test_bench_two_ranks_prints_per_rank_values():
     # value = all instances of both ranks / max-over-ranks time  <=  sum of the per-rank rates
     assert d["value"] <= sum(d["per_rank_env_steps_per_s"]) * 1.001
     assert d["value"] > 0.5 * min(d["per_rank_env_steps_per_s"])
+    # ... and the configuration that is DEFINED on several GPUs (BASELINE configs[4]: NavierStokes2D 256 x 256, 512 instances per
+    # GPU), float32 and float64: node total + every rank's own rate
+    sec = {e["name"]: e for e in d["secondary"]}
+    for name, dt in (("ns2d_c5", "f32"), ("ns2d_c5_f64", "f64")):
+        e = sec[name]
+        assert "error" not in e, e
+        assert e["dtype"] == dt and e["instances_per_gpu"] == 512 and len(e["per_rank"]) == 2
+        assert 0.5 * min(e["per_rank"]) < e["value"] <= sum(e["per_rank"]) * 1.001
+
+
+@pytest.mark.timeout(900)
+def test_bench_falls_back_to_gloo_when_rccl_cannot_initialise():
+    """bench.py's RCCL -> gloo fallback for the timing barrier (the step path has no collective): with the nccl initialisation
+    forced to fail the line is still printed, by a gloo process group."""
+    r = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--repeats", "3", "--no-also"],
+                extra_env={"PDEGYM_BENCH_SHARE_GPU": "1", "PDEGYM_BENCH_FAIL_NCCL": "1"})
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["process_group"] == "gloo" and d["n_gpus"] == 2 and len(d["per_rank_env_steps_per_s"]) == 2
+    assert "using gloo for the timing barrier" in r.stderr

@@ -252,6 +252,7 @@ def _single_cases():
             [("parabolic", c) for c in sorted(full(PARABOLIC_CASES)) if c != "P1"])       # (P1: 80 MB of history)
 
 
+@pytest.mark.filterwarnings("ignore::DeprecationWarning")        # a size-1 array stored into one node, as the reference does
 @pytest.mark.parametrize("kind,case", _single_cases())
 def test_single_env_oracle_matches_reference_goldens(golden_transport, golden_parabolic, kind, case):
     """The single-environment restatement reproduces the reference-generated fixtures directly: rows bit-exact, rewards to the
