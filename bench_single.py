@@ -146,6 +146,61 @@ def ns_cpu_leg(seconds=0.6, max_steps=60):
         return _time_env(step, lambda: env.reset(z, z, z), acts, seconds, max_steps)
 
 
+TRAFFIC = dict(T=240, dt=0.25, X=500, dx=10, v_steady=10, ro_steady=0.12, v_max=40, ro_max=0.16, tau=60)     # the reference notebook's freeway
+TUMOR = dict(T=600, X=200, dt=1, dx=1, normalize=True, dosage_termination_threshold=0.1, t1_detection_threshold=0.8,
+             t2_detection_threshold=0.16, D=0.2, rho=0.03, alpha=0.04, alpha_beta_ratio=10, k=1e5, t1_detection_radius=15,
+             t1_death_radius=35, total_dosage=61.2, verbose=False)
+
+
+def traffic_legs(device, seconds):
+    """TrafficPDE1D (float64, 51 nodes, 'outlet' control, control_freq = 2): the drop-in face vs the (batched, B = 1) NumPy oracle."""
+    import pde_control_gym
+    from oracle import pde_oracle as po
+    from pde_control_gym.src import TrafficARZReward
+    env = pde_control_gym.make("PDEControlGym-TrafficPDE1D", device=str(device), reward_class=TrafficARZReward(), simulation_type="outlet",
+                               limit_pde_state_size=True, control_freq=2, **TRAFFIC).unwrapped
+    qs = 0.12 * 10
+    acts = np.random.default_rng(1).uniform(0.8, 1.2, (64, 1)) * qs
+
+    def step(a):
+        _, _, d, tr, _ = env.step(a)
+        return d or tr
+    gpu = _time_env(step, env.reset, acts, seconds, 3000)
+    orc = po.TrafficOracle(240, 0.25, 500, 10, "outlet", 40, 0.16, 60, True, 2)
+
+    def ostep(a):
+        out = orc.step(a[None])
+        return bool(out[2][0] or out[3][0] or orc.time_index[0] >= 239)
+    with np.errstate(all="ignore"):
+        cpu = _time_env(ostep, lambda: orc.reset([0.12]), acts, seconds, 3000)
+    return {"env": "PDEControlGym-TrafficPDE1D", "nx": 51, "dtype": "f64", "gpu": gpu, "numpy": cpu, "speedup": cpu["us_per_step"] / gpu["us_per_step"]}
+
+
+def tumor_legs(device, seconds):
+    """BrainTumor1D (float64, 201 nodes, one simulated day per step) vs the (batched, B = 1) NumPy oracle."""
+    import pde_control_gym
+    from oracle import pde_oracle as po
+    from pde_control_gym.src import BrainTumorReward
+    xs = np.linspace(0, 200, 201)
+    ic = 0.8 * 1e5 * np.exp(-0.25 * (xs ** 2))
+    env = pde_control_gym.make("PDEControlGym-BrainTumor1D", device=str(device), reward_class=BrainTumorReward(),
+                               reset_init_condition_func=lambda X, nx: ic, **TUMOR).unwrapped
+    acts = np.random.default_rng(1).uniform(0, 0.05, (64, 1))
+
+    def step(a):
+        out = env.step(float(a[0]))
+        return out is None or out[2] or out[3]
+    gpu = _time_env(step, env.reset, acts, seconds, 3000)
+    orc = po.BrainTumorOracle(600, 1, 200, 1, 61.2)
+
+    def ostep(a):
+        out = orc.step(a)
+        return bool(out[2][0] or out[3][0])
+    with np.errstate(all="ignore"):
+        cpu = _time_env(ostep, lambda: orc.reset(ic[None], [363.0]), acts, seconds, 3000)
+    return {"env": "PDEControlGym-BrainTumor1D", "nx": 201, "dtype": "f64", "gpu": gpu, "numpy": cpu, "speedup": cpu["us_per_step"] / gpu["us_per_step"]}
+
+
 def single_env_block(device, seconds=0.6):
     """{shape: {"gpu": {...}, "gpu_no_history": {...}, "numpy": {...}, "speedup": gpu-vs-numpy}} + the crossover sub-step count."""
     out = {}
@@ -164,6 +219,11 @@ def single_env_block(device, seconds=0.6):
         out["ns2d_example"] = e
     except Exception as ex:
         out["ns2d_example"] = {"error": repr(ex)}
+    for name, legs in (("traffic_example", traffic_legs), ("tumor_example", tumor_legs)):
+        try:
+            out[name] = legs(device, seconds)
+        except Exception as ex:
+            out[name] = {"error": repr(ex)}
     # crossover: per-sub-step cost of both paths from the S = 1 and S = 1000 transport shapes (cost = a + b S)
     try:
         def line(leg):

@@ -85,16 +85,25 @@ class BrainTumor1D(PDEEnv1D):
     def truncate(self):
         return bool(self._truncated)
 
-    def _pull(self):
-        """One device->host read of the scalars a step produced."""
-        t = self._core.t
-        self.time_index = int(t["time_index"][0])
-        days = t["days"][0].tolist()
+    def _pull(self, row=False):
+        """ONE device->host copy (+ one synchronisation) of everything a step produced: the engine keeps its per-patient scalars and
+        the live row in one allocation (TumorBatch.host_pack).  ``row``: also return (a view of) the live row."""
+        core = self._core
+        if getattr(self, "_fetch", None) is None:
+            from pdecontrolgym_amd.hostio import HostFetch
+            self._fetch, self._views = HostFetch(core.device), None
+        raw = self._fetch([core.host_pack])[0]
+        if self._views is None or self._views[0] is not raw:
+            self._views = (raw, core.pack_layout.numpy_views(raw))
+        v = self._views[1]
+        self.time_index = int(v["time_index"][0])
+        days = v["days"][0].tolist()
         self.growthDays, self.therapyDays, self.postTherapyDays, self.simulationDays = days[:4]
         self.cDeathDay = None if days[4] < 0 else days[4]
-        self.remaining_dosage = float(t["remaining"][0])
-        self._terminated, self._truncated = bool(t["terminated"][0]), bool(t["truncated"][0])
-        return int(t["stage"][0]), t["out"][0].tolist()
+        self.remaining_dosage = float(v["remaining"][0])
+        self._terminated, self._truncated = bool(v["terminated"][0]), bool(v["truncated"][0])
+        res = (int(v["stage"][0]), v["out"][0].tolist())
+        return res + (v["u"][0],) if row else res
 
     def step(self, control: float):
         """One simulated day.  ``control`` = proportion of ``total_dosage`` to apply (used in the Therapy stage)."""
@@ -113,10 +122,15 @@ class BrainTumor1D(PDEEnv1D):
             ctl = [control]
         else:
             ctl = [0.0]
-        self._core.set_benchmark(float("nan") if self.t_benchmark is None else float(self.t_benchmark))
-        u, *_ = self._core.step(ctl, kill=kill)
-        row = u[0].cpu().numpy()
-        stage_i, (T1, T2, treatmentRadius, applied_dosage) = self._pull()
+        # the day's inputs are read by the kernel from pinned host memory in place (no upload)
+        if getattr(self, "_pins", None) is None:
+            from pdecontrolgym_amd.hostio import PinnedInputs
+            self._pins = PinnedInputs(self._core.device)
+        import torch
+        f64 = torch.float64
+        self._core.set_benchmark(self._pins("t_benchmark", [float("nan") if self.t_benchmark is None else float(self.t_benchmark)], f64))
+        self._core.step(self._pins("control", ctl, f64), kill=None if kill is None else self._pins("kill", kill, f64))
+        stage_i, (T1, T2, treatmentRadius, applied_dosage), row = self._pull(row=True)
         self.stage = _STAGES[stage_i]
         if self._record:
             self.u[self.time_index] = row

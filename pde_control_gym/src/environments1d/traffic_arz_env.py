@@ -64,16 +64,26 @@ class TrafficPDE1D(PDEEnv1D):
         self.action_space = spaces.Box(dtype=np.float64, low=self.qs * 0.8, high=1.2 * self.qs,
                                        shape=(2,) if simulation_type == "both" else (1,))
         self.info = dict()
-        self._load_state(self._core.reset([self.rs]))
+        # one launch, ONE device-to-host copy and one synchronisation per step(): the command is read by the kernel from pinned host
+        # memory in place; observation, fields, clock, reward and flags share one allocation (TrafficBatch.host_pack)
+        from pdecontrolgym_amd.hostio import HostFetch, PinnedInputs
+        self._fetch, self._pins, self._views = HostFetch(self._core.device), PinnedInputs(self._core.device), None
+        self._core.reset([self.rs])
+        self._load_state()
         self.info["V"] = self.v
 
-    def _load_state(self, obs):
-        o = obs[0].cpu().numpy()
-        self.r = self._core.t["r"][0].cpu().numpy().reshape(self.M, 1)
-        self.y = self._core.t["y"][0].cpu().numpy().reshape(self.M, 1)
+    def _load_state(self):
+        """Observation, fields, clock, reward and flags of the last launch: ONE device-to-host copy of the engine's pack."""
+        core = self._core
+        raw = self._fetch([core.host_pack])[0]
+        if self._views is None or self._views[0] is not raw:
+            self._views = (raw, core.pack_layout.numpy_views(raw))
+        v = self._views[1]
+        self.r = v["r"][0].reshape(self.M, 1).copy()
+        self.y = v["y"][0].reshape(self.M, 1).copy()
         self.v = self.y / self.r + TrafficPDE1D.Veq(self.vm, self.rm, self.r)
-        self.time_index = float(self._core.t["time"][0])
-        return o
+        self.time_index = float(v["time"][0])
+        return v["obs1" if core.t["obs"] is core._obs[1] else "obs0"][0].copy(), v
 
     def terminate(self):
         return bool(self._done_flag)
@@ -83,10 +93,11 @@ class TrafficPDE1D(PDEEnv1D):
 
     def step(self, action):
         a = np.asarray(action, dtype=np.float64).reshape(-1)
-        obs, rew, done, trunc = self._core.step(a[None, : self._core.action_dim])
-        self._done_flag, self._trunc_flag = bool(done[0]), bool(trunc[0])
-        o = self._load_state(obs)
-        reward = float(rew[0])
+        import torch
+        self._core.step(self._pins("action", a[None, : self._core.action_dim], torch.float64))
+        o, v = self._load_state()
+        self._done_flag, self._trunc_flag = bool(v["done"][0]), bool(v["truncated"][0])
+        reward = float(v["reward"][0])
         from pde_control_gym.src.rewards import TrafficARZReward
         if type(self.reward_class) is not TrafficARZReward:
             # a user reward class (docs/source/utils/customrewards.rst): called as the reference does (:228); outside
@@ -101,7 +112,8 @@ class TrafficPDE1D(PDEEnv1D):
             self.rs = {0: 0.115, 1: 0.12, 2: 0.125}[random.randint(0, 2)]
             self.vs = TrafficPDE1D.Veq(self.vm, self.rm, self.rs)
             self.qs = self.rs * self.vs
-        o = self._load_state(self._core.reset([self.rs]))
+        self._core.reset([self.rs])
+        o, _ = self._load_state()
         self._done_flag = self._trunc_flag = False
         return o, {}
 

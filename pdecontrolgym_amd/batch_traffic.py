@@ -41,14 +41,21 @@ class TrafficBatch(EngineCheckpoint):
         B, M, dev, f64 = self.num_envs, self.M, self.device, torch.float64
         # the initial profile uses NumPy's sin so that resets are bit-identical to the reference's (:256)
         self.profile = torch.as_tensor(np.sin(3 * self.x / X * np.pi) * 0.1 + np.ones(M), dtype=f64, device=dev)
+        # everything a host-facing caller reads after a step lives in ONE allocation (hostio.PackLayout): the single environment
+        # fetches observation, fields, clock, reward and flags with one device-to-host copy
+        from .hostio import PackLayout
+        u8 = torch.uint8
+        self.pack_layout = PackLayout([("obs0", (B, 2 * M), f64), ("obs1", (B, 2 * M), f64), ("r", (B, M), f64), ("y", (B, M), f64),
+                                       ("time", (B,), f64), ("reward", (B,), f64), ("done", (B,), u8), ("truncated", (B,), u8)])
+        self.host_pack, pv = self.pack_layout.allocate(dev)
         self.t = {
-            "r": torch.zeros(B, M, dtype=f64, device=dev), "y": torch.zeros(B, M, dtype=f64, device=dev),
-            "action": torch.zeros(B, 2, dtype=f64, device=dev), "time": torch.zeros(B, dtype=f64, device=dev),
+            "r": pv["r"], "y": pv["y"],
+            "action": torch.zeros(B, 2, dtype=f64, device=dev), "time": pv["time"],
             "rs": torch.zeros(B, dtype=f64, device=dev), "qs_clip": torch.zeros(B, dtype=f64, device=dev),
-            "obs": None, "reward": torch.zeros(B, dtype=f64, device=dev),
-            "done": torch.zeros(B, dtype=torch.uint8, device=dev), "truncated": torch.zeros(B, dtype=torch.uint8, device=dev),
+            "obs": None, "reward": pv["reward"],
+            "done": pv["done"], "truncated": pv["truncated"],
         }
-        self._obs = [torch.zeros(B, 2 * M, dtype=f64, device=dev) for _ in range(2)]
+        self._obs = [pv["obs0"], pv["obs1"]]
         self._flip = 0
         self.t["obs"] = self._obs[0]
 
@@ -143,7 +150,8 @@ class TrafficBatch(EngineCheckpoint):
     def step(self, action):
         """action [B] / [B,1] (inlet, outlet) or [B,2] ('both'). Returns (obs [B,2M], reward, done, truncated)."""
         import torch
-        a = torch.as_tensor(action, dtype=torch.float64, device=self.device).reshape(self.num_envs, -1)
+        from .hostio import as_kernel_input
+        a = as_kernel_input(action, torch.float64, self.device, (self.num_envs, -1))     # (a pinned host tensor is read in place)
         if a.shape[1] > 2 or (self.action_dim == 2 and a.shape[1] != 2):
             raise ValueError(f"action must be [B] / [B, 1] / [B, 2] ('both' needs two columns), got {tuple(a.shape)}")
         self.t["action"] = a.contiguous()       # used in place: the kernel takes the column count as the stride

@@ -42,18 +42,26 @@ class TumorBatch(EngineCheckpoint):
         P.total_dosage, P.dose_end, P.margin = self.total_dosage, dosage_termination_threshold, self.MARGIN
         self.params = P
         B, dev, f64, i32 = self.num_envs, self.device, torch.float64, torch.int32
+        # everything a host-facing caller reads after a day lives in ONE allocation (hostio.PackLayout): one device-to-host copy
+        from .hostio import PackLayout
+        u8 = torch.uint8
+        self.pack_layout = PackLayout([("u", (B, self.nx), f64), ("out", (B, 4), f64), ("remaining", (B,), f64), ("reward", (B,), f64),
+                                       ("time_index", (B,), i32), ("stage", (B,), i32), ("days", (B, 5), i32),
+                                       ("terminated", (B,), u8), ("truncated", (B,), u8)])
+        self.host_pack, pv = self.pack_layout.allocate(dev)
+        pv["remaining"].fill_(self.total_dosage)
         self.t = {
-            "u": torch.zeros(B, self.nx, dtype=f64, device=dev),
+            "u": pv["u"],
             "xscale": torch.as_tensor(self.xScale, dtype=f64, device=dev),
             "control": torch.zeros(B, dtype=f64, device=dev), "kill": None,
-            "time_index": torch.zeros(B, dtype=i32, device=dev), "stage": torch.zeros(B, dtype=i32, device=dev),
-            "remaining": torch.full((B,), self.total_dosage, dtype=f64, device=dev),
-            "days": torch.zeros(B, 5, dtype=i32, device=dev),
+            "time_index": pv["time_index"], "stage": pv["stage"],
+            "remaining": pv["remaining"],
+            "days": pv["days"],
             "t_benchmark": torch.full((B,), float("nan"), dtype=f64, device=dev),
-            "reward": torch.zeros(B, dtype=f64, device=dev),
-            "terminated": torch.zeros(B, dtype=torch.uint8, device=dev),
-            "truncated": torch.zeros(B, dtype=torch.uint8, device=dev),
-            "out": torch.zeros(B, 4, dtype=f64, device=dev),
+            "reward": pv["reward"],
+            "terminated": pv["terminated"],
+            "truncated": pv["truncated"],
+            "out": pv["out"],
             "active": None,
             # optional trajectory on the device: history[b, t] = row of day t, t1_log[b, t] = T1 radius / dx (NaN = invisible)
             "history": torch.zeros(B, self.nt, self.nx, dtype=f64, device=dev) if record_history else None,
@@ -64,6 +72,10 @@ class TumorBatch(EngineCheckpoint):
     def set_benchmark(self, t_benchmark):
         """Baseline survival days per patient (NaN = not set: every reward is 0, brain_tumor_reward.py:43-47)."""
         import torch
+        if torch.is_tensor(t_benchmark) and t_benchmark.dtype == torch.float64 and t_benchmark.numel() == self.num_envs and \
+                t_benchmark.device.type == "cpu" and self.device.type == "cuda" and t_benchmark.is_pinned():
+            self.t["t_benchmark"] = t_benchmark.reshape(self.num_envs)          # pinned host memory: read in place by the kernel
+            return
         tb = torch.as_tensor(t_benchmark, dtype=torch.float64, device=self.device)
         self.t["t_benchmark"] = tb.expand(self.num_envs).contiguous() if tb.dim() == 0 else tb.reshape(self.num_envs).contiguous()
 
@@ -104,9 +116,9 @@ class TumorBatch(EngineCheckpoint):
         ``1 - exp(-alpha*BED)`` evaluated by the caller (NumPy bit parity); by default the kernel evaluates it.
         Returns (u [B,nx] -- the live state, updated in place --, reward, terminated, truncated)."""
         import torch
-        self.t["control"] = torch.as_tensor(control, dtype=torch.float64, device=self.device).reshape(self.num_envs).contiguous()
-        self.t["kill"] = None if kill is None else \
-            torch.as_tensor(kill, dtype=torch.float64, device=self.device).reshape(self.num_envs).contiguous()
+        from .hostio import as_kernel_input
+        self.t["control"] = as_kernel_input(control, torch.float64, self.device, (self.num_envs,))   # (pinned host tensors: in place)
+        self.t["kill"] = None if kill is None else as_kernel_input(kill, torch.float64, self.device, (self.num_envs,))
         self._set_active(active)
         self.backend.tumor_step(self.params, self.t, self.num_envs)
         return self.t["u"], self.t["reward"], self.t["terminated"], self.t["truncated"]
