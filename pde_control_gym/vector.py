@@ -117,6 +117,7 @@ class BatchedVecEnv(VecEnv):
 
 class PDEVecEnv(BatchedVecEnv):
     _checkpoint_attrs = ("_ns_hist",)
+    _copy_note_printed = False
 
     def __init__(self, env_id: str, num_envs: int, device="cuda", backend=None, batched_reset_func=None,
                  dtype=None, copy_outputs=None, **kw):
@@ -134,8 +135,14 @@ class PDEVecEnv(BatchedVecEnv):
         # (default): views of pinned staging buffers recycled by reference count (_to_host) -- on CPython with the GIL, for
         # consumers that read the arrays on the host or on the stream the environment runs on; plain NumPy copies on any other
         # interpreter.  copy_outputs=True: always plain copies (a consumer that starts its own asynchronous copy from the array on
-        # ANOTHER stream and drops it before that copy has run, tools that hold hidden references).  False: as None (round-3 callers).
+        # ANOTHER stream and drops it before that copy has run, tools that hold hidden references) -- slower: every result is staged
+        # through a scratch buffer and copied to pageable memory (bench.py vecenv_host.copy_outputs_true: ~1.7x the time per step at
+        # the C2 shape; a one-time note is printed).  False: as None (round-3 callers).
         self.copy_outputs = None if copy_outputs is None else bool(copy_outputs)
+        if self.copy_outputs is True and not PDEVecEnv._copy_note_printed:
+            PDEVecEnv._copy_note_printed = True
+            sys.stderr.write("PDEVecEnv(copy_outputs=True): every step() result is a plain NumPy copy (no pinned-buffer recycling); "
+                             "the default copy_outputs=None is faster and equally safe for consumers that read the arrays on the host\n")
         # state_in_obs=False (1D) / interleaved_state=False (NavierStokes2D) in the parameters: the engine keeps the plant state in
         # its own tensors and the observation is a separate output -- for torch callers that normalise or perturb the tensors
         # returned by step_tensor() / reset_tensor() IN PLACE (by default those tensors ARE the state: read-only).

@@ -115,8 +115,14 @@ def build_probe(force: bool = False) -> str:
     """The HBM yardstick (tools/hbm_probe.hip: float4 copy / read / fill) as its own small library: measurement tooling, not part
     of the product ABI, and kept out of csrc/ so that the product's kernel fingerprints do not depend on it."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(PROBE_SRC):
+        if os.path.exists(PROBE_LIB):          # (an installed copy ships the built probe without tools/)
+            return PROBE_LIB
+        raise RuntimeError(f"{PROBE_SRC} is missing: the HBM probe is measurement tooling of the source tree, not of an installed package")
     if not force and os.path.exists(PROBE_LIB) and os.path.getmtime(PROBE_LIB) >= os.path.getmtime(PROBE_SRC):
         return PROBE_LIB
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libpdegym_probe.so")
     os.makedirs(LIBDIR, exist_ok=True)
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", PROBE_LIB, PROBE_SRC],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)

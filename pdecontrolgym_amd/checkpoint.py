@@ -15,6 +15,9 @@ caller), the contents of ``DeviceRollout`` buffers.
 """
 from __future__ import annotations
 
+# 1: rounds 3-4 (meta without the reward / sensing keys of the 1D engine, no "format" entry); 2: round 5 on
+CHECKPOINT_FORMAT = 2
+
 # per-call inputs, scratch and constructor constants: not part of a checkpoint
 _SKIP = {"action", "state_in", "scratch", "U_ref", "action_ref", "xscale", "active", "reset_profile", "p_out", "control", "kill"}
 
@@ -27,7 +30,7 @@ class EngineCheckpoint:
 
     def state_dict(self):
         import torch
-        sd = {"meta": self._checkpoint_meta(), "tensors": {}}
+        sd = {"format": CHECKPOINT_FORMAT, "meta": self._checkpoint_meta(), "tensors": {}}
         for k, v in self.t.items():
             if torch.is_tensor(v) and k not in _SKIP:
                 sd["tensors"][k] = v.detach().clone()
@@ -36,8 +39,15 @@ class EngineCheckpoint:
     def load_state_dict(self, sd):
         import torch
         meta = self._checkpoint_meta()
-        if sd.get("meta") != meta:
-            raise ValueError(f"checkpoint was written by {sd.get('meta')}, this engine is {meta}")
+        fmt = int(sd.get("format", 1))
+        if fmt > CHECKPOINT_FORMAT:
+            raise ValueError(f"checkpoint format {fmt} is newer than this library's ({CHECKPOINT_FORMAT}): upgrade the library")
+        saved = sd.get("meta") or {}
+        # every key the checkpoint recorded must agree; keys this library has added since (format 1 checkpoints of the 1D engine
+        # know nothing of the reward / sensing configuration) are absent from an older checkpoint and are not held against it
+        wrong = {k: (saved[k], meta.get(k)) for k in saved if saved[k] != meta.get(k)}
+        if wrong or saved.get("engine") != meta.get("engine"):
+            raise ValueError(f"checkpoint was written by {saved}, this engine is {meta} (mismatch: {wrong})")
         for k, v in sd["tensors"].items():
             cur = self.t.get(k)
             if torch.is_tensor(cur) and cur.shape == v.shape and cur.dtype == v.dtype:

@@ -124,7 +124,7 @@ def test_final_line_single_env_block_and_multi_gpu_secondary():
     d = json.loads(line)
     assert len(line) < bench.MAX_LINE
     se = d["single_env_us_per_step"]
-    assert set(se) == {"transport_c1", "parabolic_example", "transport_s1", "ns2d_example"}
+    assert set(se) == {"transport_c1", "parabolic_example", "transport_s1", "ns2d_example", "traffic_example", "tumor_example"}
     for gpu, gpu_nohist, cpu in se.values():
         assert gpu > 0 and gpu_nohist > 0 and cpu > 0
     assert se["transport_c1"][0] < se["transport_c1"][2] and se["parabolic_example"][0] < se["parabolic_example"][2]

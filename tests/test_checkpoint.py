@@ -193,3 +193,32 @@ def test_checkpoint_of_another_reward_or_sensing_configuration_is_refused(bk):
     bad = dict(sd, face={"_ns_hist": torch.zeros(2, 2)})
     with pytest.raises(ValueError, match="face tensors"):
         tuned.load_state_dict(bad)
+
+
+def test_legacy_checkpoint_without_the_round5_meta_keys_still_loads_and_newer_formats_are_refused():
+    """the 1D engine's meta gained reward / sensing keys in round 5 -- a checkpoint written before that (no "format" entry, the
+    shorter meta) must still load into the same configuration; a mismatch in a key it DOES record is still refused, and so is a
+    checkpoint of a newer format than the library knows."""
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
+    from pdecontrolgym_amd.checkpoint import CHECKPOINT_FORMAT
+    kw = dict(T=0.05, dt=1e-3, X=1, dx=0.05, control_sample_rate=5e-3, normalize=True, limit_pde_state_size=True)
+    mk = lambda: PDEBatch1D("transport", reward=RewardSpec(N.REWARD_TUNED1D, 50, -1e3, 3e2), num_envs=3, device="cpu",
+                            backend=FakeBackend(), **kw)
+    e = mk()
+    e.reset(np.ones((3, e.n), dtype=np.float32), np.ones(e.n, dtype=np.float32))
+    e.step(torch.tensor([0.1, 0.2, 0.3]))
+    sd = e.state_dict()
+    assert sd["format"] == CHECKPOINT_FORMAT
+    legacy = {"meta": {k: v for k, v in sd["meta"].items() if k not in ("reward_kind", "reward_horizon", "reward_t_horizon", "sensing", "control_type")},
+              "tensors": sd["tensors"]}
+    want = [x.clone() for x in e.step(torch.tensor([0.3, 0.2, 0.1]))]
+    f = mk()
+    f.load_state_dict(_through_disk(legacy))
+    got = f.step(torch.tensor([0.3, 0.2, 0.1]))
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError, match="mismatch"):
+        mk().load_state_dict(dict(legacy, meta=dict(legacy["meta"], substeps=7)))
+    with pytest.raises(ValueError, match="newer"):
+        mk().load_state_dict(dict(sd, format=CHECKPOINT_FORMAT + 1))

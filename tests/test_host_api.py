@@ -1021,3 +1021,24 @@ def test_integration_md_binding_stub_matches_the_abi():
         stub = ns[name]
         assert [f[0] for f in stub._fields_] == [f[0] for f in real._fields_], name
         assert C.sizeof(stub) == C.sizeof(real), name
+
+
+@pytest.mark.parametrize("kind", ["double", pytest.param("hip", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("which", range(5), ids=["transport", "parabolic", "navier_stokes", "traffic", "brain_tumor"])
+def test_every_registered_id_builds_resets_and_steps_from_its_reference_parameter_dictionary(kind, which):
+    """The five parameter dictionaries tests/test_real_sb3.py hands to the REAL ``gymnasium.make`` + ``check_env`` (skipped in this
+    image), through ``pde_control_gym.make``: spaces, reset and step types of the Env contract, checked by hand."""
+    import pde_control_gym
+    from tests.five_ids import _backend, _five_ids
+    env_id, params = _five_ids()[which]
+    env = pde_control_gym.make(env_id, **_backend(kind), **params)
+    e = env.unwrapped
+    obs, info = env.reset(seed=0)
+    assert isinstance(info, dict) and np.asarray(obs).shape == e.observation_space.shape
+    assert np.asarray(obs).dtype == e.observation_space.dtype or which in (2, 4)        # NS / tumour observe in float64 like the reference
+    a = e.action_space.sample()
+    out = env.step(a if which != 4 else float(np.asarray(a).reshape(-1)[0]))
+    assert len(out) == 5
+    o, r, te, tr, inf = out
+    assert np.asarray(o).shape == e.observation_space.shape and np.isfinite(float(r)) and isinstance(inf, dict)
+    assert isinstance(te, (bool, np.bool_)) and isinstance(tr, (bool, np.bool_))

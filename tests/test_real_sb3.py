@@ -23,40 +23,8 @@ if str(getattr(gymnasium, "__version__", "")).endswith("contract-stub"):      # 
     pytest.skip("the gymnasium on sys.path is the contract stand-in of tests/stubs", allow_module_level=True)
 
 import pde_control_gym  # noqa: E402
-from pde_control_gym.src import NSReward, TunedReward1D  # noqa: E402
 
-NX = 100
-BETA = (5 * np.cos(7.35 * np.arccos(np.linspace(0, 1, NX)))).astype(np.float32)
-ICS = [np.linspace(1.0, 2.0 + k, NX).astype(np.float32) for k in range(8)]
-
-
-def _backend(kind):
-    if kind == "double":
-        from tests.fake_backend import FakeBackend
-        return dict(device="cpu", backend=FakeBackend())
-    import torch
-    assert torch.cuda.is_available(), "hip run without a GPU"
-    return dict(device="cuda")
-
-
-def _transport_params(init, T=0.04):
-    """transport1Dppo.py:40-75 with a short horizon: control_sample_rate 0.01 -> 100 sub-steps, 4 env-steps per episode."""
-    dt = 1e-4
-    return {"T": T, "dt": dt, "X": 1, "dx": 1e-2, "reward_class": TunedReward1D(int(round(T / dt)), -1e3, 3e2), "normalize": True,
-            "sensing_loc": "full", "control_type": "Dirchilet", "sensing_type": None, "sensing_noise_func": lambda state: state,
-            "limit_pde_state_size": True, "max_state_value": 1e10, "max_control_value": 20, "control_sample_rate": 0.01,
-            "reset_init_condition_func": init, "reset_recirculation_func": lambda nx: BETA}
-
-
-def _ns_params(nt=6, n=16):
-    """NS2Dppo.py:12-27 on a small grid."""
-    dx = 1.0 / (n - 1)
-    dt = 0.2 * 0.5 * dx * dx / 0.1
-    bc = {"upper": ["Controllable", "Dirchilet"], "lower": ["Dirchilet", "Dirchilet"], "left": ["Dirchilet", "Dirchilet"],
-          "right": ["Dirchilet", "Dirchilet"]}
-    return {"T": nt * dt, "dt": dt, "X": 1, "dx": dx, "Y": 1, "dy": dx, "action_dim": 1, "reward_class": NSReward(0.1), "normalize": False,
-            "reset_init_condition_func": lambda X: (np.zeros_like(X), np.zeros_like(X), np.zeros_like(X)), "boundary_condition": bc,
-            "U_ref": np.zeros((nt, n, n, 2)), "action_ref": 2.0 * np.ones(nt), "maximum_pressure_iteration": 20}
+from tests.five_ids import BETA, ICS, NX, _backend, _five_ids, _ns_params, _transport_params  # noqa: E402,F401
 
 
 KINDS = ["double", pytest.param("hip", marks=pytest.mark.gpu)]
@@ -142,4 +110,23 @@ def test_navier_stokes_through_gym_make_runs_the_reference_loop(kind):
         obs, rew, term, trunc, info = env.step(np.array([3.0]))
         total, done, n = total + float(rew), bool(term or trunc), n + 1
     assert done and n == 5 and np.isfinite(total)          # T / dt = 6: nt = 7 frames, terminated when time_index reaches nt - 2
+    env.close()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("which", range(5), ids=["transport", "parabolic", "navier_stokes", "traffic", "brain_tumor"])
+def test_check_env_passes_on_every_registered_id(kind, which):
+    """gymnasium's (and, when installed, SB3's) ``check_env`` on ALL five ids the reference registers, each built by
+    ``gym.make`` from its own parameter dictionary."""
+    from gymnasium.utils.env_checker import check_env
+    env_id, params = _five_ids()[which]
+    env = gymnasium.make(env_id, **_backend(kind), **params)
+    assert isinstance(env.unwrapped, gymnasium.Env)
+    check_env(env.unwrapped, skip_render_check=True)
+    try:
+        from stable_baselines3.common.env_checker import check_env as sb3_check_env
+    except ImportError:
+        sb3_check_env = None
+    if sb3_check_env is not None:
+        sb3_check_env(gymnasium.make(env_id, **_backend(kind), **params).unwrapped, warn=True)
     env.close()
