@@ -10,7 +10,7 @@ namespace {
 // row written to observation slot t + 1, action / reward / flags taken from / written to row t of the [T, B] rollout arrays
 // -- every value equals what T separate step calls produce, bit for bit.  What it removes is the kernel boundary between
 // env-steps: no dispatch gap, no load phase (the state stays in registers, Carry), and the waves of a SIMD drift apart
-// instead of finishing in two generations.
+// instead of finishing in two generations (docs/HISTORY.md section 3.2).
 // FULL: the row fills the wave exactly (n - J0 == 64 EPL): the slot masks fold away (pdegym_1d_body.h: run_substeps).
 template <int EPL, bool PARABOLIC, bool BURGERS, bool FULL>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void rollout1d_kernel(pdegym_params1d P, pdegym_bufs1d Bf, pdegym_rollout1d Ro,

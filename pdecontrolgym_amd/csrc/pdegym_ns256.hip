@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kNT, 2) void ns256_fused_step(NSConst C, NSScal<flo
   const float a0 = act[0];
 
   float rq[kRR][4];
-#ifdef PDEGYM_NS256_TIMING      // developer build (tools/timing_probe_ns256.py): s_memtime at the phase boundaries of every wave
+#ifdef PDEGYM_NS256_TIMING      // developer build (tools/attic/timing_probe_ns256.py): s_memtime at the phase boundaries of every wave
   unsigned long long tm[6];
   tm[0] = __builtin_amdgcn_s_memtime();
 #define NS256_STAMP(i, dep) tm[i] = __builtin_amdgcn_s_memtime() + (unsigned long long)((dep) != (dep))

@@ -25,7 +25,7 @@
 // wave evaluates the 15 rhs rows it is about to sweep, leaves them in the rhs field and picks them up again itself) and does so
 // when one launch is the whole step (K <= 25); for K > 25 it stays a launch of its own: fused it saves no bytes (the rhs field is
 // written and read either way) and costs 1.6x the rows (slab overlap 1.41 x 17/15 per wave) at two waves per SIMD -- measured
-// 1.52 ms per 512 env-steps fused against the separate launch's figure in DESIGN.md section 4.
+// 1.52 ms per 512 env-steps fused against the separate launch's figure in docs/HISTORY.md section 4.
 #include <hip/hip_runtime.h>
 
 #include "pdegym.h"

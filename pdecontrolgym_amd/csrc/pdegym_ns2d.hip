@@ -13,7 +13,7 @@
 //                   reference's, so the float64 build is bit-faithful to NumPy.
 //   ns_tile<...>    float32 throughput path for grids up to 128x128: every thread keeps an 8x8 patch of p
 //                   and rhs in VGPRs for all K sweeps and only patch halos cross threads through LDS
-//                   (see DESIGN.md).  Same arithmetic, reassociated only where stated.
+//                   (see docs/HISTORY.md section 4).  Same arithmetic, reassociated only where stated.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -1593,7 +1593,7 @@ struct NSRollout {
 
 // (called, not inlined, from the rollout loop: with the step body inlined into a loop clang 22 / ROCm 7.2 crashes in instcombine for
 // one instantiation or another -- which one moves with every change of the body.  The call costs the callee-saved registers a
-// round trip through scratch memory per env-step: tools/bench_ns_rollout.py)
+// round trip through scratch memory per env-step: tools/attic/bench_ns_rollout.py)
 template <typename T, int NY>
 __device__ __attribute__((noinline)) void ns_col_body_call(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int B, T* red) {
   ns_col_body<T, NY>(C, S, P, B, red);
@@ -1650,7 +1650,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 8 || NY > 21 ? 2 : 3)) void ns_co
 // The column kernel is instantiated for the grid height of the reference's shipped example (21 rows) and a few neighbours
 // (8, 11, 16, 26, 31, 32); any width up to 64.  One wave works through all K sweeps of its (up to three) instances alone: in
 // float64 a lone instance finishes sooner on the workgroup-per-instance kernel (seven waves per instance; 0.77 vs 0.98 ms per
-// env-step at 21 x 21, K = 2000), so batches below a minimum (PDEGYM_DEBUG_NS_COL_MIN_BATCH overrides it; default: 400 for float64 -- round 4, tools/probe_ns_col_min_batch.py: column kernel 0.87 ms flat up to 3072 instances, workgroup kernel 0.80 ms at 256, 0.96 at 512, 1.30 at 768 -- and 1 for float32, where
+// env-step at 21 x 21, K = 2000), so batches below a minimum (PDEGYM_DEBUG_NS_COL_MIN_BATCH overrides it; default: 400 for float64 -- round 4, tools/attic/probe_ns_col_min_batch.py: column kernel 0.87 ms flat up to 3072 instances, workgroup kernel 0.80 ms at 256, 0.96 at 512, 1.30 at 768 -- and 1 for float32, where
 // the two kernels are equal at B = 1) stay there.
 template <typename T>
 bool launch_ns_col(const NSConst& C, const NSScal<T>& S, const NSPtrs<T>& P, int B, hipStream_t st) {

@@ -247,10 +247,10 @@ __device__ __forceinline__ void jacobi_row_into_north(float (&nv)[4], const floa
 
 // An s_nop 0 goes ahead of every DPP add: without it a DPP operand costs the SIMD ~15 cycles in these blocks -- the two waves of a
 // SIMD stop overlapping, any density of DPP from 2 in 16 up runs at ~4.2 cycles per instruction instead of 2.3-2.5 -- with it
-// ~6 (tools/ubench_dpp5.hip: pair block 261 -> 207 cycles per SIMD at two waves, 451 -> 386 at four; 166 / 294 without any
+// ~6 (tools/attic/ubench_dpp5.hip: pair block 261 -> 207 cycles per SIMD at two waves, 451 -> 386 at four; 166 / 294 without any
 // lane crossing).
 // Two rows per block (8 independent dependency chains instead of 4: a wave issues only about every 8 cycles along ONE
-// chain of 4, so three or four waves per SIMD cannot fill it with single-row blocks -- tools/ubench_dpp.hip).
+// chain of 4, so three or four waves per SIMD cannot fill it with single-row blocks -- tools/attic/ubench_dpp.hip).
 // UP, rows a (A) and a+1 (B):  da = old row a-1 (South of A, becomes new row a), db = old row a (centre of A, South of B,
 // becomes new row a+1), xb = old row a+1 (North of A, centre of B), nb = old row a+2 / bottom halo (North of B).
 // A accumulates in place; B keeps its partial sums in four temporaries until A has read db for the last time (A8).

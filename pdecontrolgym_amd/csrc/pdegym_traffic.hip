@@ -18,8 +18,8 @@ constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 
 // Wave-wide float64 sum on DPP (result in every lane).  Round 5: __shfl_xor compiles to ds_bpermute_b32 -- two per double and
-// step, 24 LDS round trips for the two reward norms of an env-step, each ~25 cycles of the wave's SIMD (DESIGN.md section 4:
-// tools/ab_ns_col.py).  Same scheme as wave_reduce of the 1D kernels: lane pair, quad (quad_perm), half row, row (row_half_mirror /
+// step, 24 LDS round trips for the two reward norms of an env-step, each ~25 cycles of the wave's SIMD (docs/HISTORY.md section 4:
+// tools/attic/ab_ns_col.py).  Same scheme as wave_reduce of the 1D kernels: lane pair, quad (quad_perm), half row, row (row_half_mirror /
 // row_mirror), lane 15 of rows 0 and 2 into rows 1 and 3 (row_bcast:15), lane 31 into rows 2, 3 (row_bcast:31); lane 63 holds the
 // total and v_readlane hands it to everybody.  A fixed order (deterministic): the reward norms were never bitwise against BLAS
 // ddot (tests: rtol 1e-12); step and rollout kernels share it, so they stay bit-identical to each other.

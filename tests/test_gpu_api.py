@@ -421,3 +421,44 @@ def test_hbm_probe_copies_and_reports_plausible_rates():
         torch.cuda.synchronize()
         assert torch.equal(dst, src)
     assert hp.lib().pdegym_probe_hbm(0, dst.data_ptr(), src.data_ptr(), n * 4 + 4, 333, 0, None) == -1      # not a multiple of 16 bytes
+
+
+def test_single_env_bench_block_runs_and_reports_every_shape():
+    """bench.py's single_env block (bench_single.py): every shape is measured on both sides, the shipped example shapes are faster on the
+    GPU face than in NumPy, and the crossover is a small positive number of sub-steps."""
+    import bench_single
+    out = bench_single.single_env_block(torch.device("cuda", 0), seconds=0.08)
+    for name in ("transport_c1", "parabolic_example", "transport_s1", "ns2d_example", "traffic_example", "tumor_example"):
+        assert "error" not in out[name], out[name]
+        assert out[name]["gpu"]["us_per_step"] > 0 and out[name]["numpy"]["us_per_step"] > 0
+    assert out["transport_c1"]["speedup"] > 5 and out["parabolic_example"]["speedup"] > 3 and out["ns2d_example"]["speedup"] > 5
+    assert 0 < out["crossover"]["substeps_above_which_gpu_wins"] < 50
+
+
+@pytest.mark.parametrize("kind,history", [("transport", True), ("transport", False), ("parabolic", True), ("parabolic", False)])
+def test_single_env_host_pack_mirrors_the_device_state(kind, history):
+    """The batch-of-one face keeps time_index on the host (min(t + S, nt - 1), hyperbolic.py:140) and reads observation / reward / flags
+    from pinned host views the kernel wrote: after every step they equal what the device holds, through the end of the episode and
+    past it (post-terminal calls do nothing)."""
+    import pde_control_gym
+    from pde_control_gym.src import TunedReward1D
+    nx = 40
+    n = nx + (kind == "parabolic")
+    dt, dx = (1e-4, 1.0 / nx) if kind == "parabolic" else (5e-3, 1.0 / nx)
+    S, T = 7, 45 * dt
+    env = pde_control_gym.make("PDEControlGym-TransportPDE1D" if kind == "transport" else "PDEControlGym-ReactionDiffusionPDE1D",
+                               device="cuda", record_history=history, T=T, dt=dt, X=1, dx=dx, control_sample_rate=S * dt,
+                               reward_class=TunedReward1D(int(round(T / dt)), -1e3, 3e2), normalize=True, sensing_loc="full",
+                               control_type="Dirchilet", sensing_type=None, sensing_noise_func=lambda s: s, limit_pde_state_size=True,
+                               max_state_value=1e10, max_control_value=20, reset_init_condition_func=lambda nx_: np.linspace(1, 2, n),
+                               reset_recirculation_func=lambda nx_: np.ones(n, dtype=np.float32)).unwrapped
+    env.reset()
+    core = env._core
+    for k in range(9):                  # 45 / 7: the episode ends inside step 7; steps 8 and 9 are post-terminal
+        obs, r, te, tr, _ = env.step(np.array([0.1 * k - 0.3], dtype=np.float32))
+        assert env.time_index == int(core.time_index.cpu()[0]) == min(7 * (k + 1), core.nt - 1)
+        np.testing.assert_array_equal(obs, core.u.cpu().numpy()[0])
+        assert te == bool(core.t["terminated"][0]) == (env.time_index >= core.nt - 1) and tr == bool(core.t["truncated"][0])
+        if history:
+            np.testing.assert_array_equal(env.u[env.time_index], obs)
+    assert te

@@ -160,7 +160,7 @@ def test_ns_f32_single_step_vs_f64_oracle(n, B, K, bc):
 
 
 def test_ns_f32_horizon_vs_f64_oracle_c4():
-    """STATED float32 HORIZON: BASELINE config 4 (128x128, K=50, lid-driven boundary set of NS2Dppo.py:21-26),
+    """STATED float32 HORIZON (docs/HISTORY.md section 4): BASELINE config 4 (128x128, K=50, lid-driven boundary set of NS2Dppo.py:21-26),
     smooth and constant initial fields, random lid actions U(2,4): over a 100-step episode the float32 throughput kernels stay
     within 1e-5 * max|U| of the float64 oracle in the velocity field (measured 2e-6, tools/ns_f32_horizon.py) and within
     5e-5 * max|p| in the pressure (measured 1e-6 .. 7e-6); rewards rtol 1e-5.  The flow is dissipative (nu = 0.1), the Jacobi

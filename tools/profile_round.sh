@@ -30,3 +30,13 @@ find $OUT -name p_kernel_trace.csv -delete
 find $OUT -name p_agent_info.csv -delete
 cd $R
 python3 tools/summarize_profiles.py $TAG
+# what is judged travels home small: the summaries the line above wrote under profiles/ (which gpurun does not merge back) are copied
+# into gpurun_out/<tag>_profiles/; the raw per-dispatch counter tables are dropped when they would push gpurun_out/ past the 64 MiB
+# gpurun merges (round 6: the whole directory was refused once)
+mkdir -p $R/gpurun_out/${TAG}_profiles
+cp $R/profiles/${TAG}_* $R/profiles/counters_latest.json $R/gpurun_out/${TAG}_profiles/
+if [ "$(du -sm $R/gpurun_out | cut -f1)" -gt 40 ]; then
+  find $OUT -name p_counter_collection.csv -delete
+  find $OUT -name '*.csv' -size +1M -delete
+fi
+du -sm $R/gpurun_out
