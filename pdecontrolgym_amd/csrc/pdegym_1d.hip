@@ -25,7 +25,7 @@ namespace {
 // FULL (round 5): the row fills the wave exactly (n - J0 == 64 EPL; the BASELINE shapes nx = 256 and nx = 512 do) -- the slot
 // masks of prologue / epilogue fold away (pdegym_1d_body.h: run_substeps).  The float32 Dirichlet fast path only.
 // HFAST (round 6): the fast loop + one trajectory-row store per sub-step -- what a single environment with record_history (the
-// reference's env.u) runs: 0.083 us per sub-step of one instance against 0.228 for the select form.
+// reference's env.u) runs: 0.066 us per sub-step of one instance against 0.228 for the select form.
 template <int EPL, bool PARABOLIC, bool NEUMANN, bool HIST, bool BURGERS = false, bool M64 = false, bool FULL = false, bool HFAST = false>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void step1d_kernel(pdegym_params1d P, pdegym_bufs1d Bf, int B) {
   const int lane = threadIdx.x & (kWave - 1);

@@ -485,20 +485,45 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
     int s = 0;
     // HIST: row R.t of the trajectory after every sub-step (frozen boundary slot = the commanded value, node 0 = 0: the row
     // as the reference stores it); the stores are fire-and-forget, nothing in the loop waits for them
+    // `hist` is wave-uniform (step1d_body forms it from a scalar instance index): the row address is a scalar base, advanced by one
+    // scalar add per sub-step, + the lane's slot offset.  A lane whose EPL slots all lie inside the row stores them as one vector; the
+    // at most one lane that straddles the row's end stores slot by slot -- and only when there is such a lane (hoisted, wave-uniform).
     float* hrow = nullptr;
-    bool hmask[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) hmask[e] = s0 + e < ns;
-    if constexpr (HIST) hrow = hist ? hist + (size_t)R.t * n + J0 + s0 : nullptr;
-    auto store_row = [&]() {
+    const bool hfull = s0 + EPL <= ns, hpart = !hfull && s0 < ns;
+    bool any_part = false;
+    if constexpr (HIST) {
+      if (hist) {
+        hrow = hist + (size_t)R.t * n + J0;
+        any_part = __builtin_amdgcn_ballot_w64(hpart) != 0ull;
+      }
+    }
+    // PART: some lane straddles the row's end (decided once per call: the loops below exist in both forms, so the common form has no
+    // test and no skipped block inside).  Node 0 of a parabolic row is not stored: it is 0 after any sub-step and every row >= 1 of the
+    // trajectory is zero-filled by the reset (reset_history_kernel, the fused auto-reset), so the word already holds it.
+    auto store_row = [&](auto part_tag) {
       if constexpr (HIST) {
-        if (hrow) {
-          hrow += n;
-          if (PARABOLIC && lane == 0) hrow[-J0] = 0.0f;
+        hrow += n;
+        if (hfull) {
+          float* q = hrow + s0;
+          constexpr int Q = EPL / 4 * 4, D = (EPL - Q) / 2 * 2;
 #pragma unroll
-          for (int e = 0; e < EPL; ++e)
-            if (hmask[e]) hrow[e] = R.x[e];
+          for (int e = 0; e < Q; e += 4) *reinterpret_cast<pdegym_f4u*>(q + e) = pdegym_f4u{R.x[e], R.x[e + 1], R.x[e + 2], R.x[e + 3]};
+          if constexpr (D == 2) *reinterpret_cast<pdegym_f2u*>(q + Q) = pdegym_f2u{R.x[Q], R.x[Q + 1]};
+          if constexpr (Q + D < EPL) q[EPL - 1] = R.x[EPL - 1];
         }
+        if constexpr (decltype(part_tag)::value) {
+          if (hpart) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+              if (s0 + e < ns) hrow[s0 + e] = R.x[e];
+          }
+        }
+      }
+    };
+    auto run_of = [&](int run, auto pow2_tag, auto part_tag) {
+      for (int i = 0; i < run; ++i) {
+        pde_substep(std::false_type{}, pow2_tag);
+        store_row(part_tag);
       }
     };
     if (nsub > 0) {
@@ -506,7 +531,7 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
       ++R.t;
       R.k = (R.k + 1 == S) ? 0 : R.k + 1;
       s = 1;
-      store_row();
+      if (HIST && hrow) store_row(std::true_type{});
       record_norm(s);
     }
     while (s < nsub) {
@@ -519,16 +544,20 @@ __device__ __forceinline__ void run_substeps(Row<EPL>& R, const float (&beta)[EP
         run = run < to_phase0 ? run : to_phase0;
         if (to_lookback > 0) run = run < to_lookback ? run : to_lookback;
       }
-      if (pow2_dx) {
-        for (int i = 0; i < run; ++i) {
-          pde_substep(std::false_type{}, std::true_type{});
-          store_row();
+      if constexpr (HIST) {
+        if (hrow == nullptr) {        // (never with HFAST: the launcher takes it only with a trajectory buffer)
+          if (pow2_dx) for (int i = 0; i < run; ++i) pde_substep(std::false_type{}, std::true_type{});
+          else for (int i = 0; i < run; ++i) pde_substep(std::false_type{}, std::false_type{});
+        } else if (pow2_dx) {
+          if (any_part) run_of(run, std::true_type{}, std::true_type{});
+          else run_of(run, std::true_type{}, std::false_type{});
+        } else {
+          if (any_part) run_of(run, std::false_type{}, std::true_type{});
+          else run_of(run, std::false_type{}, std::false_type{});
         }
       } else {
-        for (int i = 0; i < run; ++i) {
-          pde_substep(std::false_type{}, std::false_type{});
-          store_row();
-        }
+        if (pow2_dx) for (int i = 0; i < run; ++i) pde_substep(std::false_type{}, std::true_type{});
+        else for (int i = 0; i < run; ++i) pde_substep(std::false_type{}, std::false_type{});
       }
       R.t += run;
       R.k += run;
@@ -612,7 +641,8 @@ __device__ __forceinline__ void step1d_body(const pdegym_params1d& P, const pdeg
   RingT ring;
   if constexpr (CARRY) ring = carry->ring;
   else ring.mem = ring_mem;
-  float* hist = (HIST && Bf.history) ? Bf.history + (size_t)inst * P.nt * n : nullptr;
+  // (HFAST: a scalar instance index, so that the trajectory pointer is wave-uniform -- scalar base + lane offset addressing in the loop)
+  float* hist = (HIST && Bf.history) ? Bf.history + (size_t)(HFAST ? __builtin_amdgcn_readfirstlane(inst) : inst) * P.nt * n : nullptr;
 
   Row<EPL> R;
   float beta[EPL];
