@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The ONE roofline table of DESIGN.md section 6, from tracked files only:
-   python tools/roofline_table.py profiles/r06f_summary.json profiles/r06g_bench_also.json
+   python tools/roofline_table.py profiles/r06f_summary.json profiles/r06i_summary.json profiles/r06j_bench_also.json
 rocprof columns (kernel, average duration, HBM traffic) come from the profile round's summary, time and fractions from the driver-style
 bench run's full result (bench_also.json: HIP-event step time, SQ_INSTS_VALU / FETCH / WRITE per step / time / peak).
 Compulsory bytes per env-step (the "x" column's denominator): 1D step = row in + beta in + row/obs out (3 148 B at nx = 256); rollouts = the
@@ -9,8 +9,10 @@ observation slot + command + reward + flags of every env-step (the state is carr
 import json
 import sys
 
-summ = json.load(open(sys.argv[1]))["workloads"]
-full = json.load(open(sys.argv[2]))
+summ = {}
+for path in sys.argv[1:-1]:           # several profile rounds: a later one replaces the workloads it re-profiled
+    summ.update({k: v for k, v in json.load(open(path))["workloads"].items() if v.get("avg_ns")})
+full = json.load(open(sys.argv[-1]))
 ROWS = [("parabolic_c2", "**C2 headline** Parabolic nx=256 B=4096 S=100 f32", 309444, 3148, 4096),
         ("transport_c3", "C3 Transport nx=512 B=16384 S=100 f32", 100 * 12 * 512 + 4 * 512 + 16, 4 * 512 * 2 + 4 * 512 + 64, 16384),
         ("ns2d_c4", "C4 NS 128² K=50 B=512 f32", 4 * 166 * 128 * 128, 4 * 6 * 128 * 128, 512),
