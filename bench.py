@@ -637,6 +637,30 @@ def profiled_counters(workload_key):
         return None, None
 
 
+def live_counters_from_csvs(paths, ksub):
+    """rocprofv3's CSVs -> the per-step figures of the kernel whose name contains `ksub`: `paths["stats"]` = p_kernel_stats.csv of a
+    `--kernel-trace --stats` pass, `paths[c]` = p_counter_collection.csv of a `--pmc c` pass for c in SQ_INSTS_VALU / FETCH_SIZE /
+    WRITE_SIZE.  Per-launch averages; HBM bytes = FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 (MI355X_MICROARCH.md, HBM / rocprofv3:
+    gfx950's FETCH_SIZE tallies 128-byte reads at 64 bytes).  None if the kernel is missing or a pass saw fewer than 10 launches."""
+    import csv
+    out = {}
+    for r in csv.DictReader(open(paths["stats"])):
+        if ksub in r["Name"]:
+            out.update(kernel=r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-80:],
+                       calls=int(r["Calls"]), kernel_avg_ns=float(r["AverageNs"]), kernel_min_ns=float(r["MinNs"]))
+            break
+    else:
+        return None
+    for counter, scale, key in (("SQ_INSTS_VALU", 1.0, "valu_insts_per_step"), ("FETCH_SIZE", 2048.0, "_fetch"), ("WRITE_SIZE", 1024.0, "_write")):
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(paths[counter]))
+                if ksub in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        if len(vals) < 10:
+            return None
+        out[key] = sum(vals) / len(vals) * scale
+    out["hbm_bytes_per_step"] = out.pop("_fetch") + out.pop("_write")
+    return out
+
+
 def live_counters(workload_key, budget_s=90.0, first_timeout_s=75.0, timeout_s=40.0):
     """Counters of THIS run's headline kernel, collected on THIS box: before the parent process touches the
     GPU, four fresh child processes run the headline workload under rocprofv3 -- `--kernel-trace --stats` (the kernel's average
@@ -644,7 +668,6 @@ def live_counters(workload_key, budget_s=90.0, first_timeout_s=75.0, timeout_s=4
     sys / hip trace; `python3` directly after `--`).  Returns {"kernel", "kernel_avg_ns", "calls", "valu_insts_per_step",
     "hbm_bytes_per_step", ...} or None (any failure, profiler missing, time budget spent: the caller falls back to the committed
     counters).  Never retried, and never run from a process that has used the GPU."""
-    import csv
     import shutil
     import subprocess
     import tempfile
@@ -675,21 +698,13 @@ def live_counters(workload_key, budget_s=90.0, first_timeout_s=75.0, timeout_s=4
                     return os.path.join(base, f)
         raise FileNotFoundError(tag)
     try:
-        for r in csv.DictReader(open(run("stats", ["--kernel-trace", "--stats"]))):
-            if ksub in r["Name"]:
-                out.update(kernel=r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-80:],
-                           calls=int(r["Calls"]), kernel_avg_ns=float(r["AverageNs"]), kernel_min_ns=float(r["MinNs"]))
-                break
-        else:
+        paths = {"stats": run("stats", ["--kernel-trace", "--stats"])}
+        for counter in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
+            paths[counter] = run(counter, ["--pmc", counter, "--kernel-trace"])
+        got = live_counters_from_csvs(paths, ksub)
+        if got is None:
             return None
-        for counter, scale, key in (("SQ_INSTS_VALU", 1.0, "valu_insts_per_step"), ("FETCH_SIZE", 2048.0, "_fetch"), ("WRITE_SIZE", 1024.0, "_write")):
-            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(run(counter, ["--pmc", counter, "--kernel-trace"])))
-                    if ksub in r["Kernel_Name"] and r["Counter_Name"] == counter]
-            if len(vals) < 10:
-                return None
-            out[key] = sum(vals) / len(vals) * scale
-        # MI355X_MICROARCH.md (HBM / rocprofv3): gfx950's FETCH_SIZE tallies 128-byte reads at 64 bytes -> x 2 on the read side
-        out["hbm_bytes_per_step"] = out.pop("_fetch") + out.pop("_write")
+        out.update(got)
         out["seconds"] = time.perf_counter() - t_begin
         return out
     except Exception as ex:

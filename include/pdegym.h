@@ -21,8 +21,13 @@
  * Chorin projection step with K Jacobi sweeps for NS2D).  Instances are independent.
  *
  * Conventions
- *   - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm tensors in this repo); the
- *     library allocates nothing and keeps no state besides a thread-local error string;
+ *   - every pointer is a DEVICE-ACCESSIBLE pointer owned by the caller (PyTorch-ROCm tensors in this repo): HBM, or pinned
+ *     host memory mapped into the device's address space (hipHostMalloc).  The plant state belongs in HBM; per-call INPUTS
+ *     (action, control, kill, t_benchmark) and pure OUTPUTS (obs, reward, norm_now, norm_back, terminated, truncated, done) may
+ *     live in pinned host memory -- the kernels read / write them in place, which is how the batch-of-one faces of the Python
+ *     layer take a command and hand back a result with one launch + one stream synchronisation and no copies
+ *     (PDEBatch1D.enable_host_io; the reference's own callers step ONE environment: examples/transportPDE/transport1Dppo.py:59-90);
+ *     the library allocates nothing and keeps no state besides a thread-local error string;
  *   - calls only ENQUEUE work on `stream` (a hipStream_t passed as void*); they never synchronise;
  *   - return value 0 = success, negative = error (message via pdegym_last_error()); nothing throws;
  *   - arrays are C-contiguous; the grid axis is the fastest axis.

@@ -139,3 +139,39 @@ def test_final_line_single_env_block_and_multi_gpu_secondary():
     sec = {e["name"]: e for e in json.loads(line)["secondary"]}
     assert len(line) < bench.MAX_LINE and set(sec) == {"ns2d_c5", "ns2d_c5_f64"}
     assert all(len(e["per_rank"]) == 8 and e["instances_per_gpu"] == 512 for e in sec.values())
+
+
+def test_live_counters_parse_rocprof_csvs_and_fail_soft(tmp_path, monkeypatch):
+    """bench.live_counters_from_csvs on synthetic rocprofv3 tables (the layout tools/summarize_profiles.py reads): per-launch averages
+    of the named kernel only, the gfx950 read-side factor 2, None when a pass saw too few launches; and live_counters() itself returns
+    None -- the committed counters then serve -- when the profiler child fails."""
+    k = "void (anonymous namespace)::step1d_kernel<4, true, false, false, false, false, true>(pdegym_params1d, pdegym_bufs1d, int)"
+    other = "void at::native::elementwise_kernel<...>(int)"
+    stats = tmp_path / "p_kernel_stats.csv"
+    stats.write_text('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+                     f'"{other}",5,500,100.0,1.0,90,110,1.0\n"{k}",47,752100,16002.1,99.0,15800,17000,20.0\n')
+
+    def pmc(name, counter, values):
+        f = tmp_path / f"{name}.csv"
+        rows = ['"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name","Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value","Start_Timestamp","End_Timestamp"']
+        for i, v in enumerate(values):
+            rows.append(f'{i},{i},1,1,1,1,1048576,3,"{k}",256,0,0,40,0,96,"{counter}",{v},0,1')
+        rows.append(f'99,99,1,1,1,1,64,4,"{other}",64,0,0,8,0,16,"{counter}",123456789,0,1')
+        f.write_text("\n".join(rows) + "\n")
+        return str(f)
+    paths = {"stats": str(stats), "SQ_INSTS_VALU": pmc("valu", "SQ_INSTS_VALU", [11141120] * 12),
+             "FETCH_SIZE": pmc("fetch", "FETCH_SIZE", [4700.0] * 12), "WRITE_SIZE": pmc("write", "WRITE_SIZE", [4540.0] * 12)}
+    got = bench.live_counters_from_csvs(paths, "step1d_kernel")
+    assert got["kernel"].startswith("step1d_kernel<4, true") and got["calls"] == 47 and got["kernel_avg_ns"] == 16002.1
+    assert got["valu_insts_per_step"] == 11141120.0
+    assert got["hbm_bytes_per_step"] == 4700.0 * 2048 + 4540.0 * 1024
+    assert bench.live_counters_from_csvs(dict(paths, WRITE_SIZE=pmc("few", "WRITE_SIZE", [1.0] * 3)), "step1d_kernel") is None
+    assert bench.live_counters_from_csvs(paths, "no_such_kernel") is None
+    # the collection itself: a failing profiler child must not take the bench run down
+    import subprocess
+
+    def boom(*a, **kw):
+        raise subprocess.CalledProcessError(1, a[0])
+    monkeypatch.setattr(subprocess, "run", boom)
+    assert bench.live_counters("parabolic_c2") is None
+    assert bench.live_counters("ns2d_c4") is None             # only the headline has a live path
