@@ -690,8 +690,21 @@ def live_counters(workload_key, budget_s=90.0, first_timeout_s=75.0, timeout_s=4
             raise TimeoutError("live-counter time budget spent")
         d = os.path.join(tmp, tag)
         cmd = [rocprof] + opts + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + child
-        subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, cwd="/tmp", check=True,
-                       timeout=min(left, first_timeout_s if tag == "stats" else timeout_s))
+        # own session: on a timeout the WHOLE group goes (rocprofv3 is a launcher; an orphaned grandchild would keep the GPU busy
+        # under the timed regions that follow)
+        pr = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, cwd="/tmp", start_new_session=True)
+        try:
+            rc = pr.wait(timeout=min(left, first_timeout_s if tag == "stats" else timeout_s))
+        except subprocess.TimeoutExpired:
+            import signal
+            try:
+                os.killpg(pr.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            pr.wait()
+            raise
+        if rc != 0:
+            raise subprocess.CalledProcessError(rc, cmd[0])
         for base, _, files in os.walk(d):          # (rocprofv3 may add a host-name level under -d)
             for f in files:
                 if f in ("p_kernel_stats.csv", "p_counter_collection.csv"):

@@ -170,8 +170,26 @@ def test_live_counters_parse_rocprof_csvs_and_fail_soft(tmp_path, monkeypatch):
     # the collection itself: a failing profiler child must not take the bench run down
     import subprocess
 
-    def boom(*a, **kw):
-        raise subprocess.CalledProcessError(1, a[0])
-    monkeypatch.setattr(subprocess, "run", boom)
+    import sys
+    real_popen = subprocess.Popen
+    seen = []
+
+    def failing_child(cmd, **kw):            # stands in for rocprofv3: exits 3 at once
+        seen.append((cmd, kw))
+        return real_popen([sys.executable, "-c", "import sys; sys.exit(3)"], **kw)
+    monkeypatch.setattr(subprocess, "Popen", failing_child)
+    monkeypatch.setattr(bench.os.path, "exists", lambda p: True)
     assert bench.live_counters("parabolic_c2") is None
+    cmd, kw = seen[0]
+    assert kw.get("start_new_session") is True                       # a timeout can take the whole group down
+    i = cmd.index("--")
+    assert cmd[i + 1] == "python3" and "--pmc" not in cmd[:i]         # the program itself directly after `--`; first pass: stats only
+    assert "--no-live-counters" in cmd and "--kernel-trace" in cmd and "--sys-trace" not in cmd
+
+    def hanging_child(cmd, **kw):            # ... and one that never finishes: killed with its group, None returned
+        return real_popen([sys.executable, "-c", "import time; time.sleep(60)"], **kw)
+    monkeypatch.setattr(subprocess, "Popen", hanging_child)
+    t0 = bench.time.perf_counter()
+    assert bench.live_counters("parabolic_c2", budget_s=7.0, first_timeout_s=1.0) is None
+    assert bench.time.perf_counter() - t0 < 10
     assert bench.live_counters("ns2d_c4") is None             # only the headline has a live path
