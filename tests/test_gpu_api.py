@@ -462,3 +462,59 @@ def test_single_env_host_pack_mirrors_the_device_state(kind, history):
         if history:
             np.testing.assert_array_equal(env.u[env.time_index], obs)
     assert te
+
+
+def test_integration_md_binding_stub_reproduces_the_reference_golden(golden_transport):
+    """INTEGRATION.md section 2 as code: the ctypes stub a maintainer of the reference would put in place of hyperbolic.py:137-169 -- raw
+    C-ABI structures, device tensors for the plant state, ONE pinned host allocation for the command and the results (the kernel reads
+    and writes it in place), one launch + one synchronisation per step -- reproduces the reference-generated golden H1 (nx = 100,
+    S = 1000) bit for bit, without any of this repository's engine classes."""
+    import ctypes as C
+    from pdecontrolgym_amd import _native as N
+    from tests.cases import TRANSPORT_CASES
+    lib = N.load()
+    kw, g = TRANSPORT_CASES["H1"], golden_transport["H1"]
+    n, nt, S = 100, int(round(kw["T"] / kw["dt"]) + 1), int(round(kw["control_sample_rate"] / kw["dt"]))
+    P = N.Params1D()
+    P.n, P.nt, P.substeps, P.control_type, P.normalize, P.sensing, P.limit_state = n, nt, S, 0, 0, N.SENSE_FULL, 1
+    P.reward_kind, P.reward_nt = N.REWARD_TUNED1D, int(g.reward_args[0])
+    P.truncate_penalty, P.terminate_reward = float(g.reward_args[1]), float(g.reward_args[2])
+    P.dt, P.dx, P.F, P.max_control, P.max_state = kw["dt"], kw["dx"], kw["dt"] / kw["dx"] ** 2, 20, 1e10
+    P.rdx = 1.0 / float(C.c_float(kw["dx"]).value)
+    P.dt64, P.dx64, P.max_control64 = kw["dt"], kw["dx"], 20
+    dev = torch.device("cuda")
+    u = torch.zeros(1, n, device=dev)
+    beta = torch.as_tensor(np.asarray(g.beta, dtype=np.float32), device=dev)
+    t_idx = torch.zeros(1, dtype=torch.int32, device=dev)
+    bsum = torch.zeros(1, dtype=torch.float64, device=dev)
+    ring = torch.zeros(1, N.RING, device=dev)
+    norm_back = torch.zeros(1, device=dev)
+    hist = torch.zeros(1, nt, n, device=dev)
+    pack = torch.zeros(8 + 4 * n + 4 + 4 + 2, dtype=torch.uint8, pin_memory=True)
+    B = N.Bufs1D()
+    B.u, B.beta, B.beta_stride = u.data_ptr(), beta.data_ptr(), 0
+    B.time_index, B.bsum, B.ring, B.norm_back, B.history = t_idx.data_ptr(), bsum.data_ptr(), ring.data_ptr(), norm_back.data_ptr(), hist.data_ptr()
+    base = pack.data_ptr()
+    B.action, B.obs = base, base + 8
+    B.reward, B.norm_now = base + 8 + 4 * n, base + 12 + 4 * n
+    B.terminated, B.truncated = base + 16 + 4 * n, base + 17 + 4 * n
+    host = pack.numpy()
+    a32, obs_h, rew_h, flags_h = host[:4].view(np.float32), host[8:8 + 4 * n].view(np.float32), host[8 + 4 * n:12 + 4 * n].view(np.float32), host[16 + 4 * n:18 + 4 * n]
+    init = torch.as_tensor(np.asarray(g.init, dtype=np.float32)[None], device=dev)
+    stream = torch.cuda.current_stream()
+    N.check(lib.pdegym_reset1d_masked(C.byref(P), C.byref(B), init.data_ptr(), None, 1, stream.cuda_stream), "reset")
+    stream.synchronize()
+    np.testing.assert_array_equal(obs_h, g.obs[0])
+    t = 0
+    for i, a in enumerate(g.actions):
+        a32[0] = a
+        P.action_kind = N.ACTION_F32
+        N.check(lib.pdegym_transport_step(C.byref(P), C.byref(B), 1, stream.cuda_stream), "step")
+        stream.synchronize()
+        t = min(t + S, nt - 1)
+        np.testing.assert_array_equal(obs_h, g.rows[i], err_msg=f"row of step {i}")
+        assert t == int(g.time_index[i]) == int(t_idx.cpu()[0])
+        assert bool(flags_h[0]) == bool(g.terminate[i]) and bool(flags_h[1]) == bool(g.truncate[i])
+        if np.isfinite(g.reward[i]):
+            np.testing.assert_allclose(rew_h[0], g.reward[i], rtol=1e-6, atol=1e-6 * max(1.0, float(np.linalg.norm(g.rows[i]))))
+    np.testing.assert_array_equal(hist[0, t].cpu().numpy(), g.rows[-1])          # the trajectory (env.u) on the device
