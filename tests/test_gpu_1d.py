@@ -861,3 +861,58 @@ def test_rollout_abi_validation():
     z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device="cuda")   # noqa: E731
     with pytest.raises(Exception, match="obs"):
         env.rollout(z(4, 2, n), z(4, 2), z(4, 2), z(4, 2, dt=torch.uint8), z(4, 2, dt=torch.uint8))   # T + 1 slots needed
+
+
+@pytest.mark.parametrize("kind,nx,S,dx_pow2", [
+    ("transport", 100, 7, False),     # 50 full lanes of two slots, 14 empty: the common loop (no straddling lane)
+    ("transport", 101, 3, False),     # the last lane straddles the row's end: the loop with the slot-by-slot tail
+    ("transport", 64, 5, True),       # dx = 2^-6: the exact-multiply quotient, one slot per lane, FULL-sized row
+    ("transport", 130, 4, False),     # EPL = 3: vector store of 2 + 1
+    ("transport", 513, 2, False),     # EPL = 9 -> instantiated as 12: no fast history loop (the select form serves it)
+    ("parabolic", 200, 9, False),     # the reference's example grid: 200 slots = 50 full lanes of four
+    ("parabolic", 201, 3, False),     # straddling lane; node 0 of every stored row must read 0
+    ("parabolic", 256, 6, False),     # the C2 row
+])
+def test_history_mode_fast_loop_writes_the_reference_trajectory(kind, nx, S, dx_pow2):
+    """HFAST (round 6: fast arithmetic + one trajectory-row store per sub-step, what a single environment with record_history runs):
+    every row of ``history`` equals the oracle's kept trajectory bit for bit -- through an episode end (fewer sub-steps than S in the
+    last call, then post-terminal calls that write nothing), for an instance whose step is redone by the exact loop (a state that
+    overflows float32 inside the call), for a commanded boundary value of exactly -0.0, and next to ordinary instances in the same
+    launch."""
+    from oracle import pde_oracle as po
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
+    n = nx + (kind == "parabolic")
+    dx = 2.0 ** -6 if dx_pow2 else 1.0 / nx
+    dt = 0.25 * dx * dx if kind == "parabolic" else 0.5 * dx
+    steps = 6
+    nt1 = S * steps - 2                                  # the last call has S - 2 sub-steps left
+    kw = dict(T=nt1 * dt, dt=dt, X=nx * dx, dx=dx, control_sample_rate=S * dt, control_type="Dirchilet", sensing_loc="full",
+              sensing_type=None, normalize=False, max_control_value=20, limit_pde_state_size=True, max_state_value=1e10)
+    B = 5
+    rng = np.random.default_rng(nx + S)
+    init = rng.uniform(-2, 2, (B, n)).astype(np.float32)
+    # overflows float32 inside the call (parabolic: 2*u of parabolic.py:143 at |u| >= 2^127): non-finite rows, the exact redo
+    init[3] *= np.float32(1.6e38 if kind == "parabolic" else 3e37)
+    init[4, ::3] = 0.0
+    beta = rng.uniform(-5, 5, (B, n)).astype(np.float32)
+    # (no reward: with fewer than 100 rows the reference's look-back index u[t - 100] is out of range, tuned_reward_1d.py:40)
+    orc = (po.ParabolicOracle if kind == "parabolic" else po.TransportOracle)(reward=None, keep_history=True, **kw)
+    env = PDEBatch1D(kind, reward=RewardSpec(N.REWARD_NONE), num_envs=B, device="cuda", record_history=True, **kw)
+    orc.reset(init, beta)
+    env.reset(torch.tensor(init), torch.tensor(beta))
+    with np.errstate(all="ignore"):
+        for k in range(steps + 2):
+            a = rng.uniform(-3, 3, B).astype(np.float32)
+            a[1] = np.float32(-0.0)                      # x + 0*t would turn a frozen -0.0 into +0.0: the exact loop takes it
+            o_ref, r_ref, te_ref, tr_ref = orc.step(a)
+            o, r, te, tr = env.step(torch.tensor(a))
+            np.testing.assert_array_equal(o.cpu().numpy().view(np.uint32), np.asarray(o_ref, dtype=np.float32).view(np.uint32), err_msg=f"step {k}")
+            np.testing.assert_array_equal(te.cpu().numpy().astype(bool), te_ref)
+            np.testing.assert_array_equal(env.time_index.cpu().numpy(), orc.time_index)
+    hg, ho = env.t["history"].cpu().numpy(), orc.hist
+    assert hg.shape == ho.shape == (B, nt1 + 1, n)
+    np.testing.assert_array_equal(hg.view(np.uint32), ho.view(np.uint32))
+    assert te_ref.all() and not np.isfinite(ho[3]).all() and np.isfinite(ho[0]).all()
+    if kind == "parabolic":
+        assert (hg[:, 1:, 0] == 0).all()
