@@ -277,6 +277,10 @@ class PDEBatch1D(EngineCheckpoint):
         import torch
         if self.state_in_obs:
             raise ValueError("host I/O needs the state in its own tensor (build the engine with state_in_obs=False)")
+        if self.num_envs != 1:
+            # (the command slot is 8 bytes wide so that one address serves float32 and float64 commands: an array of float32
+            # commands would need 4-byte slots -- batches take the staged path of PDEVecEnv)
+            raise ValueError("host I/O is the batch-of-one face (num_envs = 1)")
         if getattr(self, "_hio", None) is not None:
             return self._hio["np"]
         B, od = self.num_envs, self.obs_dim

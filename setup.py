@@ -44,7 +44,7 @@ except ImportError:
 
 setup(
     name="pdecontrolgym",
-    version="0.5.0",
+    version="0.6.0",
     description="MI355X-native batched stepper behind the PDEControlGym Gymnasium API",
     packages=find_packages(include=["pde_control_gym*", "pdecontrolgym_amd*"]),
     package_data={"pdecontrolgym_amd": ["lib/*.so", "lib/*.stamp", "csrc/*"]},

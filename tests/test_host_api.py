@@ -1042,3 +1042,33 @@ def test_every_registered_id_builds_resets_and_steps_from_its_reference_paramete
     o, r, te, tr, inf = out
     assert np.asarray(o).shape == e.observation_space.shape and np.isfinite(float(r)) and isinstance(inf, dict)
     assert isinstance(te, (bool, np.bool_)) and isinstance(tr, (bool, np.bool_))
+
+
+def test_host_io_mode_of_the_1d_engine_is_the_batch_of_one_face_and_equals_the_staged_path():
+    """PDEBatch1D.enable_host_io (the single environments' hand-over through one pinned allocation): refused for engines whose
+    observation IS the state and for batches; with it, step_host() returns what step() returns (CPU double: the same tensors, plain
+    host memory) for float32 and float64 commands."""
+    import torch
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd.batch1d import PDEBatch1D, RewardSpec
+    kw = dict(T=0.3, dt=1e-3, X=1, dx=0.02, control_sample_rate=5e-3, normalize=True, limit_pde_state_size=True, max_control_value=20)
+    mk = lambda **extra: PDEBatch1D("transport", reward=RewardSpec(N.REWARD_TUNED1D, 300, -1e3, 3e2), device="cpu", backend=FakeBackend(),
+                                    **dict(kw, **extra))
+    with pytest.raises(ValueError, match="state in its own tensor"):
+        mk(num_envs=1).enable_host_io()
+    with pytest.raises(ValueError, match="batch-of-one"):
+        mk(num_envs=2, state_in_obs=False).enable_host_io()
+    a, b = mk(num_envs=1, state_in_obs=False), mk(num_envs=1, state_in_obs=False)
+    io = a.enable_host_io()
+    assert a.enable_host_io() is io                                  # idempotent
+    init, beta = np.linspace(1, 2, 50, dtype=np.float32)[None], np.ones(50, dtype=np.float32)
+    a.reset(init, beta)
+    b.reset(init, beta)
+    for k, (val, kind) in enumerate([(0.25, N.ACTION_F32), (-0.5, N.ACTION_F64), (0.125, N.ACTION_WEAK), (0.75, N.ACTION_F32)]):
+        a.step_host(val, kind)
+        o, r, te, tr = b.step(torch.tensor([val], dtype=torch.float32 if kind == N.ACTION_F32 else torch.float64), action_kind=kind)
+        np.testing.assert_array_equal(io["obs"], o.numpy())
+        np.testing.assert_array_equal(io["reward"], r.numpy())
+        assert int(io["terminated"][0]) == int(te[0]) and int(io["truncated"][0]) == int(tr[0])
+        np.testing.assert_array_equal(a.u.numpy(), b.u.numpy())
+        assert int(a.time_index[0]) == int(b.time_index[0]) == 5 * (k + 1)
