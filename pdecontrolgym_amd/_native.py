@@ -153,6 +153,7 @@ def load():
         raise NativeError(
             f"{LIB_PATH} is missing: build it with `python -m pdecontrolgym_amd.build` "
             "(there is no CPU fallback for the PDE steppers)")
+    import torch  # noqa: F401  (first: the library must bind to the HIP runtime torch has loaded, not to a second copy of libamdhip64)
     lib = C.CDLL(LIB_PATH)
     lib.pdegym_abi_version.restype = C.c_int
     lib.pdegym_last_error.restype = C.c_char_p
