@@ -1072,3 +1072,63 @@ def test_host_io_mode_of_the_1d_engine_is_the_batch_of_one_face_and_equals_the_s
         assert int(io["terminated"][0]) == int(te[0]) and int(io["truncated"][0]) == int(tr[0])
         np.testing.assert_array_equal(a.u.numpy(), b.u.numpy())
         assert int(a.time_index[0]) == int(b.time_index[0]) == 5 * (k + 1)
+
+
+def test_prepared_step_calls_switch_to_the_state_device(monkeypatch):
+    """HipBackend.prepare_step1d / prepare_ns2d_step (the batch-of-one faces' launches with pre-built argument structures) carry the
+    device guard INSIDE the prepared call: entered with the device of the state tensors when another device is current, not at all
+    when it is current already -- unit-tested with stand-ins like the decorator form above (no GPU, no library)."""
+    import ctypes as C
+    import torch
+    from pdecontrolgym_amd import _native as N
+    from pdecontrolgym_amd import backend as bk_mod
+    entered, launched = [], []
+
+    class Guard:
+        def __init__(self, dev):
+            entered.append(dev)
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    class Stream:
+        cuda_stream = 1234
+
+    current = {"dev": 0}
+    monkeypatch.setattr(torch.cuda, "device", Guard)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: current["dev"])
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda dev=None: Stream())
+
+    class T:                       # a tensor stand-in on cuda:1
+        device = torch.device("cuda", 1)
+        dtype = torch.float32
+
+        def dim(self):
+            return 2
+
+    class Lib:
+        @staticmethod
+        def pdegym_transport_step(p, b, B, stream):
+            launched.append((B, stream))
+            return 0
+        pdegym_parabolic_step = pdegym_transport_step
+        pdegym_ns2d_step_f32 = pdegym_transport_step
+
+    bk = bk_mod.HipBackend.__new__(bk_mod.HipBackend)
+    bk.lib = Lib()
+    monkeypatch.setattr(bk_mod.HipBackend, "_bufs1d", staticmethod(lambda Td: N.Bufs1D()))
+    monkeypatch.setattr(bk_mod.HipBackend, "_bufs_ns", staticmethod(lambda Td, dt: N.BufsNS2D()))
+    P = N.Params1D()
+    call = bk.prepare_step1d("transport", P, {"beta": T(), "bsum": T()}, 1)
+    call()
+    assert entered == [torch.device("cuda", 1)] and launched == [(1, 1234)]
+    current["dev"] = 1                      # the state's device is current: no context manager
+    call()
+    assert entered == [torch.device("cuda", 1)] and len(launched) == 2
+    current["dev"] = 0
+    ns = bk.prepare_ns2d_step(N.ParamsNS2D(), {"p": T()}, 1)
+    ns()
+    assert entered[-1] == torch.device("cuda", 1) and len(entered) == 2 and len(launched) == 3
