@@ -112,13 +112,15 @@ class NavierStokes2D(PDEEnv2D):
         self._core.t["p"].copy_(out)
         return out[0].cpu().numpy().astype(np.float64 if self._np_dtype == np.float64 else np.float32)
 
+    # env.u / env.v (read every step by examples/NavierStokes/NS2Doptimization.py:75-76,113-114): the observation the last launch
+    # wrote into the pinned host view IS (u, v) after the boundary rule (navier_stokes2D.py:147: U[t] = stack(u, v)) -- no copy from the device
     @property
     def u(self):
-        return self._core.u[0].cpu().numpy()
+        return self._io["obs"][0, :, :, 0].copy()
 
     @property
     def v(self):
-        return self._core.v[0].cpu().numpy()
+        return self._io["obs"][0, :, :, 1].copy()
 
     @property
     def p(self):

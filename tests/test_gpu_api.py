@@ -154,6 +154,8 @@ def test_ns_public_api_on_gpu(golden_ns):
             np.testing.assert_array_equal(env.U[t, :, :, 1], g[f"v{t}"])
             np.testing.assert_allclose(r, g.rewards[t - 1], rtol=1e-12, atol=1e-15)
     np.testing.assert_array_equal(env.u, g["u50"])
+    np.testing.assert_array_equal(env.u, env._core.u[0].cpu().numpy())     # the host view IS the device state (u, v)
+    np.testing.assert_array_equal(env.v, env._core.v[0].cpu().numpy())
     # adjoint-example usage: solve_pressure on caller arrays
     from pde_control_gym.src.environments2d.navier_stokes2D import central_difference
     pr = env.solve_pressure(env.u, env.v, np.zeros((21, 21)))
