@@ -274,5 +274,8 @@ class NSBatch2D(EngineCheckpoint):
         return word * (3 * self.iters + 16) * self.nx * self.ny
 
     def compulsory_bytes_per_env_step(self) -> int:
+        """What a fused step must move: interleaved state (the observation of the previous step IS the state) 2 fields + p in,
+        observation 2 + p out = 6 fields; with separate u, v the state is read and written next to the observation: 10 fields.
+        The shared reference frame comes from L2."""
         word = 4 if str(self.dtype).endswith("float32") else 8
-        return word * (3 + 3 + 2 + 2) * self.nx * self.ny
+        return word * (6 if self.interleaved_state else 10) * self.nx * self.ny
