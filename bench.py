@@ -661,13 +661,15 @@ def live_counters_from_csvs(paths, ksub):
     return out
 
 
-def live_counters(workload_key, budget_s=90.0, first_timeout_s=75.0, timeout_s=40.0):
+def live_counters(workload_key, budget_s=210.0, first_timeout_s=150.0, timeout_s=45.0):
     """Counters of THIS run's headline kernel, collected on THIS box: before the parent process touches the
     GPU, four fresh child processes run the headline workload under rocprofv3 -- `--kernel-trace --stats` (the kernel's average
     duration), then `--pmc SQ_INSTS_VALU`, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` in passes of their own (never combined with a
     sys / hip trace; `python3` directly after `--`).  Returns {"kernel", "kernel_avg_ns", "calls", "valu_insts_per_step",
     "hbm_bytes_per_step", ...} or None (any failure, profiler missing, time budget spent: the caller falls back to the committed
-    counters).  Never retried, and never run from a process that has used the GPU."""
+    counters).  Never retried, and never run from a process that has used the GPU.  Timeouts: the first child may meet a cold box (the
+    first `import torch` of a fresh image can take a minute or two), the others ~5 s each on a warm one; a run in which the profiler hangs
+    outright still finishes within the "few minutes" of the bench contract."""
     import shutil
     import subprocess
     import tempfile
